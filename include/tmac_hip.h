@@ -1,0 +1,172 @@
+/*
+ * tmac_hip.h — C-ABI of libtmac_hip.so: T-MAC's LUT mpGEMM hot path on MI355X (gfx950).
+ *
+ * Drop-in boundary.  Plain pointers and sizes only; every function returns
+ * 0 on success, -1 when no kernel matches the requested shape/configuration (the reference's
+ * dispatcher contract, deploy/tuned/<set>/kernels.h `return -1`), and < -1 for runtime
+ * failures (tmac_hip_last_error() explains).  No CPU fallback exists: without a HIP device
+ * every compute entry point fails with TMAC_HIP_E_NODEVICE.
+ *
+ * Three layers:
+ *   (1) reference-named entry points taking HOST pointers in the reference's own layouts —
+ *       what the llama.cpp fork binds today (generated kernels.h):
+ *         preprocessor_int8 / qgemm_lut_int8 and the shape-named kernels.
+ *   (2) device-resident extensions — weights registered (uploaded + re-tiled) once, LUT
+ *       workspace on the GPU, launches on a caller-provided hipStream_t.  This is the path
+ *       that is benchmarked; a per-call H2D copy of 11 MB would erase the point.
+ *   (3) parity taps used by tests: read back QLUT / integer partial sums.
+ *
+ * float_type: the reference uses fp16 on ARM and fp32 on x86 (python/t_mac/intrins/tbl.cc:10-15).
+ * Layer (1) follows the HOST's float_type (fp32 on the x86 hosts of MI355X boxes); layer (2)
+ * takes an explicit dtype per tensor.
+ */
+#ifndef TMAC_HIP_H_
+#define TMAC_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMAC_HIP_OK 0
+#define TMAC_HIP_E_NOMATCH (-1)   /* no kernel for this shape/config (reference: dispatcher returns -1) */
+#define TMAC_HIP_E_NODEVICE (-2)  /* no usable HIP device */
+#define TMAC_HIP_E_RUNTIME (-3)   /* a HIP call failed */
+#define TMAC_HIP_E_ARG (-4)       /* invalid argument */
+
+typedef enum { TMAC_F32 = 0, TMAC_F16 = 1 } tmac_dtype_t;
+
+/* Mirrors TMAC::TMACGeMMConfig (include/t-mac/tmac_gemm_wrapper.h:26-35) plus the three facts the
+ * reference bakes into the compiled kernel instead of kcfg.ini (zero_point, act_group_size,
+ * m_groups: python/t_mac/ops/qgemm.py:16-96). */
+typedef struct tmac_kcfg {
+    int bm;              /* M-tile in bit-plane rows                       (kcfg.ini: bm)        */
+    int simd_n_in;       /* 16                                              (kcfg.ini)            */
+    int simd_n_out;      /* 8                                               (kcfg.ini)            */
+    int kfactor;         /* LUT groups per tbl call                         (kcfg.ini)            */
+    int group_size;      /* weight quantisation group along K               (kcfg.ini)            */
+    int lut_scales_size; /* N * K / act_group_size                          (kcfg.ini)            */
+    int scales_size;     /* number of scale(+zero) values                   (kcfg.ini)            */
+    int n_tile_num;      /* M / bm                                          (kcfg.ini)            */
+    int act_group_size;  /* activations sharing one LUT scale (64; == K for BitNet on x86)       */
+    int zero_point;      /* scales interleaved with zero points                                   */
+    int m_groups;        /* -1: per-(row, group) scales; >=1: unified scale(s) (BitNet)           */
+} tmac_kcfg;
+
+typedef struct tmac_hip_weights tmac_hip_weights;      /* one registered weight matrix (device) */
+typedef struct tmac_hip_workspace tmac_hip_workspace;  /* QLUT + LUT scales/biases (device)     */
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int32_t tmac_hip_init(int device);            /* selects the device; idempotent               */
+const char* tmac_hip_last_error(void);        /* thread-local message of the last failure     */
+const char* tmac_hip_version(void);
+int32_t tmac_hip_device_count(void);
+
+/* kcfg.ini handling: same file format and section names as the reference
+ * (deploy/compile.py:153-165; lookup tmac_gemm_wrapper.h:230-255).  `path` NULL -> $TMAC_KCFG_FILE. */
+int32_t tmac_hip_load_kcfg(const char* path);
+/* M here is the number of WEIGHT rows (as in TMACGeMMWrapper::get_kcfg); fills zero_point /
+ * act_group_size / m_groups from scales_size / lut_scales_size as the reference's shapes imply. */
+int32_t tmac_hip_get_kcfg(int M, int K, int N, int bits, tmac_kcfg* out);
+/* programmatic alternative to a file (used by tests and bench) */
+int32_t tmac_hip_set_kcfg(int M, int K, int N, int bits, const tmac_kcfg* cfg);
+
+/* ---- (2) device-resident path ---------------------------------------------------------- */
+
+/* Upload + re-tile one weight matrix given in the REFERENCE layout (python/t_mac/weights.py:57-87):
+ *   A_ref      uint8 [M/bm][K/4][bm/2]           (M = Mw*bits bit-plane rows)
+ *   scales_ref float_type: zero_point [M/bm][K/gs][bm/bits/8][2][8]; else [M/bm][K/gs][bm/bits/8][8];
+ *              m_groups>=1: [m_groups]
+ * host_float : dtype of scales_ref (TMAC_F32 on x86 hosts, TMAC_F16 for ARM-produced blobs)
+ * dev_float  : dtype the scales are STORED in on the GPU (TMAC_F16 halves their HBM traffic and is
+ *              exact when the values are fp16-representable; TMAC_F32 keeps x86 bit parity)
+ * The re-tiling is a pure permutation of nibbles (+ a bijective recoding of each nibble), so every
+ * integer partial sum is identical to the reference's.  Row shards for multi-GPU: pass the tile
+ * pointers of the shard and its Mw (tiles are contiguous in the reference layout). */
+int32_t tmac_hip_register_weights(tmac_hip_weights** out, const void* A_ref, const void* scales_ref,
+                                  int Mw, int K, int bits, const tmac_kcfg* cfg,
+                                  tmac_dtype_t host_float, tmac_dtype_t dev_float, void* stream);
+/* Same, but A_ref / scales_ref already live in device memory (bench: avoids a 1.6 GB PCIe upload). */
+int32_t tmac_hip_register_weights_dev(tmac_hip_weights** out, const void* A_ref_dev, const void* scales_ref_dev,
+                                      int Mw, int K, int bits, const tmac_kcfg* cfg,
+                                      tmac_dtype_t host_float, tmac_dtype_t dev_float, void* stream);
+int32_t tmac_hip_free_weights(tmac_hip_weights* w);
+/* bytes one GEMV must read from HBM for this matrix (weights + scales), i.e. SURVEY.md §8d's
+ * algorithmic bytes minus the activation-side terms */
+size_t tmac_hip_weights_bytes(const tmac_hip_weights* w);
+
+/* LUT workspace = TMACGeMMWrapper::set_workspace (tmac_gemm_wrapper.h:257-270) on the device. */
+int32_t tmac_hip_workspace_create(tmac_hip_workspace** out, int maxK, int maxN);
+int32_t tmac_hip_workspace_free(tmac_hip_workspace* ws);
+
+/* preprocessor (lut_ctor.cc:38-266 + generated glue): activations B_dev [N][K] (act_dtype) ->
+ * ws {QLUT int8, lut_scales, lut_biases}.  Bit-exact with the reference's fp32 arithmetic. */
+int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void* B_dev, tmac_dtype_t act_dtype,
+                                  int K, int N, int act_group_size, void* stream);
+
+/* qgemm_lut (tbl.cc + glue): C_dev [N][Mw] (out_dtype) = W x LUT(ws).  ws must hold the LUT of the
+ * same K and act_group_size.  Whole matrix in one launch. */
+int32_t tmac_hip_qgemm_dev(const tmac_hip_weights* w, const tmac_hip_workspace* ws, void* C_dev,
+                           tmac_dtype_t out_dtype, int N, void* stream);
+
+/* Raw device pointers of the workspace, for collectives (RCCL all-gather of the LUT over xGMI):
+ *   qlut_dev  : kernel-layout half tables, nbytes_qlut per activation row
+ *   lut_scales/lut_biases : fp32 [N][K/act_group_size] */
+int32_t tmac_hip_workspace_ptrs(tmac_hip_workspace* ws, void** qlut_dev, size_t* nbytes_qlut_per_row,
+                                void** lut_scales, void** lut_biases);
+
+/* ---- (3) parity taps -------------------------------------------------------------------- */
+/* QLUT in the reference layout int8 [N][K/4][16] + fp32 lut_scales/lut_biases [N][K/ags] -> host */
+int32_t tmac_hip_workspace_read(tmac_hip_workspace* ws, int8_t* qlut_host, float* lut_scales_host,
+                                float* lut_biases_host, int K, int N, int act_group_size, void* stream);
+/* load a host-side reference-layout LUT into the workspace (what qgemm_lut_int8 does internally) */
+int32_t tmac_hip_workspace_write(tmac_hip_workspace* ws, const int8_t* qlut_host, const float* lut_scales_host,
+                                 const float* lut_biases_host, int K, int N, int act_group_size, void* stream);
+/* Same kernel as tmac_hip_qgemm_dev with the integer tap enabled: PS_host int32 [N][M][K/ags] in the
+ * reference's M-space (bit-plane) row order; for the unified-scale path [N][M] (K/ags == 1). */
+int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const tmac_hip_workspace* ws,
+                                    int32_t* PS_host, int N, void* stream);
+/* Runs v_perm_b32 / v_mqsad_pk_u16_u8 / lookup4 on n quadruples of host words (in[4n] -> out[4n]); the
+ * test-suite compares the result with the host models of t-mac_amd/csrc/tmac_core.h. */
+int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host, int n);
+/* Select the GEMV kernel variant (0 = default/auto).  For A/B benchmarking and tests. */
+int32_t tmac_hip_set_variant(int variant);
+
+/* ---- (1) reference-named host-pointer entry points ---------------------------------------
+ * Signatures identical to the generated deploy/tuned/<set>/kernels.h.  `m` is bm for qgemm_lut
+ * (one M-tile; A/Scales/C are the tile pointers, tmac_gemm_wrapper.h:197-228) and Mw*bits for the
+ * preprocessor.  Tile weights are uploaded on first use and cached by host pointer (llama.cpp
+ * keeps weights mmap'd for the life of the model); tmac_hip_cache_clear() drops the cache.
+ * Configuration (group_size, zero_point, act_group_size) comes from the loaded kcfg
+ * (tmac_hip_load_kcfg / $TMAC_KCFG_FILE), exactly as the reference couples kernels to kcfg.ini. */
+int32_t qgemm_lut_int8(int m, int k, int n, int b, void* A, void* LUT, void* Scales, void* LUT_Scales,
+                       void* LUT_Biases, void* C);
+int32_t preprocessor_int8(int m, int k, int n, int b, void* B, void* LUT_Scales, void* LUT_Biases, void* QLUT);
+int32_t tmac_hip_cache_clear(void);
+
+/* shape-named kernels of the four checked-in sets (deploy/tuned/aarch64-<set>/kernels.h) */
+#define TMAC_DECL_Q(bm, k, n, b) \
+    int32_t qgemm_lut_t1_int8_m##bm##_k##k##_n##n##_b##b(void* A, void* LUT, void* Scales, void* LUT_Scales, void* LUT_Biases, void* C);
+#define TMAC_DECL_P(m, k, n, b) \
+    int32_t preprocessor_t1_int8_m##m##_k##k##_n##n##_b##b(void* B, void* LUT_Scales, void* LUT_Biases, void* QLUT);
+/* llama-2-7b-2bit */
+TMAC_DECL_Q(128, 4096, 1, 2) TMAC_DECL_Q(128, 11008, 1, 2)
+TMAC_DECL_P(8192, 4096, 1, 2) TMAC_DECL_P(22016, 4096, 1, 2) TMAC_DECL_P(8192, 11008, 1, 2)
+/* llama-2-7b-4bit */
+TMAC_DECL_Q(1024, 4096, 1, 4) TMAC_DECL_Q(256, 4096, 1, 4) TMAC_DECL_Q(256, 11008, 1, 4)
+TMAC_DECL_P(16384, 4096, 1, 4) TMAC_DECL_P(44032, 4096, 1, 4) TMAC_DECL_P(16384, 11008, 1, 4)
+/* llama-3-8b-2bit */
+TMAC_DECL_Q(256, 4096, 1, 2) TMAC_DECL_Q(512, 4096, 1, 2) TMAC_DECL_Q(128, 14336, 1, 2)
+TMAC_DECL_P(28672, 4096, 1, 2) TMAC_DECL_P(8192, 14336, 1, 2) TMAC_DECL_P(2048, 4096, 1, 2)
+/* hf-bitnet-3b */
+TMAC_DECL_Q(128, 8640, 1, 2) TMAC_DECL_Q(128, 3200, 1, 2) TMAC_DECL_Q(320, 3200, 1, 2)
+TMAC_DECL_P(6400, 8640, 1, 2) TMAC_DECL_P(17280, 3200, 1, 2) TMAC_DECL_P(6400, 3200, 1, 2)
+#undef TMAC_DECL_Q
+#undef TMAC_DECL_P
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMAC_HIP_H_ */

@@ -1,0 +1,16 @@
+"""t-mac_amd — MI355X-native implementation of T-MAC's LUT mpGEMM hot path.
+
+The product is ``lib/libtmac_hip.so`` (HIP kernels + C++ dispatch behind the C-ABI of
+``include/tmac_hip.h``).  This package is the thin Python host side: a ctypes binding
+(:mod:`.binding`), the offline weight transform (:mod:`.weights`, mirrors
+``python/t_mac/weights.py`` of the reference) and a ``TMACGeMMWrapper`` with the reference's
+method names (:mod:`.wrapper`, mirrors ``include/t-mac/tmac_gemm_wrapper.h``).
+
+Importable as ``tmac_amd`` (the directory name carries a hyphen for historical reasons; the
+``tmac_amd/`` alias package at the repo root points its ``__path__`` here).
+"""
+from .binding import (TMACHipError, KCfg, lib, lib_path, F32, F16, load_library, build_library)  # noqa: F401
+from .weights import preprocess_weights  # noqa: F401
+from .wrapper import TMACGeMMWrapper, Weights, Workspace  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,101 @@
+"""ctypes binding of libtmac_hip.so (C-ABI: include/tmac_hip.h).
+
+The library is built IN-TREE (``t-mac_amd/lib/libtmac_hip.so``, ``make -C t-mac_amd/csrc``) so that
+it travels with the repo snapshot to the GPU box.  There is deliberately no fallback: if the
+library is missing, or no HIP device is visible when a compute entry point is called, an exception
+is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+F32, F16 = 0, 1
+
+
+class TMACHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"tmac_hip error {code}: {msg}")
+        self.code = code
+
+
+class KCfg(C.Structure):
+    """tmac_kcfg — TMAC::TMACGeMMConfig (tmac_gemm_wrapper.h:26-35) + zero_point/act_group_size/m_groups."""
+    _fields_ = [(n, C.c_int) for n in ("bm", "simd_n_in", "simd_n_out", "kfactor", "group_size", "lut_scales_size",
+                                       "scales_size", "n_tile_num", "act_group_size", "zero_point", "m_groups")]
+
+    @classmethod
+    def make(cls, Mw, K, bits, bm, kfactor=16, group_size=128, act_group_size=64, zero_point=True, m_groups=-1, N=1):
+        per = 2 if zero_point else 1
+        scales_size = m_groups if m_groups >= 1 else Mw * (K // group_size) * per
+        return cls(bm, 16, 8, kfactor, group_size, N * K // act_group_size, scales_size, Mw * bits // bm,
+                   act_group_size, int(bool(zero_point)) if m_groups < 1 else 0, m_groups)
+
+
+def lib_path() -> str:
+    return os.path.join(HERE, "lib", "libtmac_hip.so")
+
+
+def build_library(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of the in-tree shared library (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", os.path.join(HERE, "csrc"), "clean"], check=True)
+    subprocess.run(["make", "-s", "-j4", "-C", os.path.join(HERE, "csrc")], check=True)
+    return lib_path()
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ImportError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); tmac_amd has no fallback path")
+    L = C.CDLL(p)
+    vp, i32, sz = C.c_void_p, C.c_int32, C.c_size_t
+    sigs = {
+        "tmac_hip_init": ([C.c_int], i32),
+        "tmac_hip_last_error": ([], C.c_char_p),
+        "tmac_hip_version": ([], C.c_char_p),
+        "tmac_hip_device_count": ([], i32),
+        "tmac_hip_load_kcfg": ([C.c_char_p], i32),
+        "tmac_hip_get_kcfg": ([C.c_int] * 4 + [C.POINTER(KCfg)], i32),
+        "tmac_hip_set_kcfg": ([C.c_int] * 4 + [C.POINTER(KCfg)], i32),
+        "tmac_hip_register_weights": ([C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(KCfg), C.c_int, C.c_int, vp], i32),
+        "tmac_hip_register_weights_dev": ([C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(KCfg), C.c_int, C.c_int, vp], i32),
+        "tmac_hip_free_weights": ([vp], i32),
+        "tmac_hip_weights_bytes": ([vp], sz),
+        "tmac_hip_workspace_create": ([C.POINTER(vp), C.c_int, C.c_int], i32),
+        "tmac_hip_workspace_free": ([vp], i32),
+        "tmac_hip_preprocessor_dev": ([vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp], i32),
+        "tmac_hip_qgemm_dev": ([vp, vp, vp, C.c_int, C.c_int, vp], i32),
+        "tmac_hip_workspace_ptrs": ([vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(vp)], i32),
+        "tmac_hip_workspace_read": ([vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp], i32),
+        "tmac_hip_workspace_write": ([vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp], i32),
+        "tmac_hip_qgemm_partial_sums": ([vp, vp, vp, C.c_int, vp], i32),
+        "tmac_hip_set_variant": ([C.c_int], i32),
+        "tmac_hip_selftest": ([vp, vp, C.c_int], i32),
+        "tmac_hip_cache_clear": ([], i32),
+        "qgemm_lut_int8": ([C.c_int] * 4 + [vp] * 6, i32),
+        "preprocessor_int8": ([C.c_int] * 4 + [vp] * 4, i32),
+    }
+    for name, (argt, rest) in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes, fn.restype = argt, rest
+    _lib = L
+    return L
+
+
+def lib() -> C.CDLL:
+    return load_library()
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise TMACHipError(rc, load_library().tmac_hip_last_error().decode())

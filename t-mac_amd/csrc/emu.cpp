@@ -1,0 +1,80 @@
+// emu.cpp — CPU emulation of the tiled GEMV kernel's INTEGER path (test infrastructure).
+//
+// Built by g++ into t-mac_amd/lib/libtmac_emu.so and used only by tests/test_emulation.py
+// (-m "not gpu"): it runs the very same layout math (tmac_layout.h) and per-thread lookup /
+// accumulate code (tmac_core.h) the HIP kernels compile, with v_perm_b32 / v_mqsad_pk_u16_u8
+// replaced by their bit-exact host models, thread by thread, and returns the integer partial
+// sums.  It is NOT a product path: libtmac_hip.so contains no CPU compute.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "tmac_core.h"
+
+using namespace tmac;
+
+template <int BITS, int MODE>
+static void run(const std::vector<uint32_t>& W, const std::vector<uint32_t>& QL, const Shape& s, int32_t* PS) {
+    constexpr int NJ = TS * BITS / 8;
+    const int TG = s.ags == s.K ? TS : s.ags / 4;  // tables per act group inside a segment
+    const int NA = TS / TG, G = s.K / s.ags;
+    for (int b = 0; b < s.nb(); ++b)
+        for (int sb = 0; sb < s.nsb(); ++sb)
+            for (int rl = 0; rl < RL; ++rl)
+                for (int kl = 0; kl < KL; ++kl) {
+                    const int seg = sb * KL + kl, rq = b * RL + rl;
+                    if (seg >= s.nseg()) continue;
+                    uint32_t wd[TS * BITS / 2], tb[2 * TS];
+                    for (int j = 0; j < NJ; ++j)
+                        for (int e = 0; e < 4; ++e) wd[4 * j + e] = W[weight_u4_index(s, b, sb, j, rl, kl) * 4 + e];
+                    for (int j8 = 0; j8 < 8; ++j8)
+                        for (int e = 0; e < 4; ++e) tb[4 * j8 + e] = QL[(((size_t)sb * 8 + j8) * KL + kl) * 4 + e];
+                    for (int a = 0; a < NA; ++a) {
+                        SegAcc<BITS, MODE> acc;
+                        acc.reset();
+                        if (TG == 16) accumulate_tables<BITS, 0, 16>(wd, tb, acc);
+                        else if (a == 0) accumulate_tables<BITS, 0, 8>(wd, tb, acc);
+                        else accumulate_tables<BITS, 8, 8>(wd, tb, acc);
+                        for (int beta = 0; beta < 4; ++beta)
+                            for (int p = 0; p < BITS; ++p) {
+                                const int o = 4 * rq + beta;
+                                if (o >= s.Mw) continue;
+                                const int32_t v = acc.ps(p, beta, TG);
+                                if (s.ags == s.K) PS[mrow(o, p, BITS)] += v;  // scale-final: whole-K sum
+                                else PS[(size_t)mrow(o, p, BITS) * G + seg * NA + a] = v;
+                            }
+                    }
+                }
+}
+
+extern "C" int emu_partial_sums(const uint8_t* A_ref, const int8_t* qlut_ref, int Mw, int K, int bits, int bm,
+                                int kfactor, int ags, int mode, int32_t* PS) {
+    Shape s;
+    memset(&s, 0, sizeof(s));
+    s.Mw = Mw; s.K = K; s.bits = bits; s.bm = bm; s.kfactor = kfactor; s.gs = 128; s.ags = ags; s.m_groups = -1;
+    if (K % 64 || (ags != 32 && ags != 64 && ags != K)) return -1;
+    std::vector<uint32_t> W(s.weight_u4() * 4);
+    for (size_t i = 0; i < W.size(); ++i) W[i] = retile_dword(A_ref, s, i >> 2, (int)(i & 3));
+    std::vector<uint32_t> QL(s.qlut_dev_u4() * 4, 0x80808080u);
+    for (int t = 0; t < K / 4; ++t) {
+        uint32_t lo = 0, hi = 0;
+        for (int i = 0; i < 4; ++i) {
+            lo |= (uint32_t)(qlut_ref[t * 16 + i] + 128) << (8 * i);
+            hi |= (uint32_t)(qlut_ref[t * 16 + 4 + i] + 128) << (8 * i);
+        }
+        const int seg = t / TS, tls = t % TS;
+        const size_t u2 = qlut_dev_u4_index(seg, tls >> 1) * 2 + (tls & 1);
+        QL[u2 * 2] = lo; QL[u2 * 2 + 1] = hi;
+    }
+    const size_t n = (size_t)Mw * bits * (ags == K ? 1 : K / ags);
+    memset(PS, 0, n * sizeof(int32_t));
+#define RUN(B) (mode == 0 ? run<B, 0>(W, QL, s, PS) : run<B, 1>(W, QL, s, PS))
+    switch (bits) {
+        case 1: RUN(1); break;
+        case 2: RUN(2); break;
+        case 3: RUN(3); break;
+        case 4: RUN(4); break;
+        default: return -1;
+    }
+    return 0;
+}

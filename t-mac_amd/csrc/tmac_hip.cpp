@@ -1,0 +1,602 @@
+// tmac_hip.cpp — host side of libtmac_hip.so: the C-ABI of include/tmac_hip.h.
+//
+// Mirrors the reference's runtime boundary (include/t-mac/tmac_gemm_wrapper.h + generated
+// t-mac/kernels.h): kcfg.ini lookup, workspace ownership, preprocessor / qgemm_lut dispatch with
+// the reference's return convention (0 ok, -1 no matching kernel).  All compute is launched on the
+// GPU; there is no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/tmac_hip.h"
+#include "tmac_kernels.h"
+
+using namespace tmac;
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int32_t fail(int32_t code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(TMAC_HIP_E_RUNTIME, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// objects
+// ---------------------------------------------------------------------------------------------
+struct tmac_hip_weights {
+    Shape s;
+    void* W = nullptr;      // device layout weights
+    void* SC = nullptr;     // device layout scales
+    Dtype sc_dtype = F32;
+    void* A_ref = nullptr;  // reference blobs kept on the device only when the generic kernel needs them
+    void* S_ref = nullptr;
+    Dtype ref_dtype = F32;
+    bool lo_ok = false;
+    size_t w_bytes = 0, sc_bytes = 0;
+};
+
+struct tmac_hip_workspace {
+    int maxK = 0, maxN = 0;
+    int8_t* qlut_ref = nullptr;  // int8 [maxN][maxK/4][16]
+    void* qlut_dev = nullptr;    // uint4 [maxN][qdev_u4(maxK)]
+    float* lut_scales = nullptr; // fp32 [maxN][maxK/32]
+    float* lut_biases = nullptr;
+    int32_t* dump = nullptr;     // lazily sized parity tap
+    size_t dump_elems = 0;
+    int K = 0, N = 0, ags = 0;   // what the LUT currently holds
+    size_t qdev_u4_per_row = 0;
+};
+
+static std::mutex g_mu;
+static int g_device = -1;
+static int g_variant = V_AUTO;
+static std::map<std::string, tmac_kcfg> g_kcfg;
+
+static size_t qdev_u4_for_K(int K) { return (size_t)((K / (4 * TS) + KL - 1) / KL) * 8 * KL; }
+
+static int32_t ensure_device() {
+    if (g_device >= 0) return TMAC_HIP_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(TMAC_HIP_E_NODEVICE, "no HIP device available (%s); libtmac_hip has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    g_device = dev;
+    return TMAC_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kcfg.ini — same sections/keys as deploy/compile.py:153-165; lookup as tmac_gemm_wrapper.h:230-255
+// ---------------------------------------------------------------------------------------------
+static std::string section_name(int threads, int M_bits, int K, int N, int bits) {
+    char buf[128];
+    snprintf(buf, sizeof(buf), "qgemm_lut_t%d_int8_m%d_k%d_n%d_b%d", threads, M_bits, K, N, bits);
+    return buf;
+}
+
+static void derive_kcfg(tmac_kcfg& c, int M_bits, int K, int N, int bits) {
+    const int Mw = M_bits / bits;
+    if (c.lut_scales_size > 0) c.act_group_size = (int)((long long)N * K / c.lut_scales_size);
+    if (c.scales_size > 0 && c.scales_size < Mw) {
+        c.m_groups = c.scales_size;
+        c.zero_point = 0;
+    } else {
+        c.m_groups = -1;
+        const long long per_row = c.group_size > 0 ? K / c.group_size : 1;
+        c.zero_point = (c.scales_size == 2LL * Mw * per_row) ? 1 : 0;
+    }
+}
+
+extern "C" int32_t tmac_hip_load_kcfg(const char* path) {
+    std::string p = path ? path : "";
+    if (p.empty()) {
+        const char* e = getenv("TMAC_KCFG_FILE");  // tmac_gemm_wrapper.h:40-56
+        if (!e) return fail(TMAC_HIP_E_ARG, "no kcfg path given and TMAC_KCFG_FILE is not set");
+        p = e;
+    }
+    std::ifstream f(p);
+    if (!f) return fail(TMAC_HIP_E_ARG, "cannot open kcfg file %s", p.c_str());
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::string line, sec;
+    std::map<std::string, std::map<std::string, long long>> raw;
+    while (std::getline(f, line)) {
+        size_t a = line.find_first_not_of(" \t\r\n");
+        if (a == std::string::npos) continue;
+        line = line.substr(a);
+        if (line[0] == '#' || line[0] == ';') continue;
+        if (line[0] == '[') {
+            size_t b = line.find(']');
+            if (b != std::string::npos) sec = line.substr(1, b - 1);
+            continue;
+        }
+        size_t eq = line.find('=');
+        if (eq == std::string::npos || sec.empty()) continue;
+        std::string k = line.substr(0, eq), v = line.substr(eq + 1);
+        k.erase(k.find_last_not_of(" \t") + 1);
+        raw[sec][k] = atoll(v.c_str());
+    }
+    for (auto& kv : raw) {
+        int t, m, k, n, b;
+        if (sscanf(kv.first.c_str(), "qgemm_lut_t%d_int8_m%d_k%d_n%d_b%d", &t, &m, &k, &n, &b) != 5) continue;
+        tmac_kcfg c;
+        memset(&c, 0, sizeof(c));
+        auto& r = kv.second;
+        c.bm = (int)r["bm"]; c.simd_n_in = (int)r["simd_n_in"]; c.simd_n_out = (int)r["simd_n_out"];
+        c.kfactor = (int)r["kfactor"]; c.group_size = (int)r["group_size"];
+        c.lut_scales_size = (int)r["lut_scales_size"]; c.scales_size = (int)r["scales_size"];
+        c.n_tile_num = (int)r["n_tile_num"];
+        derive_kcfg(c, m, k, n, b);
+        g_kcfg[kv.first] = c;
+    }
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_set_kcfg(int M, int K, int N, int bits, const tmac_kcfg* cfg) {
+    if (!cfg) return fail(TMAC_HIP_E_ARG, "null cfg");
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_kcfg[section_name(1, M * bits, K, N, bits)] = *cfg;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_get_kcfg(int M, int K, int N, int bits, tmac_kcfg* out) {
+    if (!out) return fail(TMAC_HIP_E_ARG, "null out");
+    std::lock_guard<std::mutex> lk(g_mu);
+    static const int hints[] = {1, 4, 8, 16};  // tmac_gemm_wrapper.h:233
+    for (int t : hints) {
+        auto it = g_kcfg.find(section_name(t, M * bits, K, N, bits));
+        if (it != g_kcfg.end()) {
+            *out = it->second;
+            return TMAC_HIP_OK;
+        }
+    }
+    return fail(TMAC_HIP_E_NOMATCH, "no kcfg section for m=%d k=%d n=%d b=%d", M * bits, K, N, bits);
+}
+
+// ---------------------------------------------------------------------------------------------
+// lifecycle
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t tmac_hip_init(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(TMAC_HIP_E_NODEVICE, "no HIP device available; libtmac_hip has no CPU path");
+    if (device < 0 || device >= n) return fail(TMAC_HIP_E_ARG, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    g_device = device;
+    return TMAC_HIP_OK;
+}
+extern "C" const char* tmac_hip_last_error(void) { return g_err; }
+extern "C" const char* tmac_hip_version(void) { return "tmac_hip 0.1 (gfx950)"; }
+extern "C" int32_t tmac_hip_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+extern "C" int32_t tmac_hip_set_variant(int variant) {
+    if (variant < 0 || variant > 3) return fail(TMAC_HIP_E_ARG, "unknown variant %d", variant);
+    g_variant = variant;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host, int n) {
+    if (!in_host || !out_host || n <= 0) return fail(TMAC_HIP_E_ARG, "bad selftest arguments");
+    int32_t rc = ensure_device();
+    if (rc) return rc;
+    uint32_t *din = nullptr, *dout = nullptr;
+    const size_t bytes = sizeof(uint32_t) * 4 * (size_t)n;
+    HIP_TRY(hipMalloc((void**)&din, bytes));
+    HIP_TRY(hipMalloc((void**)&dout, bytes));
+    HIP_TRY(hipMemcpy(din, in_host, bytes, hipMemcpyHostToDevice));
+    hipError_t e = launch_selftest(din, dout, n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_host, dout, bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "selftest: %s", hipGetErrorString(e));
+    return TMAC_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weights
+// ---------------------------------------------------------------------------------------------
+static int32_t make_shape(Shape& s, int Mw, int K, int bits, const tmac_kcfg* cfg) {
+    if (!cfg) return fail(TMAC_HIP_E_ARG, "null kcfg");
+    memset(&s, 0, sizeof(s));
+    s.Mw = Mw; s.K = K; s.bits = bits; s.bm = cfg->bm; s.kfactor = cfg->kfactor;
+    s.m_groups = cfg->m_groups >= 1 ? cfg->m_groups : -1;
+    s.gs = s.m_groups >= 1 ? 0 : cfg->group_size;
+    s.ags = cfg->act_group_size > 0 ? cfg->act_group_size : 64;
+    s.zero_point = (s.m_groups >= 1) ? 0 : (cfg->zero_point ? 1 : 0);
+    // the reference's own shape constraints (python/t_mac/ops/qgemm.py:118-129, weights.py:57-73)
+    if (bits < 1 || bits > 4 || Mw <= 0 || K <= 0) return fail(TMAC_HIP_E_NOMATCH, "bad shape");
+    if (s.bm <= 0 || s.bm % 32 || s.bm % bits || (s.bm / bits) % 8 || (Mw * bits) % s.bm)
+        return fail(TMAC_HIP_E_NOMATCH, "M=%d*%d not tileable by bm=%d", Mw, bits, s.bm);
+    if (s.kfactor <= 0 || (K / 4) % s.kfactor || K % 4) return fail(TMAC_HIP_E_NOMATCH, "K=%d not tileable by kfactor=%d", K, s.kfactor);
+    if (s.ags % 32 || K % s.ags) return fail(TMAC_HIP_E_NOMATCH, "K=%d not divisible by act_group_size=%d", K, s.ags);
+    if (s.m_groups < 0 && (s.gs <= 0 || K % s.gs)) return fail(TMAC_HIP_E_NOMATCH, "K=%d not divisible by group_size=%d", K, s.gs);
+    if (!(s.m_groups >= 1 && s.ags == K) && (4 * s.kfactor) % s.ags)
+        return fail(TMAC_HIP_E_NOMATCH, "act_group_size=%d must divide 4*kfactor=%d (qgemm.py:113-115)", s.ags, 4 * s.kfactor);
+    if (s.m_groups < 0 && s.gs % (4 * s.kfactor)) return fail(TMAC_HIP_E_NOMATCH, "group_size %% (4*kfactor) != 0");
+    return TMAC_HIP_OK;
+}
+
+static size_t ref_weight_bytes(const Shape& s) { return (size_t)s.M() * (s.K / 4) / 2; }
+static size_t ref_scale_elems(const Shape& s) {
+    return s.m_groups >= 1 ? (size_t)s.m_groups : (size_t)s.Mw * (s.K / s.gs) * (s.zero_point ? 2 : 1);
+}
+static size_t dt_size(Dtype d) { return d == F16 ? 2 : 4; }
+
+static int32_t register_impl(tmac_hip_weights** out, const void* A_ref, const void* scales_ref, bool src_on_device,
+                             int Mw, int K, int bits, const tmac_kcfg* cfg, tmac_dtype_t host_float,
+                             tmac_dtype_t dev_float, void* stream) {
+    if (!out || !A_ref || !scales_ref) return fail(TMAC_HIP_E_ARG, "null argument");
+    int32_t rc = ensure_device();
+    if (rc) return rc;
+    Shape s;
+    rc = make_shape(s, Mw, K, bits, cfg);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    auto* w = new tmac_hip_weights();
+    w->s = s;
+    w->sc_dtype = (Dtype)dev_float;
+    w->ref_dtype = (Dtype)host_float;
+    w->lo_ok = gemv_lo_supported(s);
+    const size_t ab = ref_weight_bytes(s), se = ref_scale_elems(s), sb = se * dt_size((Dtype)host_float);
+    const bool keep_ref = !w->lo_ok || g_variant == V_REF_LAYOUT;
+    void *dA = nullptr, *dS = nullptr;
+    auto cleanup = [&](int32_t code) {  // error path: drop everything this call allocated
+        if (!(src_on_device && !keep_ref)) { if (dA) (void)hipFree(dA); if (dS) (void)hipFree(dS); }
+        tmac_hip_free_weights(w);
+        return code;
+    };
+    if (src_on_device && !keep_ref) {
+        dA = const_cast<void*>(A_ref);
+        dS = const_cast<void*>(scales_ref);
+    } else {
+        HIP_TRY(hipMalloc(&dA, ab));
+        HIP_TRY(hipMalloc(&dS, sb));
+        const hipMemcpyKind kind = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        HIP_TRY(hipMemcpyAsync(dA, A_ref, ab, kind, st));
+        HIP_TRY(hipMemcpyAsync(dS, scales_ref, sb, kind, st));
+    }
+    if (w->lo_ok) {
+        w->w_bytes = s.weight_u4() * 16;
+        HIP_TRY(hipMalloc(&w->W, w->w_bytes));
+        hipError_t e = launch_retile_weights((const uint8_t*)dA, w->W, s, st);
+        if (e != hipSuccess) return cleanup(fail(TMAC_HIP_E_RUNTIME, "retile_weights: %s", hipGetErrorString(e)));
+        const size_t de = s.m_groups >= 1 ? (size_t)s.m_groups : s.scale_elems();
+        w->sc_bytes = de * dt_size(w->sc_dtype);
+        HIP_TRY(hipMalloc(&w->SC, w->sc_bytes));
+        e = launch_retile_scales(dS, (Dtype)host_float, w->SC, w->sc_dtype, s, st);
+        if (e != hipSuccess) return cleanup(fail(TMAC_HIP_E_RUNTIME, "retile_scales: %s", hipGetErrorString(e)));
+    } else {
+        w->w_bytes = ab;
+        w->sc_bytes = sb;
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (keep_ref) {
+        w->A_ref = dA;
+        w->S_ref = dS;
+    } else if (!src_on_device) {
+        (void)hipFree(dA);
+        (void)hipFree(dS);
+    }
+    *out = w;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_register_weights(tmac_hip_weights** out, const void* A_ref, const void* scales_ref, int Mw,
+                                             int K, int bits, const tmac_kcfg* cfg, tmac_dtype_t host_float,
+                                             tmac_dtype_t dev_float, void* stream) {
+    return register_impl(out, A_ref, scales_ref, false, Mw, K, bits, cfg, host_float, dev_float, stream);
+}
+extern "C" int32_t tmac_hip_register_weights_dev(tmac_hip_weights** out, const void* A_ref_dev, const void* scales_ref_dev,
+                                                 int Mw, int K, int bits, const tmac_kcfg* cfg, tmac_dtype_t host_float,
+                                                 tmac_dtype_t dev_float, void* stream) {
+    return register_impl(out, A_ref_dev, scales_ref_dev, true, Mw, K, bits, cfg, host_float, dev_float, stream);
+}
+
+extern "C" int32_t tmac_hip_free_weights(tmac_hip_weights* w) {
+    if (!w) return TMAC_HIP_OK;
+    if (w->W) (void)hipFree(w->W);
+    if (w->SC) (void)hipFree(w->SC);
+    if (w->A_ref) (void)hipFree(w->A_ref);
+    if (w->S_ref) (void)hipFree(w->S_ref);
+    delete w;
+    return TMAC_HIP_OK;
+}
+
+extern "C" size_t tmac_hip_weights_bytes(const tmac_hip_weights* w) {
+    if (!w) return 0;
+    // algorithmic bytes: Mw*K*bits/8 of weight planes + the scale(+zero) values
+    const Shape& s = w->s;
+    const size_t se = s.m_groups >= 1 ? (size_t)s.m_groups : (size_t)s.Mw * (s.K / s.gs) * (s.zero_point ? 2 : 1);
+    return (size_t)s.Mw * s.K * s.bits / 8 + se * dt_size(w->sc_dtype);
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t tmac_hip_workspace_create(tmac_hip_workspace** out, int maxK, int maxN) {
+    if (!out || maxK <= 0 || maxN <= 0 || maxK % 64) return fail(TMAC_HIP_E_ARG, "bad workspace size (maxK must be a multiple of 64)");
+    int32_t rc = ensure_device();
+    if (rc) return rc;
+    auto* ws = new tmac_hip_workspace();
+    ws->maxK = maxK; ws->maxN = maxN;
+    HIP_TRY(hipMalloc((void**)&ws->qlut_ref, (size_t)maxN * (maxK / 4) * 16));
+    HIP_TRY(hipMalloc(&ws->qlut_dev, (size_t)maxN * qdev_u4_for_K(maxK) * 16));
+    HIP_TRY(hipMemset(ws->qlut_dev, 0x80, (size_t)maxN * qdev_u4_for_K(maxK) * 16));
+    HIP_TRY(hipMalloc((void**)&ws->lut_scales, sizeof(float) * (size_t)maxN * (maxK / 32)));
+    HIP_TRY(hipMalloc((void**)&ws->lut_biases, sizeof(float) * (size_t)maxN * (maxK / 32)));
+    *out = ws;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_workspace_free(tmac_hip_workspace* ws) {
+    if (!ws) return TMAC_HIP_OK;
+    if (ws->qlut_ref) (void)hipFree(ws->qlut_ref);
+    if (ws->qlut_dev) (void)hipFree(ws->qlut_dev);
+    if (ws->lut_scales) (void)hipFree(ws->lut_scales);
+    if (ws->lut_biases) (void)hipFree(ws->lut_biases);
+    if (ws->dump) (void)hipFree(ws->dump);
+    delete ws;
+    return TMAC_HIP_OK;
+}
+
+static int32_t check_lut_shape(tmac_hip_workspace* ws, int K, int N, int ags) {
+    if (!ws) return fail(TMAC_HIP_E_ARG, "null workspace");
+    if (K <= 0 || K > ws->maxK || N <= 0 || N > ws->maxN) return fail(TMAC_HIP_E_ARG, "K=%d N=%d exceed the workspace (%d, %d)", K, N, ws->maxK, ws->maxN);
+    if (ags <= 0 || ags % 32 || K % ags) return fail(TMAC_HIP_E_NOMATCH, "act_group_size=%d must be a multiple of 32 dividing K=%d (qgemm.py:402-404)", ags, K);
+    if (K % 64) return fail(TMAC_HIP_E_NOMATCH, "K=%d must be a multiple of 64", K);
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void* B_dev, tmac_dtype_t act_dtype, int K,
+                                             int N, int act_group_size, void* stream) {
+    int32_t rc = check_lut_shape(ws, K, N, act_group_size);
+    if (rc) return rc;
+    if (!B_dev) return fail(TMAC_HIP_E_ARG, "null activations");
+    ws->K = K; ws->N = N; ws->ags = act_group_size; ws->qdev_u4_per_row = qdev_u4_for_K(K);
+    hipError_t e = launch_preprocess(B_dev, (Dtype)act_dtype, ws->qlut_ref, ws->qlut_dev, ws->lut_scales, ws->lut_biases,
+                                     K, N, act_group_size, ws->qdev_u4_per_row, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_workspace_ptrs(tmac_hip_workspace* ws, void** qlut_dev, size_t* nbytes_qlut_per_row,
+                                           void** lut_scales, void** lut_biases) {
+    if (!ws) return fail(TMAC_HIP_E_ARG, "null workspace");
+    if (qlut_dev) *qlut_dev = ws->qlut_dev;
+    if (nbytes_qlut_per_row) *nbytes_qlut_per_row = ws->qdev_u4_per_row * 16;
+    if (lut_scales) *lut_scales = ws->lut_scales;
+    if (lut_biases) *lut_biases = ws->lut_biases;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_workspace_read(tmac_hip_workspace* ws, int8_t* qlut_host, float* lut_scales_host,
+                                           float* lut_biases_host, int K, int N, int act_group_size, void* stream) {
+    int32_t rc = check_lut_shape(ws, K, N, act_group_size);
+    if (rc) return rc;
+    if (ws->K != K || ws->N != N || ws->ags != act_group_size) return fail(TMAC_HIP_E_ARG, "workspace holds a different LUT");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t G = (size_t)K / act_group_size;
+    if (qlut_host) HIP_TRY(hipMemcpyAsync(qlut_host, ws->qlut_ref, (size_t)N * (K / 4) * 16, hipMemcpyDeviceToHost, st));
+    if (lut_scales_host) HIP_TRY(hipMemcpyAsync(lut_scales_host, ws->lut_scales, sizeof(float) * N * G, hipMemcpyDeviceToHost, st));
+    if (lut_biases_host) HIP_TRY(hipMemcpyAsync(lut_biases_host, ws->lut_biases, sizeof(float) * N * G, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_workspace_write(tmac_hip_workspace* ws, const int8_t* qlut_host, const float* lut_scales_host,
+                                            const float* lut_biases_host, int K, int N, int act_group_size, void* stream) {
+    int32_t rc = check_lut_shape(ws, K, N, act_group_size);
+    if (rc) return rc;
+    if (!qlut_host || !lut_scales_host || !lut_biases_host) return fail(TMAC_HIP_E_ARG, "null LUT pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t G = (size_t)K / act_group_size;
+    ws->K = K; ws->N = N; ws->ags = act_group_size; ws->qdev_u4_per_row = qdev_u4_for_K(K);
+    HIP_TRY(hipMemcpyAsync(ws->qlut_ref, qlut_host, (size_t)N * (K / 4) * 16, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ws->lut_scales, lut_scales_host, sizeof(float) * N * G, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ws->lut_biases, lut_biases_host, sizeof(float) * N * G, hipMemcpyHostToDevice, st));
+    hipError_t e = launch_qlut_ref_to_dev(ws->qlut_ref, ws->qlut_dev, K, N, ws->qdev_u4_per_row, st);
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "qlut_ref_to_dev launch: %s", hipGetErrorString(e));
+    return TMAC_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// qgemm
+// ---------------------------------------------------------------------------------------------
+static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* ws, void* C_dev, tmac_dtype_t out_dtype,
+                          int N, int32_t* dump, hipStream_t st) {
+    if (!w || !ws || !C_dev) return fail(TMAC_HIP_E_ARG, "null argument");
+    if (ws->K != w->s.K || ws->ags != w->s.ags)
+        return fail(TMAC_HIP_E_ARG, "workspace LUT (K=%d, ags=%d) does not match the weights (K=%d, ags=%d)", ws->K, ws->ags, w->s.K, w->s.ags);
+    if (N <= 0 || N > ws->N) return fail(TMAC_HIP_E_ARG, "N=%d but the workspace LUT holds %d rows", N, ws->N);
+    Variant v = (Variant)g_variant;
+    if (v == V_AUTO) v = w->lo_ok ? V_LO_MQSAD : V_REF_LAYOUT;
+    if ((v == V_LO_MQSAD || v == V_LO_SDWA) && !w->lo_ok) v = V_REF_LAYOUT;
+    GemvArgs a;
+    a.s = w->s; a.N = N; a.qlut_dev = ws->qlut_dev; a.qlut_ref = ws->qlut_ref;
+    a.lut_scales = ws->lut_scales; a.lut_biases = ws->lut_biases; a.C = C_dev; a.out_dtype = (Dtype)out_dtype;
+    a.ps_dump = dump;
+    if (v == V_REF_LAYOUT) {
+        if (!w->A_ref) return fail(TMAC_HIP_E_NOMATCH, "reference-layout blobs were not kept for these weights (register them with variant 3 selected)");
+        a.W = w->A_ref; a.SC = w->S_ref; a.sc_dtype = w->ref_dtype;
+    } else {
+        a.W = w->W; a.SC = w->SC; a.sc_dtype = w->sc_dtype;
+    }
+    hipError_t e = launch_gemv(a, v, st);
+    if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no GEMV kernel for this configuration");
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "gemv launch: %s", hipGetErrorString(e));
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_qgemm_dev(const tmac_hip_weights* w, const tmac_hip_workspace* ws, void* C_dev,
+                                      tmac_dtype_t out_dtype, int N, void* stream) {
+    return qgemm_impl(w, ws, C_dev, out_dtype, N, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const tmac_hip_workspace* ws_c, int32_t* PS_host,
+                                               int N, void* stream) {
+    if (!w || !ws_c || !PS_host) return fail(TMAC_HIP_E_ARG, "null argument");
+    auto* ws = const_cast<tmac_hip_workspace*>(ws_c);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t G = (w->s.m_groups >= 1 && w->s.ags == w->s.K) ? 1 : (size_t)w->s.ngroups();
+    const size_t elems = (size_t)N * w->s.M() * G;
+    if (ws->dump_elems < elems) {
+        if (ws->dump) (void)hipFree(ws->dump);
+        HIP_TRY(hipMalloc((void**)&ws->dump, elems * sizeof(int32_t)));
+        ws->dump_elems = elems;
+    }
+    HIP_TRY(hipMemsetAsync(ws->dump, 0x7f, elems * sizeof(int32_t), st));
+    void* Ctmp = nullptr;
+    HIP_TRY(hipMalloc(&Ctmp, sizeof(float) * (size_t)N * w->s.Mw));
+    int32_t rc = qgemm_impl(w, ws, Ctmp, TMAC_F32, N, ws->dump, st);
+    if (rc == TMAC_HIP_OK) {
+        hipError_t e = hipMemcpyAsync(PS_host, ws->dump, elems * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(TMAC_HIP_E_RUNTIME, "partial-sum readback: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(Ctmp);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// (1) reference-named host-pointer entry points
+// ---------------------------------------------------------------------------------------------
+struct TileKey {
+    const void* A; int bm, K, bits;
+    bool operator<(const TileKey& o) const {
+        if (A != o.A) return A < o.A;
+        if (bm != o.bm) return bm < o.bm;
+        if (K != o.K) return K < o.K;
+        return bits < o.bits;
+    }
+};
+static std::map<TileKey, tmac_hip_weights*> g_tiles;
+static tmac_hip_workspace* g_ws = nullptr;
+static void* g_hostC = nullptr;  // device staging for C / B
+static size_t g_hostC_bytes = 0;
+
+static int32_t host_ws(int K, int N) {
+    if (g_ws && g_ws->maxK >= K && g_ws->maxN >= N) return TMAC_HIP_OK;
+    if (g_ws) tmac_hip_workspace_free(g_ws);
+    g_ws = nullptr;
+    return tmac_hip_workspace_create(&g_ws, K, N);
+}
+static int32_t host_stage(size_t bytes) {
+    if (g_hostC_bytes >= bytes) return TMAC_HIP_OK;
+    if (g_hostC) (void)hipFree(g_hostC);
+    g_hostC = nullptr; g_hostC_bytes = 0;
+    HIP_TRY(hipMalloc(&g_hostC, bytes));
+    g_hostC_bytes = bytes;
+    return TMAC_HIP_OK;
+}
+
+// first kcfg entry whose (k, n, b) match and, when bm_filter > 0, whose bm matches
+static bool find_cfg(int k, int n, int b, int bm_filter, int m_filter, tmac_kcfg* out) {
+    for (auto& kv : g_kcfg) {
+        int t, m, kk, nn, bb;
+        if (sscanf(kv.first.c_str(), "qgemm_lut_t%d_int8_m%d_k%d_n%d_b%d", &t, &m, &kk, &nn, &bb) != 5) continue;
+        if (kk != k || nn != n || bb != b) continue;
+        if (bm_filter > 0 && kv.second.bm != bm_filter) continue;
+        if (m_filter > 0 && m != m_filter) continue;
+        *out = kv.second;
+        return true;
+    }
+    return false;
+}
+
+extern "C" int32_t tmac_hip_cache_clear(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto& kv : g_tiles) tmac_hip_free_weights(kv.second);
+    g_tiles.clear();
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t preprocessor_int8(int m, int k, int n, int b, void* B, void* LUT_Scales, void* LUT_Biases, void* QLUT) {
+    if (!B || !LUT_Scales || !LUT_Biases || !QLUT) return fail(TMAC_HIP_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    tmac_kcfg cfg;
+    // `m` is only a dispatch key in the reference too (qgemm.py:518-519)
+    if (!find_cfg(k, n, b, 0, m, &cfg) && !find_cfg(k, n, b, 0, 0, &cfg))
+        return fail(TMAC_HIP_E_NOMATCH, "preprocessor_int8: no kcfg for m=%d k=%d n=%d b=%d", m, k, n, b);
+    int32_t rc = ensure_device();
+    if (rc) return rc;
+    if ((rc = host_ws(k, n))) return rc;
+    if ((rc = host_stage(sizeof(float) * (size_t)n * k))) return rc;
+    const int ags = cfg.act_group_size;
+    HIP_TRY(hipMemcpy(g_hostC, B, sizeof(float) * (size_t)n * k, hipMemcpyHostToDevice));
+    if ((rc = tmac_hip_preprocessor_dev(g_ws, g_hostC, TMAC_F32, k, n, ags, nullptr))) return rc;
+    return tmac_hip_workspace_read(g_ws, (int8_t*)QLUT, (float*)LUT_Scales, (float*)LUT_Biases, k, n, ags, nullptr);
+}
+
+extern "C" int32_t qgemm_lut_int8(int m, int k, int n, int b, void* A, void* LUT, void* Scales, void* LUT_Scales,
+                                  void* LUT_Biases, void* C) {
+    if (!A || !LUT || !Scales || !LUT_Scales || !LUT_Biases || !C) return fail(TMAC_HIP_E_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    tmac_kcfg cfg;
+    if (!find_cfg(k, n, b, m, 0, &cfg)) return fail(TMAC_HIP_E_NOMATCH, "qgemm_lut_int8: no kcfg with bm=%d k=%d n=%d b=%d", m, k, n, b);
+    int32_t rc = ensure_device();
+    if (rc) return rc;
+    const int Mw_tile = m / b;
+    TileKey key{A, m, k, b};
+    tmac_hip_weights* w = nullptr;
+    auto it = g_tiles.find(key);
+    if (it == g_tiles.end()) {
+        tmac_kcfg tc = cfg;
+        if (tc.m_groups >= 1) tc.m_groups = 1;  // a tile sees one unified scale
+        if ((rc = register_impl(&w, A, Scales, false, Mw_tile, k, b, &tc, TMAC_F32, TMAC_F32, nullptr))) return rc;
+        g_tiles[key] = w;
+    } else {
+        w = it->second;
+    }
+    if ((rc = host_ws(k, n))) return rc;
+    if ((rc = tmac_hip_workspace_write(g_ws, (const int8_t*)LUT, (const float*)LUT_Scales, (const float*)LUT_Biases, k, n,
+                                       cfg.act_group_size, nullptr)))
+        return rc;
+    if ((rc = host_stage(sizeof(float) * (size_t)n * Mw_tile))) return rc;
+    if ((rc = qgemm_impl(w, g_ws, g_hostC, TMAC_F32, n, nullptr, nullptr))) return rc;
+    HIP_TRY(hipMemcpy(C, g_hostC, sizeof(float) * (size_t)n * Mw_tile, hipMemcpyDeviceToHost));
+    return TMAC_HIP_OK;
+}
+
+#define TMAC_DEF_Q(bm, k, n, b)                                                                                   \
+    extern "C" int32_t qgemm_lut_t1_int8_m##bm##_k##k##_n##n##_b##b(void* A, void* LUT, void* Scales, void* LS,   \
+                                                                     void* LB, void* C) {                         \
+        return qgemm_lut_int8(bm, k, n, b, A, LUT, Scales, LS, LB, C);                                            \
+    }
+#define TMAC_DEF_P(m, k, n, b)                                                                                     \
+    extern "C" int32_t preprocessor_t1_int8_m##m##_k##k##_n##n##_b##b(void* B, void* LS, void* LB, void* QLUT) {   \
+        return preprocessor_int8(m, k, n, b, B, LS, LB, QLUT);                                                     \
+    }
+TMAC_DEF_Q(128, 4096, 1, 2) TMAC_DEF_Q(128, 11008, 1, 2)
+TMAC_DEF_P(8192, 4096, 1, 2) TMAC_DEF_P(22016, 4096, 1, 2) TMAC_DEF_P(8192, 11008, 1, 2)
+TMAC_DEF_Q(1024, 4096, 1, 4) TMAC_DEF_Q(256, 4096, 1, 4) TMAC_DEF_Q(256, 11008, 1, 4)
+TMAC_DEF_P(16384, 4096, 1, 4) TMAC_DEF_P(44032, 4096, 1, 4) TMAC_DEF_P(16384, 11008, 1, 4)
+TMAC_DEF_Q(256, 4096, 1, 2) TMAC_DEF_Q(512, 4096, 1, 2) TMAC_DEF_Q(128, 14336, 1, 2)
+TMAC_DEF_P(28672, 4096, 1, 2) TMAC_DEF_P(8192, 14336, 1, 2) TMAC_DEF_P(2048, 4096, 1, 2)
+TMAC_DEF_Q(128, 8640, 1, 2) TMAC_DEF_Q(128, 3200, 1, 2) TMAC_DEF_Q(320, 3200, 1, 2)
+TMAC_DEF_P(6400, 8640, 1, 2) TMAC_DEF_P(17280, 3200, 1, 2) TMAC_DEF_P(6400, 3200, 1, 2)

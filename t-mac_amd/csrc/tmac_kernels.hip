@@ -1,0 +1,587 @@
+// tmac_kernels.hip — gfx950 kernels of the T-MAC LUT mpGEMM hot path.
+//
+//   k_preprocess        (a1-a3)  lut_ctor.cc:38-266 + preprocessor glue (kernels.cc:1223-1231)
+//   k_gemv_lo           (a4-a6)  tbl.cc:323-630 + qgemm_lut glue (kernels.cc:1059-1100)
+//   k_gemv_ref_layout   same contract, straight on the reference blobs (generic/slow path for
+//                       configurations the tiled kernel does not cover; also an on-GPU cross-check)
+//   k_retile_*          (a7)     reference layout -> device layout (pure permutation)
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (the preprocessor's fp32 op order is
+// part of the bit-exact contract; every fused multiply-add below is an explicit __fmaf_rn that
+// mirrors an _mm256_fmadd_ps in the reference).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "tmac_core.h"
+#include "tmac_kernels.h"
+
+namespace tmac {
+
+// ---------------------------------------------------------------------------------------------
+// small helpers
+// ---------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<__half>(__half v) { return __half2float(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ __half from_f32<__half>(float v) { return __float2half_rn(v); }
+
+__device__ __forceinline__ void store_out(void* C, int is_f16, size_t idx, float v) {
+    if (is_f16) reinterpret_cast<__half*>(C)[idx] = __float2half_rn(v);
+    else reinterpret_cast<float*>(C)[idx] = v;
+}
+
+// cvtps_epi32(round_ps(x)) + packs_epi32 + packs_epi16 (lut_ctor.cc:169-177): RNE then saturate
+__device__ __forceinline__ int rne_sat_int8(float x) {
+    const float r = rintf(x);
+    int i = (r >= -2147483648.0f && r < 2147483648.0f) ? (int)r : INT32_MIN;
+    return max(-128, min(127, i));
+}
+
+__device__ __forceinline__ float alpha_of(int p) { return p == 0 ? 0.5f : (p == 1 ? 1.0f : (p == 2 ? 2.0f : 4.0f)); }
+
+// ---------------------------------------------------------------------------------------------
+// instruction self-test: lets the test-suite check the host models in tmac_core.h against the
+// hardware (v_perm_b32 selector semantics, v_mqsad_pk_u16_u8 masking/window order).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_selftest(const uint32_t* in, uint32_t* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = in[4 * i], b = in[4 * i + 1], c = in[4 * i + 2], d = in[4 * i + 3];
+    out[4 * i] = perm_b32(a, b, c);
+    const uint64_t acc = mqsad_acc(a, ((uint64_t)(d & 0x0fff0fffu) << 32) | (b & 0x0fff0fffu));
+    out[4 * i + 1] = (uint32_t)acc;
+    out[4 * i + 2] = (uint32_t)(acc >> 32);
+    out[4 * i + 3] = lookup4<1>(c, a | 0x01010101u, b | 0x01010101u);
+}
+
+// ---------------------------------------------------------------------------------------------
+// (a7) re-tiling: one thread per output dword / scale element
+// ---------------------------------------------------------------------------------------------
+__global__ void k_retile_weights(const uint8_t* __restrict__ A_ref, uint32_t* __restrict__ Wd, Shape s) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.weight_u4() * 4) return;
+    Wd[i] = retile_dword(A_ref, s, i >> 2, (int)(i & 3));
+}
+
+template <typename TI, typename TO>
+__global__ void k_retile_scales(const TI* __restrict__ S_ref, TO* __restrict__ Sd, Shape s) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= s.scale_elems()) return;
+    const int per = s.zero_point ? 2 : 1;
+    size_t x = i;
+    const int which = (int)(x % per); x /= per;
+    const int beta = (int)(x % 4); x /= 4;
+    const int rl = (int)(x % RL); x /= RL;
+    const int sg = (int)(x % s.nsg());
+    const int b = (int)(x / s.nsg());
+    const int o = (b * RL + rl) * 4 + beta;
+    float v = 0.f;
+    if (o < s.Mw) v = to_f32<TI>(S_ref[ref_scale_index(s, o, sg, which)]);
+    Sd[i] = from_f32<TO>(v);
+}
+
+template <typename TI, typename TO>
+__global__ void k_convert(const TI* __restrict__ in, TO* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = from_f32<TO>(to_f32<TI>(in[i]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// (a1-a3) preprocessor.  One workgroup per (activation row n, act group kk); thread <-> table.
+//   outputs: qlut_ref  int8 [N][K/4][16]           reference layout (C-ABI / parity tap), optional
+//            qlut_dev  uint2 [N][qlut_dev_u4*2]    biased half tables in the kernel layout
+//            lut_scales, lut_biases  fp32 [N][K/ags]
+// fp32 op order follows lut_ctor.cc exactly (oracle/tmac_oracle.c is the scalar restatement):
+//   abssum = (|x0|+|x1|)+(|x2|+|x3|); scale = max/127; t = scale ? 1/scale : 0;
+//   L[odd j] = ((x0 +- x1) +- x2) +- x3; L[even j] = -L[15-j]; q = sat8(rne(L*t));
+//   bias = sequential sum over 8-table chunks of ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)), v = L[.][0].
+// ---------------------------------------------------------------------------------------------
+template <typename AT>
+__global__ __launch_bounds__(256) void k_preprocess(const AT* __restrict__ B, int8_t* __restrict__ qlut_ref,
+                                                    uint2* __restrict__ qlut_dev, float* __restrict__ lut_scales,
+                                                    float* __restrict__ lut_biases, int K, int ags,
+                                                    size_t qdev_u4_per_row) {
+    extern __shared__ float smem[];  // [TG] L[.][0] | [TG/8] chunk sums | [blockDim] reduction scratch
+    const int G = K / ags, TG = ags / 4, nchunk = TG / 8;
+    const int kk = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
+    float* v0buf = smem;
+    float* csum = smem + TG;
+    float* red = csum + nchunk;
+    const AT* x = B + (size_t)n * K + (size_t)kk * ags;
+
+    // pass 1: group max of abs-sums (max is exact, so any reduction order gives the reference's value)
+    float mx = 0.0f;
+    for (int tl = tid; tl < TG; tl += nt) {
+        const float x0 = to_f32<AT>(x[4 * tl]), x1 = to_f32<AT>(x[4 * tl + 1]);
+        const float x2 = to_f32<AT>(x[4 * tl + 2]), x3 = to_f32<AT>(x[4 * tl + 3]);
+        const float as = __fadd_rn(__fadd_rn(fabsf(x0), fabsf(x1)), __fadd_rn(fabsf(x2), fabsf(x3)));
+        mx = fmaxf(mx, as);
+    }
+    red[tid] = mx;
+    __syncthreads();
+    for (int st = nt >> 1; st > 0; st >>= 1) {
+        if (tid < st) red[tid] = fmaxf(red[tid], red[tid + st]);
+        __syncthreads();
+    }
+    const float scales = __fdiv_rn(red[0], 127.0f);
+    const float t_scales = (scales != 0.0f) ? __fdiv_rn(1.0f, scales) : 0.0f;
+
+    // pass 2: tables
+    for (int tl = tid; tl < TG; tl += nt) {
+        const float x0 = to_f32<AT>(x[4 * tl]), x1 = to_f32<AT>(x[4 * tl + 1]);
+        const float x2 = to_f32<AT>(x[4 * tl + 2]), x3 = to_f32<AT>(x[4 * tl + 3]);
+        float L[16];
+#pragma unroll
+        for (int g = 1; g < 16; g += 2) {
+            float v = x0;
+            v = (g & 2) ? __fadd_rn(v, x1) : __fsub_rn(v, x1);
+            v = (g & 4) ? __fadd_rn(v, x2) : __fsub_rn(v, x2);
+            v = (g & 8) ? __fadd_rn(v, x3) : __fsub_rn(v, x3);
+            L[g] = v;
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g += 2) L[g] = -L[15 - g];
+        v0buf[tl] = L[0];
+        int q[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) q[g] = rne_sat_int8(__fmul_rn(L[g], t_scales));
+        const int t = kk * TG + tl;
+        if (qlut_ref) {
+            uint32_t w[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                w[c] = (uint32_t)(q[4 * c] & 0xff) | ((uint32_t)(q[4 * c + 1] & 0xff) << 8) |
+                       ((uint32_t)(q[4 * c + 2] & 0xff) << 16) | ((uint32_t)(q[4 * c + 3] & 0xff) << 24);
+            *reinterpret_cast<uint4*>(qlut_ref + ((size_t)n * (K / 4) + t) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        // biased half table; the clamp keeps U in [1,255] even for non-finite garbage-in
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lo |= (uint32_t)(max(q[i], -127) + 128) << (8 * i);
+            hi |= (uint32_t)(max(q[4 + i], -127) + 128) << (8 * i);
+        }
+        const int seg = t / TS, tls = t % TS;
+        qlut_dev[((size_t)n * qdev_u4_per_row + qlut_dev_u4_index(seg, tls >> 1)) * 2 + (tls & 1)] = make_uint2(lo, hi);
+    }
+    __syncthreads();
+    // bias: per-chunk horizontal add in the reference's order (lut_ctor.cc:25-31) ...
+    for (int c = tid; c < nchunk; c += nt) {
+        const float* v = v0buf + 8 * c;
+        const float r0 = __fadd_rn(v[4], v[0]), r1 = __fadd_rn(v[5], v[1]);
+        const float r2 = __fadd_rn(v[6], v[2]), r3 = __fadd_rn(v[7], v[3]);
+        csum[c] = __fadd_rn(__fadd_rn(r0, r2), __fadd_rn(r1, r3));
+    }
+    __syncthreads();
+    // ... then `biases += chunk` sequentially from 0.0f (lut_ctor.cc:122,157)
+    if (tid == 0) {
+        float biases = 0.0f;
+        for (int c = 0; c < nchunk; ++c) biases = __fadd_rn(biases, csum[c]);
+        lut_scales[(size_t)n * G + kk] = scales;
+        lut_biases[(size_t)n * G + kk] = biases;
+    }
+}
+
+// host-provided reference-layout QLUT -> kernel layout (used by the host-pointer C-ABI and tests)
+__global__ void k_qlut_ref_to_dev(const int8_t* __restrict__ qlut_ref, uint2* __restrict__ qlut_dev, int K, int N,
+                                  size_t qdev_u4_per_row) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (t >= K / 4) return;
+    const int8_t* q = qlut_ref + ((size_t)n * (K / 4) + t) * 16;
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lo |= (uint32_t)(max((int)q[i], -127) + 128) << (8 * i);
+        hi |= (uint32_t)(max((int)q[4 + i], -127) + 128) << (8 * i);
+    }
+    const int seg = t / TS, tls = t % TS;
+    qlut_dev[((size_t)n * qdev_u4_per_row + qlut_dev_u4_index(seg, tls >> 1)) * 2 + (tls & 1)] = make_uint2(lo, hi);
+}
+
+// ---------------------------------------------------------------------------------------------
+// (a4-a6) GEMV, tiled "lane owns segment" kernel.
+//
+// Workgroup = 256 threads = 4 waves, owns 16 output rows (RL=4 row quads) over the whole K.
+// lane = rl*16 + kl: row quad rl, segment lane kl; wave w takes segment blocks sb = w, w+4, ...
+// (16 segments = 1024 activations each).  A thread streams, per (row quad, segment):
+//   NJ x 16 B of weights (non-temporal, perfectly coalesced: each wave-instruction reads 1 KiB),
+//   8 x 16 B of half tables (L2/L1-resident, shared by the 4 rl lanes -> 256 B per instruction),
+//   the act group's LUT scale/bias and the quad's weight scales/zeros,
+// does the lookups in registers (tmac_core.h) and keeps fp32 partial outputs per row/plane.
+// Reduction: 16 kl lanes by DPP/shuffle, 4 waves through LDS, one fp32->out store per row.
+// No cross-workgroup traffic, no atomics, deterministic summation order.
+//
+//   SM (scale mode)  0: per-(row, group) scales [+ zero points]     tbl_g4_int8_float_update  (tbl.cc:323-532)
+//                    1: one weight scale, per-group LUT scales       "os=true" flavour (tbl.cc:417-423)
+//                    2: unified scale applied last, int32 aggregation tbl_g4_int8_int32_update (tbl.cc:536-630)
+//                       + qgemm.py:170-174 epilogue
+// ---------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct GemvPtrs {
+    const uint4* W;
+    const uint4* QL;
+    const float* LS;
+    const float* LB;
+    const void* SC;
+    void* C;
+    int32_t* dump;
+    int out_f16;
+};
+
+template <int BITS, int TG, bool ZP, int SM, typename ST>
+struct Frag {
+    uint32_t wd[TS * BITS / 2];
+    uint32_t tb[2 * TS];
+    float ls[TS / TG], lb[TS / TG];
+    float sc[4], zr[4];
+};
+
+template <int BITS, int TG, bool ZP, int SM, typename ST>
+__device__ __forceinline__ void load_frag(Frag<BITS, TG, ZP, SM, ST>& f, const GemvPtrs& p, const Shape& s,
+                                          const uint4* ql, int n, int b, int sb, int rl, int kl) {
+    constexpr int NJ = TS * BITS / 8;
+    const int seg = sb * KL + kl;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p.W + weight_u4_index(s, b, sb, j, rl, kl)));
+        f.wd[4 * j] = v.x; f.wd[4 * j + 1] = v.y; f.wd[4 * j + 2] = v.z; f.wd[4 * j + 3] = v.w;
+    }
+#pragma unroll
+    for (int j8 = 0; j8 < 8; ++j8) {
+        const uint4 v = ql[((size_t)sb * 8 + j8) * KL + kl];
+        f.tb[4 * j8] = v.x; f.tb[4 * j8 + 1] = v.y; f.tb[4 * j8 + 2] = v.z; f.tb[4 * j8 + 3] = v.w;
+    }
+    if (SM != 2) {
+        constexpr int NA = TS / TG;
+        const int G = s.ngroups();
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            f.ls[a] = p.LS[(size_t)n * G + seg * NA + a];
+            f.lb[a] = p.LB[(size_t)n * G + seg * NA + a];
+        }
+    }
+    if (SM == 0) {
+        const int sg = seg * (4 * TS) / s.gs;
+        const ST* sp = reinterpret_cast<const ST*>(p.SC) + dev_scale_index(s, b, sg, rl, 0, 0);
+#pragma unroll
+        for (int beta = 0; beta < 4; ++beta) {
+            f.sc[beta] = to_f32<ST>(sp[beta * (ZP ? 2 : 1)]);
+            if (ZP) f.zr[beta] = to_f32<ST>(sp[beta * 2 + 1]);
+        }
+    }
+}
+
+template <int BITS, int TG, bool ZP, int SM, typename ST, int MODE>
+__device__ __forceinline__ void compute_frag(const Frag<BITS, TG, ZP, SM, ST>& f, const GemvPtrs& p, const Shape& s,
+                                             float one_scale, float (&cacc)[4][BITS], int32_t (&iacc)[BITS][4],
+                                             int n, int rq, int seg) {
+    constexpr int NA = (SM == 2) ? 1 : TS / TG;
+    constexpr int NT = (SM == 2) ? TS : TG;
+    const int G = s.ngroups();
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        SegAcc<BITS, MODE> acc;
+        acc.reset();
+        if (a == 0) accumulate_tables<BITS, 0, NT>(f.wd, f.tb, acc);
+        else accumulate_tables<BITS, (NA > 1 ? NT : 0), NT>(f.wd, f.tb, acc);
+#pragma unroll
+        for (int beta = 0; beta < 4; ++beta) {
+#pragma unroll
+            for (int pl = 0; pl < BITS; ++pl) {
+                const int32_t ps = acc.ps(pl, beta, NT);
+                if (SM == 2) {
+                    iacc[pl][beta] += ps;
+                } else {
+                    if (p.dump) {
+                        const int o = 4 * rq + beta;
+                        if (o < s.Mw)
+                            p.dump[((size_t)n * s.M() + mrow(o, pl, BITS)) * G + seg * NA + a] = ps;
+                    }
+                    // tbl.cc:479-492 (lut_fma) then :501-526 (scale, zero point)
+                    const float v = (pl == 0) ? __fmaf_rn((float)ps, f.ls[a], f.lb[a]) : __fmul_rn((float)ps, f.ls[a]);
+                    const float sc = (SM == 1) ? one_scale : f.sc[beta];
+                    float c = __fmaf_rn(v, sc, cacc[beta][pl]);
+                    if (ZP && pl == 0) c = __fmaf_rn(f.zr[beta], __fmul_rn(2.0f, f.lb[a]), c);
+                    cacc[beta][pl] = c;
+                }
+            }
+        }
+    }
+}
+
+template <int BITS, int TG, bool ZP, int SM, typename ST, int MODE>
+__global__ __launch_bounds__(256) void k_gemv_lo(GemvPtrs p, Shape s) {
+    __shared__ float red_f[NW][RL][4];
+    __shared__ int32_t red_i[NW][RL][4][4];
+    const int b = blockIdx.x, n = blockIdx.y;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, rl = lane >> 4, kl = lane & 15;
+    const int rq = b * RL + rl;
+    const int nsb = s.nsb(), nseg = s.nseg();
+    const uint4* ql = p.QL + (size_t)n * s.qlut_dev_u4();
+    const float one_scale = (SM == 1) ? to_f32<ST>(reinterpret_cast<const ST*>(p.SC)[0]) : 0.f;
+
+    float cacc[4][BITS];
+    int32_t iacc[BITS][4];
+#pragma unroll
+    for (int beta = 0; beta < 4; ++beta)
+#pragma unroll
+        for (int pl = 0; pl < BITS; ++pl) { cacc[beta][pl] = 0.f; iacc[pl][beta] = 0; }
+
+    using F = Frag<BITS, TG, ZP, SM, ST>;
+    F f0, f1;
+    int sb = w;
+    bool v0 = (sb < nsb) && (sb * KL + kl < nseg);
+    if (v0) load_frag(f0, p, s, ql, n, b, sb, rl, kl);
+    // two-deep software pipeline over this wave's segment blocks
+    while (sb < nsb) {
+        const int sb1 = sb + NW;
+        const bool v1 = (sb1 < nsb) && (sb1 * KL + kl < nseg);
+        if (v1) load_frag(f1, p, s, ql, n, b, sb1, rl, kl);
+        if (v0) compute_frag<BITS, TG, ZP, SM, ST, MODE>(f0, p, s, one_scale, cacc, iacc, n, rq, sb * KL + kl);
+        const int sb2 = sb1 + NW;
+        v0 = (sb2 < nsb) && (sb2 * KL + kl < nseg);
+        if (v0) load_frag(f0, p, s, ql, n, b, sb2, rl, kl);
+        if (v1) compute_frag<BITS, TG, ZP, SM, ST, MODE>(f1, p, s, one_scale, cacc, iacc, n, rq, sb1 * KL + kl);
+        sb = sb2;
+    }
+
+    if (SM != 2) {
+        // bit-plane combine (kernels.cc:1068), then sum the partials of the 16 segment lanes and 4 waves
+        float part[4];
+#pragma unroll
+        for (int beta = 0; beta < 4; ++beta) {
+            float acc = __fmul_rn(cacc[beta][0], 0.5f);
+#pragma unroll
+            for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(cacc[beta][pl], alpha_of(pl)));
+#pragma unroll
+            for (int m = 1; m < KL; m <<= 1) acc = __fadd_rn(acc, __shfl_xor(acc, m, 64));
+            part[beta] = acc;
+        }
+        if (kl == 0) {
+#pragma unroll
+            for (int beta = 0; beta < 4; ++beta) red_f[w][rl][beta] = part[beta];
+        }
+        __syncthreads();
+        if (tid < RL * 4) {
+            const int r = tid >> 2, beta = tid & 3, o = (b * RL + r) * 4 + beta;
+            float acc = red_f[0][r][beta];
+#pragma unroll
+            for (int ww = 1; ww < NW; ++ww) acc = __fadd_rn(acc, red_f[ww][r][beta]);
+            if (o < s.Mw) store_out(p.C, p.out_f16, (size_t)n * s.Mw + o, acc);
+        }
+    } else {
+        // exact integer reduction, then qgemm.py:170-174 / :192-206
+#pragma unroll
+        for (int pl = 0; pl < BITS; ++pl)
+#pragma unroll
+            for (int beta = 0; beta < 4; ++beta) {
+                int32_t v = iacc[pl][beta];
+#pragma unroll
+                for (int m = 1; m < KL; m <<= 1) v += __shfl_xor(v, m, 64);
+                if (kl == 0) red_i[w][rl][pl][beta] = v;
+            }
+        __syncthreads();
+        if (tid < RL * 4) {
+            const int r = tid >> 2, beta = tid & 3, o = (b * RL + r) * 4 + beta;
+            if (o < s.Mw) {
+                float acc = 0.f;
+#pragma unroll
+                for (int pl = 0; pl < BITS; ++pl) {
+                    int32_t cb = 0;
+#pragma unroll
+                    for (int ww = 0; ww < NW; ++ww) cb += red_i[ww][r][pl][beta];
+                    if (p.dump) p.dump[(size_t)n * s.M() + mrow(o, pl, BITS)] = cb;
+                    const float t = __fmul_rn((float)cb, alpha_of(pl));
+                    acc = (pl == 0) ? t : __fadd_rn(acc, t);
+                }
+                const float v = __fadd_rn(__fmul_rn(acc, p.LS[n]), __fmul_rn(p.LB[n], 0.5f));
+                const float sc = to_f32<ST>(reinterpret_cast<const ST*>(p.SC)[o / (s.Mw / s.m_groups)]);
+                store_out(p.C, p.out_f16, (size_t)n * s.Mw + o, __fmul_rn(v, sc));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic kernel on the REFERENCE blobs: one thread per (activation row, output row), every float
+// op in the reference's order (same loop nest as oracle_qgemm_float / oracle_qgemm_scale_final), so
+// its fp32 output is bit-identical to the x86 reference.  Uncoalesced and slow by construction; it
+// serves configurations outside the tiled kernel's envelope and cross-checks it on the GPU.
+// ---------------------------------------------------------------------------------------------
+template <typename ST>
+__global__ void k_gemv_ref_layout(const uint8_t* __restrict__ A, const int8_t* __restrict__ qlut, const ST* __restrict__ SC,
+                                  const float* __restrict__ LS, const float* __restrict__ LB, void* C, int out_f16,
+                                  int32_t* dump, Shape s, int one_scale_per_group) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
+    if (o >= s.Mw) return;
+    const int bits = s.bits, G = s.ngroups(), TGr = s.ags / 4;
+    const int8_t* q = qlut + (size_t)n * (s.K / 4) * 16;
+    float cb[4];
+    if (s.m_groups >= 1 && s.ags == s.K && !one_scale_per_group) {
+        float acc = 0.f;
+        for (int pl = 0; pl < bits; ++pl) {
+            const int r = mrow(o, pl, bits);
+            int32_t sum = 0;
+            for (int t = 0; t < s.K / 4; ++t) sum += q[(size_t)t * 16 + ref_nibble(A, s.K, s.bm, s.kfactor, r, t)];
+            if (dump) dump[(size_t)n * s.M() + r] = sum;
+            const float tt = __fmul_rn((float)sum, alpha_of(pl));
+            acc = (pl == 0) ? tt : __fadd_rn(acc, tt);
+        }
+        const float v = __fadd_rn(__fmul_rn(acc, LS[n]), __fmul_rn(LB[n], 0.5f));
+        store_out(C, out_f16, (size_t)n * s.Mw + o, __fmul_rn(v, to_f32<ST>(SC[o / (s.Mw / s.m_groups)])));
+        return;
+    }
+    const int ActK = TGr < s.kfactor ? TGr : s.kfactor;
+    const int gpc = s.kfactor / ActK, ncalls = (s.K / 4) / s.kfactor;
+    const float* ls = LS + (size_t)n * G;
+    const float* lb = LB + (size_t)n * G;
+    for (int pl = 0; pl < bits; ++pl) {
+        const int r = mrow(o, pl, bits);
+        float c = 0.f;
+        for (int ko = 0; ko < ncalls; ++ko) {
+            float vec_c = 0.f, partial_sum = -0.0f;
+            for (int j = 0; j < gpc; ++j) {
+                const int kk = ko * gpc + j;
+                int32_t sum = 0;
+                for (int tl = 0; tl < ActK; ++tl) {
+                    const int t = ko * s.kfactor + j * ActK + tl;
+                    sum += q[(size_t)t * 16 + ref_nibble(A, s.K, s.bm, s.kfactor, r, t)];
+                }
+                if (dump && ActK == TGr) dump[((size_t)n * s.M() + r) * G + kk] = sum;
+                partial_sum = __fadd_rn(partial_sum, lb[kk]);
+                const float f = (pl == 0) ? __fmaf_rn((float)sum, ls[kk], lb[kk]) : __fmul_rn((float)sum, ls[kk]);
+                vec_c = (j == 0) ? f : __fadd_rn(vec_c, f);
+            }
+            if (one_scale_per_group) {
+                c = __fmaf_rn(vec_c, to_f32<ST>(SC[0]), c);
+            } else {
+                const int sg = (ko * 4 * s.kfactor) / s.gs;
+                c = __fmaf_rn(vec_c, to_f32<ST>(SC[ref_scale_index(s, o, sg, 0)]), c);
+                if (s.zero_point && pl == 0)
+                    c = __fmaf_rn(to_f32<ST>(SC[ref_scale_index(s, o, sg, 1)]), __fmul_rn(partial_sum, 2.0f), c);
+            }
+        }
+        cb[pl] = c;
+    }
+    float acc = __fmul_rn(cb[0], 0.5f);
+    for (int pl = 1; pl < bits; ++pl) acc = __fadd_rn(acc, __fmul_rn(cb[pl], alpha_of(pl)));
+    store_out(C, out_f16, (size_t)n * s.Mw + o, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+hipError_t launch_selftest(const uint32_t* in, uint32_t* out, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_retile_weights(const uint8_t* A_ref, void* Wd, const Shape& s, hipStream_t st) {
+    const size_t n = s.weight_u4() * 4;
+    hipLaunchKernelGGL(k_retile_weights, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A_ref, (uint32_t*)Wd, s);
+    return hipGetLastError();
+}
+
+hipError_t launch_retile_scales(const void* S_ref, Dtype in_dt, void* Sd, Dtype out_dt, const Shape& s, hipStream_t st) {
+    if (s.m_groups >= 1) {  // unified scale(s): plain dtype conversion of [m_groups]
+        const size_t n = (size_t)s.m_groups;
+        dim3 g((unsigned)((n + 255) / 256)), b(256);
+        if (in_dt == F32 && out_dt == F32) hipLaunchKernelGGL((k_convert<float, float>), g, b, 0, st, (const float*)S_ref, (float*)Sd, n);
+        else if (in_dt == F32) hipLaunchKernelGGL((k_convert<float, __half>), g, b, 0, st, (const float*)S_ref, (__half*)Sd, n);
+        else if (out_dt == F32) hipLaunchKernelGGL((k_convert<__half, float>), g, b, 0, st, (const __half*)S_ref, (float*)Sd, n);
+        else hipLaunchKernelGGL((k_convert<__half, __half>), g, b, 0, st, (const __half*)S_ref, (__half*)Sd, n);
+        return hipGetLastError();
+    }
+    const size_t n = s.scale_elems();
+    dim3 g((unsigned)((n + 255) / 256)), b(256);
+    if (in_dt == F32 && out_dt == F32) hipLaunchKernelGGL((k_retile_scales<float, float>), g, b, 0, st, (const float*)S_ref, (float*)Sd, s);
+    else if (in_dt == F32) hipLaunchKernelGGL((k_retile_scales<float, __half>), g, b, 0, st, (const float*)S_ref, (__half*)Sd, s);
+    else if (out_dt == F32) hipLaunchKernelGGL((k_retile_scales<__half, float>), g, b, 0, st, (const __half*)S_ref, (float*)Sd, s);
+    else hipLaunchKernelGGL((k_retile_scales<__half, __half>), g, b, 0, st, (const __half*)S_ref, (__half*)Sd, s);
+    return hipGetLastError();
+}
+
+hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void* qlut_dev, float* lut_scales,
+                             float* lut_biases, int K, int N, int ags, size_t qdev_u4_per_row, hipStream_t st) {
+    const int TG = ags / 4;
+    int nt = 64;
+    while (nt < TG && nt < 256) nt <<= 1;
+    const size_t shmem = sizeof(float) * (size_t)(TG + TG / 8 + nt);
+    dim3 g(K / ags, N), b(nt);
+    if (act_dt == F32)
+        hipLaunchKernelGGL((k_preprocess<float>), g, b, shmem, st, (const float*)B, qlut_ref, (uint2*)qlut_dev, lut_scales, lut_biases, K, ags, qdev_u4_per_row);
+    else
+        hipLaunchKernelGGL((k_preprocess<__half>), g, b, shmem, st, (const __half*)B, qlut_ref, (uint2*)qlut_dev, lut_scales, lut_biases, K, ags, qdev_u4_per_row);
+    return hipGetLastError();
+}
+
+hipError_t launch_qlut_ref_to_dev(const int8_t* qlut_ref, void* qlut_dev, int K, int N, size_t qdev_u4_per_row, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlut_ref_to_dev, dim3((K / 4 + 255) / 256, N), dim3(256), 0, st, qlut_ref, (uint2*)qlut_dev, K, N, qdev_u4_per_row);
+    return hipGetLastError();
+}
+
+bool gemv_lo_supported(const Shape& s) {
+    if (s.bits < 1 || s.bits > 4) return false;
+    if (s.K % (4 * TS) != 0) return false;
+    if (s.m_groups >= 1 && s.ags == s.K) return s.Mw % s.m_groups == 0;          // SM 2
+    if (s.ags != 32 && s.ags != 64) return false;
+    if (s.m_groups >= 1) return !s.zero_point;                                       // SM 1
+    return s.gs >= 4 * TS && s.gs % (4 * TS) == 0 && s.K % s.gs == 0;                // SM 0
+}
+
+template <int BITS, int TG, bool ZP, int SM, typename ST, int MODE>
+static hipError_t launch_lo_t(const GemvArgs& a, hipStream_t st) {
+    GemvPtrs p;
+    p.W = (const uint4*)a.W; p.QL = (const uint4*)a.qlut_dev; p.LS = a.lut_scales; p.LB = a.lut_biases;
+    p.SC = a.SC; p.C = a.C; p.dump = a.ps_dump; p.out_f16 = a.out_dtype == F16;
+    hipLaunchKernelGGL((k_gemv_lo<BITS, TG, ZP, SM, ST, MODE>), dim3(a.s.nb(), a.N), dim3(256), 0, st, p, a.s);
+    return hipGetLastError();
+}
+
+template <int BITS, typename ST, int MODE>
+static hipError_t launch_lo_b(const GemvArgs& a, hipStream_t st) {
+    const Shape& s = a.s;
+    if (s.m_groups >= 1 && s.ags == s.K) return launch_lo_t<BITS, 16, false, 2, ST, MODE>(a, st);
+    if (s.m_groups >= 1) return s.ags == 64 ? launch_lo_t<BITS, 16, false, 1, ST, MODE>(a, st)
+                                            : launch_lo_t<BITS, 8, false, 1, ST, MODE>(a, st);
+    if (s.ags == 64) return s.zero_point ? launch_lo_t<BITS, 16, true, 0, ST, MODE>(a, st)
+                                         : launch_lo_t<BITS, 16, false, 0, ST, MODE>(a, st);
+    return s.zero_point ? launch_lo_t<BITS, 8, true, 0, ST, MODE>(a, st)
+                        : launch_lo_t<BITS, 8, false, 0, ST, MODE>(a, st);
+}
+
+template <typename ST, int MODE>
+static hipError_t launch_lo_st(const GemvArgs& a, hipStream_t st) {
+    switch (a.s.bits) {
+        case 1: return launch_lo_b<1, ST, MODE>(a, st);
+        case 2: return launch_lo_b<2, ST, MODE>(a, st);
+        case 3: return launch_lo_b<3, ST, MODE>(a, st);
+        case 4: return launch_lo_b<4, ST, MODE>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_gemv(const GemvArgs& a, Variant v, hipStream_t st) {
+    if (v == V_REF_LAYOUT) {
+        const Shape& s = a.s;
+        const int one_scale_per_group = (s.m_groups >= 1 && s.ags != s.K) ? 1 : 0;
+        dim3 g((s.Mw + 63) / 64, a.N), b(64);
+        if (a.sc_dtype == F32)
+            hipLaunchKernelGGL((k_gemv_ref_layout<float>), g, b, 0, st, (const uint8_t*)a.W, a.qlut_ref, (const float*)a.SC,
+                               a.lut_scales, a.lut_biases, a.C, a.out_dtype == F16, a.ps_dump, s, one_scale_per_group);
+        else
+            hipLaunchKernelGGL((k_gemv_ref_layout<__half>), g, b, 0, st, (const uint8_t*)a.W, a.qlut_ref, (const __half*)a.SC,
+                               a.lut_scales, a.lut_biases, a.C, a.out_dtype == F16, a.ps_dump, s, one_scale_per_group);
+        return hipGetLastError();
+    }
+    if (!gemv_lo_supported(a.s)) return hipErrorInvalidValue;
+    const bool sdwa = (v == V_LO_SDWA);
+    if (a.sc_dtype == F32) return sdwa ? launch_lo_st<float, 1>(a, st) : launch_lo_st<float, 0>(a, st);
+    return sdwa ? launch_lo_st<__half, 1>(a, st) : launch_lo_st<__half, 0>(a, st);
+}
+
+}  // namespace tmac

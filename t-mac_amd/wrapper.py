@@ -1,0 +1,197 @@
+"""Python mirror of ``TMAC::TMACGeMMWrapper`` (include/t-mac/tmac_gemm_wrapper.h:79-347) on the GPU.
+
+Same method names and argument meaning as the reference's C++ wrapper — ``set_workspace``,
+``get_kcfg``, ``llama_cpp_init`` (preprocessor), ``llama_cpp_compute`` (qgemm_lut) — with device
+pointers instead of host pointers, and weights registered once (:class:`Weights`) instead of passed
+as raw tile pointers on every call.  All compute goes through libtmac_hip.so's C-ABI.
+
+PyTorch is used only as the owner of device memory / streams when the caller passes tensors; raw
+integer device pointers work as well.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import binding as B
+from .binding import KCfg, F16, F32, check
+
+
+def _ptr(x) -> int:
+    """device pointer of a torch tensor / raw int; host pointer of a numpy array"""
+    if x is None:
+        return 0
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    return x.data_ptr()
+
+
+def _stream(stream=None) -> int:
+    if stream is not None:
+        return stream if isinstance(stream, int) else stream.cuda_stream
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.current_stream().cuda_stream
+    except Exception:
+        pass
+    return 0
+
+
+def _dtype_code(t) -> int:
+    import torch
+    if t.dtype == torch.float16:
+        return F16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+class Weights:
+    """One weight matrix resident on the GPU (tmac_hip_register_weights)."""
+
+    def __init__(self, A_ref, scales_ref, Mw: int, K: int, bits: int, cfg: KCfg, scales_dtype=F32, dev_dtype=F32,
+                 on_device: bool = False, stream=None):
+        self.Mw, self.K, self.bits, self.cfg = Mw, K, bits, cfg
+        self._h = C.c_void_p()
+        L = B.lib()
+        fn = L.tmac_hip_register_weights_dev if on_device else L.tmac_hip_register_weights
+        if not on_device:
+            A_ref = np.ascontiguousarray(A_ref, np.uint8)
+            scales_ref = np.ascontiguousarray(scales_ref, np.float16 if scales_dtype == F16 else np.float32)
+        self._keep = (A_ref, scales_ref)
+        check(fn(C.byref(self._h), _ptr(A_ref), _ptr(scales_ref), Mw, K, bits, C.byref(cfg), scales_dtype, dev_dtype,
+                 _stream(stream)))
+        self._keep = None
+
+    @property
+    def handle(self):
+        return self._h
+
+    def algorithmic_bytes(self) -> int:
+        return int(B.lib().tmac_hip_weights_bytes(self._h))
+
+    def free(self):
+        if self._h:
+            B.lib().tmac_hip_free_weights(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Workspace:
+    """QLUT / LUT_Scales / LUT_Biases on the device (TMACGeMMWrapper::set_workspace)."""
+
+    def __init__(self, maxK: int, maxN: int = 1):
+        self.maxK, self.maxN = maxK, maxN
+        self._h = C.c_void_p()
+        check(B.lib().tmac_hip_workspace_create(C.byref(self._h), maxK, maxN))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def ptrs(self):
+        q, ls, lb, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_size_t()
+        check(B.lib().tmac_hip_workspace_ptrs(self._h, C.byref(q), C.byref(n), C.byref(ls), C.byref(lb)))
+        return q.value, n.value, ls.value, lb.value
+
+    def read(self, K: int, N: int, act_group_size: int, stream=None):
+        q = np.zeros((N, K // 4, 16), np.int8)
+        ls = np.zeros((N, K // act_group_size), np.float32)
+        lb = np.zeros((N, K // act_group_size), np.float32)
+        check(B.lib().tmac_hip_workspace_read(self._h, q.ctypes.data, ls.ctypes.data, lb.ctypes.data, K, N,
+                                              act_group_size, _stream(stream)))
+        return q, ls, lb
+
+    def write(self, qlut: np.ndarray, lut_scales: np.ndarray, lut_biases: np.ndarray, act_group_size: int, stream=None):
+        q = np.ascontiguousarray(qlut, np.int8)
+        ls = np.ascontiguousarray(lut_scales, np.float32)
+        lb = np.ascontiguousarray(lut_biases, np.float32)
+        N, T, _ = q.shape
+        check(B.lib().tmac_hip_workspace_write(self._h, q.ctypes.data, ls.ctypes.data, lb.ctypes.data, T * 4, N,
+                                               act_group_size, _stream(stream)))
+
+    def free(self):
+        if self._h:
+            B.lib().tmac_hip_workspace_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class TMACGeMMWrapper:
+    """Mirror of the reference wrapper's no-TVM branch (tmac_gemm_wrapper.h:170-228).
+
+    >>> wr = TMACGeMMWrapper(act_group_size=64, kcfg_file="kcfg.ini")
+    >>> wr.set_workspace(maxK=11008, maxN=1)
+    >>> w = wr.register_weights(A_ref, scales_ref, M=4096, K=11008, bits=2)
+    >>> wr.llama_cpp_init(B_dev, M=4096, K=11008, N=1, bits=2)        # preprocessor -> workspace
+    >>> wr.llama_cpp_compute(w, C_dev, N=1)                           # qgemm_lut
+    """
+
+    def __init__(self, n_threads: int = 1, act_group_size: int = 32, kcfg_file: str = "", library_file: str = ""):
+        self._act_group_size = act_group_size
+        self._ws: Optional[Workspace] = None
+        L = B.lib()
+        if kcfg_file:
+            check(L.tmac_hip_load_kcfg(kcfg_file.encode()))
+
+    def set_num_threads(self, n_threads: int) -> None:  # no-op without a TVM threadpool, as in the reference
+        pass
+
+    def set_workspace(self, maxK: int, maxN: int) -> None:
+        self._ws = Workspace(maxK, maxN)
+
+    @property
+    def workspace(self) -> Workspace:
+        if self._ws is None:
+            raise RuntimeError("set_workspace() must be called first (tmac_gemm_wrapper.h:257-270)")
+        return self._ws
+
+    def get_kcfg(self, M: int, K: int, N: int, bits: int) -> KCfg:
+        cfg = KCfg()
+        check(B.lib().tmac_hip_get_kcfg(M, K, N, bits, C.byref(cfg)))
+        return cfg
+
+    def set_kcfg(self, M: int, K: int, N: int, bits: int, cfg: KCfg) -> None:
+        check(B.lib().tmac_hip_set_kcfg(M, K, N, bits, C.byref(cfg)))
+
+    def register_weights(self, A_ref, scales_ref, M: int, K: int, bits: int, cfg: Optional[KCfg] = None,
+                         scales_dtype=F32, dev_dtype=F32, on_device=False) -> Weights:
+        cfg = cfg or self.get_kcfg(M, K, 1, bits)
+        return Weights(A_ref, scales_ref, M, K, bits, cfg, scales_dtype, dev_dtype, on_device)
+
+    def llama_cpp_init(self, B_dev, M: int, K: int, N: int, bits: int, act_group_size: Optional[int] = None,
+                       act_dtype: Optional[int] = None, stream=None) -> None:
+        """preprocessor_int8(M*bits, K, N, bits, B, lut_scales, lut_biases, qlut) on the device."""
+        ags = act_group_size or self._act_group_size
+        if act_dtype is None:
+            act_dtype = _dtype_code(B_dev)
+        check(B.lib().tmac_hip_preprocessor_dev(self.workspace.handle, _ptr(B_dev), act_dtype, K, N, ags, _stream(stream)))
+
+    def llama_cpp_compute(self, weights: Weights, C_dev, N: int = 1, out_dtype: Optional[int] = None, stream=None) -> None:
+        """qgemm_lut_int8 over ALL M-tiles of the registered matrix in one launch."""
+        if out_dtype is None:
+            out_dtype = _dtype_code(C_dev)
+        check(B.lib().tmac_hip_qgemm_dev(weights.handle, self.workspace.handle, _ptr(C_dev), out_dtype, N, _stream(stream)))
+
+    def partial_sums(self, weights: Weights, N: int = 1, stream=None) -> np.ndarray:
+        """Parity tap: int32 [N][M][K/ags] (or [N][M] for the unified-scale path), M-space row order."""
+        s_final = weights.cfg.m_groups >= 1 and weights.cfg.act_group_size == weights.K
+        G = 1 if s_final else weights.K // weights.cfg.act_group_size
+        out = np.zeros((N, weights.Mw * weights.bits, G), np.int32)
+        check(B.lib().tmac_hip_qgemm_partial_sums(weights.handle, self.workspace.handle, out.ctypes.data, N, _stream(stream)))
+        return out

@@ -1,0 +1,96 @@
+"""Host-side logic that needs no GPU: the C-ABI library loads and exports every declared symbol, fails
+loudly without a device, parses kcfg.ini like the reference, and the Python weight transform reproduces the
+reference layout."""
+import ctypes as C
+import glob
+import os
+import re
+
+import numpy as np
+import pytest
+
+import tmac_amd
+from tmac_amd import binding as B
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "tmac_hip.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b((?:tmac_hip_|qgemm_lut_int8|preprocessor_int8)\w*)\s*\(", body))
+    for m in re.finditer(r"TMAC_DECL_Q\((\d+), (\d+), (\d+), (\d+)\)", body):
+        names.add("qgemm_lut_t1_int8_m%s_k%s_n%s_b%s" % m.groups())
+    for m in re.finditer(r"TMAC_DECL_P\((\d+), (\d+), (\d+), (\d+)\)", body):
+        names.add("preprocessor_t1_int8_m%s_k%s_n%s_b%s" % m.groups())
+    return sorted(n for n in names if not n.endswith("_t"))
+
+
+def test_library_exports_every_declared_symbol():
+    L = C.CDLL(B.lib_path())
+    syms = declared_symbols()
+    assert len(syms) > 40
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+
+
+def test_no_device_is_a_loud_failure():
+    L = tmac_amd.lib()
+    if L.tmac_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    ws = C.c_void_p()
+    assert L.tmac_hip_workspace_create(C.byref(ws), 4096, 1) == -2
+    assert b"no CPU path" in L.tmac_hip_last_error()
+    b = np.zeros(4096, np.float32); q = np.zeros((1024, 16), np.int8); s = np.zeros(64, np.float32)
+    cfg = B.KCfg.make(4096, 4096, 2, 128)
+    assert L.tmac_hip_set_kcfg(4096, 4096, 1, 2, C.byref(cfg)) == 0
+    assert L.preprocessor_int8(8192, 4096, 1, 2, b.ctypes.data, s.ctypes.data, s.ctypes.data, q.ctypes.data) == -2
+
+
+KCFG = """
+[qgemm_lut_t1_int8_m8192_k4096_n1_b2]
+bm = 128
+simd_n_in = 16
+simd_n_out = 8
+kfactor = 16
+group_size = 128
+lut_scales_size = 64
+scales_size = 262144
+n_tile_num = 64
+
+[qgemm_lut_t4_int8_m6400_k8640_n1_b2]
+bm = 128
+simd_n_in = 16
+simd_n_out = 8
+kfactor = 16
+group_size = 128
+lut_scales_size = 1
+scales_size = 1
+n_tile_num = 50
+"""
+
+
+def test_kcfg_ini_lookup(tmp_path):
+    """same file format and section naming as deploy/compile.py:153-165 / tmac_gemm_wrapper.h:230-255"""
+    p = tmp_path / "kcfg.ini"
+    p.write_text(KCFG)
+    L = tmac_amd.lib()
+    assert L.tmac_hip_load_kcfg(str(p).encode()) == 0
+    c = B.KCfg()
+    assert L.tmac_hip_get_kcfg(4096, 4096, 1, 2, C.byref(c)) == 0
+    assert (c.bm, c.kfactor, c.group_size, c.n_tile_num) == (128, 16, 128, 64)
+    assert (c.act_group_size, c.zero_point, c.m_groups) == (64, 1, -1)       # derived from the sizes
+    assert L.tmac_hip_get_kcfg(3200, 8640, 1, 2, C.byref(c)) == 0           # found through the t4 hint
+    assert (c.act_group_size, c.zero_point, c.m_groups) == (8640, 0, 1)
+    assert L.tmac_hip_get_kcfg(1234, 4096, 1, 2, C.byref(c)) == -1          # reference: dispatcher returns -1
+    assert L.tmac_hip_load_kcfg(b"/nonexistent/kcfg.ini") == -4
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))))
+def test_python_preprocess_weights_matches_golden(name):
+    d = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    Mw, K, bits, bm, kf, gs, ags, zp, mg = [int(x) for x in d["meta"]]
+    A, S = tmac_amd.preprocess_weights(d["w"], d["sc"], d.get("zr"), bits=bits, bm=bm, kfactor=kf)
+    assert np.array_equal(A, d["A_ref"])
+    assert np.array_equal(np.asarray(S, np.float32).reshape(d["S_ref"].shape), d["S_ref"])

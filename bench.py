@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py — W2A8 LUT-GEMV throughput of the T-MAC hot path on MI355X (BASELINE.json metric).
+
+Workload (config.workload = "llama-2-7b-w2a8-decode-all-layers", BASELINE.json configs[1]):
+one "step" = one decoded token's worth of the hot path = for each of 32 layers
+    preprocessor(x0)  -> q,k,v   3 x qgemm_lut (4096 x 4096)
+    preprocessor(x1)  -> o       1 x qgemm_lut (4096 x 4096)
+    preprocessor(x2)  -> gate,up 2 x qgemm_lut (11008 x 4096)
+    preprocessor(x3)  -> down    1 x qgemm_lut (4096 x 11008)
+with W2 weights (group 128, zero points, act group 64; python/t_mac/model_utils.py:27-32,
+tools/run_pipeline.py:405-419), fp16 activations/scales/outputs, fp32 accumulation, every layer's
+weights distinct (1.62 GB of 2-bit planes, > the 256 MB Infinity Cache).  The launches are chained by
+real data (x1 = q, x2 = o, x3 = gate, next x0 = down) on one stream, as a decoder would issue them.
+Synthetic data: uniform random weights, |N(0,1)|-shaped scales sized so activations stay O(1).
+
+value = algorithmic bytes of the 224 GEMVs per step (SURVEY.md 8d formula) / step time, GB/s.
+
+--gpus N > 1 (launched through torch.distributed.run, one rank per GPU, RCCL): weight ROWS are sharded
+over the ranks (tile-aligned), the integer path needs no reduction, and the only exchange step is an
+all-gather of each produced activation vector (fp16, 8-22 KB) before the next LUT build; total work is
+fixed, so "scaling" is "strong".
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+LAYERS = 32
+# (name, Mw, K, count per layer, input slot)
+MATS = [("qkv", 4096, 4096, 3, 0), ("o", 4096, 4096, 1, 1), ("gate_up", 11008, 4096, 2, 2), ("down", 4096, 11008, 1, 3)]
+BITS, GS, AGS, BM, KF = 2, 128, 64, 128, 16
+
+
+def algorithmic_bytes(Mw, K, bits=BITS, gs=GS, ags=AGS, zp=True, N=1):
+    """weight planes + fp16 scales(/zeros) + int8 QLUT + fp16 LUT scales/biases + fp16 out"""
+    return Mw * K * bits // 8 + Mw * (K // gs) * (2 if zp else 1) * 2 + N * (K // 4) * 16 + N * (K // ags) * 4 + N * Mw * 2
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--layers", type=int, default=LAYERS, help=argparse.SUPPRESS)   # debugging only
+    ap.add_argument("--variant", type=int, default=0, help="GEMV kernel variant (0 auto, 1 mqsad, 2 sdwa)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the headline GEMV with events")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds=4.0):
+    """The reference kernel (oracle/_ref, built from /root/reference) — or, if that prebuilt file is
+    absent, our scalar port — timed on this box's host cores over a bounded sample: the three W2 shapes
+    of one llama-2-7B layer (one matrix each), tiles statically split over threads exactly as llama.cpp
+    splits them (tmac_gemm_wrapper.h:197-199).  Test-infrastructure code used as a reported baseline."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    rng = np.random.default_rng(0)
+    shapes = [(4096, 4096), (11008, 4096), (4096, 11008)]
+    setname = "aarch64-llama-2-7b-2bit"
+    kind = "reference" if orc.have_ref(setname) else "port"
+    work = []
+    for Mw, K in shapes:
+        M = Mw * BITS
+        A = rng.integers(0, 256, size=(M // BM, K // 4, BM // 2), dtype=np.uint8)
+        S = np.abs(rng.standard_normal((M // BM, K // GS, BM // BITS * 2))).astype(np.float32)
+        Bv = rng.standard_normal((1, K)).astype(np.float32)
+        work.append((Mw, K, A, S, Bv))
+    total_bytes = sum(algorithmic_bytes(Mw, K) for Mw, K in shapes)
+
+    def run_once(nthreads):
+        t0 = time.perf_counter()
+        for Mw, K, A, S, Bv in work:
+            if kind == "reference":
+                L = orc.ref_lib(setname)
+                G = K // AGS
+                ls = np.zeros(G, np.float32); lb = np.zeros(G, np.float32); q = np.zeros((K // 4, 16), np.int8)
+                pre = getattr(L, f"preprocessor_t1_int8_m{8192 if Mw == 4096 else 22016}_k{K}_n1_b2")
+                pre(orc._p(Bv), orc._p(ls), orc._p(lb), orc._p(q))
+                qg = getattr(L, f"qgemm_lut_t1_int8_m{BM}_k{K}_n1_b2")
+                ntiles = Mw * BITS // BM
+                Cout = np.zeros(Mw, np.float32)
+                rpt = BM // BITS
+
+                def tiles(lo, hi):
+                    for t in range(lo, hi):
+                        qg(orc._p(A[t]), orc._p(q), orc._p(S[t]), orc._p(ls), orc._p(lb),
+                           Cout[t * rpt:(t + 1) * rpt].ctypes.data_as(orc.C.c_void_p))
+                if nthreads == 1:
+                    tiles(0, ntiles)
+                else:
+                    per = (ntiles + nthreads - 1) // nthreads
+                    list(pool.map(lambda i: tiles(i * per, min(ntiles, (i + 1) * per)), range(nthreads)))
+            else:
+                q, ls, lb = orc.preprocessor(Bv, AGS)
+                orc.qgemm_float(A, q, S, ls, lb, Mw, K, 1, BITS, BM, KF, GS, AGS, True)
+        return time.perf_counter() - t0
+
+    out = {}
+    with ThreadPoolExecutor(max_workers=cores) as pool:
+        for nthreads in ([1, cores] if kind == "reference" else [1]):
+            run_once(nthreads)
+            best, t_end = 1e9, time.perf_counter() + seconds / 2
+            reps = 0
+            while time.perf_counter() < t_end or reps < 3:
+                best = min(best, run_once(nthreads)); reps += 1
+            out[nthreads] = total_bytes / best / 1e9
+    used = max(out)
+    return {"value": round(out[used], 3), "unit": "GB/s", "cores": used, "kind": kind,
+            "single_thread_GBps": round(out[1], 3),
+            "sample": "one 4096x4096, one 11008x4096 and one 4096x11008 W2 g128 zp GEMV (preprocessor + all tiles), best of >=3"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import tmac_amd
+    from tmac_amd import KCfg, F16
+    L = tmac_amd.lib()
+    tmac_amd.binding.check(L.tmac_hip_init(local_rank))
+    tmac_amd.binding.check(L.tmac_hip_set_variant(args.variant))
+    dev = torch.device("cuda", local_rank)
+    gen = torch.Generator(device=dev); gen.manual_seed(1234)   # same weights on every rank, sliced by rank below
+    wr = tmac_amd.TMACGeMMWrapper(act_group_size=AGS)
+    wr.set_workspace(11008, 1)
+
+    # ---- synthetic, row-sharded weights, registered (re-tiled on the GPU) once --------------------
+    rpt = BM // BITS                                  # 64 output rows per reference tile
+    layers = []
+    bytes_per_step = 0
+    shard_rows = {}
+    for name, Mw, K, cnt, slot in MATS:
+        ntiles = Mw // rpt
+        tiles_per_rank = (ntiles + world - 1) // world          # ragged split -> padded with extra synthetic rows
+        shard_rows[name] = tiles_per_rank * rpt
+        bytes_per_step += cnt * algorithmic_bytes(Mw, K)
+    bytes_per_step *= args.layers
+    for li in range(args.layers):
+        mats = {}
+        for name, Mw, K, cnt, slot in MATS:
+            Mloc = shard_rows[name]
+            cfg = KCfg.make(Mloc, K, BITS, BM, KF, GS, AGS, True)
+            c = 1.0 / np.sqrt(2.5 * K)
+            ws = []
+            for _ in range(cnt):
+                A = torch.randint(0, 256, (Mloc * BITS // BM, K // 4, BM // 2), dtype=torch.uint8, device=dev, generator=gen)
+                S = (torch.randn((Mloc * BITS // BM, K // GS, rpt // 8, 2, 8), device=dev, generator=gen) * c)
+                S[:, :, :, 0, :].abs_()
+                S = S.half().contiguous()
+                ws.append(tmac_amd.Weights(A, S, Mloc, K, BITS, cfg, scales_dtype=F16, dev_dtype=F16, on_device=True))
+                del A, S
+            mats[name] = ws
+        layers.append(mats)
+    torch.cuda.synchronize()
+
+    # activations: x[slot] full vectors (fp16); per-matrix local outputs
+    xdim = {0: 4096, 1: 4096, 2: 4096, 3: 11008}
+    x = {s: torch.randn(xdim[s], device=dev, generator=gen).half() for s in xdim}
+    outs = {name: [torch.empty(shard_rows[name], dtype=torch.float16, device=dev) for _ in range(cnt)]
+            for name, Mw, K, cnt, slot in MATS}
+    gathered = {name: torch.empty(shard_rows[name] * world, dtype=torch.float16, device=dev) for name, *_ in MATS}
+    nxt = {"qkv": 1, "o": 2, "gate_up": 3, "down": 0}
+    logical = {"qkv": 4096, "o": 4096, "gate_up": 11008, "down": 4096}
+    ev_pairs = []
+    use_ev = not args.no_kernel_events
+
+    def step(record):
+        for li in range(args.layers):
+            mats = layers[li]
+            for name, Mw, K, cnt, slot in MATS:
+                wr.llama_cpp_init(x[slot], Mw, K, 1, BITS, act_dtype=F16)
+                for i in range(cnt):
+                    if record and name == "down":
+                        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        wr.llama_cpp_compute(mats[name][i], outs[name][i], 1, out_dtype=F16)
+                        e1.record()
+                        ev_pairs.append((e0, e1))
+                    else:
+                        wr.llama_cpp_compute(mats[name][i], outs[name][i], 1, out_dtype=F16)
+                # exchange step: the first output of the group becomes the next activation vector
+                if world > 1:
+                    dist.all_gather_into_tensor(gathered[name], outs[name][0])
+                    x[nxt[name]] = gathered[name][:logical[name]]
+                else:
+                    x[nxt[name]] = outs[name][0]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(use_ev)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- roofline of the dominant kernel (k_gemv_lo on the headline shape), from the events above ----
+    roof = None
+    if use_ev and ev_pairs:
+        durs = np.array([a.elapsed_time(b) for a, b in ev_pairs]) * 1e-3   # seconds
+        hb = algorithmic_bytes(shard_rows["down"], 11008)
+        ach = hb / float(np.mean(durs)) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_gemv_lo<2,16,zp,f16> (4096x11008 W2)", "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": hb, "avg_launch_us": round(float(np.mean(durs)) * 1e6, 3),
+                "min_launch_us": round(float(np.min(durs)) * 1e6, 3), "launches_timed": len(durs),
+                "timing": "hipEvent pair around each launch on the launch stream, inside the timed steps"}
+
+    if rank == 0:
+        res = {
+            "metric": "W2A8 GEMV GB/s (llama-2-7B all-layer decode, N=1)",
+            "value": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9, 2),
+            "unit": "GB/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int8",
+            "data": "synthetic",
+            "tokens_per_s": round(1e3 / ms_per_step, 1),
+            "frac_of_hbm_peak": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
+            "config": {"workload": "llama-2-7b-w2a8-decode-all-layers", "layers": args.layers,
+                       "gemv_per_step": 7 * args.layers, "preprocessors_per_step": 4 * args.layers,
+                       "algorithmic_bytes_per_step": bytes_per_step, "weights": "W2 g128 zero-point, act_group 64",
+                       "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
+                       "kernel_variant": args.variant},
+            "roofline": roof,
+            "cpu_baseline": None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

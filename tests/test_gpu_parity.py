@@ -1,0 +1,272 @@
+"""Parity of the HIP path against the oracle / golden vectors, through the C-ABI (libtmac_hip.so).
+
+Bar (BASELINE.json north_star): QLUT, lut_scales, lut_biases and the integer partial sums bit-exact;
+fp32 outputs within 1e-3 relative (max-abs-diff / max-abs-ref) — measured values are ~1e-6 because
+only the fp32 summation ORDER differs — and fp16 outputs equal to the oracle's fp32 rounded once, to
+within one fp16 ulp-class tolerance (1e-3).  The generic reference-layout kernel (variant 3) keeps the
+reference's exact float order and must match the oracle BIT FOR BIT in fp32.
+"""
+import ctypes as C
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+REL_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def tm():
+    import torch
+    import tmac_amd
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    L = tmac_amd.lib()
+    assert L.tmac_hip_device_count() > 0
+    return tmac_amd
+
+
+def rel_err(c, ref):
+    return float(np.abs(c.astype(np.float64) - ref.astype(np.float64)).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, m_groups=-1, N=1, variant=0, scale_dtype=None, out_f16=False,
+             act_f16=False, want_ps=True):
+    """register + preprocess + gemv on the GPU; returns dict(q, ls, lb, C, PS)"""
+    import torch
+    L = tm.lib()
+    tm.binding.check(L.tmac_hip_set_variant(variant))
+    A = orc.preprocess_weights(case["w"], bits, bm, kf)
+    if m_groups == -1:
+        S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm)
+    else:
+        S = case["sc"]
+    cfg = tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, zp, m_groups, N)
+    wr = tm.TMACGeMMWrapper(act_group_size=ags)
+    wr.set_workspace(K, N)
+    dev_dt = tm.F16 if scale_dtype == "f16" else tm.F32
+    w = wr.register_weights(A, S, Mw, K, bits, cfg, scales_dtype=tm.F32, dev_dtype=dev_dt)
+    Bt = torch.from_numpy(case["B"]).cuda()
+    if act_f16:
+        Bt = Bt.half()
+    Ct = torch.empty((N, Mw), dtype=torch.float16 if out_f16 else torch.float32, device="cuda")
+    wr.llama_cpp_init(Bt, Mw, K, N, bits)
+    wr.llama_cpp_compute(w, Ct, N)
+    torch.cuda.synchronize()
+    q, ls, lb = wr.workspace.read(K, N, ags)
+    out = dict(q=q, ls=ls, lb=lb, C=Ct.float().cpu().numpy(), A=A, S=S)
+    if want_ps:
+        out["PS"] = wr.partial_sums(w, N)
+    w.free()
+    L.tmac_hip_set_variant(0)
+    return out
+
+
+def oracle_case(case, A, S, Mw, K, bits, bm, kf, gs, ags, zp, m_groups=-1, N=1):
+    q, ls, lb = orc.preprocessor(case["B"], ags)
+    if m_groups == -1:
+        Cc = orc.qgemm_float(A, q, S, ls, lb, Mw, K, N, bits, bm, kf, gs, ags, zp)
+        PS = np.stack([orc.partial_sums(A, q[n], Mw, K, bits, bm, kf, ags) for n in range(N)])
+    elif ags == K:
+        Cc, cb = orc.qgemm_scale_final(A, q, S, ls[:, 0], lb[:, 0], Mw, K, N, bits, bm, kf, m_groups)
+        PS = cb[:, :, None]
+    else:
+        Cc = orc.qgemm_float(A, q, S, ls, lb, Mw, K, N, bits, bm, kf, gs, ags, False, one_scale=True)
+        PS = np.stack([orc.partial_sums(A, q[n], Mw, K, bits, bm, kf, ags) for n in range(N)])
+    return q, ls, lb, Cc, PS
+
+
+def check_bits(a, b):
+    assert np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+# -------------------------------------------------------------------------------------------------
+
+def test_isa_models(tm):
+    """v_perm_b32 / v_mqsad_pk_u16_u8 on the hardware == the host models the CPU emulation test relies on"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(0)
+    n = 4096
+    x = rng.integers(0, 2 ** 32, size=(n, 4), dtype=np.uint64).astype(np.uint32)
+    x[: n // 2, 2] &= 0x0f0f0f0f          # half of the selectors in the 0..15 range, half arbitrary bytes
+    out = np.zeros_like(x)
+    tm.binding.check(tm.lib().tmac_hip_selftest(x.ctypes.data, out.ctypes.data, n))
+
+    def perm(s0, s1, sel):
+        src = (np.uint64(s0) << np.uint64(32)) | np.uint64(s1)
+        r = 0
+        for i in range(4):
+            c = (int(sel) >> (8 * i)) & 0xff
+            if c <= 7: b = (int(src) >> (8 * c)) & 0xff
+            elif c == 8: b = 0xff if (int(s1) >> 15) & 1 else 0
+            elif c == 9: b = 0xff if (int(s1) >> 31) & 1 else 0
+            elif c == 10: b = 0xff if (int(s0) >> 15) & 1 else 0
+            elif c == 11: b = 0xff if (int(s0) >> 31) & 1 else 0
+            elif c == 12: b = 0
+            else: b = 0xff
+            r |= b << (8 * i)
+        return r
+
+    for i in range(n):
+        a, b, c, d = [int(v) for v in x[i]]
+        assert int(out[i, 0]) == perm(a, b, c), (i, hex(a), hex(b), hex(c), hex(int(out[i, 0])))
+        acc_lo, acc_hi = b & 0x0fff0fff, d & 0x0fff0fff
+        acc = [(acc_lo & 0xffff), acc_lo >> 16, acc_hi & 0xffff, acc_hi >> 16]
+        exp = [acc[k] + (255 - ((a >> (8 * k)) & 0xff)) for k in range(4)]
+        got = [int(out[i, 1]) & 0xffff, int(out[i, 1]) >> 16, int(out[i, 2]) & 0xffff, int(out[i, 2]) >> 16]
+        assert got == exp, (i, hex(a), acc, got, exp)
+
+
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("name", CASES)
+def test_golden_vectors(tm, name, variant):
+    """committed vectors produced by the reference itself (tests/golden/make_golden.py)"""
+    d = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    Mw, K, bits, bm, kf, gs, ags, zp, mg = [int(x) for x in d["meta"]]
+    case = dict(w=d["w"], sc=d["sc"], zr=d.get("zr"), B=d["B"])
+    r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, bool(zp), mg, variant=variant)
+    assert np.array_equal(r["A"], d["A_ref"])
+    assert np.array_equal(r["q"][0], d["qlut"])
+    check_bits(r["ls"][0], d["lut_scales"])
+    check_bits(r["lb"][0], d["lut_biases"])
+    if mg == -1:
+        assert np.array_equal(r["PS"][0], d["PS"])
+        if variant == 3:
+            check_bits(r["C"][0], d["C"])          # reference float order -> bit-exact
+        assert rel_err(r["C"][0], d["C"]) <= REL_TOL
+    else:
+        assert np.array_equal(r["PS"][0, :, 0], d["cbits32"])
+
+
+CFGS = [  # Mw, K, bits, bm, kf, gs, ags, zp, m_groups
+    (4096, 4096, 2, 128, 16, 128, 64, True, -1),     # BASELINE config #1 (tests/test_e2e.py)
+    (512, 11008, 2, 128, 16, 128, 64, True, -1),     # headline K (ragged last segment block)
+    (704, 4096, 2, 128, 16, 128, 64, False, -1),     # 11 tiles, no zero points
+    (256, 4096, 4, 256, 16, 128, 64, True, -1),      # W4 GPTQ-style (config #3)
+    (256, 1024, 1, 128, 16, 128, 64, True, -1),
+    (256, 1024, 3, 192, 16, 128, 64, False, -1),
+    (256, 1024, 2, 128, 8, 128, 32, True, -1),       # act_group 32
+    (256, 1024, 4, 256, 16, 64, 64, False, -1),      # group_size 64
+    (320, 3200, 2, 320, 16, 128, 3200, False, 1),    # BitNet x86: unified scale, int32 aggregation (config #4)
+    (320, 8640, 2, 128, 16, 128, 8640, False, 1),
+    (320, 3200, 2, 128, 16, 128, 64, False, 1),      # BitNet ARM flavour: one weight scale, per-group LUT scales
+]
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,mg", CFGS)
+def test_vs_oracle(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, variant):
+    case = orc.make_case(Mw + K + bits, Mw, K, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg)
+    r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, mg, variant=variant)
+    q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, kf, gs, ags, zp, mg)
+    assert np.array_equal(r["q"], q)
+    check_bits(r["ls"], ls)
+    check_bits(r["lb"], lb)
+    assert np.array_equal(r["PS"], PS)
+    assert rel_err(r["C"], Cc) <= REL_TOL
+    assert rel_err(r["C"], Cc) <= 2e-5  # what fp32 re-association actually costs
+
+
+@pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,mg", CFGS[:4] + CFGS[8:])
+def test_reference_layout_kernel_is_bit_exact(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg):
+    Mw = min(Mw, 640) // (bm // bits) * (bm // bits) or bm // bits
+    case = orc.make_case(K + bits, Mw, K, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg)
+    r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, mg, variant=3)
+    q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, kf, gs, ags, zp, mg)
+    assert np.array_equal(r["PS"], PS)
+    check_bits(r["C"], Cc)
+
+
+def test_fp16_storage_path(tm):
+    """fp16 activations, fp16 scales on the device, fp16 output — exact w.r.t. the oracle fed the same
+    fp16-representable values, up to the final rounding to fp16."""
+    Mw, K, bits, bm, kf, gs, ags = 512, 4096, 2, 128, 16, 128, 64
+    case = orc.make_case(42, Mw, K, bits=bits, fp16_values=True)
+    r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, True, scale_dtype="f16", out_f16=True, act_f16=True)
+    q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, kf, gs, ags, True)
+    assert np.array_equal(r["q"], q) and np.array_equal(r["PS"], PS)
+    check_bits(r["ls"], ls)
+    assert rel_err(r["C"], Cc.astype(np.float16).astype(np.float32)) <= REL_TOL
+
+
+def test_multi_row_activations(tm):
+    """N > 1 (small prefill): each activation row is an independent GEMV (qgemm.py:183-190)"""
+    Mw, K, bits, bm, kf, gs, ags, N = 256, 1024, 2, 128, 16, 128, 64, 5
+    case = orc.make_case(9, Mw, K, N=N, bits=bits)
+    r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, True, N=N)
+    q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, kf, gs, ags, True, N=N)
+    assert np.array_equal(r["q"], q) and np.array_equal(r["PS"], PS)
+    assert rel_err(r["C"], Cc) <= 2e-5
+
+
+def test_edge_activations(tm):
+    """all-zero act groups (scale 0 -> t_scales 0), huge/small magnitudes, exact .5 ties"""
+    Mw, K, bits, bm, kf, gs, ags = 128, 512, 2, 128, 16, 128, 64
+    case = orc.make_case(1, Mw, K, bits=bits)
+    B = case["B"]
+    B[0, :64] = 0
+    B[0, 64:128] *= 1e20
+    B[0, 128:192] *= 1e-20
+    B[0, 192:256] = np.tile(np.array([0.5, 1.5, 2.5, 127.0], np.float32), 16)
+    r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, True)
+    q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, kf, gs, ags, True)
+    assert np.array_equal(r["q"], q) and np.array_equal(r["PS"], PS)
+    check_bits(r["ls"], ls); check_bits(r["lb"], lb)
+    assert rel_err(r["C"], Cc) <= 2e-5
+
+
+def test_headline_shape_properties(tm):
+    """Full BASELINE headline shape (Mw=4096, K=11008, W2, zp): oracle comparison + size-independent
+    properties: run-to-run determinism and row-shard consistency (the multi-GPU partitioning)."""
+    import torch
+    Mw, K, bits, bm, kf, gs, ags = 4096, 11008, 2, 128, 16, 128, 64
+    case = orc.make_case(2024, Mw, K, bits=bits)
+    r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, True, want_ps=False)
+    r2 = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, True, want_ps=False)
+    check_bits(r["C"], r2["C"])
+    q, ls, lb, Cc, _ = oracle_case({**case, "w": case["w"][:64]}, r["A"][:1], r["S"][:1], 64, K, bits, bm, kf, gs, ags, True)
+    assert np.array_equal(r["q"], q)
+    Call = orc.qgemm_float(r["A"], q, r["S"], ls, lb, Mw, K, 1, bits, bm, kf, gs, ags, True)
+    assert rel_err(r["C"], Call) <= 2e-5
+    # row shards of 1024 rows (8 tiles each), as a 4-GPU split would register them
+    parts = []
+    for sh in range(4):
+        sub = dict(w=case["w"][sh * 1024:(sh + 1) * 1024], sc=case["sc"][sh * 1024:(sh + 1) * 1024],
+                   zr=case["zr"][sh * 1024:(sh + 1) * 1024], B=case["B"])
+        parts.append(run_case(tm, sub, 1024, K, bits, bm, kf, gs, ags, True, want_ps=False)["C"])
+    check_bits(np.concatenate(parts, axis=1), r["C"])
+
+
+def test_host_pointer_cabi_matches_prebuilt_reference(tm, tmp_path):
+    """the reference-named entry points (preprocessor_int8 / qgemm_lut_int8, host pointers, per-tile calls)
+    against the vector produced by the reference's checked-in prebuilt kernel"""
+    d = dict(np.load(os.path.join(GOLD, "prebuilt_llama2_7b_w2_k4096.npz")))
+    L = tm.lib()
+    ini = tmp_path / "kcfg.ini"
+    ini.write_text("[qgemm_lut_t1_int8_m8192_k4096_n1_b2]\nbm = 128\nsimd_n_in = 16\nsimd_n_out = 8\nkfactor = 16\n"
+                   "group_size = 128\nlut_scales_size = 64\nscales_size = 262144\nn_tile_num = 64\n")
+    tm.binding.check(L.tmac_hip_load_kcfg(str(ini).encode()))
+    K = 4096
+    B = np.ascontiguousarray(d["B"][0]); ls = np.zeros(64, np.float32); lb = np.zeros(64, np.float32)
+    q = np.zeros((K // 4, 16), np.int8)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    fn = L.preprocessor_t1_int8_m8192_k4096_n1_b2
+    fn.restype = C.c_int32
+    assert fn(vp(B), vp(ls), vp(lb), vp(q)) == 0
+    assert np.array_equal(q, d["qlut"]); check_bits(ls, d["lut_scales"]); check_bits(lb, d["lut_biases"])
+    A = np.ascontiguousarray(d["A_ref"][0]); S = np.ascontiguousarray(d["S_ref"][0]); c = np.zeros(64, np.float32)
+    assert L.qgemm_lut_int8(128, K, 1, 2, A.ctypes.data, q.ctypes.data, S.ctypes.data, ls.ctypes.data, lb.ctypes.data,
+                            c.ctypes.data) == 0
+    assert rel_err(c, d["C"]) <= 2e-5
+    assert L.qgemm_lut_int8(96, K, 1, 2, A.ctypes.data, q.ctypes.data, S.ctypes.data, ls.ctypes.data, lb.ctypes.data,
+                            c.ctypes.data) == -1          # unknown shape -> -1, as the reference dispatcher
+    L.tmac_hip_cache_clear()

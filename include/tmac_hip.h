@@ -111,6 +111,15 @@ int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void* B_dev, tma
 int32_t tmac_hip_qgemm_dev(const tmac_hip_weights* w, const tmac_hip_workspace* ws, void* C_dev,
                            tmac_dtype_t out_dtype, int N, void* stream);
 
+/* Fused form of llama_cpp_init + llama_cpp_compute (tmac_gemm_wrapper.h:170-228) for up to 4 weight
+ * matrices that consume the SAME activation rows (q/k/v, gate/up): the LUT is built inside the GEMV
+ * kernel (bit-exact with tmac_hip_preprocessor_dev) and every matrix is covered by one launch.
+ *   weights[i] : registered matrices sharing K, bits and quantisation config
+ *   B_dev      : activations [N][K] (act_dtype);   C_dev[i] : [N][Mw_i] (out_dtype) */
+int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weights, int nmat, const void* B_dev,
+                                 tmac_dtype_t act_dtype, void* const* C_dev, tmac_dtype_t out_dtype, int N,
+                                 void* stream);
+
 /* Raw device pointers of the workspace, for collectives (RCCL all-gather of the LUT over xGMI):
  *   qlut_dev  : kernel-layout half tables, nbytes_qlut per activation row
  *   lut_scales/lut_biases : fp32 [N][K/act_group_size] */
@@ -128,10 +137,15 @@ int32_t tmac_hip_workspace_write(tmac_hip_workspace* ws, const int8_t* qlut_host
  * reference's M-space (bit-plane) row order; for the unified-scale path [N][M] (K/ags == 1). */
 int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const tmac_hip_workspace* ws,
                                     int32_t* PS_host, int N, void* stream);
+/* integer tap of the fused kernel (one matrix): PS_host as above, optional fp32 C_host [N][Mw] */
+int32_t tmac_hip_qgemm_fused_partial_sums(const tmac_hip_weights* w, const void* B_dev, tmac_dtype_t act_dtype,
+                                          int32_t* PS_host, float* C_host, int N, void* stream);
 /* Runs v_perm_b32 / v_mqsad_pk_u16_u8 / lookup4 on n quadruples of host words (in[4n] -> out[4n]); the
  * test-suite compares the result with the host models of t-mac_amd/csrc/tmac_core.h. */
 int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host, int n);
-/* Select the GEMV kernel variant (0 = default/auto).  For A/B benchmarking and tests. */
+/* Select the GEMV kernel variant: 0 auto (fused layout where supported), 1/2 two-kernel tiled path
+ * (mqsad / byte-add accumulate), 3 generic reference-layout kernel, 4 fused.  Affects weights
+ * registered AFTER the call (the variant fixes their device layout).  For A/B benchmarking and tests. */
 int32_t tmac_hip_set_variant(int variant);
 
 /* ---- (1) reference-named host-pointer entry points ---------------------------------------

@@ -47,12 +47,51 @@ static void run(const std::vector<uint32_t>& W, const std::vector<uint32_t>& QL,
                 }
 }
 
+// fused-layout kernel (ts = 8): a thread owns (row quad, 8-table unit); the LUT sits in the LDS image
+// [4][nu_pad+1] uint4; lanes (ul, ul^1) add their packed u16 sums to complete a 64-activation group.
+template <int BITS>
+static void run8(const std::vector<uint32_t>& W, const std::vector<uint32_t>& QLDS, const Shape& s, int32_t* PS) {
+    constexpr int NJ = 8 * BITS / 8;
+    const int nu = s.K / 32, tstride = ((nu + 15) & ~15) + 1, G = s.K / s.ags;
+    for (int b = 0; b < s.nb(); ++b)
+        for (int ub = 0; ub < s.nsb(); ++ub)
+            for (int rl = 0; rl < RL; ++rl)
+                for (int ul = 0; ul < KL; ul += 2) {
+                    uint64_t pair[BITS] = {};
+                    for (int half = 0; half < 2; ++half) {
+                        const int u = ub * KL + ul + half;
+                        if (u >= nu) continue;
+                        uint32_t wd[8 * BITS / 2], tb[16];
+                        for (int j = 0; j < NJ; ++j)
+                            for (int e = 0; e < 4; ++e) wd[4 * j + e] = W[weight_u4_index(s, b, ub, j, rl, ul + half) * 4 + e];
+                        for (int j4 = 0; j4 < 4; ++j4)
+                            for (int e = 0; e < 4; ++e) tb[4 * j4 + e] = QLDS[((size_t)j4 * tstride + u) * 4 + e];
+                        SegAcc<BITS, 0> acc;
+                        acc.reset();
+                        accumulate_tables<BITS, 0, 8>(wd, tb, acc);
+                        for (int p = 0; p < BITS; ++p) pair[p] += acc.a[p];   // packed u16 add, no carries
+                    }
+                    const int u0 = ub * KL + ul;
+                    if (u0 >= nu) continue;
+                    for (int beta = 0; beta < 4; ++beta)
+                        for (int p = 0; p < BITS; ++p) {
+                            const int o = 4 * (b * RL + rl) + beta;
+                            if (o >= s.Mw) continue;
+                            const int32_t v = 127 * 16 - (int32_t)((pair[p] >> (16 * beta)) & 0xffff);
+                            if (s.ags == s.K) PS[mrow(o, p, BITS)] += v;
+                            else PS[(size_t)mrow(o, p, BITS) * G + u0 / 2] = v;
+                        }
+                }
+}
+
 extern "C" int emu_partial_sums(const uint8_t* A_ref, const int8_t* qlut_ref, int Mw, int K, int bits, int bm,
                                 int kfactor, int ags, int mode, int32_t* PS) {
     Shape s;
     memset(&s, 0, sizeof(s));
     s.Mw = Mw; s.K = K; s.bits = bits; s.bm = bm; s.kfactor = kfactor; s.gs = 128; s.ags = ags; s.m_groups = -1;
+    s.ts = (mode == 2) ? 8 : 16;     // mode 2 = fused-layout kernel
     if (K % 64 || (ags != 32 && ags != 64 && ags != K)) return -1;
+    if (mode == 2 && ags == 32) return -1;
     std::vector<uint32_t> W(s.weight_u4() * 4);
     for (size_t i = 0; i < W.size(); ++i) W[i] = retile_dword(A_ref, s, i >> 2, (int)(i & 3));
     std::vector<uint32_t> QL(s.qlut_dev_u4() * 4, 0x80808080u);
@@ -68,6 +107,27 @@ extern "C" int emu_partial_sums(const uint8_t* A_ref, const int8_t* qlut_ref, in
     }
     const size_t n = (size_t)Mw * bits * (ags == K ? 1 : K / ags);
     memset(PS, 0, n * sizeof(int32_t));
+    if (mode == 2) {
+        const int nu = K / 32, tstride = ((nu + 15) & ~15) + 1;
+        std::vector<uint32_t> QLDS((size_t)4 * tstride * 4, 0x80808080u);
+        for (int t = 0; t < K / 4; ++t) {
+            uint32_t lo = 0, hi = 0;
+            for (int i = 0; i < 4; ++i) {
+                lo |= (uint32_t)(qlut_ref[t * 16 + i] + 128) << (8 * i);
+                hi |= (uint32_t)(qlut_ref[t * 16 + 4 + i] + 128) << (8 * i);
+            }
+            const size_t u2 = ((size_t)((t & 7) >> 1) * tstride + (t >> 3)) * 2 + (t & 1);
+            QLDS[u2 * 2] = lo; QLDS[u2 * 2 + 1] = hi;
+        }
+        switch (bits) {
+            case 1: run8<1>(W, QLDS, s, PS); break;
+            case 2: run8<2>(W, QLDS, s, PS); break;
+            case 3: run8<3>(W, QLDS, s, PS); break;
+            case 4: run8<4>(W, QLDS, s, PS); break;
+            default: return -1;
+        }
+        return 0;
+    }
 #define RUN(B) (mode == 0 ? run<B, 0>(W, QL, s, PS) : run<B, 1>(W, QL, s, PS))
     switch (bits) {
         case 1: RUN(1); break;

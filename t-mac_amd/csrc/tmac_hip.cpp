@@ -61,7 +61,8 @@ struct tmac_hip_weights {
 struct tmac_hip_workspace {
     int maxK = 0, maxN = 0;
     int8_t* qlut_ref = nullptr;  // int8 [maxN][maxK/4][16]
-    void* qlut_dev = nullptr;    // uint4 [maxN][qdev_u4(maxK)]
+    void* qlut_dev = nullptr;    // uint4 [maxN][qdev_u4(maxK)]   (ts = 16 layout)
+    void* qlut_lds = nullptr;    // uint4 [maxN][qlut_lds_u4(K)]  (LDS image for the fused-layout kernel)
     float* lut_scales = nullptr; // fp32 [maxN][maxK/32]
     float* lut_biases = nullptr;
     int32_t* dump = nullptr;     // lazily sized parity tap
@@ -196,7 +197,7 @@ extern "C" int32_t tmac_hip_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 extern "C" int32_t tmac_hip_set_variant(int variant) {
-    if (variant < 0 || variant > 3) return fail(TMAC_HIP_E_ARG, "unknown variant %d", variant);
+    if (variant < 0 || variant > 4) return fail(TMAC_HIP_E_ARG, "unknown variant %d", variant);
     g_variant = variant;
     return TMAC_HIP_OK;
 }
@@ -239,6 +240,10 @@ static int32_t make_shape(Shape& s, int Mw, int K, int bits, const tmac_kcfg* cf
     if (!(s.m_groups >= 1 && s.ags == K) && (4 * s.kfactor) % s.ags)
         return fail(TMAC_HIP_E_NOMATCH, "act_group_size=%d must divide 4*kfactor=%d (qgemm.py:113-115)", s.ags, 4 * s.kfactor);
     if (s.m_groups < 0 && s.gs % (4 * s.kfactor)) return fail(TMAC_HIP_E_NOMATCH, "group_size %% (4*kfactor) != 0");
+    // device layout: 8-table units for the fused kernel, 16-table segments for the two-kernel path
+    s.ts = 8;
+    const bool fused_ok = gemv_fused_supported(s);
+    if (g_variant == V_LO_MQSAD || g_variant == V_LO_SDWA || !fused_ok) s.ts = 16;
     return TMAC_HIP_OK;
 }
 
@@ -262,7 +267,7 @@ static int32_t register_impl(tmac_hip_weights** out, const void* A_ref, const vo
     w->s = s;
     w->sc_dtype = (Dtype)dev_float;
     w->ref_dtype = (Dtype)host_float;
-    w->lo_ok = gemv_lo_supported(s);
+    w->lo_ok = (s.ts == 8) ? gemv_fused_supported(s) : gemv_lo_supported(s);
     const size_t ab = ref_weight_bytes(s), se = ref_scale_elems(s), sb = se * dt_size((Dtype)host_float);
     const bool keep_ref = !w->lo_ok || g_variant == V_REF_LAYOUT;
     void *dA = nullptr, *dS = nullptr;
@@ -348,6 +353,8 @@ extern "C" int32_t tmac_hip_workspace_create(tmac_hip_workspace** out, int maxK,
     HIP_TRY(hipMalloc((void**)&ws->qlut_ref, (size_t)maxN * (maxK / 4) * 16));
     HIP_TRY(hipMalloc(&ws->qlut_dev, (size_t)maxN * qdev_u4_for_K(maxK) * 16));
     HIP_TRY(hipMemset(ws->qlut_dev, 0x80, (size_t)maxN * qdev_u4_for_K(maxK) * 16));
+    HIP_TRY(hipMalloc(&ws->qlut_lds, (size_t)maxN * qlut_lds_u4(maxK) * 16));
+    HIP_TRY(hipMemset(ws->qlut_lds, 0x80, (size_t)maxN * qlut_lds_u4(maxK) * 16));
     HIP_TRY(hipMalloc((void**)&ws->lut_scales, sizeof(float) * (size_t)maxN * (maxK / 32)));
     HIP_TRY(hipMalloc((void**)&ws->lut_biases, sizeof(float) * (size_t)maxN * (maxK / 32)));
     *out = ws;
@@ -358,6 +365,7 @@ extern "C" int32_t tmac_hip_workspace_free(tmac_hip_workspace* ws) {
     if (!ws) return TMAC_HIP_OK;
     if (ws->qlut_ref) (void)hipFree(ws->qlut_ref);
     if (ws->qlut_dev) (void)hipFree(ws->qlut_dev);
+    if (ws->qlut_lds) (void)hipFree(ws->qlut_lds);
     if (ws->lut_scales) (void)hipFree(ws->lut_scales);
     if (ws->lut_biases) (void)hipFree(ws->lut_biases);
     if (ws->dump) (void)hipFree(ws->dump);
@@ -379,7 +387,7 @@ extern "C" int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void*
     if (rc) return rc;
     if (!B_dev) return fail(TMAC_HIP_E_ARG, "null activations");
     ws->K = K; ws->N = N; ws->ags = act_group_size; ws->qdev_u4_per_row = qdev_u4_for_K(K);
-    hipError_t e = launch_preprocess(B_dev, (Dtype)act_dtype, ws->qlut_ref, ws->qlut_dev, ws->lut_scales, ws->lut_biases,
+    hipError_t e = launch_preprocess(B_dev, (Dtype)act_dtype, ws->qlut_ref, ws->qlut_dev, ws->qlut_lds, ws->lut_scales, ws->lut_biases,
                                      K, N, act_group_size, ws->qdev_u4_per_row, (hipStream_t)stream);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
     return TMAC_HIP_OK;
@@ -420,7 +428,7 @@ extern "C" int32_t tmac_hip_workspace_write(tmac_hip_workspace* ws, const int8_t
     HIP_TRY(hipMemcpyAsync(ws->qlut_ref, qlut_host, (size_t)N * (K / 4) * 16, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ws->lut_scales, lut_scales_host, sizeof(float) * N * G, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ws->lut_biases, lut_biases_host, sizeof(float) * N * G, hipMemcpyHostToDevice, st));
-    hipError_t e = launch_qlut_ref_to_dev(ws->qlut_ref, ws->qlut_dev, K, N, ws->qdev_u4_per_row, st);
+    hipError_t e = launch_qlut_ref_to_dev(ws->qlut_ref, ws->qlut_dev, ws->qlut_lds, K, N, ws->qdev_u4_per_row, st);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "qlut_ref_to_dev launch: %s", hipGetErrorString(e));
     return TMAC_HIP_OK;
 }
@@ -435,8 +443,23 @@ static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* w
         return fail(TMAC_HIP_E_ARG, "workspace LUT (K=%d, ags=%d) does not match the weights (K=%d, ags=%d)", ws->K, ws->ags, w->s.K, w->s.ags);
     if (N <= 0 || N > ws->N) return fail(TMAC_HIP_E_ARG, "N=%d but the workspace LUT holds %d rows", N, ws->N);
     Variant v = (Variant)g_variant;
-    if (v == V_AUTO) v = w->lo_ok ? V_LO_MQSAD : V_REF_LAYOUT;
-    if ((v == V_LO_MQSAD || v == V_LO_SDWA) && !w->lo_ok) v = V_REF_LAYOUT;
+    if (v != V_REF_LAYOUT) {   // the weights' device layout decides which tiled kernel can run
+        if (!w->lo_ok) v = V_REF_LAYOUT;
+        else if (w->s.ts == 8) v = V_FUSED;
+        else if (v != V_LO_SDWA) v = V_LO_MQSAD;
+    }
+    if (v == V_FUSED) {
+        FusedArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.nmat = 1; fa.s = w->s;
+        fa.m[0].W = (const uint4*)w->W; fa.m[0].SC = w->SC; fa.m[0].C = C_dev; fa.m[0].Mw = w->s.Mw; fa.m[0].nb_end = w->s.nb();
+        fa.qlut_lds = ws->qlut_lds; fa.lut_scales = ws->lut_scales; fa.lut_biases = ws->lut_biases;
+        fa.sc_f16 = w->sc_dtype == F16; fa.out_f16 = out_dtype == TMAC_F16; fa.dump = dump;
+        hipError_t e = launch_gemv_fused(fa, N, false, st);
+        if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no fused GEMV kernel for this configuration");
+        if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "fused gemv launch: %s", hipGetErrorString(e));
+        return TMAC_HIP_OK;
+    }
     GemvArgs a;
     a.s = w->s; a.N = N; a.qlut_dev = ws->qlut_dev; a.qlut_ref = ws->qlut_ref;
     a.lut_scales = ws->lut_scales; a.lut_biases = ws->lut_biases; a.C = C_dev; a.out_dtype = (Dtype)out_dtype;
@@ -479,6 +502,62 @@ extern "C" int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const 
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(TMAC_HIP_E_RUNTIME, "partial-sum readback: %s", hipGetErrorString(e));
     }
+    (void)hipFree(Ctmp);
+    return rc;
+}
+
+static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
+                          void* const* C_list, tmac_dtype_t out_dtype, int N, int32_t* dump, hipStream_t st) {
+    if (!wl || !C_list || !B_dev || nmat < 1 || nmat > 4 || N < 1) return fail(TMAC_HIP_E_ARG, "bad fused arguments (1..4 matrices)");
+    FusedArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.nmat = nmat;
+    int nb = 0;
+    for (int i = 0; i < nmat; ++i) {
+        const tmac_hip_weights* w = wl[i];
+        if (!w || !C_list[i]) return fail(TMAC_HIP_E_ARG, "null matrix or output");
+        if (w->s.ts != 8 || !w->lo_ok) return fail(TMAC_HIP_E_NOMATCH, "matrix %d is not registered in the fused layout", i);
+        const Shape &a = w->s, &b = wl[0]->s;
+        if (a.K != b.K || a.bits != b.bits || a.gs != b.gs || a.ags != b.ags || a.zero_point != b.zero_point ||
+            a.m_groups != b.m_groups || w->sc_dtype != wl[0]->sc_dtype)
+            return fail(TMAC_HIP_E_ARG, "matrices fused in one launch must share K, bits and quantisation config");
+        nb += a.nb();
+        fa.m[i].W = (const uint4*)w->W; fa.m[i].SC = w->SC; fa.m[i].C = C_list[i]; fa.m[i].Mw = a.Mw; fa.m[i].nb_end = nb;
+    }
+    fa.s = wl[0]->s;
+    fa.B = B_dev; fa.act_f16 = act_dtype == TMAC_F16;
+    fa.sc_f16 = wl[0]->sc_dtype == F16; fa.out_f16 = out_dtype == TMAC_F16; fa.dump = dump;
+    hipError_t e = launch_gemv_fused(fa, N, true, st);
+    if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no fused GEMV kernel for this configuration");
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "fused gemv launch: %s", hipGetErrorString(e));
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weights, int nmat, const void* B_dev,
+                                            tmac_dtype_t act_dtype, void* const* C_dev, tmac_dtype_t out_dtype, int N,
+                                            void* stream) {
+    return fused_impl(weights, nmat, B_dev, act_dtype, C_dev, out_dtype, N, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int32_t tmac_hip_qgemm_fused_partial_sums(const tmac_hip_weights* w, const void* B_dev, tmac_dtype_t act_dtype,
+                                                     int32_t* PS_host, float* C_host, int N, void* stream) {
+    if (!w || !PS_host) return fail(TMAC_HIP_E_ARG, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t G = (w->s.m_groups >= 1 && w->s.ags == w->s.K) ? 1 : (size_t)w->s.ngroups();
+    const size_t elems = (size_t)N * w->s.M() * G;
+    int32_t* dump = nullptr;
+    void* Ctmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&dump, elems * sizeof(int32_t)));
+    HIP_TRY(hipMalloc(&Ctmp, sizeof(float) * (size_t)N * w->s.Mw));
+    HIP_TRY(hipMemsetAsync(dump, 0x7f, elems * sizeof(int32_t), st));
+    int32_t rc = fused_impl(&w, 1, B_dev, act_dtype, &Ctmp, TMAC_F32, N, dump, st);
+    if (rc == TMAC_HIP_OK) {
+        hipError_t e = hipMemcpyAsync(PS_host, dump, elems * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && C_host) e = hipMemcpyAsync(C_host, Ctmp, sizeof(float) * (size_t)N * w->s.Mw, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(TMAC_HIP_E_RUNTIME, "fused tap readback: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(dump);
     (void)hipFree(Ctmp);
     return rc;
 }

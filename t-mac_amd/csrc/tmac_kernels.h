@@ -14,7 +14,29 @@ enum Variant {
     V_AUTO = 0,
     V_LO_MQSAD = 1,  // tiled kernel, v_mqsad_pk_u16_u8 accumulate
     V_LO_SDWA = 2,   // tiled kernel, byte-select adds
-    V_REF_LAYOUT = 3 // generic kernel on the reference blobs
+    V_REF_LAYOUT = 3,// generic kernel on the reference blobs
+    V_FUSED = 4      // fused kernel (ts = 8 layout): LUT in LDS, multi-matrix launches
+};
+
+struct FusedMat {
+    const uint4* W;   // ts = 8 device layout
+    const void* SC;   // device layout scales (or [m_groups] unified scales)
+    void* C;          // [N][Mw]
+    int Mw;
+    int nb_end;       // cumulative number of 16-row blocks up to and including this matrix
+};
+
+struct FusedArgs {
+    FusedMat m[4];
+    int nmat;
+    Shape s;                 // K, bits, gs, ags, zero_point, m_groups, ts = 8 (Mw unused)
+    const void* B;           // activations [N][K]                       (LUT built in-kernel)
+    int act_f16;
+    const void* qlut_lds;    // uint4 [N][qlut_lds_u4(K)]                (LUT prebuilt by k_preprocess)
+    const float* lut_scales; // fp32 [N][K/ags]
+    const float* lut_biases;
+    int sc_f16, out_f16;
+    int32_t* dump;           // optional integer tap (nmat == 1)
 };
 
 struct GemvArgs {
@@ -35,9 +57,13 @@ struct GemvArgs {
 hipError_t launch_selftest(const uint32_t* in, uint32_t* out, int n, hipStream_t st);
 hipError_t launch_retile_weights(const uint8_t* A_ref, void* Wd, const Shape& s, hipStream_t st);
 hipError_t launch_retile_scales(const void* S_ref, Dtype in_dt, void* Sd, Dtype out_dt, const Shape& s, hipStream_t st);
-hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void* qlut_dev, float* lut_scales,
+hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, float* lut_scales,
                              float* lut_biases, int K, int N, int ags, size_t qdev_u4_per_row, hipStream_t st);
-hipError_t launch_qlut_ref_to_dev(const int8_t* qlut_ref, void* qlut_dev, int K, int N, size_t qdev_u4_per_row, hipStream_t st);
+hipError_t launch_qlut_ref_to_dev(const int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, int K, int N, size_t qdev_u4_per_row, hipStream_t st);
+// fused kernel (tmac_fused.hip)
+bool gemv_fused_supported(const Shape& s);
+size_t qlut_lds_u4(int K);   // uint4 per activation row of the LDS-image LUT
+hipError_t launch_gemv_fused(const FusedArgs& a, int N, bool build_lut, hipStream_t st);
 // returns hipErrorInvalidValue when the variant does not cover the configuration
 hipError_t launch_gemv(const GemvArgs& a, Variant v, hipStream_t st);
 bool gemv_lo_supported(const Shape& s);

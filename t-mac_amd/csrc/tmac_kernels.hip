@@ -101,9 +101,9 @@ __global__ void k_convert(const TI* __restrict__ in, TO* __restrict__ out, size_
 // ---------------------------------------------------------------------------------------------
 template <typename AT>
 __global__ __launch_bounds__(256) void k_preprocess(const AT* __restrict__ B, int8_t* __restrict__ qlut_ref,
-                                                    uint2* __restrict__ qlut_dev, float* __restrict__ lut_scales,
-                                                    float* __restrict__ lut_biases, int K, int ags,
-                                                    size_t qdev_u4_per_row) {
+                                                    uint2* __restrict__ qlut_dev, uint2* __restrict__ qlut_lds,
+                                                    float* __restrict__ lut_scales, float* __restrict__ lut_biases, int K,
+                                                    int ags, size_t qdev_u4_per_row) {
     extern __shared__ float smem[];  // [TG] L[.][0] | [TG/8] chunk sums | [blockDim] reduction scratch
     const int G = K / ags, TG = ags / 4, nchunk = TG / 8;
     const int kk = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, nt = blockDim.x;
@@ -166,6 +166,10 @@ __global__ __launch_bounds__(256) void k_preprocess(const AT* __restrict__ B, in
         }
         const int seg = t / TS, tls = t % TS;
         qlut_dev[((size_t)n * qdev_u4_per_row + qlut_dev_u4_index(seg, tls >> 1)) * 2 + (tls & 1)] = make_uint2(lo, hi);
+        {   // LDS image for the fused-layout kernel: [4][nu_pad+1] uint4, unit = 8 tables
+            const int nu_pad = ((K / 32) + 15) & ~15, tstride = nu_pad + 1, u = t >> 3, t8 = t & 7;
+            qlut_lds[((size_t)n * 4 * tstride + (size_t)(t8 >> 1) * tstride + u) * 2 + (t8 & 1)] = make_uint2(lo, hi);
+        }
     }
     __syncthreads();
     // bias: per-chunk horizontal add in the reference's order (lut_ctor.cc:25-31) ...
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(256) void k_preprocess(const AT* __restrict__ B, in
 }
 
 // host-provided reference-layout QLUT -> kernel layout (used by the host-pointer C-ABI and tests)
-__global__ void k_qlut_ref_to_dev(const int8_t* __restrict__ qlut_ref, uint2* __restrict__ qlut_dev, int K, int N,
-                                  size_t qdev_u4_per_row) {
+__global__ void k_qlut_ref_to_dev(const int8_t* __restrict__ qlut_ref, uint2* __restrict__ qlut_dev,
+                                  uint2* __restrict__ qlut_lds, int K, int N, size_t qdev_u4_per_row) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
     if (t >= K / 4) return;
     const int8_t* q = qlut_ref + ((size_t)n * (K / 4) + t) * 16;
@@ -199,6 +203,8 @@ __global__ void k_qlut_ref_to_dev(const int8_t* __restrict__ qlut_ref, uint2* __
     }
     const int seg = t / TS, tls = t % TS;
     qlut_dev[((size_t)n * qdev_u4_per_row + qlut_dev_u4_index(seg, tls >> 1)) * 2 + (tls & 1)] = make_uint2(lo, hi);
+    const int nu_pad = ((K / 32) + 15) & ~15, tstride = nu_pad + 1, u = t >> 3, t8 = t & 7;
+    qlut_lds[((size_t)n * 4 * tstride + (size_t)(t8 >> 1) * tstride + u) * 2 + (t8 & 1)] = make_uint2(lo, hi);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -505,7 +511,7 @@ hipError_t launch_retile_scales(const void* S_ref, Dtype in_dt, void* Sd, Dtype 
     return hipGetLastError();
 }
 
-hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void* qlut_dev, float* lut_scales,
+hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, float* lut_scales,
                              float* lut_biases, int K, int N, int ags, size_t qdev_u4_per_row, hipStream_t st) {
     const int TG = ags / 4;
     int nt = 64;
@@ -513,19 +519,19 @@ hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void
     const size_t shmem = sizeof(float) * (size_t)(TG + TG / 8 + nt);
     dim3 g(K / ags, N), b(nt);
     if (act_dt == F32)
-        hipLaunchKernelGGL((k_preprocess<float>), g, b, shmem, st, (const float*)B, qlut_ref, (uint2*)qlut_dev, lut_scales, lut_biases, K, ags, qdev_u4_per_row);
+        hipLaunchKernelGGL((k_preprocess<float>), g, b, shmem, st, (const float*)B, qlut_ref, (uint2*)qlut_dev, (uint2*)qlut_lds, lut_scales, lut_biases, K, ags, qdev_u4_per_row);
     else
-        hipLaunchKernelGGL((k_preprocess<__half>), g, b, shmem, st, (const __half*)B, qlut_ref, (uint2*)qlut_dev, lut_scales, lut_biases, K, ags, qdev_u4_per_row);
+        hipLaunchKernelGGL((k_preprocess<__half>), g, b, shmem, st, (const __half*)B, qlut_ref, (uint2*)qlut_dev, (uint2*)qlut_lds, lut_scales, lut_biases, K, ags, qdev_u4_per_row);
     return hipGetLastError();
 }
 
-hipError_t launch_qlut_ref_to_dev(const int8_t* qlut_ref, void* qlut_dev, int K, int N, size_t qdev_u4_per_row, hipStream_t st) {
-    hipLaunchKernelGGL(k_qlut_ref_to_dev, dim3((K / 4 + 255) / 256, N), dim3(256), 0, st, qlut_ref, (uint2*)qlut_dev, K, N, qdev_u4_per_row);
+hipError_t launch_qlut_ref_to_dev(const int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, int K, int N, size_t qdev_u4_per_row, hipStream_t st) {
+    hipLaunchKernelGGL(k_qlut_ref_to_dev, dim3((K / 4 + 255) / 256, N), dim3(256), 0, st, qlut_ref, (uint2*)qlut_dev, (uint2*)qlut_lds, K, N, qdev_u4_per_row);
     return hipGetLastError();
 }
 
 bool gemv_lo_supported(const Shape& s) {
-    if (s.bits < 1 || s.bits > 4) return false;
+    if (s.bits < 1 || s.bits > 4 || s.ts != TS) return false;
     if (s.K % (4 * TS) != 0) return false;
     if (s.m_groups >= 1 && s.ags == s.K) return s.Mw % s.m_groups == 0;          // SM 2
     if (s.ags != 32 && s.ags != 64) return false;

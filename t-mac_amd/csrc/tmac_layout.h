@@ -34,7 +34,7 @@
 
 namespace tmac {
 
-constexpr int TS = 16;  // tables per segment
+constexpr int TS = 16;  // tables per segment in the two-kernel ("LO") layout; the fused kernel uses ts = 8
 constexpr int KL = 16;  // segment lanes per wave
 constexpr int RL = 4;   // row-quad lanes per wave
 constexpr int NW = 4;   // waves per workgroup (each takes a different segment block)
@@ -47,17 +47,18 @@ struct Shape {
     int ags;          // act group size
     int zero_point;
     int m_groups;     // -1 or >= 1
+    int ts;           // tables per layout unit ("segment"): 16 (two-kernel path) or 8 (fused path)
     // derived
     TMAC_HD int M() const { return Mw * bits; }
-    TMAC_HD int nseg() const { return K / (4 * TS); }
+    TMAC_HD int nseg() const { return K / (4 * ts); }
     TMAC_HD int nsb() const { return (nseg() + KL - 1) / KL; }
     TMAC_HD int nb() const { return (Mw + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK; }
-    TMAC_HD int nj() const { return TS * bits / 8; }  // uint4 per (row quad, segment)
+    TMAC_HD int nj() const { return ts * bits / 8; }  // uint4 per (row quad, segment)
     TMAC_HD int ngroups() const { return K / ags; }
     TMAC_HD int nsg() const { return gs > 0 ? K / gs : 1; }
     TMAC_HD size_t weight_u4() const { return (size_t)nb() * nsb() * nj() * RL * KL; }
     TMAC_HD size_t scale_elems() const { return (size_t)nb() * nsg() * RL * 4 * (zero_point ? 2 : 1); }
-    TMAC_HD size_t qlut_dev_u4() const { return (size_t)nsb() * 8 * KL; }  // per activation row
+    TMAC_HD size_t qlut_dev_u4() const { return (size_t)((K / (4 * TS) + KL - 1) / KL) * 8 * KL; }  // per activation row (TS=16 layout)
 };
 
 // M-space row of (output row o, plane p)  — weights.py:65
@@ -86,7 +87,7 @@ TMAC_HD uint32_t retile_dword(const uint8_t* A_ref, const Shape& s, size_t u4, i
     uint32_t out = 0;
     for (int h = 0; h < 2; ++h) {
         const int q = 2 * d + h, tl = q / s.bits, p = q % s.bits;
-        const int t = seg * TS + tl;
+        const int t = seg * s.ts + tl;
         for (int beta = 0; beta < 4; ++beta) {
             const int o = 4 * rq + beta;
             if (o >= s.Mw) continue;

@@ -188,6 +188,36 @@ class TMACGeMMWrapper:
             out_dtype = _dtype_code(C_dev)
         check(B.lib().tmac_hip_qgemm_dev(weights.handle, self.workspace.handle, _ptr(C_dev), out_dtype, N, _stream(stream)))
 
+    def fused(self, weights_list, B_dev, C_list, N: int = 1, act_dtype: Optional[int] = None,
+              out_dtype: Optional[int] = None, stream=None) -> None:
+        """llama_cpp_init + llama_cpp_compute in ONE launch for up to 4 matrices that share the activation
+        rows B_dev (q/k/v, gate/up): tmac_hip_qgemm_fused_dev.  The LUT is built inside the kernel."""
+        n = len(weights_list)
+        if act_dtype is None:
+            act_dtype = _dtype_code(B_dev)
+        if out_dtype is None:
+            out_dtype = _dtype_code(C_list[0])
+        key = (tuple(id(w) for w in weights_list), tuple(_ptr(c) for c in C_list))
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        if key not in cache:   # the ctypes pointer arrays are reused across calls (cheap host path)
+            wa = (C.c_void_p * n)(*[w.handle.value for w in weights_list])
+            ca = (C.c_void_p * n)(*[_ptr(c) for c in C_list])
+            cache[key] = (wa, ca)
+        wa, ca = cache[key]
+        check(B.lib().tmac_hip_qgemm_fused_dev(wa, n, _ptr(B_dev), act_dtype, ca, out_dtype, N, _stream(stream)))
+
+    def fused_partial_sums(self, weights: Weights, B_dev, N: int = 1, act_dtype: Optional[int] = None, stream=None):
+        """Parity tap of the fused kernel: (int32 PS as partial_sums(), fp32 C [N][Mw])."""
+        if act_dtype is None:
+            act_dtype = _dtype_code(B_dev)
+        s_final = weights.cfg.m_groups >= 1 and weights.cfg.act_group_size == weights.K
+        G = 1 if s_final else weights.K // weights.cfg.act_group_size
+        ps = np.zeros((N, weights.Mw * weights.bits, G), np.int32)
+        c = np.zeros((N, weights.Mw), np.float32)
+        check(B.lib().tmac_hip_qgemm_fused_partial_sums(weights.handle, _ptr(B_dev), act_dtype, ps.ctypes.data,
+                                                        c.ctypes.data, N, _stream(stream)))
+        return ps, c
+
     def partial_sums(self, weights: Weights, N: int = 1, stream=None) -> np.ndarray:
         """Parity tap: int32 [N][M][K/ags] (or [N][M] for the unified-scale path), M-space row order."""
         s_final = weights.cfg.m_groups >= 1 and weights.cfg.act_group_size == weights.K

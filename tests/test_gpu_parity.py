@@ -126,7 +126,7 @@ def test_isa_models(tm):
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", CASES)
 def test_golden_vectors(tm, name, variant):
     """committed vectors produced by the reference itself (tests/golden/make_golden.py)"""
@@ -162,7 +162,7 @@ CFGS = [  # Mw, K, bits, bm, kf, gs, ags, zp, m_groups
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 @pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,mg", CFGS)
 def test_vs_oracle(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, variant):
     case = orc.make_case(Mw + K + bits, Mw, K, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg)
@@ -270,3 +270,64 @@ def test_host_pointer_cabi_matches_prebuilt_reference(tm, tmp_path):
     assert L.qgemm_lut_int8(96, K, 1, 2, A.ctypes.data, q.ctypes.data, S.ctypes.data, ls.ctypes.data, lb.ctypes.data,
                             c.ctypes.data) == -1          # unknown shape -> -1, as the reference dispatcher
     L.tmac_hip_cache_clear()
+
+
+FUSED_CFGS = [c for c in CFGS if (c[6] == 64 and c[8] == -1) or c[6] == c[1]]
+
+
+@pytest.mark.parametrize("act_f16", [False, True])
+@pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,mg", FUSED_CFGS)
+def test_fused_kernel_builds_the_same_lut(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, act_f16):
+    """tmac_hip_qgemm_fused_dev: LUT constructed inside the GEMV kernel.  The integer partial sums can only
+    be bit-exact if the in-kernel LUT (QLUT, and through C the scales/biases) equals the oracle's."""
+    import torch
+    case = orc.make_case(7 * Mw + K, Mw, K, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg, fp16_values=act_f16)
+    A = orc.preprocess_weights(case["w"], bits, bm, kf)
+    S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm) if mg == -1 else case["sc"]
+    cfg = tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, zp, mg)
+    wr = tm.TMACGeMMWrapper(act_group_size=ags)
+    wr.set_workspace(K, 1)
+    w = wr.register_weights(A, S, Mw, K, bits, cfg)
+    Bt = torch.from_numpy(case["B"]).cuda()
+    if act_f16:
+        Bt = Bt.half()
+    PS, Cf = wr.fused_partial_sums(w, Bt)
+    Ct = torch.empty((1, Mw), dtype=torch.float32, device="cuda")
+    wr.fused([w], Bt, [Ct])
+    torch.cuda.synchronize()
+    q, ls, lb, Cc, PSo = oracle_case(case, A, S, Mw, K, bits, bm, kf, gs, ags, zp, mg)
+    assert np.array_equal(PS, PSo)
+    assert rel_err(Cf, Cc) <= 2e-5
+    check_bits(Ct.cpu().numpy(), Cf)
+    w.free()
+
+
+def test_fused_multi_matrix_launch(tm):
+    """q/k/v-style: three matrices, one activation vector, one launch == three separate launches, bit for bit"""
+    import torch
+    K, bits, bm, kf, gs, ags = 4096, 2, 128, 16, 128, 64
+    rows = [256, 512, 128]
+    wr = tm.TMACGeMMWrapper(act_group_size=ags)
+    wr.set_workspace(K, 1)
+    Bv = orc.make_case(5, 64, K)["B"]
+    Bt = torch.from_numpy(Bv).cuda().half()
+    ws, refs = [], []
+    for i, Mw in enumerate(rows):
+        case = orc.make_case(100 + i, Mw, K, bits=bits)
+        A = orc.preprocess_weights(case["w"], bits, bm, kf)
+        S = orc.preprocess_scales(case["sc"], case["zr"], bits, bm)
+        w = wr.register_weights(A, S, Mw, K, bits, tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, True))
+        ws.append(w)
+        q, ls, lb = orc.preprocessor(Bt.float().cpu().numpy(), ags)
+        refs.append(orc.qgemm_float(A, q, S, ls, lb, Mw, K, 1, bits, bm, kf, gs, ags, True))
+    outs = [torch.empty((1, Mw), dtype=torch.float32, device="cuda") for Mw in rows]
+    wr.fused(ws, Bt, outs)
+    singles = [torch.empty((1, Mw), dtype=torch.float32, device="cuda") for Mw in rows]
+    for w, c in zip(ws, singles):
+        wr.fused([w], Bt, [c])
+    torch.cuda.synchronize()
+    for o, s1, ref in zip(outs, singles, refs):
+        check_bits(o.cpu().numpy(), s1.cpu().numpy())
+        assert rel_err(o.cpu().numpy(), ref) <= 2e-5
+    for w in ws:
+        w.free()

@@ -137,9 +137,10 @@ int32_t tmac_hip_workspace_write(tmac_hip_workspace* ws, const int8_t* qlut_host
  * reference's M-space (bit-plane) row order; for the unified-scale path [N][M] (K/ags == 1). */
 int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const tmac_hip_workspace* ws,
                                     int32_t* PS_host, int N, void* stream);
-/* integer tap of the fused kernel (one matrix): PS_host as above, optional fp32 C_host [N][Mw] */
+/* integer tap of the fused kernel (one matrix): PS_host as above, optional fp32 C_host [N][Mw], optional
+ * lut_host [N][2][K/ags] = the LUT scales then biases the kernel built in LDS */
 int32_t tmac_hip_qgemm_fused_partial_sums(const tmac_hip_weights* w, const void* B_dev, tmac_dtype_t act_dtype,
-                                          int32_t* PS_host, float* C_host, int N, void* stream);
+                                          int32_t* PS_host, float* C_host, float* lut_host, int N, void* stream);
 /* Runs v_perm_b32 / v_mqsad_pk_u16_u8 / lookup4 on n quadruples of host words (in[4n] -> out[4n]); the
  * test-suite compares the result with the host models of t-mac_amd/csrc/tmac_core.h. */
 int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host, int n);

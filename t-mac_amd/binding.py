@@ -76,7 +76,7 @@ def load_library() -> C.CDLL:
         "tmac_hip_preprocessor_dev": ([vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp], i32),
         "tmac_hip_qgemm_dev": ([vp, vp, vp, C.c_int, C.c_int, vp], i32),
         "tmac_hip_qgemm_fused_dev": ([C.POINTER(vp), C.c_int, vp, C.c_int, C.POINTER(vp), C.c_int, C.c_int, vp], i32),
-        "tmac_hip_qgemm_fused_partial_sums": ([vp, vp, C.c_int, vp, vp, C.c_int, vp], i32),
+        "tmac_hip_qgemm_fused_partial_sums": ([vp, vp, C.c_int, vp, vp, vp, C.c_int, vp], i32),
         "tmac_hip_workspace_ptrs": ([vp, C.POINTER(vp), C.POINTER(sz), C.POINTER(vp), C.POINTER(vp)], i32),
         "tmac_hip_workspace_read": ([vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp], i32),
         "tmac_hip_workspace_write": ([vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp], i32),

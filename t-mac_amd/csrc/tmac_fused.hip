@@ -45,20 +45,75 @@ __device__ __forceinline__ void st_out(void* C, int f16, size_t i, float v) {
     else reinterpret_cast<float*>(C)[i] = v;
 }
 
+// Cross-lane moves as DPP modifiers (no LDS round trip, unlike __shfl_xor -> ds_bpermute_b32).
+//   quad_perm [1,0,3,2] = 0xB1 (lane^1)   quad_perm [2,3,0,1] = 0x4E (lane^2)
+//   row_shl:n = 0x100+n (lane i reads lane i+n of its 16-lane row)   row_ror:n = 0x120+n
+//   row_half_mirror = 0x141 (i -> 7-i within 8)   row_mirror = 0x140 (i -> 15-i within 16)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+// max over the 16 lanes of a DPP row, result in every lane (max is commutative and idempotent)
+__device__ __forceinline__ float row_allmax(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+
+#define TMAC_STAMP(i) do { if (a.stamps && tid == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+
 constexpr int FT = 512;        // threads per workgroup
 constexpr int FW = FT / 64;    // waves
 constexpr int UPS = FW * KL;   // units per step (128)
 
 template <int BITS>
-struct WFrag { uint32_t wd[8 * BITS / 2]; };
+struct WFrag {
+    uint32_t wd[8 * BITS / 2];
+    uint32_t sraw[4];     // raw scale / zero-point words of this lane's two rows, fetched WITH the weights
+};                        // (converted at use: converting at load time would stall on the load)
 
-template <int BITS>
-__device__ __forceinline__ void load_w(WFrag<BITS>& f, const uint4* W, const Shape& s, int b, int ub, int rl, int ul) {
+// scale (which = 0) or zero point (which = 1) of row i (0/1) from the raw words
+template <bool ZP>
+__device__ __forceinline__ float frag_scale(const uint32_t (&sraw)[4], int f16, int i, int which) {
+    const int e = i * (ZP ? 2 : 1) + which;          // element index within the lane's 2*per values
+    if (f16) {
+        const uint32_t wv = sraw[e >> 1];
+        return __half2float(__ushort_as_half((unsigned short)((e & 1) ? (wv >> 16) : (wv & 0xffff))));
+    }
+    return __uint_as_float(sraw[e]);
+}
+
+// weights (non-temporal, 1 KiB per wave-instruction) + the lane's scale values for unit u
+template <int BITS, bool ZP, int SM>
+__device__ __forceinline__ void load_w(WFrag<BITS>& f, const FusedArgs& a, const FusedMat& M, int b, int ub, int u, int rl,
+                                       int ul) {
     constexpr int NJ = 8 * BITS / 8;
+    const uint4* wp = M.W + ((size_t)(b * a.nsb + ub) * NJ * RL + rl) * KL + ul;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(W + weight_u4_index(s, b, ub, j, rl, ul)));
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)j * RL * KL));
         f.wd[4 * j] = v.x; f.wd[4 * j + 1] = v.y; f.wd[4 * j + 2] = v.z; f.wd[4 * j + 3] = v.w;
+    }
+    if (SM == 0) {
+        constexpr int per = ZP ? 2 : 1;
+        const int sg = u >> a.gs_shift;                        // scale group = u*32 / gs
+        const size_t sidx = ((((size_t)b * a.nsg + sg) * RL + rl) * 4 + 2 * (ul & 1)) * per;
+        // 2*per consecutive elements: 4 B (f16) / 8 B (f16 zp, f32) / 16 B (f32 zp), naturally aligned
+        if (a.sc_f16) {
+            const uint32_t* p32 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const __half*>(M.SC) + sidx);
+            f.sraw[0] = p32[0];
+            if (ZP) f.sraw[1] = p32[1];
+        } else {
+            const uint32_t* p32 = reinterpret_cast<const uint32_t*>(M.SC) + sidx;
+#pragma unroll
+            for (int e = 0; e < 2 * per; ++e) f.sraw[e] = p32[e];
+        }
     }
 }
 
@@ -66,27 +121,27 @@ __device__ __forceinline__ void load_w(WFrag<BITS>& f, const uint4* W, const Sha
 template <int BITS, bool ZP, int SM, int LUTSRC, int NR>
 __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
     extern __shared__ uint4 lds[];
-    const Shape s = a.s;  // s.Mw is not meaningful here (per-matrix Mw in a.m[])
+    const Shape& s = a.s;  // s.Mw is not meaningful here (per-matrix Mw in a.m[])
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, rl = lane >> 4, ul = lane & 15;
     const int n = blockIdx.y;
-    const int T = s.K / 4, nu = s.K / 32, nu_pad = (nu + 15) & ~15, G = s.K / s.ags;
-    const int tstride = nu_pad + 1;
+    const int T = s.K / 4, nu = a.nu, G = a.G, tstride = a.tstride;   // host-precomputed: no integer divides here
     uint4* tab = lds;                                             // [4][tstride]
     float* l_ls = reinterpret_cast<float*>(lds + 4 * tstride);    // [G]   (SM2: [1])
     float* l_lb = l_ls + G;                                       // [G]
     float* l_red = l_lb + G;                                      // [FW][RL][4] floats / ints, then build scratch
-    float* l_scr = l_red + FW * RL * 4 * 4;                       // SM2 build: [FW] maxima + [T/8] chunk sums
+    float* l_scr = l_red + 2 * FW * RL * 4 * 4;                   // SM2 build: [FW] maxima + [T/8] chunk sums
 
-    // ---- which matrix / row block ---------------------------------------------------------------
-    int mi = 0;
+    TMAC_STAMP(0);
+    // ---- persistent row-block loop: global block gb = blockIdx.x + i*gridDim.x -> (matrix, local block) ----
+    const int total_nb = a.m[a.nmat - 1].nb_end;
+    const int nsteps = (nu + UPS - 1) / UPS;
+    auto locate = [&](int gb, int& mi, int& bl) {
+        mi = 0;
 #pragma unroll
-    for (int i = 1; i < 4; ++i)
-        if (i < a.nmat && (int)blockIdx.x >= a.m[i - 1].nb_end) mi = i;
-    const FusedMat& M = a.m[mi];
-    const int b = blockIdx.x - (mi ? a.m[mi - 1].nb_end : 0);
-    Shape sm = s;
-    sm.Mw = M.Mw;
-    const int rq = b * RL + rl;
+        for (int i = 1; i < 4; ++i)
+            if (i < a.nmat && gb >= a.m[i - 1].nb_end) mi = i;
+        bl = gb - (mi ? a.m[mi - 1].nb_end : 0);
+    };
 
     // ---- 1. activation loads for the LUT build (issued FIRST: vmcnt retires in order) -----------
     uint32_t xr[NR][4];
@@ -106,15 +161,22 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
         }
     }
 
-    // ---- 2. first weight fragments ------------------------------------------------------------
-    const int nsteps = (nu + UPS - 1) / UPS;
+    // ---- 2. first two weight fragments (items = (row block, step) pairs in execution order) -------
     WFrag<BITS> f0, f1;
-    {
-        const int u = w * KL + ul;
-        if (u < nu) load_w<BITS>(f0, M.W, sm, b, w, rl, ul);
-        if (UPS + u < nu) load_w<BITS>(f1, M.W, sm, b, FW + w, rl, ul);
-    }
+    int p_gb = blockIdx.x, p_step = 0;   // prefetch cursor
+    auto issue = [&](WFrag<BITS>& f) {
+        if (p_gb < total_nb) {
+            int mi, bl;
+            locate(p_gb, mi, bl);
+            const int u = p_step * UPS + w * KL + ul;
+            if (u < nu) load_w<BITS, ZP, SM>(f, a, a.m[mi], bl, p_step * FW + w, u, rl, ul);
+            if (++p_step == nsteps) { p_step = 0; p_gb += gridDim.x; }
+        }
+    };
+    issue(f0);
+    issue(f1);
 
+    TMAC_STAMP(1);
     // ---- 3. LUT into LDS ----------------------------------------------------------------------
     if (LUTSRC == 0) {
         const uint4* src = reinterpret_cast<const uint4*>(a.qlut_lds) + (size_t)n * 4 * tstride;
@@ -138,8 +200,9 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
                     mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x0), fabsf(x1)), __fadd_rn(fabsf(x2), fabsf(x3))));
                 }
             }
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+            mx = row_allmax(mx);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             if (lane == 0) l_scr[w] = mx;
             __syncthreads();
             mx = l_scr[0];
@@ -161,9 +224,7 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
                 float scales, t_scales;
                 if (SM == 2) { scales = gscale; t_scales = gtinv; }
                 else {
-                    float mx = __fadd_rn(__fadd_rn(fabsf(x0), fabsf(x1)), __fadd_rn(fabsf(x2), fabsf(x3)));
-#pragma unroll
-                    for (int m = 1; m < 16; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+                    const float mx = row_allmax(__fadd_rn(__fadd_rn(fabsf(x0), fabsf(x1)), __fadd_rn(fabsf(x2), fabsf(x3))));
                     scales = __fdiv_rn(mx, 127.0f);
                     t_scales = (scales != 0.0f) ? __fdiv_rn(1.0f, scales) : 0.0f;
                 }
@@ -184,14 +245,15 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
                 const int u = t >> 3, tl = t & 7;
                 reinterpret_cast<uint2*>(tab + (tl >> 1) * tstride + u)[tl & 1] = make_uint2(lo, hi);
                 // bias: chunk (8 tables) horizontal add in the reference order, then sequential over chunks
+                // (lut_ctor.cc:25-31): lane 8c gets ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)); row_shl:n reads lane i+n
                 float v = -L15;
-                v = __fadd_rn(v, __shfl_xor(v, 4, 64));
-                v = __fadd_rn(v, __shfl_xor(v, 2, 64));
-                v = __fadd_rn(v, __shfl_xor(v, 1, 64));
+                v = __fadd_rn(v, dpp_f<0x104>(v));
+                v = __fadd_rn(v, dpp_f<0x102>(v));
+                v = __fadd_rn(v, dpp_f<0x101>(v));
                 if (SM == 2) {
                     if ((t & 7) == 0) l_scr[FW + (t >> 3)] = v;
                 } else {
-                    const float c1 = __shfl_xor(v, 8, 64);
+                    const float c1 = dpp_f<0x108>(v);
                     if ((t & 15) == 0) {
                         l_ls[t >> 4] = scales;
                         l_lb[t >> 4] = __fadd_rn(__fadd_rn(0.0f, v), c1);
@@ -209,20 +271,28 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
             }
         }
     }
+    TMAC_STAMP(2);
     __syncthreads();
+    TMAC_STAMP(3);
+    if (a.lut_tap && blockIdx.x == 0) {   // parity tap: the LUT scales/biases this kernel built
+        for (int i = tid; i < (SM == 2 ? 1 : G); i += FT) { a.lut_tap[(size_t)n * 2 * G + i] = l_ls[i]; a.lut_tap[(size_t)n * 2 * G + G + i] = l_lb[i]; }
+    }
 
-    // ---- 4. lookups --------------------------------------------------------------------------
+    // ---- 4. lookups over this workgroup's row blocks ------------------------------------------
     float cacc[2][BITS];
     int32_t iacc[BITS][4];
+    auto reset_acc = [&]() {
 #pragma unroll
-    for (int pl = 0; pl < BITS; ++pl) {
-        cacc[0][pl] = 0.f; cacc[1][pl] = 0.f;
+        for (int pl = 0; pl < BITS; ++pl) {
+            cacc[0][pl] = 0.f; cacc[1][pl] = 0.f;
 #pragma unroll
-        for (int be = 0; be < 4; ++be) iacc[pl][be] = 0;
-    }
+            for (int be = 0; be < 4; ++be) iacc[pl][be] = 0;
+        }
+    };
+    reset_acc();
     const int beta0 = 2 * (ul & 1);
 
-    auto compute = [&](const WFrag<BITS>& f, int u) {
+    auto compute = [&](const WFrag<BITS>& f, int u, int Mw_m, int bl) {
         uint32_t tb[16];
 #pragma unroll
         for (int j4 = 0; j4 < 4; ++j4) {
@@ -241,108 +311,136 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
         }
         const int kk = u >> 1;
         const float ls = l_ls[kk], lb = l_lb[kk];
-        const int sg = (u * 32) / s.gs;
-        const size_t sidx = dev_scale_index(sm, b, sg, rl, beta0, 0);
-        const int per = ZP ? 2 : 1;
 #pragma unroll
         for (int pl = 0; pl < BITS; ++pl) {
             // the two halves of the act group live in lanes (ul, ul^1): packed u16 sums add without carry
             uint32_t lo = (uint32_t)acc.a[pl], hi = (uint32_t)(acc.a[pl] >> 32);
-            lo += __shfl_xor(lo, 1, 64);
-            hi += __shfl_xor(hi, 1, 64);
+            lo += dpp_u<0xB1>(lo);
+            hi += dpp_u<0xB1>(hi);
             const uint32_t mine = (ul & 1) ? hi : lo;   // rows beta0, beta0+1
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int32_t ps = 127 * 16 - (int32_t)((mine >> (16 * i)) & 0xffff);
                 if (a.dump) {
-                    const int o = 4 * rq + beta0 + i;
-                    if (o < M.Mw) a.dump[((size_t)n * M.Mw * BITS + mrow(o, pl, BITS)) * G + kk] = ps;
+                    const int o = 4 * (bl * RL + rl) + beta0 + i;
+                    if (o < Mw_m) a.dump[((size_t)n * Mw_m * BITS + mrow(o, pl, BITS)) * G + kk] = ps;
                 }
                 const float v = (pl == 0) ? __fmaf_rn((float)ps, ls, lb) : __fmul_rn((float)ps, ls);
-                float c = __fmaf_rn(v, ld_scale(M.SC, a.sc_f16, sidx + i * per), cacc[i][pl]);
-                if (ZP && pl == 0) c = __fmaf_rn(ld_scale(M.SC, a.sc_f16, sidx + i * per + 1), __fmul_rn(2.0f, lb), c);
+                float c = __fmaf_rn(v, frag_scale<ZP>(f.sraw, a.sc_f16, i, 0), cacc[i][pl]);
+                if (ZP && pl == 0) c = __fmaf_rn(frag_scale<ZP>(f.sraw, a.sc_f16, i, 1), __fmul_rn(2.0f, lb), c);
                 cacc[i][pl] = c;
             }
         }
     };
 
-    for (int i = 0; i < nsteps; i += 2) {
-        const int u0 = i * UPS + w * KL + ul;
-        if (u0 < nu) compute(f0, u0);
-        const int u2 = u0 + 2 * UPS;
-        if (u2 < nu) load_w<BITS>(f0, M.W, sm, b, (i + 2) * FW + w, rl, ul);
-        const int u1 = u0 + UPS;
-        if (u1 < nu) compute(f1, u1);
-        const int u3 = u1 + 2 * UPS;
-        if (u3 < nu) load_w<BITS>(f1, M.W, sm, b, (i + 3) * FW + w, rl, ul);
-    }
-
-    // ---- 5. reduce over unit lanes and waves, store ------------------------------------------
-    if (SM != 2) {
-        float part[2];
+    // reduce over unit lanes and waves, store 16 outputs; l_red is double-buffered by block parity so
+    // one barrier per row block suffices
+    int parity = 0;
+    auto finish_block = [&](const FusedMat& M, int bl) {
+        float* red = l_red + parity * (FW * RL * 4 * 4);
+        if (SM != 2) {
+            float part[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float acc = __fmul_rn(cacc[i][0], 0.5f);
+            for (int i = 0; i < 2; ++i) {
+                float acc = __fmul_rn(cacc[i][0], 0.5f);
 #pragma unroll
-            for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(cacc[i][pl], f_alpha(pl)));
-#pragma unroll
-            for (int m = 2; m < KL; m <<= 1) acc = __fadd_rn(acc, __shfl_xor(acc, m, 64));
-            part[i] = acc;
-        }
-        if (ul < 2) {
-            l_red[(w * RL + rl) * 4 + beta0] = part[0];
-            l_red[(w * RL + rl) * 4 + beta0 + 1] = part[1];
-        }
-        __syncthreads();
-        if (tid < RL * 4) {
-            const int o = b * 16 + tid;
-            float acc = l_red[tid];
-#pragma unroll
-            for (int ww = 1; ww < FW; ++ww) acc = __fadd_rn(acc, l_red[ww * RL * 4 + tid]);
-            if (o < M.Mw) st_out(M.C, a.out_f16, (size_t)n * M.Mw + o, acc);
-        }
-    } else {
-        int32_t* l_redi = reinterpret_cast<int32_t*>(l_red);
-#pragma unroll
-        for (int pl = 0; pl < BITS; ++pl)
-#pragma unroll
-            for (int be = 0; be < 4; ++be) {
-                int32_t v = iacc[pl][be];
-#pragma unroll
-                for (int m = 1; m < KL; m <<= 1) v += __shfl_xor(v, m, 64);
-                if (ul == 0) l_redi[((w * RL + rl) * 4 + pl) * 4 + be] = v;
+                for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(cacc[i][pl], f_alpha(pl)));
+                // sum over the 8 same-parity lanes of the row: lane^2, then rotate by 4 and by 8
+                acc = __fadd_rn(acc, dpp_f<0x4E>(acc));
+                acc = __fadd_rn(acc, dpp_f<0x124>(acc));
+                acc = __fadd_rn(acc, dpp_f<0x128>(acc));
+                part[i] = acc;
             }
-        __syncthreads();
-        if (tid < RL * 4) {
-            const int r = tid >> 2, be = tid & 3, o = b * 16 + tid;
-            if (o < M.Mw) {
-                float acc = 0.f;
+            if (ul < 2) {
+                red[(w * RL + rl) * 4 + beta0] = part[0];
+                red[(w * RL + rl) * 4 + beta0 + 1] = part[1];
+            }
+            __syncthreads();
+            if (tid < RL * 4) {
+                const int o = bl * 16 + tid;
+                float acc = red[tid];
 #pragma unroll
-                for (int pl = 0; pl < BITS; ++pl) {
-                    int32_t cb = 0;
+                for (int ww = 1; ww < FW; ++ww) acc = __fadd_rn(acc, red[ww * RL * 4 + tid]);
+                if (o < M.Mw) st_out(M.C, a.out_f16, (size_t)n * M.Mw + o, acc);
+            }
+        } else {
+            int32_t* redi = reinterpret_cast<int32_t*>(red);
 #pragma unroll
-                    for (int ww = 0; ww < FW; ++ww) cb += l_redi[((ww * RL + r) * 4 + pl) * 4 + be];
-                    if (a.dump) a.dump[(size_t)n * M.Mw * BITS + mrow(o, pl, BITS)] = cb;
-                    const float t = __fmul_rn((float)cb, f_alpha(pl));
-                    acc = (pl == 0) ? t : __fadd_rn(acc, t);
+            for (int pl = 0; pl < BITS; ++pl)
+#pragma unroll
+                for (int be = 0; be < 4; ++be) {
+                    int32_t v = iacc[pl][be];
+#pragma unroll
+                    for (int m = 1; m < KL; m <<= 1) v += __shfl_xor(v, m, 64);
+                    if (ul == 0) redi[((w * RL + rl) * 4 + pl) * 4 + be] = v;
                 }
-                const float v = __fadd_rn(__fmul_rn(acc, l_ls[0]), __fmul_rn(l_lb[0], 0.5f));
-                st_out(M.C, a.out_f16, (size_t)n * M.Mw + o, __fmul_rn(v, ld_scale(M.SC, a.sc_f16, o / (M.Mw / s.m_groups))));
+            __syncthreads();
+            if (tid < RL * 4) {
+                const int r = tid >> 2, be = tid & 3, o = bl * 16 + tid;
+                if (o < M.Mw) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int pl = 0; pl < BITS; ++pl) {
+                        int32_t cb = 0;
+#pragma unroll
+                        for (int ww = 0; ww < FW; ++ww) cb += redi[((ww * RL + r) * 4 + pl) * 4 + be];
+                        if (a.dump) a.dump[(size_t)n * M.Mw * BITS + mrow(o, pl, BITS)] = cb;
+                        const float t = __fmul_rn((float)cb, f_alpha(pl));
+                        acc = (pl == 0) ? t : __fadd_rn(acc, t);
+                    }
+                    const float v = __fadd_rn(__fmul_rn(acc, l_ls[0]), __fmul_rn(l_lb[0], 0.5f));
+                    st_out(M.C, a.out_f16, (size_t)n * M.Mw + o, __fmul_rn(v, ld_scale(M.SC, a.sc_f16, o / (M.Mw / s.m_groups))));
+                }
             }
         }
+        parity ^= 1;
+        reset_acc();
+    };
+
+    int c_gb = blockIdx.x, c_step = 0;   // compute cursor (uniform across the workgroup)
+    while (c_gb < total_nb) {
+        int mi, bl;
+        locate(c_gb, mi, bl);
+        {
+            const int u = c_step * UPS + w * KL + ul;
+            if (u < nu) compute(f0, u, a.m[mi].Mw, bl);
+            if (++c_step == nsteps) { finish_block(a.m[mi], bl); c_step = 0; c_gb += gridDim.x; }
+            issue(f0);
+        }
+        if (c_gb >= total_nb) break;
+        locate(c_gb, mi, bl);
+        {
+            const int u = c_step * UPS + w * KL + ul;
+            if (u < nu) compute(f1, u, a.m[mi].Mw, bl);
+            if (++c_step == nsteps) { finish_block(a.m[mi], bl); c_step = 0; c_gb += gridDim.x; }
+            issue(f1);
+        }
     }
+    TMAC_STAMP(4);
 }
 
 // ---------------------------------------------------------------------------------------------
 bool gemv_fused_supported(const Shape& s) {
     if (s.bits < 1 || s.bits > 4 || s.K % 64 != 0 || s.K > 16384) return false;
     if (s.m_groups >= 1) return s.ags == s.K && s.Mw % s.m_groups == 0;
-    return s.ags == 64 && s.gs >= 64 && s.gs % 64 == 0 && s.K % s.gs == 0;
+    const int gu = s.gs / 32;   // scale group in units; must be a power of two (shift instead of divide)
+    return s.ags == 64 && s.gs >= 64 && s.gs % 64 == 0 && s.K % s.gs == 0 && (gu & (gu - 1)) == 0;
+}
+
+void fused_precompute(FusedArgs& a) {
+    const Shape& s = a.s;
+    a.nu = s.K / 32;
+    a.nsb = (a.nu + KL - 1) / KL;
+    a.tstride = ((a.nu + 15) & ~15) + 1;
+    a.G = s.K / s.ags;
+    a.nsg = s.gs > 0 ? s.K / s.gs : 1;
+    a.gs_shift = 0;
+    if (s.gs > 0) for (int g = s.gs / 32; g > 1; g >>= 1) ++a.gs_shift;
 }
 
 size_t fused_lds_bytes(const Shape& s) {
     const int nu = s.K / 32, nu_pad = (nu + 15) & ~15, G = s.K / s.ags;
-    return (size_t)4 * (nu_pad + 1) * 16 + sizeof(float) * (2 * G + FW * RL * 4 * 4 + FW + s.K / 32);
+    return (size_t)4 * (nu_pad + 1) * 16 + sizeof(float) * (2 * G + 2 * FW * RL * 4 * 4 + FW + s.K / 32);
 }
 
 size_t qlut_lds_u4(int K) {
@@ -353,7 +451,8 @@ size_t qlut_lds_u4(int K) {
 template <int BITS, bool ZP, int SM, int LUTSRC>
 static hipError_t launch_nr(const FusedArgs& a, int total_nb, int N, hipStream_t st) {
     const size_t shmem = fused_lds_bytes(a.s);
-    dim3 g(total_nb, N), b(FT);
+    // persistent workgroups: at most 2 per CU (256 CUs); each builds the LUT once and walks its row blocks
+    dim3 g(total_nb < 512 ? total_nb : 512, N), b(FT);
     const int T = a.s.K / 4;
     if (LUTSRC == 0 || T <= 2 * FT) hipLaunchKernelGGL((k_gemv_fused<BITS, ZP, SM, LUTSRC, 2>), g, b, shmem, st, a);
     else if (T <= 6 * FT) hipLaunchKernelGGL((k_gemv_fused<BITS, ZP, SM, LUTSRC, 6>), g, b, shmem, st, a);
@@ -367,8 +466,10 @@ static hipError_t launch_b(const FusedArgs& a, int total_nb, int N, hipStream_t 
     return a.s.zero_point ? launch_nr<BITS, true, 0, LUTSRC>(a, total_nb, N, st) : launch_nr<BITS, false, 0, LUTSRC>(a, total_nb, N, st);
 }
 
-hipError_t launch_gemv_fused(const FusedArgs& a, int N, bool build_lut, hipStream_t st) {
-    if (!gemv_fused_supported(a.s) || a.nmat < 1 || a.nmat > 4) return hipErrorInvalidValue;
+hipError_t launch_gemv_fused(const FusedArgs& a_in, int N, bool build_lut, hipStream_t st) {
+    if (!gemv_fused_supported(a_in.s) || a_in.nmat < 1 || a_in.nmat > 4) return hipErrorInvalidValue;
+    FusedArgs a = a_in;
+    fused_precompute(a);
     const int total_nb = a.m[a.nmat - 1].nb_end;
 #define DISPATCH(B)                                                     \
     case B: return build_lut ? launch_b<B, 1>(a, total_nb, N, st) : launch_b<B, 0>(a, total_nb, N, st);

@@ -506,8 +506,10 @@ extern "C" int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const 
     return rc;
 }
 
+static unsigned long long* g_stamps = nullptr;   // debug: phase stamps of the next fused launches
+
 static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
-                          void* const* C_list, tmac_dtype_t out_dtype, int N, int32_t* dump, hipStream_t st) {
+                          void* const* C_list, tmac_dtype_t out_dtype, int N, int32_t* dump, float* lut_tap, hipStream_t st) {
     if (!wl || !C_list || !B_dev || nmat < 1 || nmat > 4 || N < 1) return fail(TMAC_HIP_E_ARG, "bad fused arguments (1..4 matrices)");
     FusedArgs fa;
     memset(&fa, 0, sizeof(fa));
@@ -527,6 +529,8 @@ static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const voi
     fa.s = wl[0]->s;
     fa.B = B_dev; fa.act_f16 = act_dtype == TMAC_F16;
     fa.sc_f16 = wl[0]->sc_dtype == F16; fa.out_f16 = out_dtype == TMAC_F16; fa.dump = dump;
+    fa.stamps = g_stamps;
+    fa.lut_tap = lut_tap;
     hipError_t e = launch_gemv_fused(fa, N, true, st);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no fused GEMV kernel for this configuration");
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "fused gemv launch: %s", hipGetErrorString(e));
@@ -536,27 +540,38 @@ static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const voi
 extern "C" int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weights, int nmat, const void* B_dev,
                                             tmac_dtype_t act_dtype, void* const* C_dev, tmac_dtype_t out_dtype, int N,
                                             void* stream) {
-    return fused_impl(weights, nmat, B_dev, act_dtype, C_dev, out_dtype, N, nullptr, (hipStream_t)stream);
+    return fused_impl(weights, nmat, B_dev, act_dtype, C_dev, out_dtype, N, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// debug/profiling: s_memtime phase stamps [nblocks][8] of the fused launches issued while enabled
+extern "C" int32_t tmac_hip_debug_stamps(unsigned long long* dev_buffer) {
+    g_stamps = dev_buffer;
+    return TMAC_HIP_OK;
 }
 
 extern "C" int32_t tmac_hip_qgemm_fused_partial_sums(const tmac_hip_weights* w, const void* B_dev, tmac_dtype_t act_dtype,
-                                                     int32_t* PS_host, float* C_host, int N, void* stream) {
+                                                     int32_t* PS_host, float* C_host, float* lut_host, int N, void* stream) {
     if (!w || !PS_host) return fail(TMAC_HIP_E_ARG, "null argument");
     hipStream_t st = (hipStream_t)stream;
     const size_t G = (w->s.m_groups >= 1 && w->s.ags == w->s.K) ? 1 : (size_t)w->s.ngroups();
     const size_t elems = (size_t)N * w->s.M() * G;
     int32_t* dump = nullptr;
     void* Ctmp = nullptr;
+    float* ltap = nullptr;
+    const size_t lt = (size_t)N * 2 * w->s.ngroups();
+    HIP_TRY(hipMalloc((void**)&ltap, lt * sizeof(float)));
     HIP_TRY(hipMalloc((void**)&dump, elems * sizeof(int32_t)));
     HIP_TRY(hipMalloc(&Ctmp, sizeof(float) * (size_t)N * w->s.Mw));
     HIP_TRY(hipMemsetAsync(dump, 0x7f, elems * sizeof(int32_t), st));
-    int32_t rc = fused_impl(&w, 1, B_dev, act_dtype, &Ctmp, TMAC_F32, N, dump, st);
+    int32_t rc = fused_impl(&w, 1, B_dev, act_dtype, &Ctmp, TMAC_F32, N, dump, ltap, st);
     if (rc == TMAC_HIP_OK) {
         hipError_t e = hipMemcpyAsync(PS_host, dump, elems * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess && C_host) e = hipMemcpyAsync(C_host, Ctmp, sizeof(float) * (size_t)N * w->s.Mw, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && lut_host) e = hipMemcpyAsync(lut_host, ltap, lt * sizeof(float), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(TMAC_HIP_E_RUNTIME, "fused tap readback: %s", hipGetErrorString(e));
     }
+    (void)hipFree(ltap);
     (void)hipFree(dump);
     (void)hipFree(Ctmp);
     return rc;

@@ -37,6 +37,9 @@ struct FusedArgs {
     const float* lut_biases;
     int sc_f16, out_f16;
     int32_t* dump;           // optional integer tap (nmat == 1)
+    unsigned long long* stamps; // optional s_memtime phase stamps [blocks][8] (debug/profiling)
+    float* lut_tap;          // optional: block 0 writes [N][2][G] LUT scales | biases it built (parity tap)
+    int nu, nsb, tstride, G, nsg, gs_shift;   // filled by launch_gemv_fused (host-side divides)
 };
 
 struct GemvArgs {

@@ -207,15 +207,18 @@ class TMACGeMMWrapper:
         check(B.lib().tmac_hip_qgemm_fused_dev(wa, n, _ptr(B_dev), act_dtype, ca, out_dtype, N, _stream(stream)))
 
     def fused_partial_sums(self, weights: Weights, B_dev, N: int = 1, act_dtype: Optional[int] = None, stream=None):
-        """Parity tap of the fused kernel: (int32 PS as partial_sums(), fp32 C [N][Mw])."""
+        """Parity tap of the fused kernel: (int32 PS as partial_sums(), fp32 C [N][Mw]); the in-kernel LUT
+        scales/biases are left in ``self.last_fused_lut``."""
         if act_dtype is None:
             act_dtype = _dtype_code(B_dev)
         s_final = weights.cfg.m_groups >= 1 and weights.cfg.act_group_size == weights.K
         G = 1 if s_final else weights.K // weights.cfg.act_group_size
         ps = np.zeros((N, weights.Mw * weights.bits, G), np.int32)
         c = np.zeros((N, weights.Mw), np.float32)
+        lut = np.zeros((N, 2, weights.K // weights.cfg.act_group_size), np.float32)
         check(B.lib().tmac_hip_qgemm_fused_partial_sums(weights.handle, _ptr(B_dev), act_dtype, ps.ctypes.data,
-                                                        c.ctypes.data, N, _stream(stream)))
+                                                        c.ctypes.data, lut.ctypes.data, N, _stream(stream)))
+        self.last_fused_lut = lut   # [N][0] = LUT scales, [N][1] = LUT biases built inside the kernel
         return ps, c
 
     def partial_sums(self, weights: Weights, N: int = 1, stream=None) -> np.ndarray:

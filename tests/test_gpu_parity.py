@@ -297,6 +297,8 @@ def test_fused_kernel_builds_the_same_lut(tm, Mw, K, bits, bm, kf, gs, ags, zp, 
     torch.cuda.synchronize()
     q, ls, lb, Cc, PSo = oracle_case(case, A, S, Mw, K, bits, bm, kf, gs, ags, zp, mg)
     assert np.array_equal(PS, PSo)
+    check_bits(wr.last_fused_lut[:, 0, :], ls)        # LUT scales built in LDS, bit for bit
+    check_bits(wr.last_fused_lut[:, 1, :], lb)        # LUT biases (the reference's horizontal-add order)
     assert rel_err(Cf, Cc) <= 2e-5
     check_bits(Ct.cpu().numpy(), Cf)
     w.free()

@@ -144,8 +144,11 @@ int32_t tmac_hip_qgemm_fused_partial_sums(const tmac_hip_weights* w, const void*
 /* Runs v_perm_b32 / v_mqsad_pk_u16_u8 / lookup4 on n quadruples of host words (in[4n] -> out[4n]); the
  * test-suite compares the result with the host models of t-mac_amd/csrc/tmac_core.h. */
 int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host, int n);
+/* one wave of v_mfma_i32_16x16x64_i8: in[64][8] (A regs 0-3, B regs 4-7 per lane) -> out[64][4] (D regs) */
+int32_t tmac_hip_selftest_mfma(const uint32_t* in_host, int32_t* out_host);
 /* Select the GEMV kernel variant: 0 auto (fused layout where supported), 1/2 two-kernel tiled path
- * (mqsad / byte-add accumulate), 3 generic reference-layout kernel, 4 fused.  Affects weights
+ * (mqsad / byte-add accumulate), 3 generic reference-layout kernel, 4 fused (v_mqsad accumulate),
+ * 5 fused with the MFMA accumulate.  Affects weights
  * registered AFTER the call (the variant fixes their device layout).  For A/B benchmarking and tests. */
 int32_t tmac_hip_set_variant(int variant);
 

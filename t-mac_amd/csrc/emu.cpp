@@ -84,14 +84,75 @@ static void run8(const std::vector<uint32_t>& W, const std::vector<uint32_t>& QL
                 }
 }
 
+// fused-layout kernel with the MFMA accumulate (ACC = 1): whole-wave emulation with the operand model of
+// v_mfma_i32_16x16x64_i8 that tools/mfma_probe.py checks against the hardware:
+//   D[i][j] = sum_g sum_{16 bytes} A[lane 16g+i] . B[lane 16g+j];  D[i][j] lives in lane j + 16*(i/4), reg i%4
+template <int BITS>
+static void run8_mfma(const std::vector<uint32_t>& W, const std::vector<uint32_t>& QS, const Shape& s, int32_t* PS) {
+    constexpr int NJ = 8 * BITS / 8;
+    const int nu = s.K / 32, tstride = ((nu + 15) & ~15) + 1, G = s.K / s.ags;
+    uint32_t bsel[64][4];
+    for (int lane = 0; lane < 64; ++lane) {
+        const int jrel = (lane & 15) - 4 * (lane >> 4);
+        const uint32_t be = (jrel >= 0 && jrel < 4) ? (0x01u << (8 * jrel)) : 0u, bo = (jrel >= 0 && jrel < 4) ? (0xffu << (8 * jrel)) : 0u;
+        bsel[lane][0] = be; bsel[lane][1] = bo; bsel[lane][2] = be; bsel[lane][3] = bo;
+    }
+    for (int b = 0; b < s.nb(); ++b)
+        for (int ub = 0; ub < s.nsb(); ++ub) {          // one wave-step: 16 units x 4 row quads
+            int32_t c[BITS][64][4] = {};
+            for (int tp = 0; tp < 4; ++tp)
+                for (int pl = 0; pl < BITS; ++pl) {
+                    uint32_t A[64][4];
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int rl = lane >> 4, ul = lane & 15, u = ub * KL + ul;
+                        uint32_t wd[8 * BITS / 2] = {}, tb[16] = {};
+                        if (u < nu) {
+                            for (int j = 0; j < NJ; ++j)
+                                for (int e = 0; e < 4; ++e) wd[4 * j + e] = W[weight_u4_index(s, b, ub, j, rl, ul) * 4 + e];
+                            for (int j4 = 0; j4 < 4; ++j4)
+                                for (int e = 0; e < 4; ++e) tb[4 * j4 + e] = QS[((size_t)j4 * tstride + u) * 4 + e];
+                        }
+                        const int qa = (2 * tp) * BITS + pl, qb = (2 * tp + 1) * BITS + pl;
+                        if (qa & 1) lookup4_pm<1>(wd[qa >> 1], tb[4 * tp], tb[4 * tp + 1], A[lane][0], A[lane][1]);
+                        else lookup4_pm<0>(wd[qa >> 1], tb[4 * tp], tb[4 * tp + 1], A[lane][0], A[lane][1]);
+                        if (qb & 1) lookup4_pm<1>(wd[qb >> 1], tb[4 * tp + 2], tb[4 * tp + 3], A[lane][2], A[lane][3]);
+                        else lookup4_pm<0>(wd[qb >> 1], tb[4 * tp + 2], tb[4 * tp + 3], A[lane][2], A[lane][3]);
+                    }
+                    for (int i = 0; i < 16; ++i)
+                        for (int j = 0; j < 16; ++j) {
+                            int32_t acc = 0;
+                            for (int g = 0; g < 4; ++g)
+                                for (int q = 0; q < 4; ++q)
+                                    for (int be = 0; be < 4; ++be)
+                                        acc += (int32_t)(int8_t)(A[16 * g + i][q] >> (8 * be)) * (int32_t)(int8_t)(bsel[16 * g + j][q] >> (8 * be));
+                            c[pl][j + 16 * (i / 4)][i % 4] += acc;
+                        }
+                }
+            for (int lane = 0; lane < 64; ++lane) {
+                const int lg = lane >> 4, rlp = (lane & 15) >> 2, bp = lane & 3, ub4 = ub * KL + 4 * lg;
+                const int o = 4 * (b * RL + rlp) + bp;
+                if (o >= s.Mw) continue;
+                for (int gi = 0; gi < 2; ++gi) {
+                    const int ug = ub4 + 2 * gi;
+                    if (ug >= nu) continue;
+                    for (int pl = 0; pl < BITS; ++pl) {
+                        const int32_t ps = c[pl][lane][2 * gi] + c[pl][lane][2 * gi + 1];
+                        if (s.ags == s.K) PS[mrow(o, pl, BITS)] += ps;
+                        else PS[(size_t)mrow(o, pl, BITS) * G + ug / 2] = ps;
+                    }
+                }
+            }
+        }
+}
+
 extern "C" int emu_partial_sums(const uint8_t* A_ref, const int8_t* qlut_ref, int Mw, int K, int bits, int bm,
                                 int kfactor, int ags, int mode, int32_t* PS) {
     Shape s;
     memset(&s, 0, sizeof(s));
     s.Mw = Mw; s.K = K; s.bits = bits; s.bm = bm; s.kfactor = kfactor; s.gs = 128; s.ags = ags; s.m_groups = -1;
-    s.ts = (mode == 2) ? 8 : 16;     // mode 2 = fused-layout kernel
+    s.ts = (mode >= 2) ? 8 : 16;     // mode 2 = fused-layout kernel (mqsad), 3 = fused-layout kernel (MFMA accumulate)
     if (K % 64 || (ags != 32 && ags != 64 && ags != K)) return -1;
-    if (mode == 2 && ags == 32) return -1;
+    if (mode >= 2 && ags == 32) return -1;
     std::vector<uint32_t> W(s.weight_u4() * 4);
     for (size_t i = 0; i < W.size(); ++i) W[i] = retile_dword(A_ref, s, i >> 2, (int)(i & 3));
     std::vector<uint32_t> QL(s.qlut_dev_u4() * 4, 0x80808080u);
@@ -107,6 +168,27 @@ extern "C" int emu_partial_sums(const uint8_t* A_ref, const int8_t* qlut_ref, in
     }
     const size_t n = (size_t)Mw * bits * (ags == K ? 1 : K / ags);
     memset(PS, 0, n * sizeof(int32_t));
+    if (mode == 3) {
+        const int nu = K / 32, tstride = ((nu + 15) & ~15) + 1;
+        std::vector<uint32_t> QS((size_t)4 * tstride * 4, 0u);   // signed half tables
+        for (int t = 0; t < K / 4; ++t) {
+            uint32_t lo = 0, hi = 0;
+            for (int i = 0; i < 4; ++i) {
+                lo |= (uint32_t)(uint8_t)qlut_ref[t * 16 + i] << (8 * i);
+                hi |= (uint32_t)(uint8_t)qlut_ref[t * 16 + 4 + i] << (8 * i);
+            }
+            const size_t u2 = ((size_t)((t & 7) >> 1) * tstride + (t >> 3)) * 2 + (t & 1);
+            QS[u2 * 2] = lo; QS[u2 * 2 + 1] = hi;
+        }
+        switch (bits) {
+            case 1: run8_mfma<1>(W, QS, s, PS); break;
+            case 2: run8_mfma<2>(W, QS, s, PS); break;
+            case 3: run8_mfma<3>(W, QS, s, PS); break;
+            case 4: run8_mfma<4>(W, QS, s, PS); break;
+            default: return -1;
+        }
+        return 0;
+    }
     if (mode == 2) {
         const int nu = K / 32, tstride = ((nu + 15) & ~15) + 1;
         std::vector<uint32_t> QLDS((size_t)4 * tstride * 4, 0x80808080u);

@@ -72,6 +72,20 @@ TMAC_HD uint32_t lookup4(uint32_t w, uint32_t tab_lo, uint32_t tab_hi) {
     return perm_b32(rN, rP, sel3);
 }
 
+// MFMA-accumulate flavour (signed tables, no bias): the sign bit routes each looked-up byte either to
+// the "plus" word or to the "minus" word (the other gets 0), and v_mfma_i32_16x16x64_i8 against a
+// constant +1/-1 selector matrix adds plus - minus of 2 tables x 4 rows per lane in one instruction on
+// the matrix pipe (see k_gemv_fused, ACC = 1).  tab = {Q[0..3], Q[4..7]} as signed bytes.
+template <int H>
+TMAC_HD void lookup4_pm(uint32_t w, uint32_t tab_lo, uint32_t tab_hi, uint32_t& plus, uint32_t& minus) {
+    const uint32_t x = H ? (w >> 4) : w;
+    const uint32_t sel = x & 0x07070707u;
+    const uint32_t rP = perm_b32(tab_hi, tab_lo, sel);
+    const uint32_t sel3 = ((x >> 1) & 0x04040404u) | 0x03020100u;   // byte beta: beta (keep) or 4+beta (negate)
+    plus = perm_b32(0u, rP, sel3);    // selectors 0-3 -> rP, 4-7 -> 0
+    minus = perm_b32(rP, 0u, sel3);   // selectors 0-3 -> 0,  4-7 -> rP
+}
+
 // Accumulators for one (row quad, act group): per bit-plane, four row sums.
 //   MODE 0: one packed-u16 quad per plane, fed by v_mqsad_pk_u16_u8 (1 instruction / 4 lookups)
 //   MODE 1: four int32 per plane, fed by byte-select adds (v_add_u32_sdwa, 4 instructions)

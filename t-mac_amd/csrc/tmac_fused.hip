@@ -90,17 +90,42 @@ __device__ __forceinline__ float frag_scale(const uint32_t (&sraw)[4], int f16, 
 }
 
 // weights (non-temporal, 1 KiB per wave-instruction) + the lane's scale values for unit u
-template <int BITS, bool ZP, int SM>
+template <int BITS, bool ZP, int SM, int ACC>
 __device__ __forceinline__ void load_w(WFrag<BITS>& f, const FusedArgs& a, const FusedMat& M, int b, int ub, int u, int rl,
                                        int ul) {
     constexpr int NJ = 8 * BITS / 8;
-    const uint4* wp = M.W + ((size_t)(b * a.nsb + ub) * NJ * RL + rl) * KL + ul;
+    const bool src_valid = u < a.nu;     // ragged last step: lanes past K load no weights
+    if (src_valid) {
+        const uint4* wp = M.W + ((size_t)(b * a.nsb + ub) * NJ * RL + rl) * KL + ul;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)j * RL * KL));
-        f.wd[4 * j] = v.x; f.wd[4 * j + 1] = v.y; f.wd[4 * j + 2] = v.z; f.wd[4 * j + 3] = v.w;
+        for (int j = 0; j < NJ; ++j) {
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (size_t)j * RL * KL));
+            f.wd[4 * j] = v.x; f.wd[4 * j + 1] = v.y; f.wd[4 * j + 2] = v.z; f.wd[4 * j + 3] = v.w;
+        }
     }
-    if (SM == 0) {
+    if (SM == 0 && ACC == 1) {
+        // epilogue lane l' = 16*lg + 4*rlp + bp owns row (rlp, bp) and units ub*16 + 4*lg .. +3 (2 act groups)
+        constexpr int per = ZP ? 2 : 1;
+        const int lane = rl * KL + ul, lg = lane >> 4, rlp = (lane & 15) >> 2, bp = lane & 3;
+        const int ub4 = ub * KL + 4 * lg;
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            if (gi == 1 && a.gs_shift >= 2) break;               // gs >= 128: both act groups share the scale group
+            const int sg = (ub4 + 2 * gi) >> a.gs_shift;
+            if (ub4 + 2 * gi < a.nu) {
+                const size_t sidx = ((((size_t)b * a.nsg + sg) * RL + rlp) * 4 + bp) * per;
+                if (a.sc_f16) {
+                    const __half* ph = reinterpret_cast<const __half*>(M.SC) + sidx;
+                    if (ZP) f.sraw[gi] = *reinterpret_cast<const uint32_t*>(ph);
+                    else f.sraw[gi] = *reinterpret_cast<const unsigned short*>(ph);
+                } else {
+                    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(M.SC) + sidx;
+                    f.sraw[2 * gi] = p32[0];
+                    if (ZP) f.sraw[2 * gi + 1] = p32[1];
+                }
+            }
+        }
+    } else if (SM == 0 && src_valid) {
         constexpr int per = ZP ? 2 : 1;
         const int sg = u >> a.gs_shift;                        // scale group = u*32 / gs
         const size_t sidx = ((((size_t)b * a.nsg + sg) * RL + rl) * 4 + 2 * (ul & 1)) * per;
@@ -118,7 +143,17 @@ __device__ __forceinline__ void load_w(WFrag<BITS>& f, const FusedArgs& a, const
 }
 
 // SM 0: per-(row, group) scales (+ zero points), act group 64.   SM 2: unified scale applied last (ags == K).
-template <int BITS, bool ZP, int SM, int LUTSRC, int NR>
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+// ACC 0: v_mqsad_pk_u16_u8 accumulate on the VALU (biased tables).
+// ACC 1: v_mfma_i32_16x16x64_i8 accumulate on the matrix pipe (signed tables): each lane's 4 operand
+//        registers {plus(ta), minus(ta), plus(tb), minus(tb)} x 4 row bytes are summed, per lane and row
+//        byte, against the constant selector B[(g,q,beta)][j] = (q even ? +1 : -1) * [j == 4g+beta]; the
+//        result C[unit lane][4*row quad + beta] lands transposed: lane l' = 16*(unit/4) + 4*rl + beta holds,
+//        in its 4 accumulator registers, ONE output row and FOUR consecutive units (= 2 act groups, one
+//        128-wide scale group), which is exactly what the fp32 epilogue wants.  VALU cost per 4 lookups
+//        drops from ~37 to ~23 cycles (measured rates: v_perm_b32 4.8, v_mqsad 17.5, simple VALU 2.8 cycles).
+template <int BITS, bool ZP, int SM, int LUTSRC, int NR, int ACC>
 __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
     extern __shared__ uint4 lds[];
     const Shape& s = a.s;  // s.Mw is not meaningful here (per-matrix Mw in a.m[])
@@ -169,7 +204,7 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
             int mi, bl;
             locate(p_gb, mi, bl);
             const int u = p_step * UPS + w * KL + ul;
-            if (u < nu) load_w<BITS, ZP, SM>(f, a, a.m[mi], bl, p_step * FW + w, u, rl, ul);
+            if (p_step * UPS + w * KL < nu) load_w<BITS, ZP, SM, ACC>(f, a, a.m[mi], bl, p_step * FW + w, u, rl, ul);
             if (++p_step == nsteps) { p_step = 0; p_gb += gridDim.x; }
         }
     };
@@ -180,7 +215,11 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
     // ---- 3. LUT into LDS ----------------------------------------------------------------------
     if (LUTSRC == 0) {
         const uint4* src = reinterpret_cast<const uint4*>(a.qlut_lds) + (size_t)n * 4 * tstride;
-        for (int i = tid; i < 4 * tstride; i += FT) tab[i] = src[i];
+        for (int i = tid; i < 4 * tstride; i += FT) {
+            uint4 v = src[i];
+            if (ACC == 1) { v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u; }  // biased -> signed
+            tab[i] = v;
+        }
         if (SM == 2) { if (tid == 0) { l_ls[0] = a.lut_scales[n]; l_lb[0] = a.lut_biases[n]; } }
         else for (int i = tid; i < G; i += FT) { l_ls[i] = a.lut_scales[(size_t)n * G + i]; l_lb[i] = a.lut_biases[(size_t)n * G + i]; }
     } else {
@@ -242,6 +281,7 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
                     lo |= (uint32_t)(max(f_rne_sat_int8(__fmul_rn(e[i], t_scales)), -127) + 128) << (8 * i);
                     hi |= (uint32_t)(max(f_rne_sat_int8(__fmul_rn(e[4 + i], t_scales)), -127) + 128) << (8 * i);
                 }
+                if (ACC == 1) { lo ^= 0x80808080u; hi ^= 0x80808080u; }   // signed entries for the MFMA path
                 const int u = t >> 3, tl = t & 7;
                 reinterpret_cast<uint2*>(tab + (tl >> 1) * tstride + u)[tl & 1] = make_uint2(lo, hi);
                 // bias: chunk (8 tables) horizontal add in the reference order, then sequential over chunks
@@ -333,12 +373,93 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
         }
     };
 
+    // ---- ACC == 1: matrix-pipe accumulate --------------------------------------------------------
+    const int lg = lane >> 4, rlp = (lane & 15) >> 2, bp = lane & 3;   // epilogue role of this lane (see ACC note)
+    v4i_t bsel;
+    {
+        const int jrel = (lane & 15) - 4 * (lane >> 4);                 // selector column of this lane as B operand
+        const uint32_t be = (jrel >= 0 && jrel < 4) ? (0x01u << (8 * jrel)) : 0u;
+        const uint32_t bo = (jrel >= 0 && jrel < 4) ? (0xffu << (8 * jrel)) : 0u;
+        bsel = (v4i_t){(int)be, (int)bo, (int)be, (int)bo};
+    }
+    auto compute_mfma = [&](const WFrag<BITS>& f, int step, int Mw_m, int bl) {
+        const int u = step * UPS + w * KL + ul;                         // this lane's unit as a SOURCE of lookups
+        uint32_t tb[16];
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+            uint4 v = make_uint4(0, 0, 0, 0);                           // units past K contribute zero tables
+            if (u < nu) v = tab[j4 * tstride + u];
+            tb[4 * j4] = v.x; tb[4 * j4 + 1] = v.y; tb[4 * j4 + 2] = v.z; tb[4 * j4 + 3] = v.w;
+        }
+        v4i_t c[BITS];
+#pragma unroll
+        for (int pl = 0; pl < BITS; ++pl) c[pl] = (v4i_t){0, 0, 0, 0};
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+            for (int pl = 0; pl < BITS; ++pl) {
+                uint32_t pa, ma, pb, mb;
+                const int qa = (2 * tp) * BITS + pl, qb = (2 * tp + 1) * BITS + pl;   // nibble quads of tables 2tp, 2tp+1
+                if (qa & 1) lookup4_pm<1>(f.wd[qa >> 1], tb[4 * tp], tb[4 * tp + 1], pa, ma);
+                else lookup4_pm<0>(f.wd[qa >> 1], tb[4 * tp], tb[4 * tp + 1], pa, ma);
+                if (qb & 1) lookup4_pm<1>(f.wd[qb >> 1], tb[4 * tp + 2], tb[4 * tp + 3], pb, mb);
+                else lookup4_pm<0>(f.wd[qb >> 1], tb[4 * tp + 2], tb[4 * tp + 3], pb, mb);
+                c[pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8((v4i_t){(int)pa, (int)ma, (int)pb, (int)mb}, bsel, c[pl], 0, 0, 0);
+            }
+        }
+        // epilogue: this lane now holds, for output row (rlp, bp), the sums of units ub4 .. ub4+3
+        const int ub4 = step * UPS + w * KL + 4 * lg;
+        const int o = 4 * (bl * RL + rlp) + bp;
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int ug = ub4 + 2 * gi;
+            if (ug < nu) {
+                const int kk = ug >> 1;
+                const float ls = l_ls[kk], lb = l_lb[kk];
+                const int si = (a.gs_shift >= 2) ? 0 : gi;              // which prefetched scale group
+                float sc, zr = 0.f;
+                if (a.sc_f16) {
+                    const uint32_t wv = f.sraw[si];
+                    sc = __half2float(__ushort_as_half((unsigned short)(wv & 0xffff)));
+                    if (ZP) zr = __half2float(__ushort_as_half((unsigned short)(wv >> 16)));
+                } else {
+                    sc = __uint_as_float(f.sraw[2 * si]);
+                    if (ZP) zr = __uint_as_float(f.sraw[2 * si + 1]);
+                }
+#pragma unroll
+                for (int pl = 0; pl < BITS; ++pl) {
+                    const int32_t ps = (gi == 0) ? (c[pl].x + c[pl].y) : (c[pl].z + c[pl].w);   // two 8-table halves
+                    if (a.dump && o < Mw_m) a.dump[((size_t)n * Mw_m * BITS + mrow(o, pl, BITS)) * G + kk] = ps;
+                    const float v = (pl == 0) ? __fmaf_rn((float)ps, ls, lb) : __fmul_rn((float)ps, ls);
+                    float cc = __fmaf_rn(v, sc, cacc[0][pl]);
+                    if (ZP && pl == 0) cc = __fmaf_rn(zr, __fmul_rn(2.0f, lb), cc);
+                    cacc[0][pl] = cc;
+                }
+            }
+        }
+    };
+
     // reduce over unit lanes and waves, store 16 outputs; l_red is double-buffered by block parity so
     // one barrier per row block suffices
     int parity = 0;
     auto finish_block = [&](const FusedMat& M, int bl) {
         float* red = l_red + parity * (FW * RL * 4 * 4);
-        if (SM != 2) {
+        if (ACC == 1 && SM != 2) {
+            float acc = __fmul_rn(cacc[0][0], 0.5f);
+#pragma unroll
+            for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(cacc[0][pl], f_alpha(pl)));
+            acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));   // the 4 lane groups hold different unit quads of the row
+            acc = __fadd_rn(acc, __shfl_xor(acc, 32, 64));
+            if (lane < 16) red[w * 16 + lane] = acc;         // lane = 4*rlp + bp = row within the block
+            __syncthreads();
+            if (tid < RL * 4) {
+                const int o = bl * 16 + tid;
+                float t = red[tid];
+#pragma unroll
+                for (int ww = 1; ww < FW; ++ww) t = __fadd_rn(t, red[ww * 16 + tid]);
+                if (o < M.Mw) st_out(M.C, a.out_f16, (size_t)n * M.Mw + o, t);
+            }
+        } else if (SM != 2) {
             float part[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -403,7 +524,8 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
         locate(c_gb, mi, bl);
         {
             const int u = c_step * UPS + w * KL + ul;
-            if (u < nu) compute(f0, u, a.m[mi].Mw, bl);
+            if (ACC == 1 && SM != 2) { if (c_step * UPS + w * KL < nu) compute_mfma(f0, c_step, a.m[mi].Mw, bl); }
+            else if (u < nu) compute(f0, u, a.m[mi].Mw, bl);
             if (++c_step == nsteps) { finish_block(a.m[mi], bl); c_step = 0; c_gb += gridDim.x; }
             issue(f0);
         }
@@ -411,7 +533,8 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
         locate(c_gb, mi, bl);
         {
             const int u = c_step * UPS + w * KL + ul;
-            if (u < nu) compute(f1, u, a.m[mi].Mw, bl);
+            if (ACC == 1 && SM != 2) { if (c_step * UPS + w * KL < nu) compute_mfma(f1, c_step, a.m[mi].Mw, bl); }
+            else if (u < nu) compute(f1, u, a.m[mi].Mw, bl);
             if (++c_step == nsteps) { finish_block(a.m[mi], bl); c_step = 0; c_gb += gridDim.x; }
             issue(f1);
         }
@@ -448,22 +571,24 @@ size_t qlut_lds_u4(int K) {
     return (size_t)4 * (nu_pad + 1);
 }
 
-template <int BITS, bool ZP, int SM, int LUTSRC>
+template <int BITS, bool ZP, int SM, int LUTSRC, int ACC>
 static hipError_t launch_nr(const FusedArgs& a, int total_nb, int N, hipStream_t st) {
     const size_t shmem = fused_lds_bytes(a.s);
     // persistent workgroups: at most 2 per CU (256 CUs); each builds the LUT once and walks its row blocks
     dim3 g(total_nb < 512 ? total_nb : 512, N), b(FT);
     const int T = a.s.K / 4;
-    if (LUTSRC == 0 || T <= 2 * FT) hipLaunchKernelGGL((k_gemv_fused<BITS, ZP, SM, LUTSRC, 2>), g, b, shmem, st, a);
-    else if (T <= 6 * FT) hipLaunchKernelGGL((k_gemv_fused<BITS, ZP, SM, LUTSRC, 6>), g, b, shmem, st, a);
-    else hipLaunchKernelGGL((k_gemv_fused<BITS, ZP, SM, LUTSRC, 8>), g, b, shmem, st, a);
+    if (LUTSRC == 0 || T <= 2 * FT) hipLaunchKernelGGL((k_gemv_fused<BITS, ZP, SM, LUTSRC, 2, ACC>), g, b, shmem, st, a);
+    else if (T <= 6 * FT) hipLaunchKernelGGL((k_gemv_fused<BITS, ZP, SM, LUTSRC, 6, ACC>), g, b, shmem, st, a);
+    else hipLaunchKernelGGL((k_gemv_fused<BITS, ZP, SM, LUTSRC, 8, ACC>), g, b, shmem, st, a);
     return hipGetLastError();
 }
 
 template <int BITS, int LUTSRC>
 static hipError_t launch_b(const FusedArgs& a, int total_nb, int N, hipStream_t st) {
-    if (a.s.m_groups >= 1) return launch_nr<BITS, false, 2, LUTSRC>(a, total_nb, N, st);
-    return a.s.zero_point ? launch_nr<BITS, true, 0, LUTSRC>(a, total_nb, N, st) : launch_nr<BITS, false, 0, LUTSRC>(a, total_nb, N, st);
+    if (a.s.m_groups >= 1) return launch_nr<BITS, false, 2, LUTSRC, 0>(a, total_nb, N, st);
+    if (a.acc_mfma)
+        return a.s.zero_point ? launch_nr<BITS, true, 0, LUTSRC, 1>(a, total_nb, N, st) : launch_nr<BITS, false, 0, LUTSRC, 1>(a, total_nb, N, st);
+    return a.s.zero_point ? launch_nr<BITS, true, 0, LUTSRC, 0>(a, total_nb, N, st) : launch_nr<BITS, false, 0, LUTSRC, 0>(a, total_nb, N, st);
 }
 
 hipError_t launch_gemv_fused(const FusedArgs& a_in, int N, bool build_lut, hipStream_t st) {

@@ -197,7 +197,7 @@ extern "C" int32_t tmac_hip_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 extern "C" int32_t tmac_hip_set_variant(int variant) {
-    if (variant < 0 || variant > 4) return fail(TMAC_HIP_E_ARG, "unknown variant %d", variant);
+    if (variant < 0 || variant > 5) return fail(TMAC_HIP_E_ARG, "unknown variant %d", variant);
     g_variant = variant;
     return TMAC_HIP_OK;
 }
@@ -216,6 +216,21 @@ extern "C" int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host
     (void)hipFree(din);
     (void)hipFree(dout);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "selftest: %s", hipGetErrorString(e));
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_selftest_mfma(const uint32_t* in_host, int32_t* out_host) {
+    if (!in_host || !out_host) return fail(TMAC_HIP_E_ARG, "bad selftest arguments");
+    int32_t rc = ensure_device();
+    if (rc) return rc;
+    uint32_t* din = nullptr; int32_t* dout = nullptr;
+    HIP_TRY(hipMalloc((void**)&din, 64 * 8 * 4));
+    HIP_TRY(hipMalloc((void**)&dout, 64 * 4 * 4));
+    HIP_TRY(hipMemcpy(din, in_host, 64 * 8 * 4, hipMemcpyHostToDevice));
+    hipError_t e = launch_selftest_mfma(din, dout, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_host, dout, 64 * 4 * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(din); (void)hipFree(dout);
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "selftest_mfma: %s", hipGetErrorString(e));
     return TMAC_HIP_OK;
 }
 
@@ -455,6 +470,7 @@ static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* w
         fa.m[0].W = (const uint4*)w->W; fa.m[0].SC = w->SC; fa.m[0].C = C_dev; fa.m[0].Mw = w->s.Mw; fa.m[0].nb_end = w->s.nb();
         fa.qlut_lds = ws->qlut_lds; fa.lut_scales = ws->lut_scales; fa.lut_biases = ws->lut_biases;
         fa.sc_f16 = w->sc_dtype == F16; fa.out_f16 = out_dtype == TMAC_F16; fa.dump = dump;
+        fa.acc_mfma = g_variant == V_FUSED_MFMA;
         hipError_t e = launch_gemv_fused(fa, N, false, st);
         if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no fused GEMV kernel for this configuration");
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "fused gemv launch: %s", hipGetErrorString(e));
@@ -531,6 +547,7 @@ static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const voi
     fa.sc_f16 = wl[0]->sc_dtype == F16; fa.out_f16 = out_dtype == TMAC_F16; fa.dump = dump;
     fa.stamps = g_stamps;
     fa.lut_tap = lut_tap;
+    fa.acc_mfma = g_variant == V_FUSED_MFMA;
     hipError_t e = launch_gemv_fused(fa, N, true, st);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no fused GEMV kernel for this configuration");
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "fused gemv launch: %s", hipGetErrorString(e));

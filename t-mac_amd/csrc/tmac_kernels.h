@@ -15,7 +15,8 @@ enum Variant {
     V_LO_MQSAD = 1,  // tiled kernel, v_mqsad_pk_u16_u8 accumulate
     V_LO_SDWA = 2,   // tiled kernel, byte-select adds
     V_REF_LAYOUT = 3,// generic kernel on the reference blobs
-    V_FUSED = 4      // fused kernel (ts = 8 layout): LUT in LDS, multi-matrix launches
+    V_FUSED = 4,     // fused kernel (ts = 8 layout): LUT in LDS, multi-matrix launches, v_mqsad accumulate (default)
+    V_FUSED_MFMA = 5 // same kernel with the matrix-pipe (v_mfma_i32_16x16x64_i8) accumulate
 };
 
 struct FusedMat {
@@ -39,6 +40,7 @@ struct FusedArgs {
     int32_t* dump;           // optional integer tap (nmat == 1)
     unsigned long long* stamps; // optional s_memtime phase stamps [blocks][8] (debug/profiling)
     float* lut_tap;          // optional: block 0 writes [N][2][G] LUT scales | biases it built (parity tap)
+    int acc_mfma;            // 1: v_mfma_i32_16x16x64_i8 accumulate, 0: v_mqsad_pk_u16_u8 (default: measured faster, profiles/)
     int nu, nsb, tstride, G, nsg, gs_shift;   // filled by launch_gemv_fused (host-side divides)
 };
 
@@ -58,6 +60,7 @@ struct GemvArgs {
 };
 
 hipError_t launch_selftest(const uint32_t* in, uint32_t* out, int n, hipStream_t st);
+hipError_t launch_selftest_mfma(const uint32_t* in, int32_t* out, hipStream_t st);
 hipError_t launch_retile_weights(const uint8_t* A_ref, void* Wd, const Shape& s, hipStream_t st);
 hipError_t launch_retile_scales(const void* S_ref, Dtype in_dt, void* Sd, Dtype out_dt, const Shape& s, hipStream_t st);
 hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, float* lut_scales,

@@ -57,6 +57,17 @@ __global__ void k_selftest(const uint32_t* in, uint32_t* out, int n) {
     out[4 * i + 3] = lookup4<1>(c, a | 0x01010101u, b | 0x01010101u);
 }
 
+// MFMA probe: one wave, D = A x B with v_mfma_i32_16x16x64_i8; in[lane][0..3] = A regs, in[lane][4..7] = B regs
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+__global__ void k_selftest_mfma(const uint32_t* in, int32_t* out) {
+    const int l = threadIdx.x;
+    v4i_t a = {(int)in[l * 8], (int)in[l * 8 + 1], (int)in[l * 8 + 2], (int)in[l * 8 + 3]};
+    v4i_t b = {(int)in[l * 8 + 4], (int)in[l * 8 + 5], (int)in[l * 8 + 6], (int)in[l * 8 + 7]};
+    v4i_t c = {0, 0, 0, 0};
+    c = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
+    out[l * 4] = c.x; out[l * 4 + 1] = c.y; out[l * 4 + 2] = c.z; out[l * 4 + 3] = c.w;
+}
+
 // ---------------------------------------------------------------------------------------------
 // (a7) re-tiling: one thread per output dword / scale element
 // ---------------------------------------------------------------------------------------------
@@ -483,6 +494,11 @@ __global__ void k_gemv_ref_layout(const uint8_t* __restrict__ A, const int8_t* _
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_selftest(const uint32_t* in, uint32_t* out, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_mfma(const uint32_t* in, int32_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, st, in, out);
     return hipGetLastError();
 }
 

@@ -126,7 +126,7 @@ def test_isa_models(tm):
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
 @pytest.mark.parametrize("name", CASES)
 def test_golden_vectors(tm, name, variant):
     """committed vectors produced by the reference itself (tests/golden/make_golden.py)"""
@@ -162,7 +162,7 @@ CFGS = [  # Mw, K, bits, bm, kf, gs, ags, zp, m_groups
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 5])
 @pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,mg", CFGS)
 def test_vs_oracle(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, variant):
     case = orc.make_case(Mw + K + bits, Mw, K, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg)
@@ -275,9 +275,10 @@ def test_host_pointer_cabi_matches_prebuilt_reference(tm, tmp_path):
 FUSED_CFGS = [c for c in CFGS if (c[6] == 64 and c[8] == -1) or c[6] == c[1]]
 
 
+@pytest.mark.parametrize("variant", [0, 5])
 @pytest.mark.parametrize("act_f16", [False, True])
 @pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,mg", FUSED_CFGS)
-def test_fused_kernel_builds_the_same_lut(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, act_f16):
+def test_fused_kernel_builds_the_same_lut(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, act_f16, variant):
     """tmac_hip_qgemm_fused_dev: LUT constructed inside the GEMV kernel.  The integer partial sums can only
     be bit-exact if the in-kernel LUT (QLUT, and through C the scales/biases) equals the oracle's."""
     import torch
@@ -285,6 +286,7 @@ def test_fused_kernel_builds_the_same_lut(tm, Mw, K, bits, bm, kf, gs, ags, zp, 
     A = orc.preprocess_weights(case["w"], bits, bm, kf)
     S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm) if mg == -1 else case["sc"]
     cfg = tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, zp, mg)
+    tm.binding.check(tm.lib().tmac_hip_set_variant(variant))   # 0: v_mqsad accumulate (default), 5: MFMA accumulate
     wr = tm.TMACGeMMWrapper(act_group_size=ags)
     wr.set_workspace(K, 1)
     w = wr.register_weights(A, S, Mw, K, bits, cfg)
@@ -302,6 +304,7 @@ def test_fused_kernel_builds_the_same_lut(tm, Mw, K, bits, bm, kf, gs, ags, zp, 
     assert rel_err(Cf, Cc) <= 2e-5
     check_bits(Ct.cpu().numpy(), Cf)
     w.free()
+    tm.lib().tmac_hip_set_variant(0)
 
 
 def test_fused_multi_matrix_launch(tm):

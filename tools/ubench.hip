@@ -40,7 +40,9 @@ static void run(const char* tag, std::vector<u32x4*>& bufs, size_t bytes, int th
     printf("%-28s bytes=%8zu blocks=%5d thr=%4d NL=%2d nt=%d : %7.3f us/launch  %7.1f GB/s\n", tag, bytes, blocks, threads, NL, (int)NT, us, bytes / us * 1e-3);
 }
 
-int main() {
+int rate_main();
+int main(int argc, char** argv) {
+    if (argc > 1) return rate_main();
     const size_t big = 12734128 / 16384 * 16384 + 16384, small = 4743424 / 16384 * 16384 + 16384;
     const int nbuf = 32;   // 32 x 12.7 MB = 407 MB > 256 MB MALL
     std::vector<u32x4*> bufs(nbuf);
@@ -67,5 +69,53 @@ int main() {
     run<4, true>("stream 4.7MB", bufs, small, 512, out);
     run<2, true>("stream 4.7MB", bufs, small, 512, out);
     run<1, true>("stream 4.7MB", bufs, small, 256, out);
+    return 0;
+}
+
+// ---- instruction-rate probes (v_perm_b32, v_mqsad_pk_u16_u8, sdwa byte add) --------------------------
+template <int WHICH>
+__global__ void k_rate(uint32_t* out, int iters) {
+    uint32_t a = threadIdx.x * 2654435761u, b = a ^ 0x9e3779b9u, c = a + 7, d = b + 11;
+    unsigned long long q0 = a, q1 = b, q2 = c, q3 = d;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (WHICH == 0) {  // 4 independent v_perm_b32 chains
+                a = __builtin_amdgcn_perm(a, b, 0x07060100u); b = __builtin_amdgcn_perm(b, c, 0x03020504u);
+                c = __builtin_amdgcn_perm(c, d, 0x01000302u); d = __builtin_amdgcn_perm(d, a, 0x05040706u);
+            } else if (WHICH == 1) {  // 4 independent v_mqsad_pk_u16_u8 chains
+                q0 = __builtin_amdgcn_mqsad_pk_u16_u8(q1, 0xffu, q0); q1 = __builtin_amdgcn_mqsad_pk_u16_u8(q2, 0xffu, q1);
+                q2 = __builtin_amdgcn_mqsad_pk_u16_u8(q3, 0xffu, q2); q3 = __builtin_amdgcn_mqsad_pk_u16_u8(q0, 0xffu, q3);
+            } else if (WHICH == 2) {  // 4 independent v_add_u32 (baseline)
+                a += b; b += c; c += d; d += a;
+            } else {                  // byte-select adds (sdwa)
+                a += (b >> 8) & 0xff; b += (c >> 16) & 0xff; c += d >> 24; d += a & 0xff;
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a ^ b ^ c ^ d ^ (uint32_t)(q0 ^ q1 ^ q2 ^ q3);
+}
+
+template <int WHICH>
+static void rate(const char* name, uint32_t* out) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int iters = 2000, blocks = 256 * 8, threads = 256;   // 8 waves per SIMD worth of work queued
+    hipLaunchKernelGGL((k_rate<WHICH>), dim3(blocks), dim3(threads), 0, 0, out, 10);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_rate<WHICH>), dim3(blocks), dim3(threads), 0, 0, out, iters);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double insts = (double)blocks * (threads / 64) * iters * 16 * 4;   // wave-instructions
+    printf("%-24s %.2f G wave-instr/s chip-wide -> %.2f cycles per wave-instr per SIMD at 2.4 GHz (1024 SIMDs)\n", name,
+           insts / (ms * 1e-3) * 1e-9, 1024 * 2.4e9 / (insts / (ms * 1e-3)));
+}
+
+int rate_main() {
+    uint32_t* out; CK(hipMalloc((void**)&out, 256 * 8 * 256 * 4));
+    rate<2>("v_add_u32", out);
+    rate<0>("v_perm_b32", out);
+    rate<1>("v_mqsad_pk_u16_u8", out);
+    rate<3>("v_add_u32_sdwa (byte)", out);
     return 0;
 }

@@ -84,6 +84,41 @@ static void run8(const std::vector<uint32_t>& W, const std::vector<uint32_t>& QL
                 }
 }
 
+// QUAD layout kernel (k_gemv_quad): the 64 lanes of a wave are 64 consecutive units of one row quad
+template <int BITS>
+static void run_quad(const std::vector<uint32_t>& W, const std::vector<uint32_t>& QLDS, const Shape& s, int32_t* PS) {
+    constexpr int NJ = 8 * BITS / 8;
+    const int nu = s.K / 32, tstride = ((nu + 15) & ~15) + 1, G = s.K / s.ags;
+    for (int quad = 0; quad < s.nquads(); ++quad)
+        for (int st = 0; st < s.nst64(); ++st)
+            for (int lane = 0; lane < 64; lane += 2) {
+                uint64_t pair[BITS] = {};
+                for (int half = 0; half < 2; ++half) {
+                    const int u = st * 64 + lane + half;
+                    if (u >= nu) continue;
+                    uint32_t wd[8 * BITS / 2], tb[16];
+                    for (int j = 0; j < NJ; ++j)
+                        for (int e = 0; e < 4; ++e) wd[4 * j + e] = W[quad_weight_u4_index(s, quad, st, j, lane + half) * 4 + e];
+                    for (int j4 = 0; j4 < 4; ++j4)
+                        for (int e = 0; e < 4; ++e) tb[4 * j4 + e] = QLDS[((size_t)j4 * tstride + u) * 4 + e];
+                    SegAcc<BITS, 0> acc;
+                    acc.reset();
+                    accumulate_tables<BITS, 0, 8>(wd, tb, acc);
+                    for (int p = 0; p < BITS; ++p) pair[p] += acc.a[p];
+                }
+                const int u0 = st * 64 + lane;
+                if (u0 >= nu) continue;
+                for (int beta = 0; beta < 4; ++beta)
+                    for (int p = 0; p < BITS; ++p) {
+                        const int o = 4 * quad + beta;
+                        if (o >= s.Mw) continue;
+                        const int32_t v = 127 * 16 - (int32_t)((pair[p] >> (16 * beta)) & 0xffff);
+                        if (s.ags == s.K) PS[mrow(o, p, BITS)] += v;
+                        else PS[(size_t)mrow(o, p, BITS) * G + u0 / 2] = v;
+                    }
+            }
+}
+
 // fused-layout kernel with the MFMA accumulate (ACC = 1): whole-wave emulation with the operand model of
 // v_mfma_i32_16x16x64_i8 that tools/mfma_probe.py checks against the hardware:
 //   D[i][j] = sum_g sum_{16 bytes} A[lane 16g+i] . B[lane 16g+j];  D[i][j] lives in lane j + 16*(i/4), reg i%4
@@ -151,6 +186,7 @@ extern "C" int emu_partial_sums(const uint8_t* A_ref, const int8_t* qlut_ref, in
     memset(&s, 0, sizeof(s));
     s.Mw = Mw; s.K = K; s.bits = bits; s.bm = bm; s.kfactor = kfactor; s.gs = 128; s.ags = ags; s.m_groups = -1;
     s.ts = (mode >= 2) ? 8 : 16;     // mode 2 = fused-layout kernel (mqsad), 3 = fused-layout kernel (MFMA accumulate)
+    s.lay = (mode == 4) ? 2 : 0;     // mode 4 = QUAD layout kernel
     if (K % 64 || (ags != 32 && ags != 64 && ags != K)) return -1;
     if (mode >= 2 && ags == 32) return -1;
     std::vector<uint32_t> W(s.weight_u4() * 4);
@@ -189,7 +225,7 @@ extern "C" int emu_partial_sums(const uint8_t* A_ref, const int8_t* qlut_ref, in
         }
         return 0;
     }
-    if (mode == 2) {
+    if (mode == 2 || mode == 4) {
         const int nu = K / 32, tstride = ((nu + 15) & ~15) + 1;
         std::vector<uint32_t> QLDS((size_t)4 * tstride * 4, 0x80808080u);
         for (int t = 0; t < K / 4; ++t) {
@@ -200,6 +236,16 @@ extern "C" int emu_partial_sums(const uint8_t* A_ref, const int8_t* qlut_ref, in
             }
             const size_t u2 = ((size_t)((t & 7) >> 1) * tstride + (t >> 3)) * 2 + (t & 1);
             QLDS[u2 * 2] = lo; QLDS[u2 * 2 + 1] = hi;
+        }
+        if (mode == 4) {
+            switch (bits) {
+                case 1: run_quad<1>(W, QLDS, s, PS); break;
+                case 2: run_quad<2>(W, QLDS, s, PS); break;
+                case 3: run_quad<3>(W, QLDS, s, PS); break;
+                case 4: run_quad<4>(W, QLDS, s, PS); break;
+                default: return -1;
+            }
+            return 0;
         }
         switch (bits) {
             case 1: run8<1>(W, QLDS, s, PS); break;

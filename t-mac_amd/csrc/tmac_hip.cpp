@@ -74,6 +74,7 @@ struct tmac_hip_workspace {
 static std::mutex g_mu;
 static int g_device = -1;
 static int g_variant = V_AUTO;
+static int g_force_ft = 0, g_force_wpq = 0;   // A/B knobs of the quad kernel (0 = heuristic)
 static std::map<std::string, tmac_kcfg> g_kcfg;
 
 static size_t qdev_u4_for_K(int K) { return (size_t)((K / (4 * TS) + KL - 1) / KL) * 8 * KL; }
@@ -197,7 +198,7 @@ extern "C" int32_t tmac_hip_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 extern "C" int32_t tmac_hip_set_variant(int variant) {
-    if (variant < 0 || variant > 5) return fail(TMAC_HIP_E_ARG, "unknown variant %d", variant);
+    if (variant < 0 || variant > 7) return fail(TMAC_HIP_E_ARG, "unknown variant %d", variant);
     g_variant = variant;
     return TMAC_HIP_OK;
 }
@@ -216,6 +217,20 @@ extern "C" int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host
     (void)hipFree(din);
     (void)hipFree(dout);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "selftest: %s", hipGetErrorString(e));
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_selftest_permlane(const uint32_t* in_host, uint32_t* out_host) {
+    int32_t rc = ensure_device();
+    if (rc) return rc;
+    uint32_t *din = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void**)&din, 128 * 4));
+    HIP_TRY(hipMalloc((void**)&dout, 256 * 4));
+    HIP_TRY(hipMemcpy(din, in_host, 128 * 4, hipMemcpyHostToDevice));
+    hipError_t e = launch_selftest_permlane(din, dout, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_host, dout, 256 * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(din); (void)hipFree(dout);
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "selftest_permlane: %s", hipGetErrorString(e));
     return TMAC_HIP_OK;
 }
 
@@ -257,8 +272,10 @@ static int32_t make_shape(Shape& s, int Mw, int K, int bits, const tmac_kcfg* cf
     if (s.m_groups < 0 && s.gs % (4 * s.kfactor)) return fail(TMAC_HIP_E_NOMATCH, "group_size %% (4*kfactor) != 0");
     // device layout: 8-table units for the fused kernel, 16-table segments for the two-kernel path
     s.ts = 8;
-    const bool fused_ok = gemv_fused_supported(s);
-    if (g_variant == V_LO_MQSAD || g_variant == V_LO_SDWA || !fused_ok) s.ts = 16;
+    s.lay = 0;
+    const bool fused_ok = gemv_fused_supported(s), quad_ok = gemv_quad_supported(s);
+    if ((g_variant == V_AUTO || g_variant == V_QUAD || g_variant == V_QUAD_MQSAD) && quad_ok) s.lay = 2;
+    else if (g_variant == V_LO_MQSAD || g_variant == V_LO_SDWA || !fused_ok) s.ts = 16;
     return TMAC_HIP_OK;
 }
 
@@ -282,7 +299,7 @@ static int32_t register_impl(tmac_hip_weights** out, const void* A_ref, const vo
     w->s = s;
     w->sc_dtype = (Dtype)dev_float;
     w->ref_dtype = (Dtype)host_float;
-    w->lo_ok = (s.ts == 8) ? gemv_fused_supported(s) : gemv_lo_supported(s);
+    w->lo_ok = (s.lay == 2) ? gemv_quad_supported(s) : (s.ts == 8) ? gemv_fused_supported(s) : gemv_lo_supported(s);
     const size_t ab = ref_weight_bytes(s), se = ref_scale_elems(s), sb = se * dt_size((Dtype)host_float);
     const bool keep_ref = !w->lo_ok || g_variant == V_REF_LAYOUT;
     void *dA = nullptr, *dS = nullptr;
@@ -470,8 +487,9 @@ static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* w
         fa.m[0].W = (const uint4*)w->W; fa.m[0].SC = w->SC; fa.m[0].C = C_dev; fa.m[0].Mw = w->s.Mw; fa.m[0].nb_end = w->s.nb();
         fa.qlut_lds = ws->qlut_lds; fa.lut_scales = ws->lut_scales; fa.lut_biases = ws->lut_biases;
         fa.sc_f16 = w->sc_dtype == F16; fa.out_f16 = out_dtype == TMAC_F16; fa.dump = dump;
-        fa.acc_mfma = g_variant == V_FUSED_MFMA;
-        hipError_t e = launch_gemv_fused(fa, N, false, st);
+        fa.acc_mfma = (w->s.lay == 2) ? (g_variant != V_QUAD_MQSAD) : (g_variant == V_FUSED_MFMA);
+        if (w->s.lay == 2) fa.m[0].nb_end = w->s.nquads();
+        hipError_t e = (w->s.lay == 2) ? launch_gemv_quad(fa, N, false, g_force_ft, g_force_wpq, st) : launch_gemv_fused(fa, N, false, st);
         if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no fused GEMV kernel for this configuration");
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "fused gemv launch: %s", hipGetErrorString(e));
         return TMAC_HIP_OK;
@@ -534,12 +552,12 @@ static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const voi
     for (int i = 0; i < nmat; ++i) {
         const tmac_hip_weights* w = wl[i];
         if (!w || !C_list[i]) return fail(TMAC_HIP_E_ARG, "null matrix or output");
-        if (w->s.ts != 8 || !w->lo_ok) return fail(TMAC_HIP_E_NOMATCH, "matrix %d is not registered in the fused layout", i);
+        if (w->s.ts != 8 || !w->lo_ok || w->s.lay != wl[0]->s.lay) return fail(TMAC_HIP_E_NOMATCH, "matrix %d is not registered in the fused layout", i);
         const Shape &a = w->s, &b = wl[0]->s;
         if (a.K != b.K || a.bits != b.bits || a.gs != b.gs || a.ags != b.ags || a.zero_point != b.zero_point ||
             a.m_groups != b.m_groups || w->sc_dtype != wl[0]->sc_dtype)
             return fail(TMAC_HIP_E_ARG, "matrices fused in one launch must share K, bits and quantisation config");
-        nb += a.nb();
+        nb += (a.lay == 2) ? a.nquads() : a.nb();
         fa.m[i].W = (const uint4*)w->W; fa.m[i].SC = w->SC; fa.m[i].C = C_list[i]; fa.m[i].Mw = a.Mw; fa.m[i].nb_end = nb;
     }
     fa.s = wl[0]->s;
@@ -547,8 +565,8 @@ static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const voi
     fa.sc_f16 = wl[0]->sc_dtype == F16; fa.out_f16 = out_dtype == TMAC_F16; fa.dump = dump;
     fa.stamps = g_stamps;
     fa.lut_tap = lut_tap;
-    fa.acc_mfma = g_variant == V_FUSED_MFMA;
-    hipError_t e = launch_gemv_fused(fa, N, true, st);
+    fa.acc_mfma = (fa.s.lay == 2) ? (g_variant != V_QUAD_MQSAD) : (g_variant == V_FUSED_MFMA);
+    hipError_t e = (fa.s.lay == 2) ? launch_gemv_quad(fa, N, true, g_force_ft, g_force_wpq, st) : launch_gemv_fused(fa, N, true, st);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no fused GEMV kernel for this configuration");
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "fused gemv launch: %s", hipGetErrorString(e));
     return TMAC_HIP_OK;
@@ -558,6 +576,12 @@ extern "C" int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weigh
                                             tmac_dtype_t act_dtype, void* const* C_dev, tmac_dtype_t out_dtype, int N,
                                             void* stream) {
     return fused_impl(weights, nmat, B_dev, act_dtype, C_dev, out_dtype, N, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// A/B knobs of the quad kernel: threads per workgroup (512/1024) and waves per quad (1/2); 0 = heuristic
+extern "C" int32_t tmac_hip_debug_quad_config(int force_ft, int force_wpq) {
+    g_force_ft = force_ft; g_force_wpq = force_wpq;
+    return TMAC_HIP_OK;
 }
 
 // debug/profiling: s_memtime phase stamps [nblocks][8] of the fused launches issued while enabled

@@ -16,7 +16,9 @@ enum Variant {
     V_LO_SDWA = 2,   // tiled kernel, byte-select adds
     V_REF_LAYOUT = 3,// generic kernel on the reference blobs
     V_FUSED = 4,     // fused kernel (ts = 8 layout): LUT in LDS, multi-matrix launches, v_mqsad accumulate (default)
-    V_FUSED_MFMA = 5 // same kernel with the matrix-pipe (v_mfma_i32_16x16x64_i8) accumulate
+    V_FUSED_MFMA = 5,// same kernel with the matrix-pipe (v_mfma_i32_16x16x64_i8) accumulate
+    V_QUAD = 6,      // wave-owns-row-quad fused kernel (QUAD layout), MFMA accumulate (default)
+    V_QUAD_MQSAD = 7 // same with the v_mqsad_pk_u16_u8 accumulate
 };
 
 struct FusedMat {
@@ -61,6 +63,7 @@ struct GemvArgs {
 
 hipError_t launch_selftest(const uint32_t* in, uint32_t* out, int n, hipStream_t st);
 hipError_t launch_selftest_mfma(const uint32_t* in, int32_t* out, hipStream_t st);
+hipError_t launch_selftest_permlane(const uint32_t* in, uint32_t* out, hipStream_t st);
 hipError_t launch_retile_weights(const uint8_t* A_ref, void* Wd, const Shape& s, hipStream_t st);
 hipError_t launch_retile_scales(const void* S_ref, Dtype in_dt, void* Sd, Dtype out_dt, const Shape& s, hipStream_t st);
 hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, float* lut_scales,
@@ -70,6 +73,9 @@ hipError_t launch_qlut_ref_to_dev(const int8_t* qlut_ref, void* qlut_dev, void* 
 bool gemv_fused_supported(const Shape& s);
 size_t qlut_lds_u4(int K);   // uint4 per activation row of the LDS-image LUT
 hipError_t launch_gemv_fused(const FusedArgs& a, int N, bool build_lut, hipStream_t st);
+// quad kernel (tmac_quad.hip): a.m[i].nb_end = cumulative ROW QUAD counts; force_ft/force_wpq 0 = heuristic
+bool gemv_quad_supported(const Shape& s);
+hipError_t launch_gemv_quad(const FusedArgs& a, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st);
 // returns hipErrorInvalidValue when the variant does not cover the configuration
 hipError_t launch_gemv(const GemvArgs& a, Variant v, hipStream_t st);
 bool gemv_lo_supported(const Shape& s);

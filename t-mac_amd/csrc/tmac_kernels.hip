@@ -57,6 +57,15 @@ __global__ void k_selftest(const uint32_t* in, uint32_t* out, int n) {
     out[4 * i + 3] = lookup4<1>(c, a | 0x01010101u, b | 0x01010101u);
 }
 
+// permlane swap probe: out[lane][0..3] = {p16.first, p16.second, p32.first, p32.second} for a = in[lane], b = in[64+lane]
+__global__ void k_selftest_permlane(const uint32_t* in, uint32_t* out) {
+    const int l = threadIdx.x;
+    const unsigned a = in[l], b = in[64 + l];
+    auto r16 = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    auto r32 = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    out[l * 4] = r16[0]; out[l * 4 + 1] = r16[1]; out[l * 4 + 2] = r32[0]; out[l * 4 + 3] = r32[1];
+}
+
 // MFMA probe: one wave, D = A x B with v_mfma_i32_16x16x64_i8; in[lane][0..3] = A regs, in[lane][4..7] = B regs
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 __global__ void k_selftest_mfma(const uint32_t* in, int32_t* out) {
@@ -85,10 +94,16 @@ __global__ void k_retile_scales(const TI* __restrict__ S_ref, TO* __restrict__ S
     size_t x = i;
     const int which = (int)(x % per); x /= per;
     const int beta = (int)(x % 4); x /= 4;
-    const int rl = (int)(x % RL); x /= RL;
-    const int sg = (int)(x % s.nsg());
-    const int b = (int)(x / s.nsg());
-    const int o = (b * RL + rl) * 4 + beta;
+    int o, sg;
+    if (s.lay == 2) {            // [quad][sg][beta][per]
+        sg = (int)(x % s.nsg());
+        o = (int)(x / s.nsg()) * 4 + beta;
+    } else {                     // [b][sg][rl][beta][per]
+        const int rl = (int)(x % RL); x /= RL;
+        sg = (int)(x % s.nsg());
+        const int b = (int)(x / s.nsg());
+        o = (b * RL + rl) * 4 + beta;
+    }
     float v = 0.f;
     if (o < s.Mw) v = to_f32<TI>(S_ref[ref_scale_index(s, o, sg, which)]);
     Sd[i] = from_f32<TO>(v);
@@ -494,6 +509,11 @@ __global__ void k_gemv_ref_layout(const uint8_t* __restrict__ A, const int8_t* _
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_selftest(const uint32_t* in, uint32_t* out, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, st, in, out, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_permlane(const uint32_t* in, uint32_t* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_selftest_permlane, dim3(1), dim3(64), 0, st, in, out);
     return hipGetLastError();
 }
 

@@ -47,7 +47,10 @@ struct Shape {
     int ags;          // act group size
     int zero_point;
     int m_groups;     // -1 or >= 1
-    int ts;           // tables per layout unit ("segment"): 16 (two-kernel path) or 8 (fused path)
+    int ts;           // tables per layout unit ("segment"): 16 (two-kernel path) or 8 (fused paths)
+    int lay;          // 0: row-block layouts above (ts = 16 "LO" / ts = 8 fused);  2: QUAD layout (ts = 8):
+                      //    uint4 index = ((quad*nst64 + st)*NJ + j)*64 + lane, unit = st*64 + lane — the 64 lanes
+                      //    of a wave hold 64 consecutive 8-table units of ONE row quad (k_gemv_quad)
     // derived
     TMAC_HD int M() const { return Mw * bits; }
     TMAC_HD int nseg() const { return K / (4 * ts); }
@@ -56,8 +59,14 @@ struct Shape {
     TMAC_HD int nj() const { return ts * bits / 8; }  // uint4 per (row quad, segment)
     TMAC_HD int ngroups() const { return K / ags; }
     TMAC_HD int nsg() const { return gs > 0 ? K / gs : 1; }
-    TMAC_HD size_t weight_u4() const { return (size_t)nb() * nsb() * nj() * RL * KL; }
-    TMAC_HD size_t scale_elems() const { return (size_t)nb() * nsg() * RL * 4 * (zero_point ? 2 : 1); }
+    TMAC_HD int nquads() const { return (Mw + 3) / 4; }
+    TMAC_HD int nst64() const { return (K / 32 + 63) / 64; }
+    TMAC_HD size_t weight_u4() const {
+        return lay == 2 ? (size_t)nquads() * nst64() * nj() * 64 : (size_t)nb() * nsb() * nj() * RL * KL;
+    }
+    TMAC_HD size_t scale_elems() const {
+        return (lay == 2 ? (size_t)nquads() : (size_t)nb() * RL) * nsg() * 4 * (zero_point ? 2 : 1);
+    }
     TMAC_HD size_t qlut_dev_u4() const { return (size_t)((K / (4 * TS) + KL - 1) / KL) * 8 * KL; }  // per activation row (TS=16 layout)
 };
 
@@ -77,12 +86,22 @@ TMAC_HD uint32_t recode_nibble(uint32_t j) { return j < 8 ? j : (8u | (15u - j))
 
 // One dword of the device weight layout: position (u4 index, e = dword within the uint4).
 TMAC_HD uint32_t retile_dword(const uint8_t* A_ref, const Shape& s, size_t u4, int e) {
-    const int kl = (int)(u4 % KL); size_t x = u4 / KL;
-    const int rl = (int)(x % RL); x /= RL;
-    const int j = (int)(x % s.nj()); x /= s.nj();
-    const int sb = (int)(x % s.nsb());
-    const int b = (int)(x / s.nsb());
-    const int rq = b * RL + rl, seg = sb * KL + kl, d = 4 * j + e;
+    int rq, seg, j;
+    if (s.lay == 2) {
+        const int lane = (int)(u4 % 64); size_t x = u4 / 64;
+        j = (int)(x % s.nj()); x /= s.nj();
+        const int st = (int)(x % s.nst64());
+        rq = (int)(x / s.nst64());
+        seg = st * 64 + lane;
+    } else {
+        const int kl = (int)(u4 % KL); size_t x = u4 / KL;
+        const int rl = (int)(x % RL); x /= RL;
+        j = (int)(x % s.nj()); x /= s.nj();
+        const int sb = (int)(x % s.nsb());
+        const int b = (int)(x / s.nsb());
+        rq = b * RL + rl; seg = sb * KL + kl;
+    }
+    const int d = 4 * j + e;
     if (seg >= s.nseg()) return 0;
     uint32_t out = 0;
     for (int h = 0; h < 2; ++h) {
@@ -109,6 +128,15 @@ TMAC_HD size_t ref_scale_index(const Shape& s, int o, int sg, int which) {
 TMAC_HD size_t dev_scale_index(const Shape& s, int b, int sg, int rl, int beta, int which) {
     const int per = s.zero_point ? 2 : 1;
     return ((((size_t)b * s.nsg() + sg) * RL + rl) * 4 + beta) * per + which;
+}
+
+// QUAD layout: scale element index for (row quad, scale group sg, beta, which); weights uint4 index
+TMAC_HD size_t quad_scale_index(const Shape& s, int quad, int sg, int beta, int which) {
+    const int per = s.zero_point ? 2 : 1;
+    return (((size_t)quad * s.nsg() + sg) * 4 + beta) * per + which;
+}
+TMAC_HD size_t quad_weight_u4_index(const Shape& s, int quad, int st, int j, int lane) {
+    return (((size_t)quad * s.nst64() + st) * s.nj() + j) * 64 + lane;
 }
 
 // uint4 index of weights for (row block b, segment block sb, j, rl, kl)

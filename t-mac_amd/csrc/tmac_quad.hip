@@ -1,0 +1,657 @@
+// tmac_quad.hip — k_gemv_quad: the wave-owns-row-quad form of the fused LUT-build + GEMV kernel.
+//
+// Same arithmetic as k_gemv_fused (tmac_fused.hip; lut_ctor.cc / tbl.cc citations there), different
+// work decomposition, chosen from the measured phase timeline of that kernel (profiles/r01_*):
+// its 8 waves split K for one 16-row block and meet at a barrier + LDS reduction per block, which
+// costs ~40 % of the block time.  Here a WAVE owns a row quad (4 output rows): its 64 lanes hold 64
+// consecutive 8-table units (QUAD layout, tmac_layout.h), so every weight instruction still reads 1 KiB
+// contiguous, the LUT in LDS is read conflict-free (lane u reads 16 B at u*16), and the reduction over
+// K is wave-local (DPP within rows of 16 lanes + 2 cross-row moves).  No barrier in the steady state.
+//   WPQ = 1 : one wave does all of K for its quad                     (large Mw: q/k/v, gate/up)
+//   WPQ = 2 : two waves split the K steps of a quad, combined in LDS  (Mw = 4096: o, down; better balance)
+// Workgroups are persistent (<= 1 per CU for FT = 1024), build the LUT once (bit-exact with k_preprocess)
+// while the first weight fragments are in flight, then stream quads.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "tmac_core.h"
+#include "tmac_kernels.h"
+
+namespace tmac {
+
+typedef uint32_t u32x4q __attribute__((ext_vector_type(4)));
+
+template <int CTRL>
+__device__ __forceinline__ float qdpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t qdpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float q_row_allmax(float v) {
+    v = fmaxf(v, qdpp_f<0xB1>(v));
+    v = fmaxf(v, qdpp_f<0x4E>(v));
+    v = fmaxf(v, qdpp_f<0x141>(v));
+    v = fmaxf(v, qdpp_f<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float q_alpha(int p) { return p == 0 ? 0.5f : (p == 1 ? 1.0f : (p == 2 ? 2.0f : 4.0f)); }
+__device__ __forceinline__ float q_ld_scale(const void* p, int f16, size_t i) {
+    return f16 ? __half2float(reinterpret_cast<const __half*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void q_st_out(void* C, int f16, size_t i, float v) {
+    if (f16) reinterpret_cast<__half*>(C)[i] = __float2half_rn(v);
+    else reinterpret_cast<float*>(C)[i] = v;
+}
+
+// biased half-table byte U = sat8(rne(x)) + 128 packed into byte `pos` of `acc`:
+// v_mul, v_rndne, v_med3, v_add, v_cvt_pk_u8_f32 (the conversion of an integer-valued float is exact)
+__device__ __forceinline__ uint32_t q_quant_pack(float e, float t_scales, int pos, uint32_t acc) {
+    float y = rintf(__fmul_rn(e, t_scales));
+    y = fminf(fmaxf(y, -127.0f), 127.0f);   // finite inputs never exceed +-127; keeps U in [1,255]
+    return __builtin_amdgcn_cvt_pk_u8_f32(__fadd_rn(y, 128.0f), pos, acc);
+}
+
+template <int BITS>
+struct QFrag {
+    uint32_t wd[8 * BITS / 2];
+    uint32_t sraw[4];
+};
+
+template <bool ZP>
+__device__ __forceinline__ float qfrag_scale(const uint32_t (&sraw)[4], int f16, int i, int which) {
+    const int e = i * (ZP ? 2 : 1) + which;
+    if (f16) {
+        const uint32_t wv = sraw[e >> 1];
+        return __half2float(__ushort_as_half((unsigned short)((e & 1) ? (wv >> 16) : (wv & 0xffff))));
+    }
+    return __uint_as_float(sraw[e]);
+}
+
+// weights of (local quad lq, step st) + the lane's scales (rows beta0, beta0+1 of its unit's scale group)
+template <int BITS, bool ZP, int SM, int ACC>
+__device__ __forceinline__ void load_q(QFrag<BITS>& f, const FusedArgs& a, const FusedMat& M, int lq, int st, int nst, int lane) {
+    constexpr int NJ = 8 * BITS / 8;
+    const int u = st * 64 + lane;
+    if (SM == 0 && ACC == 1) {
+        // epilogue role of this lane: row beta = lane & 3, units st*64 + 16g + 4*lg .. +3 (g = (lane & 15) >> 2, lg = lane >> 4)
+        constexpr int per = ZP ? 2 : 1;
+        const int ub4 = st * 64 + 4 * (lane & 12) + 4 * (lane >> 4);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            if (gi == 1 && a.gs_shift >= 2) break;
+            if (ub4 + 2 * gi < a.nu) {
+                const uint32_t sidx = (((uint32_t)lq * (uint32_t)a.nsg + (uint32_t)((ub4 + 2 * gi) >> a.gs_shift)) * 4 + (lane & 3)) * per;
+                if (a.sc_f16) {
+                    const __half* ph = reinterpret_cast<const __half*>(M.SC) + sidx;
+                    if (ZP) f.sraw[gi] = *reinterpret_cast<const uint32_t*>(ph);
+                    else f.sraw[gi] = *reinterpret_cast<const unsigned short*>(ph);
+                } else {
+                    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(M.SC) + sidx;
+                    f.sraw[2 * gi] = p32[0];
+                    if (ZP) f.sraw[2 * gi + 1] = p32[1];
+                }
+            }
+        }
+    }
+    if (u >= a.nu) return;
+    const uint4* wp = M.W + (size_t)((uint32_t)(lq * nst + st) * (uint32_t)(NJ * 64)) + lane;   // uniform base + lane
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const u32x4q v = __builtin_nontemporal_load(reinterpret_cast<const u32x4q*>(wp + (size_t)j * 64));
+        f.wd[4 * j] = v.x; f.wd[4 * j + 1] = v.y; f.wd[4 * j + 2] = v.z; f.wd[4 * j + 3] = v.w;
+    }
+    if (SM == 0 && ACC == 0) {
+        constexpr int per = ZP ? 2 : 1;
+        const int sg = u >> a.gs_shift;
+        const uint32_t sidx = (((uint32_t)lq * (uint32_t)a.nsg + (uint32_t)sg) * 4 + 2 * (lane & 1)) * per;
+        if (a.sc_f16) {
+            const uint32_t* p32 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const __half*>(M.SC) + sidx);
+            f.sraw[0] = p32[0];
+            if (ZP) f.sraw[1] = p32[1];
+        } else {
+            const uint32_t* p32 = reinterpret_cast<const uint32_t*>(M.SC) + sidx;
+#pragma unroll
+            for (int e = 0; e < 2 * per; ++e) f.sraw[e] = p32[e];
+        }
+    }
+}
+
+typedef int qv4i_t __attribute__((ext_vector_type(4)));
+
+// (x & m) | k in one VALU instruction (hipcc emits v_and_b32 + v_or_b32 for two literal operands: VOP3 takes no
+// literals on gfx9, so the constants are kept in an SGPR and a VGPR)
+__device__ __forceinline__ uint32_t q_and_or(uint32_t x, uint32_t m_sgpr, uint32_t k_vgpr) {
+    uint32_t d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "s"(m_sgpr), "v"(k_vgpr));
+    return d;
+}
+
+// signed plus/minus lookup for the MFMA accumulate (tmac_core.h lookup4_pm) with the fused and_or
+template <int H>
+__device__ __forceinline__ void q_lookup4_pm(uint32_t w, uint32_t tab_lo, uint32_t tab_hi, uint32_t k3, uint32_t& plus, uint32_t& minus) {
+    const uint32_t x = H ? (w >> 4) : w;
+    const uint32_t rP = __builtin_amdgcn_perm(tab_hi, tab_lo, x & 0x07070707u);
+    const uint32_t sel3 = q_and_or(x >> 1, 0x04040404u, k3);
+    plus = __builtin_amdgcn_perm(0u, rP, sel3);
+    minus = __builtin_amdgcn_perm(rP, 0u, sel3);
+}
+
+// ACC 0: v_mqsad_pk_u16_u8 accumulate (VALU).  ACC 1: v_mfma_i32_16x16x64_i8 accumulate (matrix pipe), see
+// k_gemv_fused for the operand construction; with 64 lanes = 64 units of one quad, source lane l = 16g + i and
+// D[i][4g+beta] lands in lane l' = 16*(i/4) + 4g + beta, register i%4: lane l' owns output row beta and the four
+// units 16g + 4*(l'/16) .. +3 of the step (two act groups, one 128-wide scale group).
+template <int BITS, bool ZP, int SM, int LUTSRC, int NR, int FT, int WPQ, bool DUMP, int ACC>
+__global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
+    extern __shared__ uint4 lds[];
+    constexpr int NWV = FT / 64, IPI = NWV / WPQ;
+    const Shape& s = a.s;
+    // the wave index is uniform but the compiler cannot prove it from threadIdx: readfirstlane moves every
+    // per-wave quantity (quad, step, base pointers, loop control) to SGPRs / the scalar ALU
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int n = blockIdx.y;
+    const int T = s.K / 4, nu = a.nu, G = a.G, tstride = a.tstride, nst = (nu + 63) >> 6;
+    uint4* tab = lds;                                            // [4][tstride]
+    float* l_ls = reinterpret_cast<float*>(lds + 4 * tstride);   // [G]
+    float* l_lb = l_ls + G;                                      // [G]
+    float* l_red = l_lb + G;                                     // [2][NWV][4][4] partials (WPQ == 2 / SM 2)
+    float* l_scr = l_red + 2 * NWV * 16;                         // SM 2 build scratch: [NWV] maxima + [T/8] chunk sums
+    const int total_q = a.m[a.nmat - 1].nb_end;                  // cumulative QUAD counts in this launch mode
+
+#define QSTAMP(i) do { if (a.stamps && lane == 0 && (w == 0 || w == NWV - 1)) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    QSTAMP(0);
+    auto locate = [&](int gq, int& mi, int& lq) {
+        mi = 0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (i < a.nmat && gq >= a.m[i - 1].nb_end) mi = i;
+        lq = gq - (mi ? a.m[mi - 1].nb_end : 0);
+    };
+
+    // ---- 1. activation loads for the LUT build (issued first: vmcnt retires in order) ----------
+    uint32_t xr[NR][4];
+    if (LUTSRC == 1) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int t = r * FT + tid;
+            if (t < T) {
+                if (a.act_f16) {
+                    const uint2 v = reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(a.B) + (size_t)n * s.K)[t];
+                    xr[r][0] = v.x; xr[r][1] = v.y;
+                } else {
+                    const uint4 v = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(a.B) + (size_t)n * s.K)[t];
+                    xr[r][0] = v.x; xr[r][1] = v.y; xr[r][2] = v.z; xr[r][3] = v.w;
+                }
+            }
+        }
+    }
+
+    // ---- 2. this wave's work: quads slot, slot + stride, ...; steps h, h + WPQ, ... of each ------
+    const int slot0 = blockIdx.x * IPI + w / WPQ, h = w % WPQ, stride = gridDim.x * IPI;
+    QFrag<BITS> f0, f1;
+    int p_q = slot0, p_st = h;    // prefetch cursor
+    auto issue = [&](QFrag<BITS>& f) {
+        if (p_q < total_q) {
+            int mi, lq;
+            locate(p_q, mi, lq);
+            load_q<BITS, ZP, SM, ACC>(f, a, a.m[mi], lq, p_st, nst, lane);
+            p_st += WPQ;
+            if (p_st >= nst) { p_st = h; p_q += stride; }
+        }
+    };
+    issue(f0);
+    issue(f1);
+    QSTAMP(1);
+
+    // ---- 3. LUT into LDS (all FT threads) ------------------------------------------------------
+    if (LUTSRC == 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.qlut_lds) + (size_t)n * 4 * tstride;
+        for (int i = tid; i < 4 * tstride; i += FT) {
+            uint4 v = src[i];
+            if (ACC == 1 && SM != 2) { v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u; }
+            tab[i] = v;
+        }
+        if (SM == 2) { if (tid == 0) { l_ls[0] = a.lut_scales[n]; l_lb[0] = a.lut_biases[n]; } }
+        else for (int i = tid; i < G; i += FT) { l_ls[i] = a.lut_scales[(size_t)n * G + i]; l_lb[i] = a.lut_biases[(size_t)n * G + i]; }
+    } else {
+        float gscale = 0.f, gtinv = 0.f;
+        if (SM == 2) {
+            float mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int t = r * FT + tid;
+                if (t < T) {
+                    float x0, x1, x2, x3;
+                    if (a.act_f16) {
+                        const __half2 h0 = *reinterpret_cast<const __half2*>(&xr[r][0]), h1 = *reinterpret_cast<const __half2*>(&xr[r][1]);
+                        x0 = __low2float(h0); x1 = __high2float(h0); x2 = __low2float(h1); x3 = __high2float(h1);
+                    } else { x0 = __uint_as_float(xr[r][0]); x1 = __uint_as_float(xr[r][1]); x2 = __uint_as_float(xr[r][2]); x3 = __uint_as_float(xr[r][3]); }
+                    mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x0), fabsf(x1)), __fadd_rn(fabsf(x2), fabsf(x3))));
+                }
+            }
+            mx = q_row_allmax(mx);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (lane == 0) l_scr[w] = mx;
+            __syncthreads();
+            mx = l_scr[0];
+#pragma unroll
+            for (int i = 1; i < NWV; ++i) mx = fmaxf(mx, l_scr[i]);
+            gscale = __fdiv_rn(mx, 127.0f);
+            gtinv = (gscale != 0.0f) ? __fdiv_rn(1.0f, gscale) : 0.0f;
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int t = r * FT + tid;
+            if (t < T) {   // T % 16 == 0: a 16-lane act group is valid or invalid as a whole
+                float x0, x1, x2, x3;
+                if (a.act_f16) {
+                    const __half2 h0 = *reinterpret_cast<const __half2*>(&xr[r][0]), h1 = *reinterpret_cast<const __half2*>(&xr[r][1]);
+                    x0 = __low2float(h0); x1 = __high2float(h0); x2 = __low2float(h1); x3 = __high2float(h1);
+                } else { x0 = __uint_as_float(xr[r][0]); x1 = __uint_as_float(xr[r][1]); x2 = __uint_as_float(xr[r][2]); x3 = __uint_as_float(xr[r][3]); }
+                float scales, t_scales;
+                if (SM == 2) { scales = gscale; t_scales = gtinv; }
+                else {
+                    const float mx = q_row_allmax(__fadd_rn(__fadd_rn(fabsf(x0), fabsf(x1)), __fadd_rn(fabsf(x2), fabsf(x3))));
+                    scales = __fdiv_rn(mx, 127.0f);
+                    t_scales = (scales != 0.0f) ? __fdiv_rn(1.0f, scales) : 0.0f;
+                }
+                const float a_p = __fadd_rn(x0, x1), a_m = __fsub_rn(x0, x1);
+                const float L1 = __fsub_rn(__fsub_rn(a_m, x2), x3), L3 = __fsub_rn(__fsub_rn(a_p, x2), x3);
+                const float L5 = __fsub_rn(__fadd_rn(a_m, x2), x3), L7 = __fsub_rn(__fadd_rn(a_p, x2), x3);
+                const float L9 = __fadd_rn(__fsub_rn(a_m, x2), x3), L11 = __fadd_rn(__fsub_rn(a_p, x2), x3);
+                const float L13 = __fadd_rn(__fadd_rn(a_m, x2), x3), L15 = __fadd_rn(__fadd_rn(a_p, x2), x3);
+                const float e[8] = {-L15, L1, -L13, L3, -L11, L5, -L9, L7};   // half table j = 0..7 (even j: -L[15-j])
+                uint32_t lo = 0, hi = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    lo = q_quant_pack(e[i], t_scales, i, lo);
+                    hi = q_quant_pack(e[4 + i], t_scales, i, hi);
+                }
+                if (ACC == 1 && SM != 2) { lo ^= 0x80808080u; hi ^= 0x80808080u; }   // signed entries for the MFMA path
+                const int u = t >> 3, tl = t & 7;
+                reinterpret_cast<uint2*>(tab + (tl >> 1) * tstride + u)[tl & 1] = make_uint2(lo, hi);
+                float v = -L15;   // lut_ctor.cc:25-31 horizontal add; row_shl:n reads lane i+n
+                v = __fadd_rn(v, qdpp_f<0x104>(v));
+                v = __fadd_rn(v, qdpp_f<0x102>(v));
+                v = __fadd_rn(v, qdpp_f<0x101>(v));
+                if (SM == 2) {
+                    if ((t & 7) == 0) l_scr[NWV + (t >> 3)] = v;
+                } else {
+                    const float c1 = qdpp_f<0x108>(v);
+                    if ((t & 15) == 0) {
+                        l_ls[t >> 4] = scales;
+                        l_lb[t >> 4] = __fadd_rn(__fadd_rn(0.0f, v), c1);
+                    }
+                }
+            }
+        }
+        if (SM == 2) {
+            __syncthreads();
+            if (tid == 0) {
+                float biases = 0.0f;
+                for (int c = 0; c < T / 8; ++c) biases = __fadd_rn(biases, l_scr[NWV + c]);
+                l_ls[0] = gscale;
+                l_lb[0] = biases;
+            }
+        }
+    }
+    QSTAMP(2);
+    __syncthreads();
+    QSTAMP(3);
+    if (a.lut_tap && blockIdx.x == 0) {
+        for (int i = tid; i < (SM == 2 ? 1 : G); i += FT) { a.lut_tap[(size_t)n * 2 * G + i] = l_ls[i]; a.lut_tap[(size_t)n * 2 * G + G + i] = l_lb[i]; }
+    }
+
+    // ---- 4. stream this wave's quads -----------------------------------------------------------
+    float cacc[2][BITS];
+    int32_t iacc[BITS][4];
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int pl = 0; pl < BITS; ++pl) {
+            cacc[0][pl] = 0.f; cacc[1][pl] = 0.f;
+#pragma unroll
+            for (int be = 0; be < 4; ++be) iacc[pl][be] = 0;
+        }
+    };
+    reset_acc();
+    const int beta0 = 2 * (lane & 1);
+
+    auto compute = [&](const QFrag<BITS>& f, int st, int Mw_m, int lq) {
+        const int u = st * 64 + lane;
+        if (u >= nu) return;                 // nu is even: both lanes of a pair are valid or not
+        uint32_t tb[16];
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+            const uint4 v = tab[j4 * tstride + u];
+            tb[4 * j4] = v.x; tb[4 * j4 + 1] = v.y; tb[4 * j4 + 2] = v.z; tb[4 * j4 + 3] = v.w;
+        }
+        SegAcc<BITS, 0> acc;
+        acc.reset();
+        accumulate_tables<BITS, 0, 8>(f.wd, tb, acc);
+        if (SM == 2) {
+#pragma unroll
+            for (int pl = 0; pl < BITS; ++pl)
+#pragma unroll
+                for (int be = 0; be < 4; ++be) iacc[pl][be] += acc.ps(pl, be, 8);
+            return;
+        }
+        const int kk = u >> 1;
+        const float ls = l_ls[kk], lb = l_lb[kk];
+#pragma unroll
+        for (int pl = 0; pl < BITS; ++pl) {
+            uint32_t lo = (uint32_t)acc.a[pl], hi = (uint32_t)(acc.a[pl] >> 32);
+            lo += qdpp_u<0xB1>(lo);          // the two 8-table halves of the act group: lanes (l, l^1)
+            hi += qdpp_u<0xB1>(hi);
+            const uint32_t mine = (lane & 1) ? hi : lo;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int32_t ps = 127 * 16 - (int32_t)((mine >> (16 * i)) & 0xffff);
+                if (DUMP && a.dump) {
+                    const int o = 4 * lq + beta0 + i;
+                    if (o < Mw_m) a.dump[((size_t)n * Mw_m * BITS + mrow(o, pl, BITS)) * G + kk] = ps;
+                }
+                const float v = (pl == 0) ? __fmaf_rn((float)ps, ls, lb) : __fmul_rn((float)ps, ls);
+                float c = __fmaf_rn(v, qfrag_scale<ZP>(f.sraw, a.sc_f16, i, 0), cacc[i][pl]);
+                if (ZP && pl == 0) c = __fmaf_rn(qfrag_scale<ZP>(f.sraw, a.sc_f16, i, 1), __fmul_rn(2.0f, lb), c);
+                cacc[i][pl] = c;
+            }
+        }
+    };
+
+    // ---- ACC == 1 ------------------------------------------------------------------------------
+    qv4i_t bsel;
+    {
+        const int jrel = (lane & 15) - 4 * (lane >> 4);
+        const uint32_t be = (jrel >= 0 && jrel < 4) ? (0x01u << (8 * jrel)) : 0u, bo = (jrel >= 0 && jrel < 4) ? (0xffu << (8 * jrel)) : 0u;
+        bsel = (qv4i_t){(int)be, (int)bo, (int)be, (int)bo};
+    }
+    uint32_t k3 = 0x03020100u;
+    asm volatile("" : "+v"(k3));     // keep the selector constant in a VGPR (operand of v_and_or_b32)
+    auto compute_mfma = [&](const QFrag<BITS>& f, int st, int Mw_m, int lq) {
+        const int u = st * 64 + lane;
+        uint32_t tb[16];
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+            uint4 v = make_uint4(0, 0, 0, 0);                 // units past K: zero tables -> zero contribution
+            if (u < nu) v = tab[j4 * tstride + u];
+            tb[4 * j4] = v.x; tb[4 * j4 + 1] = v.y; tb[4 * j4 + 2] = v.z; tb[4 * j4 + 3] = v.w;
+        }
+        qv4i_t c[BITS];
+#pragma unroll
+        for (int pl = 0; pl < BITS; ++pl) c[pl] = (qv4i_t){0, 0, 0, 0};
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+            for (int pl = 0; pl < BITS; ++pl) {
+                uint32_t pa, ma, pb, mb;
+                const int qa = (2 * tp) * BITS + pl, qb = (2 * tp + 1) * BITS + pl;
+                if (qa & 1) q_lookup4_pm<1>(f.wd[qa >> 1], tb[4 * tp], tb[4 * tp + 1], k3, pa, ma);
+                else q_lookup4_pm<0>(f.wd[qa >> 1], tb[4 * tp], tb[4 * tp + 1], k3, pa, ma);
+                if (qb & 1) q_lookup4_pm<1>(f.wd[qb >> 1], tb[4 * tp + 2], tb[4 * tp + 3], k3, pb, mb);
+                else q_lookup4_pm<0>(f.wd[qb >> 1], tb[4 * tp + 2], tb[4 * tp + 3], k3, pb, mb);
+                c[pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8((qv4i_t){(int)pa, (int)ma, (int)pb, (int)mb}, bsel, c[pl], 0, 0, 0);
+            }
+        }
+        const int ub4 = st * 64 + 4 * (lane & 12) + 4 * (lane >> 4);
+        const int o = 4 * lq + (lane & 3);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int ug = ub4 + 2 * gi;
+            if (ug < nu) {
+                const int kk = ug >> 1;
+                const float ls = l_ls[kk], lb = l_lb[kk];
+                const int si = (a.gs_shift >= 2) ? 0 : gi;
+                float sc, zr = 0.f;
+                if (a.sc_f16) {
+                    const uint32_t wv = f.sraw[si];
+                    sc = __half2float(__ushort_as_half((unsigned short)(wv & 0xffff)));
+                    if (ZP) zr = __half2float(__ushort_as_half((unsigned short)(wv >> 16)));
+                } else {
+                    sc = __uint_as_float(f.sraw[2 * si]);
+                    if (ZP) zr = __uint_as_float(f.sraw[2 * si + 1]);
+                }
+#pragma unroll
+                for (int pl = 0; pl < BITS; ++pl) {
+                    const int32_t ps = (gi == 0) ? (c[pl].x + c[pl].y) : (c[pl].z + c[pl].w);
+                    if (DUMP && a.dump && o < Mw_m) a.dump[((size_t)n * Mw_m * BITS + mrow(o, pl, BITS)) * G + kk] = ps;
+                    const float v = (pl == 0) ? __fmaf_rn((float)ps, ls, lb) : __fmul_rn((float)ps, ls);
+                    float cc = __fmaf_rn(v, sc, cacc[0][pl]);
+                    if (ZP && pl == 0) cc = __fmaf_rn(zr, __fmul_rn(2.0f, lb), cc);
+                    cacc[0][pl] = cc;
+                }
+            }
+        }
+    };
+
+    // reduce one quad over the 64 lanes (same-parity lanes of a row by DPP, rows by ds_bpermute), combine the
+    // WPQ waves through LDS (double-buffered by iteration parity), store 4 outputs
+    int parity = 0;
+    auto finish_quad = [&](bool have, const FusedMat& M, int lq) {
+        float* red = l_red + parity * (NWV * 16);
+        if (ACC == 1 && SM != 2) {
+            float acc = 0.f;
+            if (have) {
+                acc = __fmul_rn(cacc[0][0], 0.5f);
+#pragma unroll
+                for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(cacc[0][pl], q_alpha(pl)));
+                acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // lanes with the same beta: rotate by 4, 8 within the row
+                acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
+                acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));
+                acc = __fadd_rn(acc, __shfl_xor(acc, 32, 64));
+            }
+            if (WPQ == 1) {
+                const int o = 4 * lq + lane;
+                if (have && lane < 4 && o < M.Mw) q_st_out(M.C, a.out_f16, (size_t)n * M.Mw + o, acc);
+            } else {
+                if (lane < 4) red[w * 4 + lane] = acc;
+                __syncthreads();
+                if (have && h == 0 && lane < 4) {
+                    float t = red[w * 4 + lane];
+#pragma unroll
+                    for (int ww = 1; ww < WPQ; ++ww) t = __fadd_rn(t, red[(w + ww) * 4 + lane]);
+                    const int o = 4 * lq + lane;
+                    if (o < M.Mw) q_st_out(M.C, a.out_f16, (size_t)n * M.Mw + o, t);
+                }
+            }
+        } else if (SM != 2) {
+            float part[2] = {0.f, 0.f};
+            if (have) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float acc = __fmul_rn(cacc[i][0], 0.5f);
+#pragma unroll
+                    for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(cacc[i][pl], q_alpha(pl)));
+                    acc = __fadd_rn(acc, qdpp_f<0x4E>(acc));      // lane ^ 2
+                    acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // rotate by 4, 8 within the 16-lane row
+                    acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
+                    acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));
+                    acc = __fadd_rn(acc, __shfl_xor(acc, 32, 64));
+                    part[i] = acc;
+                }
+            }
+            if (WPQ == 1) {
+                if (have && lane < 2) {
+                    const int o = 4 * lq + 2 * lane;
+                    if (o < M.Mw) q_st_out(M.C, a.out_f16, (size_t)n * M.Mw + o, part[0]);
+                    if (o + 1 < M.Mw) q_st_out(M.C, a.out_f16, (size_t)n * M.Mw + o + 1, part[1]);
+                }
+            } else {
+                if (lane < 2) { red[w * 4 + 2 * lane] = part[0]; red[w * 4 + 2 * lane + 1] = part[1]; }
+                __syncthreads();
+                if (have && h == 0 && lane < 4) {
+                    float t = red[w * 4 + lane];
+#pragma unroll
+                    for (int ww = 1; ww < WPQ; ++ww) t = __fadd_rn(t, red[(w + ww) * 4 + lane]);
+                    const int o = 4 * lq + lane;
+                    if (o < M.Mw) q_st_out(M.C, a.out_f16, (size_t)n * M.Mw + o, t);
+                }
+            }
+        } else {
+            int32_t* redi = reinterpret_cast<int32_t*>(red);
+            int32_t tot[BITS];
+#pragma unroll
+            for (int pl = 0; pl < BITS; ++pl) {
+                int32_t mine = 0;
+#pragma unroll
+                for (int be = 0; be < 4; ++be) {
+                    int32_t v = have ? iacc[pl][be] : 0;
+#pragma unroll
+                    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+                    if (lane == be) mine = v;
+                }
+                tot[pl] = mine;       // lane be (< 4) holds row be's integer sum of this wave
+            }
+            if (WPQ > 1) {
+                if (lane < 4)
+#pragma unroll
+                    for (int pl = 0; pl < BITS; ++pl) redi[(w * 4 + lane) * 4 + pl] = tot[pl];
+                __syncthreads();
+            }
+            if (have && h == 0 && lane < 4) {
+                const int o = 4 * lq + lane;
+                if (o < M.Mw) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int pl = 0; pl < BITS; ++pl) {
+                        int32_t cb = tot[pl];
+                        if (WPQ > 1)
+#pragma unroll
+                            for (int ww = 1; ww < WPQ; ++ww) cb += redi[((w + ww) * 4 + lane) * 4 + pl];
+                        if (DUMP && a.dump) a.dump[(size_t)n * M.Mw * BITS + mrow(o, pl, BITS)] = cb;
+                        const float t = __fmul_rn((float)cb, q_alpha(pl));
+                        acc = (pl == 0) ? t : __fadd_rn(acc, t);
+                    }
+                    const float v = __fadd_rn(__fmul_rn(acc, l_ls[0]), __fmul_rn(l_lb[0], 0.5f));
+                    q_st_out(M.C, a.out_f16, (size_t)n * M.Mw + o, __fmul_rn(v, q_ld_scale(M.SC, a.sc_f16, o / (M.Mw / s.m_groups))));
+                }
+            }
+        }
+        parity ^= 1;
+        reset_acc();
+    };
+
+    // the fragment ring alternates f0, f1 in issue order; `odd` tracks which one the next compute consumes
+    bool odd = false;
+    for (int it = 0; blockIdx.x * IPI + it * stride < total_q; ++it) {   // uniform trip count across the workgroup
+        const int gq = slot0 + it * stride;
+        const bool have = gq < total_q;
+        int mi = 0, lq = 0;
+        if (have) {
+            locate(gq, mi, lq);
+            for (int st = h; st < nst; st += WPQ) {
+                if (ACC == 1 && SM != 2) {
+                    if (!odd) { compute_mfma(f0, st, a.m[mi].Mw, lq); issue(f0); }
+                    else { compute_mfma(f1, st, a.m[mi].Mw, lq); issue(f1); }
+                } else {
+                    if (!odd) { compute(f0, st, a.m[mi].Mw, lq); issue(f0); }
+                    else { compute(f1, st, a.m[mi].Mw, lq); issue(f1); }
+                }
+                odd = !odd;
+            }
+        }
+        finish_quad(have, a.m[mi], lq);
+    }
+    QSTAMP(4);
+}
+
+// ---------------------------------------------------------------------------------------------
+bool gemv_quad_supported(const Shape& s) {
+    if (s.bits < 1 || s.bits > 4 || s.K % 64 != 0 || s.K > 24576 || s.Mw % 4 != 0) return false;
+    if (s.m_groups >= 1) return s.ags == s.K && s.Mw % s.m_groups == 0;
+    const int gu = s.gs / 32;
+    return s.ags == 64 && s.gs >= 64 && s.gs % 64 == 0 && s.K % s.gs == 0 && (gu & (gu - 1)) == 0;
+}
+
+static size_t quad_lds_bytes(const Shape& s, int nwv) {
+    const int nu = s.K / 32, nu_pad = (nu + 15) & ~15, G = s.K / s.ags;
+    return (size_t)4 * (nu_pad + 1) * 16 + sizeof(float) * (2 * G + 2 * nwv * 16 + nwv + s.K / 32);
+}
+
+void fused_precompute(FusedArgs& a);   // tmac_fused.hip
+
+template <int BITS, bool ZP, int SM, int LUTSRC, int FT, int WPQ>
+static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t st) {
+    constexpr int IPI = FT / 64 / WPQ;
+    const size_t shmem = quad_lds_bytes(a.s, FT / 64);
+    int gx = (total_q + IPI - 1) / IPI;
+    const int cap = (FT == 1024) ? 256 : 512;     // persistent: <= 1 (FT = 1024) / 2 (FT = 512) workgroups per CU
+    if (gx > cap) gx = cap;
+    dim3 g(gx, N), b(FT);
+    const int T = a.s.K / 4;
+    constexpr int A1 = (SM == 2) ? 0 : 1;   // the unified-scale path keeps the VALU accumulate
+#define QL(NRV, FTV, DV, AV) hipLaunchKernelGGL((k_gemv_quad<BITS, ZP, SM, LUTSRC, NRV, FTV, WPQ, DV, AV>), g, b, shmem, st, a)
+    const bool two = (LUTSRC == 0 || T <= 2 * FT);
+    if (!two && T > 6 * FT) return hipErrorInvalidValue;
+    if (a.dump) {   // parity tap: one configuration (FT = 512) carries the tap code
+        if (FT != 512) return hipErrorInvalidValue;
+        if (a.acc_mfma) { if (two) QL(2, 512, true, A1); else QL(6, 512, true, A1); }
+        else { if (two) QL(2, 512, true, 0); else QL(6, 512, true, 0); }
+        return hipGetLastError();
+    }
+    if (a.acc_mfma) { if (two) QL(2, FT, false, A1); else QL(6, FT, false, A1); }
+    else { if (two) QL(2, FT, false, 0); else QL(6, FT, false, 0); }
+#undef QL
+    return hipGetLastError();
+}
+
+template <int BITS, bool ZP, int SM, int LUTSRC>
+static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_ft, int force_wpq, hipStream_t st) {
+    // makespan heuristic (in wave-steps): rounds of work over 256 CUs x FT/64 waves, WPQ splits the K steps
+    const int nst = (a.s.K / 32 + 63) / 64;
+    int best_ft = 512, best_wpq = 1;
+    double best = 1e30;
+    bool best_fills = false;
+    for (int ft : {512, 1024})
+        for (int wpq : {1, 2}) {
+            if (wpq > nst) continue;
+            if (force_ft && ft != force_ft) continue;
+            if (a.dump && ft != 512) continue;
+            if (force_wpq && wpq != force_wpq) continue;
+            if (a.s.K / 4 > 6 * ft) continue;
+            const int ipi = ft / 64 / wpq;
+            int wgs = (total_q + ipi - 1) / ipi;
+            const bool fills = wgs >= 256;                       // a workgroup on every CU
+            const int cap = (ft == 1024) ? 256 : 512;
+            if (wgs > cap) wgs = cap;
+            const int slots = wgs * ipi;                         // quads in flight chip-wide
+            const double rounds = (double)((total_q + slots - 1) / slots);
+            const double steps = (double)((nst + wpq - 1) / wpq);
+            const double cost = rounds * (steps + (wpq > 1 ? 0.35 : 0.0)) + (wgs > 256 ? 0.3 : 0.0);   // > 1 LUT build per CU
+            if ((fills && !best_fills) || (fills == best_fills && cost < best)) {
+                best = cost; best_ft = ft; best_wpq = wpq; best_fills = fills;
+            }
+        }
+    if (best >= 1e30) return hipErrorInvalidValue;
+    if (best_ft == 512) return best_wpq == 1 ? qlaunch_nr<BITS, ZP, SM, LUTSRC, 512, 1>(a, total_q, N, st)
+                                             : qlaunch_nr<BITS, ZP, SM, LUTSRC, 512, 2>(a, total_q, N, st);
+    return best_wpq == 1 ? qlaunch_nr<BITS, ZP, SM, LUTSRC, 1024, 1>(a, total_q, N, st)
+                         : qlaunch_nr<BITS, ZP, SM, LUTSRC, 1024, 2>(a, total_q, N, st);
+}
+
+template <int BITS, int LUTSRC>
+static hipError_t qlaunch_b(const FusedArgs& a, int total_q, int N, int fft, int fwpq, hipStream_t st) {
+    if (a.s.m_groups >= 1) return qlaunch_cfg<BITS, false, 2, LUTSRC>(a, total_q, N, fft, fwpq, st);
+    return a.s.zero_point ? qlaunch_cfg<BITS, true, 0, LUTSRC>(a, total_q, N, fft, fwpq, st)
+                          : qlaunch_cfg<BITS, false, 0, LUTSRC>(a, total_q, N, fft, fwpq, st);
+}
+
+// a.m[i].nb_end must hold cumulative QUAD counts.  force_ft / force_wpq: 0 = heuristic (A/B knobs)
+hipError_t launch_gemv_quad(const FusedArgs& a_in, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st) {
+    if (!gemv_quad_supported(a_in.s) || a_in.nmat < 1 || a_in.nmat > 4) return hipErrorInvalidValue;
+    FusedArgs a = a_in;
+    fused_precompute(a);
+    const int total_q = a.m[a.nmat - 1].nb_end;
+#define QDISPATCH(B) \
+    case B: return build_lut ? qlaunch_b<B, 1>(a, total_q, N, force_ft, force_wpq, st) : qlaunch_b<B, 0>(a, total_q, N, force_ft, force_wpq, st);
+    switch (a.s.bits) {
+        QDISPATCH(1) QDISPATCH(2) QDISPATCH(3) QDISPATCH(4)
+    }
+#undef QDISPATCH
+    return hipErrorInvalidValue;
+}
+
+}  // namespace tmac

@@ -28,7 +28,7 @@ def run_emu(emu, A, q, Mw, K, bits, bm, kf, ags, mode):
     return PS
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("name", sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))))
 def test_emulation_matches_golden(emu, name, mode):
     d = dict(np.load(os.path.join(GOLD, name + ".npz")))
@@ -55,7 +55,7 @@ def test_emulation_matches_oracle(emu, bits, bm, kf, ags, Mw, K):
     A = orc.preprocess_weights(case["w"], bits, bm, kf)
     q, _, _ = orc.preprocessor(case["B"], ags)
     PSo = orc.partial_sums(A, q[0], Mw, K, bits, bm, kf, ags)
-    for mode in (0, 1, 2, 3):
+    for mode in (0, 1, 2, 3, 4):
         assert np.array_equal(run_emu(emu, A, q[0], Mw, K, bits, bm, kf, ags, mode), PSo)
 
 
@@ -69,5 +69,5 @@ def test_extreme_tables(emu):
         q = np.full((K // 4, 16), fill, np.int8)
         q[:, 8:] = -q[:, 7::-1]   # keep the antisymmetry the kernel relies on
         PSo = orc.partial_sums(A, q, Mw, K, bits, bm, kf, ags)
-        for mode in (0, 1, 2, 3):
+        for mode in (0, 1, 2, 3, 4):
             assert np.array_equal(run_emu(emu, A, q, Mw, K, bits, bm, kf, ags, mode), PSo)

@@ -126,7 +126,7 @@ def test_isa_models(tm):
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz")))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7])
 @pytest.mark.parametrize("name", CASES)
 def test_golden_vectors(tm, name, variant):
     """committed vectors produced by the reference itself (tests/golden/make_golden.py)"""
@@ -162,7 +162,7 @@ CFGS = [  # Mw, K, bits, bm, kf, gs, ags, zp, m_groups
 ]
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 7])
 @pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,mg", CFGS)
 def test_vs_oracle(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, variant):
     case = orc.make_case(Mw + K + bits, Mw, K, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg)
@@ -275,7 +275,7 @@ def test_host_pointer_cabi_matches_prebuilt_reference(tm, tmp_path):
 FUSED_CFGS = [c for c in CFGS if (c[6] == 64 and c[8] == -1) or c[6] == c[1]]
 
 
-@pytest.mark.parametrize("variant", [0, 5])
+@pytest.mark.parametrize("variant", [0, 4, 5, 7])
 @pytest.mark.parametrize("act_f16", [False, True])
 @pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,mg", FUSED_CFGS)
 def test_fused_kernel_builds_the_same_lut(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, act_f16, variant):
@@ -286,7 +286,7 @@ def test_fused_kernel_builds_the_same_lut(tm, Mw, K, bits, bm, kf, gs, ags, zp, 
     A = orc.preprocess_weights(case["w"], bits, bm, kf)
     S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm) if mg == -1 else case["sc"]
     cfg = tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, zp, mg)
-    tm.binding.check(tm.lib().tmac_hip_set_variant(variant))   # 0: v_mqsad accumulate (default), 5: MFMA accumulate
+    tm.binding.check(tm.lib().tmac_hip_set_variant(variant))   # 0: quad kernel, MFMA accumulate (default); 7: quad kernel, v_mqsad accumulate; 4 / 5: row-block fused kernel
     wr = tm.TMACGeMMWrapper(act_group_size=ags)
     wr.set_workspace(K, 1)
     w = wr.register_weights(A, S, Mw, K, bits, cfg)
@@ -336,3 +336,39 @@ def test_fused_multi_matrix_launch(tm):
         assert rel_err(o.cpu().numpy(), ref) <= 2e-5
     for w in ws:
         w.free()
+
+
+@pytest.mark.parametrize("variant", [0, 7])
+@pytest.mark.parametrize("ft,wpq", [(512, 1), (512, 2), (1024, 1), (1024, 2)])
+@pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,mg", [CFGS[0], CFGS[1], CFGS[3], CFGS[8]])
+def test_quad_kernel_configurations(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, ft, wpq, variant):
+    """every (threads per workgroup, waves per quad, accumulate) configuration of k_gemv_quad, LUT built
+    in-kernel; the integer tap exists in the 512-thread configurations"""
+    import torch
+    L = tm.lib()
+    L.tmac_hip_debug_quad_config.argtypes = [C.c_int, C.c_int]
+    case = orc.make_case(3 * Mw + K, Mw, K, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg)
+    A = orc.preprocess_weights(case["w"], bits, bm, kf)
+    S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm) if mg == -1 else case["sc"]
+    tm.binding.check(L.tmac_hip_set_variant(variant))
+    wr = tm.TMACGeMMWrapper(act_group_size=ags)
+    wr.set_workspace(K, 1)
+    w = wr.register_weights(A, S, Mw, K, bits, tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, zp, mg))
+    Bt = torch.from_numpy(case["B"]).cuda()
+    Ct = torch.empty((1, Mw), dtype=torch.float32, device="cuda")
+    q, ls, lb, Cc, PSo = oracle_case(case, A, S, Mw, K, bits, bm, kf, gs, ags, zp, mg)
+    L.tmac_hip_debug_quad_config(ft, wpq)
+    try:
+        wr.fused([w], Bt, [Ct])
+        torch.cuda.synchronize()
+        assert rel_err(Ct.cpu().numpy(), Cc) <= 2e-5
+        if ft == 512:
+            PS, Cf = wr.fused_partial_sums(w, Bt)
+            assert np.array_equal(PS, PSo)
+            check_bits(wr.last_fused_lut[:, 0, :], ls)
+            check_bits(wr.last_fused_lut[:, 1, :], lb)
+            check_bits(Ct.cpu().numpy(), Cf)
+    finally:
+        L.tmac_hip_debug_quad_config(0, 0)
+        L.tmac_hip_set_variant(0)
+    w.free()

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
 
     // ---- 2. this wave's work: quads slot, slot + stride, ...; steps h, h + WPQ, ... of each ------
     const int slot0 = blockIdx.x * IPI + w / WPQ, h = w % WPQ, stride = gridDim.x * IPI;
-    QFrag<BITS> f0, f1;
+    constexpr int RING = (BITS <= 2) ? 4 : 2;      // weight fragments in flight per wave (register budget)
+    QFrag<BITS> f0, f1, f2, f3;
     int p_q = slot0, p_st = h;    // prefetch cursor
     auto issue = [&](QFrag<BITS>& f) {
         if (p_q < total_q) {
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     };
     issue(f0);
     issue(f1);
+    if (RING == 4) { issue(f2); issue(f3); }
     QSTAMP(1);
 
     // ---- 3. LUT into LDS (all FT threads) ------------------------------------------------------
@@ -534,8 +536,8 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
         reset_acc();
     };
 
-    // the fragment ring alternates f0, f1 in issue order; `odd` tracks which one the next compute consumes
-    bool odd = false;
+    // the fragment ring is consumed in issue order; `pos` tracks which fragment the next compute consumes
+    int pos = 0;
     for (int it = 0; blockIdx.x * IPI + it * stride < total_q; ++it) {   // uniform trip count across the workgroup
         const int gq = slot0 + it * stride;
         const bool have = gq < total_q;
@@ -543,28 +545,37 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
         if (have) {
             locate(gq, mi, lq);
             for (int st = h; st < nst; st += WPQ) {
-                if (ACC == 1 && SM != 2) {
-                    if (!odd) { compute_mfma(f0, st, a.m[mi].Mw, lq); issue(f0); }
-                    else { compute_mfma(f1, st, a.m[mi].Mw, lq); issue(f1); }
-                } else {
-                    if (!odd) { compute(f0, st, a.m[mi].Mw, lq); issue(f0); }
-                    else { compute(f1, st, a.m[mi].Mw, lq); issue(f1); }
-                }
-                odd = !odd;
+#define QSTEP(F) do { if (ACC == 1 && SM != 2) compute_mfma(F, st, a.m[mi].Mw, lq); else compute(F, st, a.m[mi].Mw, lq); issue(F); } while (0)
+                if (pos == 0) QSTEP(f0);
+                else if (pos == 1) QSTEP(f1);
+                else if (pos == 2) QSTEP(f2);
+                else QSTEP(f3);
+#undef QSTEP
+                pos = (pos + 1) & (RING - 1);
             }
         }
+        if (it == 0) QSTAMP(4);
         finish_quad(have, a.m[mi], lq);
+        if (it == 0) QSTAMP(5);
     }
-    QSTAMP(4);
+    QSTAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------
+#ifndef TMAC_QUAD_BITS
+#error "compile with -DTMAC_QUAD_BITS=2 or 4 (one translation unit per bit width keeps the build parallel)"
+#endif
+
+#if TMAC_QUAD_BITS == 2
 bool gemv_quad_supported(const Shape& s) {
-    if (s.bits < 1 || s.bits > 4 || s.K % 64 != 0 || s.K > 24576 || s.Mw % 4 != 0) return false;
+    // instantiated for the shipped bit widths (W2, W4); W1 / W3 use the row-block fused kernel
+    if ((s.bits != 2 && s.bits != 4) || s.K % 64 != 0 || s.K > 24576 || s.Mw % 4 != 0) return false;
     if (s.m_groups >= 1) return s.ags == s.K && s.Mw % s.m_groups == 0;
     const int gu = s.gs / 32;
     return s.ags == 64 && s.gs >= 64 && s.gs % 64 == 0 && s.K % s.gs == 0 && (gu & (gu - 1)) == 0;
 }
+
+#endif
 
 static size_t quad_lds_bytes(const Shape& s, int nwv) {
     const int nu = s.K / 32, nu_pad = (nu + 15) & ~15, G = s.K / s.ags;
@@ -573,6 +584,9 @@ static size_t quad_lds_bytes(const Shape& s, int nwv) {
 
 void fused_precompute(FusedArgs& a);   // tmac_fused.hip
 
+// Instantiation policy (compile time): the v_mqsad accumulate (ACC 0) exists for the unified-scale path and, as an
+// A/B variant, for 512-thread workgroups; the prebuilt-LUT source (LUTSRC 0) and the integer tap (DUMP) only for
+// 512-thread workgroups.
 template <int BITS, bool ZP, int SM, int LUTSRC, int FT, int WPQ>
 static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t st) {
     constexpr int IPI = FT / 64 / WPQ;
@@ -583,51 +597,45 @@ static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t
     dim3 g(gx, N), b(FT);
     const int T = a.s.K / 4;
     constexpr int A1 = (SM == 2) ? 0 : 1;   // the unified-scale path keeps the VALU accumulate
-#define QL(NRV, FTV, DV, AV) hipLaunchKernelGGL((k_gemv_quad<BITS, ZP, SM, LUTSRC, NRV, FTV, WPQ, DV, AV>), g, b, shmem, st, a)
+#define QL(NRV, DV, AV) hipLaunchKernelGGL((k_gemv_quad<BITS, ZP, SM, LUTSRC, NRV, FT, WPQ, DV, AV>), g, b, shmem, st, a)
     const bool two = (LUTSRC == 0 || T <= 2 * FT);
     if (!two && T > 6 * FT) return hipErrorInvalidValue;
-    if (a.dump) {   // parity tap: one configuration (FT = 512) carries the tap code
-        if (FT != 512) return hipErrorInvalidValue;
-        if (a.acc_mfma) { if (two) QL(2, 512, true, A1); else QL(6, 512, true, A1); }
-        else { if (two) QL(2, 512, true, 0); else QL(6, 512, true, 0); }
-        return hipGetLastError();
+    if constexpr (FT == 512) {
+        const int acc = (SM == 2) ? 0 : (a.acc_mfma ? 1 : 0);
+        if (a.dump) {
+            if (acc) { if (two) QL(2, true, A1); else if constexpr (LUTSRC == 1) QL(6, true, A1); }
+            else { if (two) QL(2, true, 0); else if constexpr (LUTSRC == 1) QL(6, true, 0); }
+        } else {
+            if (acc) { if (two) QL(2, false, A1); else if constexpr (LUTSRC == 1) QL(6, false, A1); }
+            else { if (two) QL(2, false, 0); else if constexpr (LUTSRC == 1) QL(6, false, 0); }
+        }
+    } else {
+        if (a.dump || LUTSRC == 0 || (SM != 2 && !a.acc_mfma)) return hipErrorInvalidValue;
+        if constexpr (LUTSRC == 1) { if (two) QL(2, false, A1); else QL(6, false, A1); }
     }
-    if (a.acc_mfma) { if (two) QL(2, FT, false, A1); else QL(6, FT, false, A1); }
-    else { if (two) QL(2, FT, false, 0); else QL(6, FT, false, 0); }
 #undef QL
     return hipGetLastError();
 }
 
 template <int BITS, bool ZP, int SM, int LUTSRC>
 static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_ft, int force_wpq, hipStream_t st) {
-    // makespan heuristic (in wave-steps): rounds of work over 256 CUs x FT/64 waves, WPQ splits the K steps
+    // Configuration choice, from tools/tune_quad.py on MI355X (profiles/r01_tune_quad.txt, us per launch in a graph):
+    //   o 4096x4096: (512,2) 6.1 | qkv 12288x4096: (512,1) 9.7, (1024,1) 9.3 | gate_up 22016x4096: (512,1) 13.1,
+    //   (1024,1) 15.6 | down 4096x11008: (512,2) 11.0, (512,1) 14.9.  -> 512-thread workgroups; two waves per quad
+    //   while there are too few quads to give every wave of the chip one (<= 2048).
     const int nst = (a.s.K / 32 + 63) / 64;
-    int best_ft = 512, best_wpq = 1;
-    double best = 1e30;
-    bool best_fills = false;
-    for (int ft : {512, 1024})
-        for (int wpq : {1, 2}) {
-            if (wpq > nst) continue;
-            if (force_ft && ft != force_ft) continue;
-            if (a.dump && ft != 512) continue;
-            if (force_wpq && wpq != force_wpq) continue;
-            if (a.s.K / 4 > 6 * ft) continue;
-            const int ipi = ft / 64 / wpq;
-            int wgs = (total_q + ipi - 1) / ipi;
-            const bool fills = wgs >= 256;                       // a workgroup on every CU
-            const int cap = (ft == 1024) ? 256 : 512;
-            if (wgs > cap) wgs = cap;
-            const int slots = wgs * ipi;                         // quads in flight chip-wide
-            const double rounds = (double)((total_q + slots - 1) / slots);
-            const double steps = (double)((nst + wpq - 1) / wpq);
-            const double cost = rounds * (steps + (wpq > 1 ? 0.35 : 0.0)) + (wgs > 256 ? 0.3 : 0.0);   // > 1 LUT build per CU
-            if ((fills && !best_fills) || (fills == best_fills && cost < best)) {
-                best = cost; best_ft = ft; best_wpq = wpq; best_fills = fills;
-            }
-        }
+    int best_ft = 512, best_wpq = (total_q <= 2048 && nst >= 2) ? 2 : 1;
+    double best = 0.0;
+    if (force_ft) best_ft = force_ft;
+    if (force_wpq) best_wpq = force_wpq;
+    const bool need512 = a.dump || LUTSRC == 0 || (SM != 2 && !a.acc_mfma);
+    if ((need512 && best_ft != 512) || (best_wpq == 4 && best_ft != 1024) || (best_ft != 512 && best_ft != 1024) ||
+        (best_wpq != 1 && best_wpq != 2 && best_wpq != 4) || a.s.K / 4 > 6 * best_ft)
+        best = 1e30;
     if (best >= 1e30) return hipErrorInvalidValue;
     if (best_ft == 512) return best_wpq == 1 ? qlaunch_nr<BITS, ZP, SM, LUTSRC, 512, 1>(a, total_q, N, st)
                                              : qlaunch_nr<BITS, ZP, SM, LUTSRC, 512, 2>(a, total_q, N, st);
+    if (best_wpq == 4) return qlaunch_nr<BITS, ZP, SM, LUTSRC, 1024, 4>(a, total_q, N, st);
     return best_wpq == 1 ? qlaunch_nr<BITS, ZP, SM, LUTSRC, 1024, 1>(a, total_q, N, st)
                          : qlaunch_nr<BITS, ZP, SM, LUTSRC, 1024, 2>(a, total_q, N, st);
 }
@@ -640,18 +648,20 @@ static hipError_t qlaunch_b(const FusedArgs& a, int total_q, int N, int fft, int
 }
 
 // a.m[i].nb_end must hold cumulative QUAD counts.  force_ft / force_wpq: 0 = heuristic (A/B knobs)
+#if TMAC_QUAD_BITS == 2
+hipError_t launch_gemv_quad_b4(const FusedArgs& a, int total_q, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st);
 hipError_t launch_gemv_quad(const FusedArgs& a_in, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st) {
     if (!gemv_quad_supported(a_in.s) || a_in.nmat < 1 || a_in.nmat > 4) return hipErrorInvalidValue;
     FusedArgs a = a_in;
     fused_precompute(a);
     const int total_q = a.m[a.nmat - 1].nb_end;
-#define QDISPATCH(B) \
-    case B: return build_lut ? qlaunch_b<B, 1>(a, total_q, N, force_ft, force_wpq, st) : qlaunch_b<B, 0>(a, total_q, N, force_ft, force_wpq, st);
-    switch (a.s.bits) {
-        QDISPATCH(1) QDISPATCH(2) QDISPATCH(3) QDISPATCH(4)
-    }
-#undef QDISPATCH
-    return hipErrorInvalidValue;
+    if (a.s.bits == 4) return launch_gemv_quad_b4(a, total_q, N, build_lut, force_ft, force_wpq, st);
+    return build_lut ? qlaunch_b<2, 1>(a, total_q, N, force_ft, force_wpq, st) : qlaunch_b<2, 0>(a, total_q, N, force_ft, force_wpq, st);
 }
+#else
+hipError_t launch_gemv_quad_b4(const FusedArgs& a, int total_q, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st) {
+    return build_lut ? qlaunch_b<4, 1>(a, total_q, N, force_ft, force_wpq, st) : qlaunch_b<4, 0>(a, total_q, N, force_ft, force_wpq, st);
+}
+#endif
 
 }  // namespace tmac

@@ -302,7 +302,8 @@ def test_fused_kernel_builds_the_same_lut(tm, Mw, K, bits, bm, kf, gs, ags, zp, 
     check_bits(wr.last_fused_lut[:, 0, :], ls)        # LUT scales built in LDS, bit for bit
     check_bits(wr.last_fused_lut[:, 1, :], lb)        # LUT biases (the reference's horizontal-add order)
     assert rel_err(Cf, Cc) <= 2e-5
-    check_bits(Ct.cpu().numpy(), Cf)
+    # the tap launch may use another (threads, waves-per-quad) configuration, i.e. another fp32 summation order
+    assert rel_err(Ct.cpu().numpy(), Cf) <= 2e-6
     w.free()
     tm.lib().tmac_hip_set_variant(0)
 
@@ -339,7 +340,7 @@ def test_fused_multi_matrix_launch(tm):
 
 
 @pytest.mark.parametrize("variant", [0, 7])
-@pytest.mark.parametrize("ft,wpq", [(512, 1), (512, 2), (1024, 1), (1024, 2)])
+@pytest.mark.parametrize("ft,wpq", [(512, 1), (512, 2), (1024, 1), (1024, 2), (1024, 4)])
 @pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,mg", [CFGS[0], CFGS[1], CFGS[3], CFGS[8]])
 def test_quad_kernel_configurations(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, ft, wpq, variant):
     """every (threads per workgroup, waves per quad, accumulate) configuration of k_gemv_quad, LUT built
@@ -357,6 +358,8 @@ def test_quad_kernel_configurations(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, ft
     Bt = torch.from_numpy(case["B"]).cuda()
     Ct = torch.empty((1, Mw), dtype=torch.float32, device="cuda")
     q, ls, lb, Cc, PSo = oracle_case(case, A, S, Mw, K, bits, bm, kf, gs, ags, zp, mg)
+    if variant == 7 and ft == 1024:
+        pytest.skip("the v_mqsad accumulate is instantiated for 512-thread workgroups only")
     L.tmac_hip_debug_quad_config(ft, wpq)
     try:
         wr.fused([w], Bt, [Ct])

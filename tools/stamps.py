@@ -28,12 +28,12 @@ for name, Mw, K, cnt in [("o", 4096, 4096, 1), ("qkv", 4096, 4096, 3), ("gate_up
     s = s[s[:, 0] > 0]
     nb = len(s)
     t0 = s[:, 0].min()
-    rel = (s[:, :5] - t0)
-    d = np.diff(s[:, :5], axis=1)
+    rel = (s[:, :7] - t0)
+    d = np.diff(s[:, :7], axis=1)
     print(f"== {name} Mw={Mw}x{cnt} K={K}: blocks={nb}; stamps in s_memtime ticks")
-    print("   kernel span (last end - first start):", rel[:, 4].max())
+    print("   kernel span (last end - first start):", rel[:, 6].max())
     print("   block start spread: min/median/max", rel[:, 0].min(), np.median(rel[:, 0]), rel[:, 0].max())
-    print("   phase medians [issue loads, build LUT, barrier, all row blocks]:", np.median(d, axis=0))
+    print("   phase medians [issue loads, build LUT, barrier, first quad lookups, first quad reduce+store, remaining quads]:", np.median(d, axis=0))
     print("   phase p90:", np.percentile(d, 90, axis=0))
-    print("   workgroup duration median/max:", np.median(rel[:, 4] - rel[:, 0]), (rel[:, 4] - rel[:, 0]).max())
+    print("   workgroup duration median/max:", np.median(rel[:, 6] - rel[:, 0]), (rel[:, 6] - rel[:, 0]).max())
     for w in ws: w.free()

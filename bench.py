@@ -34,6 +34,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+# HBM bytes per launch of the headline GEMV from rocprofv3 --pmc FETCH_SIZE (separate pass, x2 gfx950 correction,
+# MI355X_MICROARCH.md HBM section): profiles/r01_pmc_fetch_size.txt — 7186 KiB x 2 = 14.72 MB vs 12.73 MB algorithmic
+# (the x2 rule is calibrated for 16 B/lane streams; the 8 B/lane scale loads are probably double-counted by it)
+PMC_TRAFFIC_BYTES = 14716928
 LAYERS = 32
 # (name, Mw, K, count per layer, input slot)
 MATS = [("qkv", 4096, 4096, 3, 0), ("o", 4096, 4096, 1, 1), ("gate_up", 11008, 4096, 2, 2), ("down", 4096, 11008, 1, 3)]
@@ -206,7 +210,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = not args.no_graph
+    # RCCL collectives inside a captured graph are not exercised on the 1-GPU development box: multi-GPU runs launch eagerly
+    use_graph = (not args.no_graph) and world == 1
     graph = None
     if use_graph:
         # capture ONE step (352 launches on one stream) into a hipGraph; the timed region replays it
@@ -264,8 +269,8 @@ def main():
         durs = np.array(durs)
         hb = algorithmic_bytes(shard_rows["down"], 11008)
         ach = hb / float(np.mean(durs)) / 1e9
-        roof = {"bound": "hbm", "kernel": ("k_gemv_fused (LUT build + GEMV)" if args.path == "fused" else "k_gemv (LUT prebuilt)") + " on the headline shape 4096x11008 W2 g128 zp", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+        roof = {"bound": "hbm", "kernel": ("k_gemv_quad, LUT build fused" if args.path == "fused" else "k_gemv_quad, LUT prebuilt") + ", headline shape 4096x11008 W2 g128 zp", "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES,
                 "algorithmic_bytes_per_launch": hb, "avg_launch_us": round(float(np.mean(durs)) * 1e6, 3),
                 "min_launch_us": round(float(np.min(durs)) * 1e6, 3), "launches_timed": reps * args.layers,
                 "timing": "hipEvent pair on the launch stream around 32 back-to-back launches (distinct weights), mean of 5"}

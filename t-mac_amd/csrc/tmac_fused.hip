@@ -103,8 +103,12 @@ __device__ __forceinline__ void load_w(WFrag<BITS>& f, const FusedArgs& a, const
             f.wd[4 * j] = v.x; f.wd[4 * j + 1] = v.y; f.wd[4 * j + 2] = v.z; f.wd[4 * j + 3] = v.w;
         }
     }
+    // scale words go through scalar locals and reach f.sraw with constant subscripts: stores to different elements
+    // in the two dtype branches would be sunk into one store with a run-time subscript (-> scratch memory)
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
     if (SM == 0 && ACC == 1) {
-        // epilogue lane l' = 16*lg + 4*rlp + bp owns row (rlp, bp) and units ub*16 + 4*lg .. +3 (2 act groups)
+        // epilogue lane l' = 16*lg + 4*rlp + bp owns row (rlp, bp) and units ub*16 + 4*lg .. +3 (2 act groups);
+        // sraw[2*gi], sraw[2*gi+1]: scale (, zero) of act-group pair gi; f16 packs both into sraw[2*gi]
         constexpr int per = ZP ? 2 : 1;
         const int lane = rl * KL + ul, lg = lane >> 4, rlp = (lane & 15) >> 2, bp = lane & 3;
         const int ub4 = ub * KL + 4 * lg;
@@ -112,18 +116,20 @@ __device__ __forceinline__ void load_w(WFrag<BITS>& f, const FusedArgs& a, const
         for (int gi = 0; gi < 2; ++gi) {
             if (gi == 1 && a.gs_shift >= 2) break;               // gs >= 128: both act groups share the scale group
             const int sg = (ub4 + 2 * gi) >> a.gs_shift;
+            uint32_t v0 = 0, v1 = 0;
             if (ub4 + 2 * gi < a.nu) {
                 const size_t sidx = ((((size_t)b * a.nsg + sg) * RL + rlp) * 4 + bp) * per;
                 if (a.sc_f16) {
                     const __half* ph = reinterpret_cast<const __half*>(M.SC) + sidx;
-                    if (ZP) f.sraw[gi] = *reinterpret_cast<const uint32_t*>(ph);
-                    else f.sraw[gi] = *reinterpret_cast<const unsigned short*>(ph);
+                    if (ZP) v0 = *reinterpret_cast<const uint32_t*>(ph);
+                    else v0 = *reinterpret_cast<const unsigned short*>(ph);
                 } else {
                     const uint32_t* p32 = reinterpret_cast<const uint32_t*>(M.SC) + sidx;
-                    f.sraw[2 * gi] = p32[0];
-                    if (ZP) f.sraw[2 * gi + 1] = p32[1];
+                    v0 = p32[0];
+                    if (ZP) v1 = p32[1];
                 }
             }
+            if (gi == 0) { r0 = v0; r1 = v1; } else { r2 = v0; r3 = v1; }
         }
     } else if (SM == 0 && src_valid) {
         constexpr int per = ZP ? 2 : 1;
@@ -132,14 +138,15 @@ __device__ __forceinline__ void load_w(WFrag<BITS>& f, const FusedArgs& a, const
         // 2*per consecutive elements: 4 B (f16) / 8 B (f16 zp, f32) / 16 B (f32 zp), naturally aligned
         if (a.sc_f16) {
             const uint32_t* p32 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const __half*>(M.SC) + sidx);
-            f.sraw[0] = p32[0];
-            if (ZP) f.sraw[1] = p32[1];
+            r0 = p32[0];
+            if (ZP) r1 = p32[1];
         } else {
             const uint32_t* p32 = reinterpret_cast<const uint32_t*>(M.SC) + sidx;
-#pragma unroll
-            for (int e = 0; e < 2 * per; ++e) f.sraw[e] = p32[e];
+            r0 = p32[0]; r1 = p32[1];
+            if (ZP) { r2 = p32[2]; r3 = p32[3]; }
         }
     }
+    if (SM == 0) { f.sraw[0] = r0; f.sraw[1] = r1; f.sraw[2] = r2; f.sraw[3] = r3; }
 }
 
 // SM 0: per-(row, group) scales (+ zero points), act group 64.   SM 2: unified scale applied last (ags == K).
@@ -416,15 +423,15 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
             if (ug < nu) {
                 const int kk = ug >> 1;
                 const float ls = l_ls[kk], lb = l_lb[kk];
-                const int si = (a.gs_shift >= 2) ? 0 : gi;              // which prefetched scale group
+                const bool first = (gi == 0) || (a.gs_shift >= 2);     // which prefetched scale group (constant subscripts)
                 float sc, zr = 0.f;
                 if (a.sc_f16) {
-                    const uint32_t wv = f.sraw[si];
+                    const uint32_t wv = first ? f.sraw[0] : f.sraw[2];
                     sc = __half2float(__ushort_as_half((unsigned short)(wv & 0xffff)));
                     if (ZP) zr = __half2float(__ushort_as_half((unsigned short)(wv >> 16)));
                 } else {
-                    sc = __uint_as_float(f.sraw[2 * si]);
-                    if (ZP) zr = __uint_as_float(f.sraw[2 * si + 1]);
+                    sc = __uint_as_float(first ? f.sraw[0] : f.sraw[2]);
+                    if (ZP) zr = __uint_as_float(first ? f.sraw[1] : f.sraw[3]);
                 }
 #pragma unroll
                 for (int pl = 0; pl < BITS; ++pl) {

@@ -203,6 +203,14 @@ extern "C" int32_t tmac_hip_set_variant(int variant) {
     return TMAC_HIP_OK;
 }
 
+// N at and above which qgemm runs the one-hot MFMA GEMM instead of looping the GEMV kernel (0 = never)
+static int g_gemm_min_n = 8;
+extern "C" int32_t tmac_hip_set_gemm_min_n(int n) {
+    if (n < 0) return fail(TMAC_HIP_E_ARG, "gemm_min_n must be >= 0");
+    g_gemm_min_n = n;
+    return TMAC_HIP_OK;
+}
+
 extern "C" int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host, int n) {
     if (!in_host || !out_host || n <= 0) return fail(TMAC_HIP_E_ARG, "bad selftest arguments");
     int32_t rc = ensure_device();
@@ -479,6 +487,16 @@ static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* w
         if (!w->lo_ok) v = V_REF_LAYOUT;
         else if (w->s.ts == 8) v = V_FUSED;
         else if (v != V_LO_SDWA) v = V_LO_MQSAD;
+    }
+    if (v == V_FUSED && g_gemm_min_n > 0 && N >= g_gemm_min_n && gemm_onehot_supported(w->s)) {
+        GemmArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        ga.s = w->s; ga.W = w->W; ga.SC = w->SC; ga.sc_f16 = w->sc_dtype == F16; ga.out_f16 = out_dtype == TMAC_F16;
+        ga.qlut_ref = ws->qlut_ref; ga.lut_scales = ws->lut_scales; ga.lut_biases = ws->lut_biases;
+        ga.C = C_dev; ga.dump = dump; ga.N = N;
+        hipError_t e = launch_gemm_onehot(ga, st);
+        if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "one-hot gemm launch: %s", hipGetErrorString(e));
+        return TMAC_HIP_OK;
     }
     if (v == V_FUSED) {
         FusedArgs fa;

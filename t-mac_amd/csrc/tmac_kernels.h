@@ -46,6 +46,20 @@ struct FusedArgs {
     int nu, nsb, tstride, G, nsg, gs_shift;   // filled by launch_gemv_fused (host-side divides)
 };
 
+// one-hot MFMA GEMM for N > 1 activation rows (tmac_gemm.hip); weights in the QUAD layout
+struct GemmArgs {
+    Shape s;
+    const void* W;            // QUAD layout weights
+    const void* SC;           // QUAD layout scales
+    int sc_f16, out_f16;
+    const int8_t* qlut_ref;   // int8 [N][K/4][16]  (k_preprocess)
+    const float* lut_scales;  // fp32 [N][K/ags]
+    const float* lut_biases;
+    void* C;                  // [N][Mw]
+    int32_t* dump;            // optional integer tap [N][M][K/ags]
+    int N;
+};
+
 struct GemvArgs {
     Shape s;
     const void* W;        // device layout weights (uint4)        | reference blob for V_REF_LAYOUT
@@ -69,6 +83,8 @@ hipError_t launch_retile_scales(const void* S_ref, Dtype in_dt, void* Sd, Dtype 
 hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, float* lut_scales,
                              float* lut_biases, int K, int N, int ags, size_t qdev_u4_per_row, hipStream_t st);
 hipError_t launch_qlut_ref_to_dev(const int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, int K, int N, size_t qdev_u4_per_row, hipStream_t st);
+bool gemm_onehot_supported(const Shape& s);
+hipError_t launch_gemm_onehot(const GemmArgs& a, hipStream_t st);
 // fused kernel (tmac_fused.hip)
 bool gemv_fused_supported(const Shape& s);
 size_t qlut_lds_u4(int K);   // uint4 per activation row of the LDS-image LUT

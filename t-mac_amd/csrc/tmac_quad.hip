@@ -17,6 +17,7 @@
 
 #include "tmac_core.h"
 #include "tmac_kernels.h"
+#include "tmac_fastdiv.h"
 
 namespace tmac {
 
@@ -30,11 +31,15 @@ template <int CTRL>
 __device__ __forceinline__ uint32_t qdpp_u(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
+// max over the 16 lanes of a DPP row, result in every lane.  v_max_f32 with a DPP source operand: fmaxf() through
+// update_dpp costs a v_mov_dpp plus canonicalising v_max pairs (5 instructions per step instead of 1).  The s_nop
+// covers the VALU-write -> DPP-read hazard, which the compiler does not track through inline asm.
 __device__ __forceinline__ float q_row_allmax(float v) {
-    v = fmaxf(v, qdpp_f<0xB1>(v));
-    v = fmaxf(v, qdpp_f<0x4E>(v));
-    v = fmaxf(v, qdpp_f<0x141>(v));
-    v = fmaxf(v, qdpp_f<0x140>(v));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
     return v;
 }
 __device__ __forceinline__ float q_alpha(int p) { return p == 0 ? 0.5f : (p == 1 ? 1.0f : (p == 2 ? 2.0f : 4.0f)); }
@@ -74,52 +79,62 @@ __device__ __forceinline__ float qfrag_scale(const uint32_t (&sraw)[4], int f16,
 template <int BITS, bool ZP, int SM, int ACC>
 __device__ __forceinline__ void load_q(QFrag<BITS>& f, const FusedArgs& a, const FusedMat& M, int lq, int st, int nst, int lane) {
     constexpr int NJ = 8 * BITS / 8;
+    constexpr int per = ZP ? 2 : 1;
     const int u = st * 64 + lane;
+    // Scale words go through scalar locals and are stored to f.sraw with constant subscripts at the end: stores to
+    // different elements in the two dtype branches get sunk into one store with a run-time subscript, which
+    // keeps the whole fragment in scratch memory.
+    uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
     if (SM == 0 && ACC == 1) {
         // epilogue role of this lane: row beta = lane & 3, units st*64 + 16g + 4*lg .. +3 (g = (lane & 15) >> 2, lg = lane >> 4)
-        constexpr int per = ZP ? 2 : 1;
+        // sraw[2*gi], sraw[2*gi+1]: scale (, zero) of act-group pair gi; f16 packs both into sraw[2*gi]
         const int ub4 = st * 64 + 4 * (lane & 12) + 4 * (lane >> 4);
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
             if (gi == 1 && a.gs_shift >= 2) break;
+            uint32_t v0 = 0, v1 = 0;
             if (ub4 + 2 * gi < a.nu) {
                 const uint32_t sidx = (((uint32_t)lq * (uint32_t)a.nsg + (uint32_t)((ub4 + 2 * gi) >> a.gs_shift)) * 4 + (lane & 3)) * per;
                 if (a.sc_f16) {
                     const __half* ph = reinterpret_cast<const __half*>(M.SC) + sidx;
-                    if (ZP) f.sraw[gi] = *reinterpret_cast<const uint32_t*>(ph);
-                    else f.sraw[gi] = *reinterpret_cast<const unsigned short*>(ph);
+                    if (ZP) v0 = *reinterpret_cast<const uint32_t*>(ph);
+                    else v0 = *reinterpret_cast<const unsigned short*>(ph);
                 } else {
                     const uint32_t* p32 = reinterpret_cast<const uint32_t*>(M.SC) + sidx;
-                    f.sraw[2 * gi] = p32[0];
-                    if (ZP) f.sraw[2 * gi + 1] = p32[1];
+                    v0 = p32[0];
+                    if (ZP) v1 = p32[1];
                 }
+            }
+            if (gi == 0) { r0 = v0; r1 = v1; } else { r2 = v0; r3 = v1; }
+        }
+    }
+    if (u < a.nu) {
+        const uint4* wp = M.W + (size_t)((uint32_t)(lq * nst + st) * (uint32_t)(NJ * 64)) + lane;   // uniform base + lane
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const u32x4q v = __builtin_nontemporal_load(reinterpret_cast<const u32x4q*>(wp + (size_t)j * 64));
+            f.wd[4 * j] = v.x; f.wd[4 * j + 1] = v.y; f.wd[4 * j + 2] = v.z; f.wd[4 * j + 3] = v.w;
+        }
+        if (SM == 0 && ACC == 0) {
+            // rows beta0, beta0+1 of this unit's scale group: fp32 -> one word per element, f16 -> two per word
+            const int sg = u >> a.gs_shift;
+            const uint32_t sidx = (((uint32_t)lq * (uint32_t)a.nsg + (uint32_t)sg) * 4 + 2 * (lane & 1)) * per;
+            if (a.sc_f16) {
+                const uint32_t* p32 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const __half*>(M.SC) + sidx);
+                r0 = p32[0];
+                if (ZP) r1 = p32[1];
+            } else {
+                const uint32_t* p32 = reinterpret_cast<const uint32_t*>(M.SC) + sidx;
+                r0 = p32[0]; r1 = p32[1];
+                if (ZP) { r2 = p32[2]; r3 = p32[3]; }
             }
         }
     }
-    if (u >= a.nu) return;
-    const uint4* wp = M.W + (size_t)((uint32_t)(lq * nst + st) * (uint32_t)(NJ * 64)) + lane;   // uniform base + lane
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const u32x4q v = __builtin_nontemporal_load(reinterpret_cast<const u32x4q*>(wp + (size_t)j * 64));
-        f.wd[4 * j] = v.x; f.wd[4 * j + 1] = v.y; f.wd[4 * j + 2] = v.z; f.wd[4 * j + 3] = v.w;
-    }
-    if (SM == 0 && ACC == 0) {
-        constexpr int per = ZP ? 2 : 1;
-        const int sg = u >> a.gs_shift;
-        const uint32_t sidx = (((uint32_t)lq * (uint32_t)a.nsg + (uint32_t)sg) * 4 + 2 * (lane & 1)) * per;
-        if (a.sc_f16) {
-            const uint32_t* p32 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const __half*>(M.SC) + sidx);
-            f.sraw[0] = p32[0];
-            if (ZP) f.sraw[1] = p32[1];
-        } else {
-            const uint32_t* p32 = reinterpret_cast<const uint32_t*>(M.SC) + sidx;
-#pragma unroll
-            for (int e = 0; e < 2 * per; ++e) f.sraw[e] = p32[e];
-        }
-    }
+    if (SM == 0) { f.sraw[0] = r0; f.sraw[1] = r1; f.sraw[2] = r2; f.sraw[3] = r3; }
 }
 
 typedef int qv4i_t __attribute__((ext_vector_type(4)));
+typedef float qv2f __attribute__((ext_vector_type(2)));
 
 // (x & m) | k in one VALU instruction (hipcc emits v_and_b32 + v_or_b32 for two literal operands: VOP3 takes no
 // literals on gfx9, so the constants are kept in an SGPR and a VGPR)
@@ -258,22 +273,40 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                 if (SM == 2) { scales = gscale; t_scales = gtinv; }
                 else {
                     const float mx = q_row_allmax(__fadd_rn(__fadd_rn(fabsf(x0), fabsf(x1)), __fadd_rn(fabsf(x2), fabsf(x3))));
-                    scales = __fdiv_rn(mx, 127.0f);
-                    t_scales = (scales != 0.0f) ? __fdiv_rn(1.0f, scales) : 0.0f;
+                    scales = div127(mx);
+                    t_scales = (scales != 0.0f) ? rcp_exact(scales) : 0.0f;
                 }
-                const float a_p = __fadd_rn(x0, x1), a_m = __fsub_rn(x0, x1);
-                const float L1 = __fsub_rn(__fsub_rn(a_m, x2), x3), L3 = __fsub_rn(__fsub_rn(a_p, x2), x3);
-                const float L5 = __fsub_rn(__fadd_rn(a_m, x2), x3), L7 = __fsub_rn(__fadd_rn(a_p, x2), x3);
-                const float L9 = __fadd_rn(__fsub_rn(a_m, x2), x3), L11 = __fadd_rn(__fsub_rn(a_p, x2), x3);
-                const float L13 = __fadd_rn(__fadd_rn(a_m, x2), x3), L15 = __fadd_rn(__fadd_rn(a_p, x2), x3);
-                const float e[8] = {-L15, L1, -L13, L3, -L11, L5, -L9, L7};   // half table j = 0..7 (even j: -L[15-j])
-                uint32_t lo = 0, hi = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    lo = q_quant_pack(e[i], t_scales, i, lo);
-                    hi = q_quant_pack(e[4 + i], t_scales, i, hi);
-                }
-                if (ACC == 1 && SM != 2) { lo ^= 0x80808080u; hi ^= 0x80808080u; }   // signed entries for the MFMA path
+                // the 8 distinct magnitudes ((x0 +- x1) +- x2) +- x3 in the reference's association order
+                // (lut_ctor.cc:40-52), two per v_pk_add_f32
+                const qv2f x01 = {x0, x1}, x23 = {x2, x3};
+                qv2f apm, l2m, l2p, L31, L119, L75, L1513;
+                asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(apm) : "v"(x01));                      // {x0+x1, x0-x1}
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(l2m) : "v"(apm), "v"(x23)); // {a_p-x2, a_m-x2}
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(l2p) : "v"(apm), "v"(x23));                          // {a_p+x2, a_m+x2}
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(L31) : "v"(l2m), "v"(x23)); // {L3, L1}
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(L119) : "v"(l2m), "v"(x23));                         // {L11, L9}
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(L75) : "v"(l2p), "v"(x23)); // {L7, L5}
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(L1513) : "v"(l2p), "v"(x23));                        // {L15, L13}
+                const float L15 = L1513.x;
+                // quantise: q = rne(L * t_scales) via the 1.5*2^23 magic add (|L * t_scales| <= 127 for finite input, so
+                // the sum's ulp is 1 and its low byte is q in two's complement; + 128 in the magic gives the biased byte).
+                // Half table j = 0..7 holds {-L15, L1, -L13, L3, -L11, L5, -L9, L7}: negated entries as magic - product.
+                const qv2f tt = {t_scales, t_scales};
+                const qv2f mg = {(ACC == 1 && SM != 2) ? 12582912.0f : 12583040.0f, 0.0f};
+                qv2f za, zb, zc, zd;
+                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(za) : "v"(L31), "v"(tt));
+                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zb) : "v"(L75), "v"(tt));
+                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zc) : "v"(L119), "v"(tt));
+                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zd) : "v"(L1513), "v"(tt));
+                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(za) : "v"(za), "v"(mg));                                  // j = 3 | 1
+                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(zb) : "v"(zb), "v"(mg));                                  // j = 7 | 5
+                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]" : "=v"(zc) : "v"(zc), "v"(mg));        // j = 4 | 6
+                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]" : "=v"(zd) : "v"(zd), "v"(mg));        // j = 0 | 2
+                // low bytes -> dwords [j0 j1 j2 j3], [j4 j5 j6 j7]
+                const uint32_t lo = __builtin_amdgcn_perm(__float_as_uint(za.y), __float_as_uint(zd.x), 0x0c0c0400u) |
+                                    __builtin_amdgcn_perm(__float_as_uint(za.x), __float_as_uint(zd.y), 0x04000c0cu);
+                const uint32_t hi = __builtin_amdgcn_perm(__float_as_uint(zb.y), __float_as_uint(zc.x), 0x0c0c0400u) |
+                                    __builtin_amdgcn_perm(__float_as_uint(zb.x), __float_as_uint(zc.y), 0x04000c0cu);
                 const int u = t >> 3, tl = t & 7;
                 reinterpret_cast<uint2*>(tab + (tl >> 1) * tstride + u)[tl & 1] = make_uint2(lo, hi);
                 float v = -L15;   // lut_ctor.cc:25-31 horizontal add; row_shl:n reads lane i+n
@@ -406,15 +439,15 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
             if (ug < nu) {
                 const int kk = ug >> 1;
                 const float ls = l_ls[kk], lb = l_lb[kk];
-                const int si = (a.gs_shift >= 2) ? 0 : gi;
-                float sc, zr = 0.f;
+                const bool first = (gi == 0) || (a.gs_shift >= 2);   // static register indices only: a run-time
+                float sc, zr = 0.f;                                   // subscript would put sraw in scratch memory
                 if (a.sc_f16) {
-                    const uint32_t wv = f.sraw[si];
+                    const uint32_t wv = first ? f.sraw[0] : f.sraw[2];
                     sc = __half2float(__ushort_as_half((unsigned short)(wv & 0xffff)));
                     if (ZP) zr = __half2float(__ushort_as_half((unsigned short)(wv >> 16)));
                 } else {
-                    sc = __uint_as_float(f.sraw[2 * si]);
-                    if (ZP) zr = __uint_as_float(f.sraw[2 * si + 1]);
+                    sc = __uint_as_float(first ? f.sraw[0] : f.sraw[2]);
+                    if (ZP) zr = __uint_as_float(first ? f.sraw[1] : f.sraw[3]);
                 }
 #pragma unroll
                 for (int pl = 0; pl < BITS; ++pl) {

@@ -36,11 +36,13 @@ def rel_err(c, ref):
 
 
 def run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, m_groups=-1, N=1, variant=0, scale_dtype=None, out_f16=False,
-             act_f16=False, want_ps=True):
+             act_f16=False, want_ps=True, gemm_min_n=None):
     """register + preprocess + gemv on the GPU; returns dict(q, ls, lb, C, PS)"""
     import torch
     L = tm.lib()
     tm.binding.check(L.tmac_hip_set_variant(variant))
+    if gemm_min_n is not None:
+        tm.binding.check(L.tmac_hip_set_gemm_min_n(gemm_min_n))
     A = orc.preprocess_weights(case["w"], bits, bm, kf)
     if m_groups == -1:
         S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm)
@@ -64,6 +66,7 @@ def run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, m_groups=-1, N=1, varia
         out["PS"] = wr.partial_sums(w, N)
     w.free()
     L.tmac_hip_set_variant(0)
+    L.tmac_hip_set_gemm_min_n(8)
     return out
 
 
@@ -206,6 +209,26 @@ def test_multi_row_activations(tm):
     q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, kf, gs, ags, True, N=N)
     assert np.array_equal(r["q"], q) and np.array_equal(r["PS"], PS)
     assert rel_err(r["C"], Cc) <= 2e-5
+
+
+@pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,N", [
+    (256, 1024, 2, 128, 16, 128, 64, True, 5),      # ragged n tile
+    (256, 1024, 2, 128, 16, 128, 64, False, 32),
+    (320, 3200, 2, 320, 16, 128, 64, True, 33),     # K/32 = 100 units, ragged everything
+    (512, 2048, 4, 256, 16, 128, 64, True, 16),
+    (256, 1024, 4, 256, 16, 64, 64, False, 130),    # two workgroups along n
+    (704, 1024, 2, 128, 16, 128, 64, True, 8),      # Mw not a multiple of the 32-row workgroup tile
+])
+def test_onehot_mfma_gemm(tm, Mw, K, bits, bm, kf, gs, ags, zp, N):
+    """N > 1 through k_gemm_onehot (one-hot(nibble) x QLUT on v_mfma_i32_16x16x64_i8): integer sums bit-exact,
+    outputs equal to the GEMV loop and within tolerance of the oracle"""
+    case = orc.make_case(77 + N, Mw, K, N=N, bits=bits, gs=gs, ags=ags)
+    r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, N=N, gemm_min_n=1)
+    q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, kf, gs, ags, zp, N=N)
+    assert np.array_equal(r["q"], q) and np.array_equal(r["PS"], PS)
+    assert rel_err(r["C"], Cc) <= 2e-5
+    r2 = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, N=N, gemm_min_n=0, want_ps=False)
+    assert rel_err(r["C"], r2["C"]) <= 2e-6
 
 
 def test_edge_activations(tm):

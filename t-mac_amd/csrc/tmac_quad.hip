@@ -569,28 +569,41 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
         reset_acc();
     };
 
-    // the fragment ring is consumed in issue order; `pos` tracks which fragment the next compute consumes
-    int pos = 0;
-    for (int it = 0; blockIdx.x * IPI + it * stride < total_q; ++it) {   // uniform trip count across the workgroup
-        const int gq = slot0 + it * stride;
-        const bool have = gq < total_q;
-        int mi = 0, lq = 0;
-        if (have) {
-            locate(gq, mi, lq);
-            for (int st = h; st < nst; st += WPQ) {
-#define QSTEP(F) do { if (ACC == 1 && SM != 2) compute_mfma(F, st, a.m[mi].Mw, lq); else compute(F, st, a.m[mi].Mw, lq); issue(F); } while (0)
-                if (pos == 0) QSTEP(f0);
-                else if (pos == 1) QSTEP(f1);
-                else if (pos == 2) QSTEP(f2);
-                else QSTEP(f3);
-#undef QSTEP
-                pos = (pos + 1) & (RING - 1);
+    // The fragment ring is consumed in issue order.  The (quad, step) work list of this wave is walked by one
+    // cursor in a loop unrolled over the ring, so every fragment has a fixed role in the loop body (a run-time ring
+    // position makes the compiler merge four control-flow paths with ~40 register copies per step).  A quad is
+    // closed (reduce + store, workgroup barrier for WPQ > 1) when the cursor leaves it; every wave closes the
+    // same number of quads, with or without work, so the barriers inside finish_quad stay matched.
+    int c_it = 0, c_st = h, mi = 0, lq = 0;
+    bool have = slot0 < total_q && h < nst;
+    if (have) locate(slot0, mi, lq);
+    if (blockIdx.x * IPI < total_q) {      // uniform: this workgroup has at least one quad iteration
+#define QSTEP(F)                                                                                              \
+        while (!(have && c_st < nst)) {                                                                       \
+            if (c_it == 0) QSTAMP(4);                                                                         \
+            finish_quad(have, a.m[mi], lq);                                                                   \
+            if (c_it == 0) QSTAMP(5);                                                                         \
+            ++c_it;                                                                                           \
+            if (blockIdx.x * IPI + c_it * stride >= total_q) goto q_done;                                     \
+            const int gq = slot0 + c_it * stride;                                                             \
+            have = gq < total_q && h < nst;                                                                   \
+            if (have) locate(gq, mi, lq);                                                                     \
+            c_st = h;                                                                                         \
+        }                                                                                                     \
+        if (ACC == 1 && SM != 2) compute_mfma(F, c_st, a.m[mi].Mw, lq); else compute(F, c_st, a.m[mi].Mw, lq); \
+        issue(F);                                                                                             \
+        c_st += WPQ;
+        for (;;) {
+            QSTEP(f0)
+            QSTEP(f1)
+            if (RING == 4) {
+                QSTEP(f2)
+                QSTEP(f3)
             }
         }
-        if (it == 0) QSTAMP(4);
-        finish_quad(have, a.m[mi], lq);
-        if (it == 0) QSTAMP(5);
+#undef QSTEP
     }
+q_done:
     QSTAMP(6);
 }
 
@@ -659,6 +672,7 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
     const int nst = (a.s.K / 32 + 63) / 64;
     int best_ft = 512, best_wpq = (total_q <= 2048 && nst >= 2) ? 2 : 1;
     double best = 0.0;
+    if (a.s.K / 4 > 6 * 512 && !(a.dump || LUTSRC == 0 || (SM != 2 && !a.acc_mfma))) best_ft = 1024;   // LUT build: <= 6 tables per thread
     if (force_ft) best_ft = force_ft;
     if (force_wpq) best_wpq = force_wpq;
     const bool need512 = a.dump || LUTSRC == 0 || (SM != 2 && !a.acc_mfma);

@@ -1,0 +1,49 @@
+"""Prefill (N > 1) timing of qgemm_lut on the llama-2-7B W2 shapes: preprocessor (LUT build for N rows) + qgemm,
+one-hot MFMA GEMM (k_gemm_onehot) against the GEMV kernel looped over the rows, plus a dense fp16 torch.matmul of
+the same shape for scale.  hipEvent timing, eager launches (kernels are 50+ us).  usage: bench_prefill.py [N]"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tmac_amd
+from tmac_amd import KCfg, F16
+L = tmac_amd.lib()
+dev = torch.device("cuda")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+wr = tmac_amd.TMACGeMMWrapper(act_group_size=64); wr.set_workspace(11008, N)
+
+def timeit(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps): fn()
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
+
+tot = {"gemm": 0.0, "loop": 0.0, "pre": 0.0, "dense": 0.0}
+for name, Mw, K, cnt in [("qkv/o", 4096, 4096, 4), ("gate/up", 11008, 4096, 2), ("down", 4096, 11008, 1)]:
+    A = torch.randint(0, 256, (Mw * 2 // 128, K // 4, 64), dtype=torch.uint8, device=dev)
+    S = (torch.randn((Mw * 2 // 128, K // 128, 8, 2, 8), device=dev) * 0.01).half().contiguous()
+    w = tmac_amd.Weights(A, S, Mw, K, 2, KCfg.make(Mw, K, 2, 128), scales_dtype=F16, dev_dtype=F16, on_device=True)
+    x = torch.randn(N, K, device=dev).half()
+    out = torch.empty(N, Mw, dtype=torch.float16, device=dev)
+    Wd = torch.randn(Mw, K, device=dev).half()
+    t_pre = timeit(lambda: wr.llama_cpp_init(x, Mw, K, N, 2))
+    L.tmac_hip_set_gemm_min_n(1)
+    t_gemm = timeit(lambda: wr.llama_cpp_compute(w, out, N))
+    L.tmac_hip_set_gemm_min_n(0)
+    t_loop = timeit(lambda: wr.llama_cpp_compute(w, out, N), reps=3)
+    L.tmac_hip_set_gemm_min_n(8)
+    t_dense = timeit(lambda: torch.matmul(x, Wd.t()))
+    ops = 2.0 * (Mw * 2) * (K / 4 * 16) * N
+    print(f"{name:8s} Mw={Mw} K={K} N={N}: preprocessor {t_pre:8.1f} us | one-hot MFMA gemm {t_gemm:8.1f} us "
+          f"({ops / t_gemm * 1e-6:7.1f} int8 TOP/s, {2.0 * Mw * K * N / t_gemm * 1e-6:6.1f} dense-equivalent TFLOP/s) | "
+          f"gemv loop {t_loop:9.1f} us | dense fp16 matmul {t_dense:7.1f} us")
+    tot["gemm"] += cnt * t_gemm; tot["loop"] += cnt * t_loop; tot["dense"] += cnt * t_dense
+    tot["pre"] += t_pre * (1 if name != "qkv/o" else 2)     # one LUT build per distinct activation tensor
+    w.free()
+for k in ("gemm", "loop", "dense"):
+    t = 32 * (tot[k] + (tot["pre"] if k != "dense" else 0.0))
+    print(f"llama-2-7B prefill, {N} tokens, 32 layers of mpGEMMs, {k:5s}: {t * 1e-3:9.2f} ms  -> {N / t * 1e6:10.0f} tokens/s")

@@ -88,13 +88,15 @@ __device__ __forceinline__ void load_q(QFrag<BITS>& f, const FusedArgs& a, const
     if (SM == 0 && ACC == 1) {
         // epilogue role of this lane: row beta = lane & 3, units st*64 + 16g + 4*lg .. +3 (g = (lane & 15) >> 2, lg = lane >> 4)
         // sraw[2*gi], sraw[2*gi+1]: scale (, zero) of act-group pair gi; f16 packs both into sraw[2*gi]
+        // Loads are unconditional with clamped indices (no exec-mask branches around them); units past K read zero
+        // tables from LDS, so what the clamped lanes load never reaches a result.
         const int ub4 = st * 64 + 4 * (lane & 12) + 4 * (lane >> 4);
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
-            if (gi == 1 && a.gs_shift >= 2) break;
             uint32_t v0 = 0, v1 = 0;
-            if (ub4 + 2 * gi < a.nu) {
-                const uint32_t sidx = (((uint32_t)lq * (uint32_t)a.nsg + (uint32_t)((ub4 + 2 * gi) >> a.gs_shift)) * 4 + (lane & 3)) * per;
+            {
+                const int ug = min(ub4 + 2 * gi, a.nu - 1);
+                const uint32_t sidx = (((uint32_t)lq * (uint32_t)a.nsg + (uint32_t)(ug >> a.gs_shift)) * 4 + (lane & 3)) * per;
                 if (a.sc_f16) {
                     const __half* ph = reinterpret_cast<const __half*>(M.SC) + sidx;
                     if (ZP) v0 = *reinterpret_cast<const uint32_t*>(ph);
@@ -108,7 +110,7 @@ __device__ __forceinline__ void load_q(QFrag<BITS>& f, const FusedArgs& a, const
             if (gi == 0) { r0 = v0; r1 = v1; } else { r2 = v0; r3 = v1; }
         }
     }
-    if (u < a.nu) {
+    if ((SM == 0 && ACC == 1) || u < a.nu) {   // nst*64 lanes of every step exist in the QUAD layout (zero padded)
         const uint4* wp = M.W + (size_t)((uint32_t)(lq * nst + st) * (uint32_t)(NJ * 64)) + lane;   // uniform base + lane
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -167,7 +169,8 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     // per-wave quantity (quad, step, base pointers, loop control) to SGPRs / the scalar ALU
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int n = blockIdx.y;
-    const int T = s.K / 4, nu = a.nu, G = a.G, tstride = a.tstride, nst = (nu + 63) >> 6;
+    const int T = s.K / 4, nu = a.nu, G = a.G, nst = (nu + 63) >> 6;
+    const int tstride = nst * 64 + 1;                            // whole steps: units past K hold zero tables
     uint4* tab = lds;                                            // [4][tstride]
     float* l_ls = reinterpret_cast<float*>(lds + 4 * tstride);   // [G]
     float* l_lb = l_ls + G;                                      // [G]
@@ -190,15 +193,13 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     if (LUTSRC == 1) {
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
-            const int t = r * FT + tid;
-            if (t < T) {
-                if (a.act_f16) {
-                    const uint2 v = reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(a.B) + (size_t)n * s.K)[t];
-                    xr[r][0] = v.x; xr[r][1] = v.y;
-                } else {
-                    const uint4 v = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(a.B) + (size_t)n * s.K)[t];
-                    xr[r][0] = v.x; xr[r][1] = v.y; xr[r][2] = v.z; xr[r][3] = v.w;
-                }
+            const int t = min(r * FT + tid, T - 1);     // clamped, not predicated (see load_q)
+            if (a.act_f16) {
+                const uint2 v = reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(a.B) + (size_t)n * s.K)[t];
+                xr[r][0] = v.x; xr[r][1] = v.y;
+            } else {
+                const uint4 v = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(a.B) + (size_t)n * s.K)[t];
+                xr[r][0] = v.x; xr[r][1] = v.y; xr[r][2] = v.z; xr[r][3] = v.w;
             }
         }
     }
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     QFrag<BITS> f0, f1, f2, f3;
     int p_q = slot0, p_st = h;    // prefetch cursor
     auto issue = [&](QFrag<BITS>& f) {
-        if (p_q < total_q) {
+        if (p_q < total_q && p_st < nst) {      // p_st >= nst: a wave without steps (WPQ > number of steps)
             int mi, lq;
             locate(p_q, mi, lq);
             load_q<BITS, ZP, SM, ACC>(f, a, a.m[mi], lq, p_st, nst, lane);
@@ -224,12 +225,14 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
 
     // ---- 3. LUT into LDS (all FT threads) ------------------------------------------------------
     if (LUTSRC == 0) {
-        const uint4* src = reinterpret_cast<const uint4*>(a.qlut_lds) + (size_t)n * 4 * tstride;
-        for (int i = tid; i < 4 * tstride; i += FT) {
-            uint4 v = src[i];
-            if (ACC == 1 && SM != 2) { v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u; }
-            tab[i] = v;
-        }
+        const uint4* src = reinterpret_cast<const uint4*>(a.qlut_lds) + (size_t)n * 4 * a.tstride;   // image stride (k_preprocess)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4)
+            for (int u = tid; u < nu; u += FT) {
+                uint4 v = src[j4 * a.tstride + u];
+                if (ACC == 1 && SM != 2) { v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u; }
+                tab[j4 * tstride + u] = v;
+            }
         if (SM == 2) { if (tid == 0) { l_ls[0] = a.lut_scales[n]; l_lb[0] = a.lut_biases[n]; } }
         else for (int i = tid; i < G; i += FT) { l_ls[i] = a.lut_scales[(size_t)n * G + i]; l_lb[i] = a.lut_biases[(size_t)n * G + i]; }
     } else {
@@ -334,6 +337,12 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
             }
         }
     }
+    {   // zero tables for the units between K and the end of the last 64-unit step
+        const uint32_t z = (ACC == 1 && SM != 2) ? 0u : 0x80808080u;
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4)
+            for (int u = nu + tid; u < nst * 64; u += FT) tab[j4 * tstride + u] = make_uint4(z, z, z, z);
+    }
     QSTAMP(2);
     __syncthreads();
     QSTAMP(3);
@@ -411,8 +420,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
         uint32_t tb[16];
 #pragma unroll
         for (int j4 = 0; j4 < 4; ++j4) {
-            uint4 v = make_uint4(0, 0, 0, 0);                 // units past K: zero tables -> zero contribution
-            if (u < nu) v = tab[j4 * tstride + u];
+            const uint4 v = tab[j4 * tstride + u];            // units past K read the zero tables: no contribution
             tb[4 * j4] = v.x; tb[4 * j4 + 1] = v.y; tb[4 * j4 + 2] = v.z; tb[4 * j4 + 3] = v.w;
         }
         qv4i_t c[BITS];
@@ -624,8 +632,8 @@ bool gemv_quad_supported(const Shape& s) {
 #endif
 
 static size_t quad_lds_bytes(const Shape& s, int nwv) {
-    const int nu = s.K / 32, nu_pad = (nu + 15) & ~15, G = s.K / s.ags;
-    return (size_t)4 * (nu_pad + 1) * 16 + sizeof(float) * (2 * G + 2 * nwv * 16 + nwv + s.K / 32);
+    const int nu = s.K / 32, nst = (nu + 63) / 64, G = s.K / s.ags;
+    return (size_t)4 * (nst * 64 + 1) * 16 + sizeof(float) * (2 * G + 2 * nwv * 16 + nwv + s.K / 32);
 }
 
 void fused_precompute(FusedArgs& a);   // tmac_fused.hip

@@ -1,22 +1,31 @@
 // tmac_gemm.hip — k_gemm_onehot: qgemm_lut for N > 1 activation rows (prefill) on the matrix cores.
 //
 // The reference handles N > 1 by looping its GEMV micro-kernel over the activation rows
-// (python/t_mac/ops/qgemm.py:183-190,228-231): per (row, act group) the integer partial sum
+// (python/t_mac/ops/qgemm.py:183-190,228-231): per (activation row n, bit-plane row r, act group kk) the integer
+// partial sum
 //     PS[n][r][kk] = sum_t QLUT[n][t][nibble(r, t)]
-// is a gather.  It becomes a dense int8 contraction — and therefore MFMA work — by writing the gather as
-//     PS = onehot(nibble(r, t)) [16 bit-plane rows x (4 tables x 16 entries)]  x  QLUT[n][t][:] [(4 x 16) x 16 rows n]
-// i.e. one v_mfma_i32_16x16x64_i8 adds 4 tables for a 16 x 16 (row, n) tile, exactly (int32 accumulate):
-//   A operand, lane (g, i): the 16 one-hot bytes of nibble(row i, table 4*tb + g)        (built on the VALU)
-//   B operand, lane (g, j): QLUT[n_j][4*tb + g][0..15] — one 16-byte row of the reference-layout QLUT
-// Four MFMAs complete an act group (64 activations); the int32 tile is then scaled in fp32 exactly like the
-// GEMV epilogue (tbl.cc:464-526 per act group) and accumulated; bit-planes are combined in-lane at the end
-// (the 16 rows of a tile are ordered [output row][plane], so a lane's 4 accumulator rows are planes of the
-// same output rows).  Same integer contract as the GEMV kernels: PS is bit-exact.
+// is a gather.  It becomes a dense int8 contraction — MFMA work — by writing the gather as a product with a signed
+// one-hot matrix.  With the antisymmetric tables (QLUT[15-j] = -QLUT[j]) only the 8-entry half table is needed:
+//     PS = S [rows x (tables x 8)]  x  H [(tables x 8) x n],   S[r][(t, e)] = +-1 if the recoded nibble of (r, t)
+// selects entry e (sign = its bit 3), 0 otherwise;  H = the half tables k_preprocess already writes for the GEMV
+// kernels (workspace qlut_lds image: one uint4 = the half tables of two consecutive tables).
+// One v_mfma_i32_16x16x64_i8 covers 8 tables (one 32-activation "unit" of the weight layout) for a 16 x 16 tile:
+//   A operand, lane (g, i): 16 bytes = one-hot rows of tables 2g, 2g+1 of the unit for bit-plane row i
+//   B operand, lane (g, j): 16 bytes = half tables 2g, 2g+1 of the unit for activation row j   (one uint4 load)
+// Two MFMAs complete an act group (64 activations); the int32 tile is then scaled in fp32 exactly like the GEMV
+// epilogue (tbl.cc:464-526 per act group) and accumulated; bit-planes are combined in-lane at the end (the 16 rows
+// of a tile are ordered [output row][plane], so the 4 accumulator rows of a lane are planes of its own output
+// rows).  Same integer contract as the GEMV kernels: PS is bit-exact with the reference.
 //
-// Tiling (v1): wave = 64 bit-plane rows x 32 activation rows (4 x 2 MFMA tiles), workgroup = 4 waves along n.
-// Weights are read straight from the QUAD layout (one dword gather per lane and table step, L1/L2 resident:
-// 2-4 bit weights are tiny next to the 16x inflated one-hot operand), B rows from the workspace QLUT (L2).
-// Roofline: int8 MFMA.  ops = 2 * (Mw*bits) * (K/4*16) * N.
+// Tiling: workgroup = 4 waves = 128 bit-plane rows x 64 activation rows; wave = 32 rows x 64 columns (2 x 4 MFMA
+// tiles, 8 MFMAs per unit).  Everything the inner loop consumes is staged through LDS in chunks of 4 units (two act
+// groups), double buffered and fetched one chunk ahead with ~22 registers per thread:
+//   B: every thread fetches the 64 contiguous bytes [n][j4][u0..u0+3] of the half-table image and stores them
+//      unit-major, so a wave's operand read is one conflict-free 1 KB ds_read_b128 (4 KB per unit and workgroup);
+//   weights: the workgroup's 16 (W2) / 8 (W4) row quads x 4 units of the QUAD layout, 2 KB, one uint4 per thread;
+//   epilogue operands: LUT scale/bias of the 64 columns and weight scale/zero of the rows for the two act groups.
+// The signed one-hot bytes are formed on the VALU from the nibble (8 instructions per table).
+// Roofline: int8 MFMA.  ops = 2 * (Mw*bits) * (K/4*8) * N.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -29,115 +38,177 @@ namespace tmac {
 typedef int gv4i_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float g_alpha(int p) { return p == 0 ? 0.5f : (p == 1 ? 1.0f : (p == 2 ? 2.0f : 4.0f)); }
-__device__ __forceinline__ float g_ld(const void* p, int f16, size_t i) {
-    return f16 ? __half2float(reinterpret_cast<const __half*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
-}
 __device__ __forceinline__ void g_st(void* C, int f16, size_t i, float v) {
     if (f16) reinterpret_cast<__half*>(C)[i] = __float2half_rn(v);
     else reinterpret_cast<float*>(C)[i] = v;
 }
 
-constexpr int GRT = 4;   // MFMA row tiles per wave (16 bit-plane rows each)
-constexpr int GNT = 2;   // MFMA n tiles per wave (16 activation rows each)
+constexpr int GRT = 2;   // MFMA row tiles per wave (16 bit-plane rows each)
+constexpr int GNT = 4;   // MFMA n tiles per workgroup and wave (16 activation rows each)
+constexpr int GWV = 4;   // waves per workgroup (consecutive row blocks)
+constexpr int GCH = 4;   // units (8 tables = 32 activations each) per LDS chunk
 
-template <int BITS, bool ZP>
-__global__ __launch_bounds__(256) void k_gemm_onehot(GemmArgs a) {
+typedef float gv2f_t __attribute__((ext_vector_type(2)));
+
+template <int BITS, bool ZP, bool DUMP>
+__global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
+    constexpr int NJ = BITS;                               // uint4 per unit and quad in the QUAD layout
+    constexpr int ORPT = 16 / BITS;                        // output rows per MFMA row tile
+    constexpr int ORW = GWV * GRT * ORPT;                  // output rows per workgroup (64 / 32)
+    constexpr int QW = ORW / 4;                            // row quads per workgroup
+    __shared__ uint4 bt[2][GCH][GNT * 16][4];              // [buffer][unit][n][j4]            2 x 16 KB
+    __shared__ uint4 wt[2][GCH][QW][NJ];                   // [buffer][unit][quad][j]          2 x 2 KB
+    __shared__ float ep[2][2][4][64];                      // [buffer][act group][ls, lb, sc, zr][n | row]
+    __shared__ uint2 pat[16];                              // signed one-hot row of a recoded nibble c: byte (c & 7) = +1, or -1 if c & 8
     const Shape& s = a.s;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int g = lane >> 4, i16 = lane & 15;
-    const int T = s.K / 4, G = s.K / s.ags, nst = (s.K / 32 + 63) >> 6;
-    constexpr int NJ = 8 * BITS / 8;
-    constexpr int ORPT = 16 / BITS;                        // output rows per MFMA row tile
-    const int orow_blk = blockIdx.x * (GRT * ORPT);        // first output row of this workgroup's 64 bit-plane rows
-    const int n0 = (blockIdx.y * 4 + w) * (GNT * 16);      // first activation row of this wave
+    const int G = s.K / s.ags, nu = s.K / 32, nst = (nu + 63) >> 6, nq = (s.Mw + 3) >> 2;
+    const int orow_wg = blockIdx.x * ORW;                  // first output row of this workgroup
+    const int n0 = blockIdx.y * (GNT * 16);                // first activation row of this workgroup
+    const int nchunk = (nu + GCH - 1) / GCH;
 
-    // ---- per-lane constants of the A gather: lane (g, i16) looks up row (o, p) of tile rt at table 4*tb + g ----
+    if (tid < 16) {
+        const uint32_t v = ((tid & 8) ? 0xffu : 0x01u) << (8 * (tid & 3));
+        pat[tid] = (tid & 4) ? make_uint2(0u, v) : make_uint2(v, 0u);
+    }
+    // ---- staging roles of this thread -----------------------------------------------------------------------
+    // B: activation row n0 + tid/4, j4 = tid%4, the chunk's GCH consecutive units
+    const uint4* bsrc = reinterpret_cast<const uint4*>(a.qlut_lds) + ((size_t)min(n0 + (tid >> 2), a.N - 1) * 4 + (tid & 3)) * a.tstride;
+    // weights (tid < GCH*QW*NJ = 128): unit tid / (QW*NJ), quad (tid / NJ) % QW, uint4 j = tid % NJ
+    const int w_ul = tid / (QW * NJ), w_ql = (tid / NJ) % QW, w_j = tid % NJ;
+    const uint4* wsrc = reinterpret_cast<const uint4*>(a.W) + ((size_t)min(orow_wg / 4 + w_ql, nq - 1) * nst * NJ + w_j) * 64;
+    // epilogue operands: e1 = ls / lb of column tid%64, e2 = scale / zero of row (tid/2)%64, act group tid/128
+    const int e_ag = tid >> 7, e1_which = (tid >> 6) & 1, e1_n = min(n0 + (tid & 63), a.N - 1);
+    const int e2_o = min(orow_wg + ((tid >> 1) & 63), s.Mw - 1), e2_which = tid & 1;
+    const float* e1_src = (e1_which ? a.lut_biases : a.lut_scales) + (size_t)e1_n * G;
+
+    uint4 bst[GCH], wst;
+    float e1, e2;
+    auto fetch_chunk = [&](int c) {
+#pragma unroll
+        for (int ul = 0; ul < GCH; ++ul) bst[ul] = bsrc[min(c * GCH + ul, nu - 1)];   // tail units: clamped here, skipped below
+        if (tid < GCH * QW * NJ) {
+            const int u = min(c * GCH + w_ul, nu - 1);
+            wst = wsrc[(size_t)(u >> 6) * NJ * 64 + (u & 63)];
+        }
+        const int kk = min(c * (GCH / 2) + e_ag, G - 1);
+        e1 = e1_src[kk];
+        e2 = 0.f;
+        if (ZP || !e2_which) {
+            const size_t si = quad_scale_index(s, e2_o >> 2, (kk * s.ags) / s.gs, e2_o & 3, e2_which);
+            e2 = a.sc_f16 ? __half2float(reinterpret_cast<const __half*>(a.SC)[si]) : reinterpret_cast<const float*>(a.SC)[si];
+        }
+    };
+    auto stage_chunk = [&](int buf) {       // biased -> signed table bytes on the way into LDS
+#pragma unroll
+        for (int ul = 0; ul < GCH; ++ul)
+            bt[buf][ul][tid >> 2][tid & 3] = make_uint4(bst[ul].x ^ 0x80808080u, bst[ul].y ^ 0x80808080u,
+                                                        bst[ul].z ^ 0x80808080u, bst[ul].w ^ 0x80808080u);
+        if (tid < GCH * QW * NJ) wt[buf][w_ul][w_ql][w_j] = wst;
+        ep[buf][e_ag][e1_which][tid & 63] = e1;
+        ep[buf][e_ag][2 + e2_which][(tid >> 1) & 63] = e2;
+    };
+
+    // ---- compute roles ----------------------------------------------------------------------------------------
+    // A operand, lane (g, i16): bit-plane row (o, p) of row tile rt; tables 2g, 2g+1 of the unit are nibble quads
+    // q = 2g*BITS + p and q + BITS -> dwords q >> 1 (and + BITS/2) of the unit's BITS uint4 (tmac_layout.h)
     const int p_a = i16 % BITS;
-    int quad_a[GRT], beta_a[GRT];
+    const int d0 = (2 * g * BITS + p_a) >> 1;              // BITS 2: 2g, 2g+1;  BITS 4: 4g + (p>>1), + 2
+    int a_ql[GRT], a_sh[GRT];
 #pragma unroll
     for (int rt = 0; rt < GRT; ++rt) {
-        const int o = orow_blk + rt * ORPT + i16 / BITS;
-        quad_a[rt] = o >> 2;
-        beta_a[rt] = o & 3;
+        const int ol = (w * GRT + rt) * ORPT + i16 / BITS;  // output row within the workgroup
+        a_ql[rt] = ol >> 2;
+        a_sh[rt] = (8 * (ol & 3) + 4 * (p_a & 1) + 29) & 31; // rotate-right count that puts the nibble (byte beta, half q & 1) at bits 3..6
     }
-    const uint32_t* W32 = reinterpret_cast<const uint32_t*>(a.W);
 
     gv4i_t c[GRT][GNT];
-    float facc[GRT][GNT][4];
+    gv2f_t facc[GRT][GNT][2];                               // rows (4g, 4g+1), (4g+2, 4g+3) of the tile: v_pk_*_f32 operands
 #pragma unroll
     for (int rt = 0; rt < GRT; ++rt)
 #pragma unroll
         for (int nt = 0; nt < GNT; ++nt) {
             c[rt][nt] = (gv4i_t){0, 0, 0, 0};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) facc[rt][nt][r] = 0.f;
+            facc[rt][nt][0] = (gv2f_t){0.f, 0.f};
+            facc[rt][nt][1] = (gv2f_t){0.f, 0.f};
         }
 
-    const int tpg = s.ags / 4;                              // tables per act group (16)
-    for (int tb = 0; tb < T / 4; ++tb) {
-        const int t = 4 * tb + g;
-        // B rows: QLUT[n][t][0..15]
-        gv4i_t b[GNT];
+    fetch_chunk(0);
+    stage_chunk(0);
+    for (int ck = 0; ck < nchunk; ++ck) {
+        __syncthreads();                                    // chunk ck is in LDS buffer ck & 1; buffer (ck+1) & 1 is free
+        if (ck + 1 < nchunk) fetch_chunk(ck + 1);
+        const int buf = ck & 1;
 #pragma unroll
-        for (int nt = 0; nt < GNT; ++nt) {
-            const int n = n0 + nt * 16 + i16;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (n < a.N) v = *reinterpret_cast<const uint4*>(a.qlut_ref + ((size_t)n * T + t) * 16);
-            b[nt] = (gv4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-        }
-        // weight nibble position in the QUAD layout (tmac_layout.h): unit u = t/8, table tl = t%8 of the unit,
-        // nibble quad q = tl*BITS + p -> dword d = q/2, half h = q%2
-        const int u = t >> 3, tl = t & 7, q = tl * BITS + p_a, d = q >> 1, hsh = 4 * (q & 1);
-        const uint32_t dw_off = ((uint32_t)((u >> 6) * NJ + (d >> 2)) * 64 + (u & 63)) * 4 + (d & 3);
+        for (int ul = 0; ul < GCH; ++ul) {
+            if (ck * GCH + ul < nu) {
+                gv4i_t bv[GNT];
 #pragma unroll
-        for (int rt = 0; rt < GRT; ++rt) {
-            uint32_t code = 0;
-            if (4 * quad_a[rt] < s.Mw) {
-                const uint32_t dw = W32[(size_t)quad_a[rt] * nst * NJ * 256 + dw_off];
-                code = (dw >> (8 * beta_a[rt] + hsh)) & 15u;
-            }
-            const uint32_t j = code ^ ((code & 8u) ? 7u : 0u);          // undo the device recode: c -> reference nibble
-            const uint32_t one = 1u << (8 * (j & 3));
-            const uint32_t jd = j >> 2;
-            const gv4i_t av = {(int)(jd == 0 ? one : 0u), (int)(jd == 1 ? one : 0u), (int)(jd == 2 ? one : 0u), (int)(jd == 3 ? one : 0u)};
-#pragma unroll
-            for (int nt = 0; nt < GNT; ++nt) c[rt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, b[nt], c[rt][nt], 0, 0, 0);
-        }
-        // ---- act group complete: fp32 scale-apply of the int32 tiles, then reset them ----------------------
-        if ((4 * tb + 4) % tpg == 0) {
-            const int kk = (4 * tb) / tpg;
-            const int sg = (kk * s.ags) / s.gs;
-#pragma unroll
-            for (int nt = 0; nt < GNT; ++nt) {
-                const int n = n0 + nt * 16 + i16;                           // C layout: col = lane & 15
-                float ls = 0.f, lb = 0.f;
-                if (n < a.N) { ls = a.lut_scales[(size_t)n * G + kk]; lb = a.lut_biases[(size_t)n * G + kk]; }
+                for (int nt = 0; nt < GNT; ++nt) {
+                    const uint4 v = bt[buf][ul][nt * 16 + i16][g];
+                    bv[nt] = (gv4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+                }
 #pragma unroll
                 for (int rt = 0; rt < GRT; ++rt) {
+                    const uint32_t* wq = reinterpret_cast<const uint32_t*>(&wt[buf][ul][a_ql[rt]][0]);
+                    const uint32_t w0 = wq[d0], w1 = wq[d0 + BITS / 2];
+                    const char* pb = reinterpret_cast<const char*>(pat);     // byte offset = nibble * 8
+                    const uint2 p0 = *reinterpret_cast<const uint2*>(pb + (__builtin_amdgcn_alignbit(w0, w0, a_sh[rt]) & 0x78u));
+                    const uint2 p1 = *reinterpret_cast<const uint2*>(pb + (__builtin_amdgcn_alignbit(w1, w1, a_sh[rt]) & 0x78u));
+                    const gv4i_t av = {(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = 4 * g + r;                              // C layout: row = 4*(lane>>4) + reg
-                        const int pl = i % BITS, o = orow_blk + rt * ORPT + i / BITS;
-                        const int32_t ps = c[rt][nt][r];
-                        if (a.dump && n < a.N && o < s.Mw) a.dump[((size_t)n * s.M() + mrow(o, pl, BITS)) * G + kk] = ps;
-                        float sc = 0.f, zr = 0.f;
-                        if (o < s.Mw) {
-                            const size_t si = quad_scale_index(s, o >> 2, sg, o & 3, 0);
-                            sc = g_ld(a.SC, a.sc_f16, si);
-                            if (ZP) zr = g_ld(a.SC, a.sc_f16, si + 1);
+                    for (int nt = 0; nt < GNT; ++nt)         // first unit of an act group starts from a zero accumulator operand
+                        c[rt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv[nt], (ul & 1) ? c[rt][nt] : (gv4i_t){0, 0, 0, 0}, 0, 0, 0);
+                }
+                // ---- act group complete: fp32 scale-apply of the int32 tiles, then reset them --------------
+                if (ul & 1) {                                // ags = 64: units 2kk, 2kk+1
+                    const int ag = ul >> 1, kk = (ck * GCH + ul) >> 1;
+                    float sc[GRT][4 / BITS], zr[GRT][4 / BITS];
+#pragma unroll
+                    for (int rt = 0; rt < GRT; ++rt)
+#pragma unroll
+                        for (int oo = 0; oo < 4 / BITS; ++oo) {
+                            const int ol = (w * GRT + rt) * ORPT + (4 * g) / BITS + oo;
+                            sc[rt][oo] = ep[buf][ag][2][ol];
+                            zr[rt][oo] = ep[buf][ag][3][ol];
                         }
-                        const float v = (pl == 0) ? __fmaf_rn((float)ps, ls, lb) : __fmul_rn((float)ps, ls);
-                        float acc = __fmaf_rn(v, sc, facc[rt][nt][r]);
-                        if (ZP && pl == 0) acc = __fmaf_rn(zr, __fmul_rn(2.0f, lb), acc);
-                        facc[rt][nt][r] = acc;
+#pragma unroll
+                    for (int nt = 0; nt < GNT; ++nt) {
+                        const float ls = ep[buf][ag][0][nt * 16 + i16], lb = ep[buf][ag][1][nt * 16 + i16];
+                        const float lb2 = __fmul_rn(2.0f, lb);
+#pragma unroll
+                        for (int rt = 0; rt < GRT; ++rt) {
+                            if (DUMP) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int o = orow_wg + (w * GRT + rt) * ORPT + (4 * g + r) / BITS, nn = n0 + nt * 16 + i16;
+                                    if (nn < a.N && o < s.Mw) a.dump[((size_t)nn * s.M() + mrow(o, r % BITS, BITS)) * G + kk] = c[rt][nt][r];
+                                }
+                            }
+                            // rows 4g + 2pr, 4g + 2pr + 1 = planes (2pr) % BITS and the next one (never plane 0) of output
+                            // row oo = 2pr / BITS.  tbl.cc: plane 0 takes v = fma(ps, ls, lb), the others v = ps * ls
+                            // (= fma(ps, ls, +0) up to the sign of a zero), then acc = fma(v, scale, acc) and, plane 0 with
+                            // zero points, acc = fma(zero, 2 lb, acc) (adding fma(0, 2 lb, acc) = acc to the odd lane).
+#pragma unroll
+                            for (int pr = 0; pr < 2; ++pr) {
+                                const int oo = (2 * pr) / BITS;
+                                const bool p0 = (2 * pr) % BITS == 0;
+                                const gv2f_t ps = {(float)c[rt][nt][2 * pr], (float)c[rt][nt][2 * pr + 1]};
+                                const gv2f_t v = __builtin_elementwise_fma(ps, (gv2f_t){ls, ls}, (gv2f_t){p0 ? lb : 0.f, 0.f});
+                                gv2f_t acc = __builtin_elementwise_fma(v, (gv2f_t){sc[rt][oo], sc[rt][oo]}, facc[rt][nt][pr]);
+                                if (ZP && p0) acc = __builtin_elementwise_fma((gv2f_t){zr[rt][oo], 0.f}, (gv2f_t){lb2, lb2}, acc);
+                                facc[rt][nt][pr] = acc;
+                            }
+                        }
                     }
-                    c[rt][nt] = (gv4i_t){0, 0, 0, 0};
                 }
             }
         }
+        if (ck + 1 < nchunk) stage_chunk((ck + 1) & 1);     // buffer (ck+1)&1 was last read in iteration ck-1, before this iteration's barrier
     }
 
-    // ---- bit-plane combine (in-lane: a lane's 4 rows are consecutive [output row][plane] rows) and store ----
+    // ---- bit-plane combine (in-lane) and store --------------------------------------------------------------
 #pragma unroll
     for (int nt = 0; nt < GNT; ++nt) {
         const int n = n0 + nt * 16 + i16;
@@ -146,10 +217,10 @@ __global__ __launch_bounds__(256) void k_gemm_onehot(GemmArgs a) {
         for (int rt = 0; rt < GRT; ++rt) {
 #pragma unroll
             for (int oo = 0; oo < 4 / BITS; ++oo) {
-                const int o = orow_blk + rt * ORPT + (4 * g) / BITS + oo;
-                float acc = __fmul_rn(facc[rt][nt][oo * BITS], 0.5f);
+                const int o = orow_wg + (w * GRT + rt) * ORPT + (4 * g) / BITS + oo;
+                float acc = __fmul_rn(facc[rt][nt][(oo * BITS) >> 1][0], 0.5f);
 #pragma unroll
-                for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(facc[rt][nt][oo * BITS + pl], g_alpha(pl)));
+                for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(facc[rt][nt][(oo * BITS + pl) >> 1][(oo * BITS + pl) & 1], g_alpha(pl)));
                 if (o < s.Mw) g_st(a.C, a.out_f16, (size_t)n * s.Mw + o, acc);
             }
         }
@@ -157,16 +228,16 @@ __global__ __launch_bounds__(256) void k_gemm_onehot(GemmArgs a) {
 }
 
 bool gemm_onehot_supported(const Shape& s) {
-    return s.lay == 2 && (s.bits == 2 || s.bits == 4) && s.m_groups < 0 && s.ags == 64 && s.gs % 64 == 0 &&
-           s.K % 64 == 0;
+    return s.lay == 2 && (s.bits == 2 || s.bits == 4) && s.m_groups < 0 && s.ags == 64 && s.gs % 64 == 0 && s.K % 64 == 0;
 }
 
 hipError_t launch_gemm_onehot(const GemmArgs& a, hipStream_t st) {
     if (!gemm_onehot_supported(a.s)) return hipErrorInvalidValue;
     const int bits = a.s.bits;
-    const int rows_per_wg = GRT * 16 / bits;
-    dim3 g((a.s.Mw + rows_per_wg - 1) / rows_per_wg, (a.N + 4 * GNT * 16 - 1) / (4 * GNT * 16)), b(256);
-#define GL(B, Z) hipLaunchKernelGGL((k_gemm_onehot<B, Z>), g, b, 0, st, a)
+    const int rows_per_wg = GWV * GRT * 16 / bits;
+    dim3 g((a.s.Mw + rows_per_wg - 1) / rows_per_wg, (a.N + GNT * 16 - 1) / (GNT * 16)), b(64 * GWV);
+#define GL(B, Z) do { if (a.dump) hipLaunchKernelGGL((k_gemm_onehot<B, Z, true>), g, b, 0, st, a); \
+                      else hipLaunchKernelGGL((k_gemm_onehot<B, Z, false>), g, b, 0, st, a); } while (0)
     if (bits == 2) { if (a.s.zero_point) GL(2, true); else GL(2, false); }
     else { if (a.s.zero_point) GL(4, true); else GL(4, false); }
 #undef GL

@@ -204,7 +204,7 @@ extern "C" int32_t tmac_hip_set_variant(int variant) {
 }
 
 // N at and above which qgemm runs the one-hot MFMA GEMM instead of looping the GEMV kernel (0 = never)
-static int g_gemm_min_n = 8;
+static int g_gemm_min_n = 40;   // measured crossover on MI355X (llama-2-7B W2 shapes): GEMV loop ~1.9 us per row, GEMM ~74 us per 64 rows
 extern "C" int32_t tmac_hip_set_gemm_min_n(int n) {
     if (n < 0) return fail(TMAC_HIP_E_ARG, "gemm_min_n must be >= 0");
     g_gemm_min_n = n;
@@ -492,7 +492,7 @@ static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* w
         GemmArgs ga;
         memset(&ga, 0, sizeof(ga));
         ga.s = w->s; ga.W = w->W; ga.SC = w->SC; ga.sc_f16 = w->sc_dtype == F16; ga.out_f16 = out_dtype == TMAC_F16;
-        ga.qlut_ref = ws->qlut_ref; ga.lut_scales = ws->lut_scales; ga.lut_biases = ws->lut_biases;
+        ga.qlut_lds = ws->qlut_lds; ga.tstride = (((w->s.K / 32) + 15) & ~15) + 1; ga.lut_scales = ws->lut_scales; ga.lut_biases = ws->lut_biases;
         ga.C = C_dev; ga.dump = dump; ga.N = N;
         hipError_t e = launch_gemm_onehot(ga, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "one-hot gemm launch: %s", hipGetErrorString(e));

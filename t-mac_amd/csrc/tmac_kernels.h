@@ -52,7 +52,8 @@ struct GemmArgs {
     const void* W;            // QUAD layout weights
     const void* SC;           // QUAD layout scales
     int sc_f16, out_f16;
-    const int8_t* qlut_ref;   // int8 [N][K/4][16]  (k_preprocess)
+    const void* qlut_lds;     // uint4 [N][4][tstride]: half tables, unit-major image written by k_preprocess
+    int tstride;
     const float* lut_scales;  // fp32 [N][K/ags]
     const float* lut_biases;
     void* C;                  // [N][Mw]

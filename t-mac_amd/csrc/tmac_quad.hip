@@ -172,9 +172,10 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     const int T = s.K / 4, nu = a.nu, G = a.G, nst = (nu + 63) >> 6;
     const int tstride = nst * 64 + 1;                            // whole steps: units past K hold zero tables
     uint4* tab = lds;                                            // [4][tstride]
-    float* l_ls = reinterpret_cast<float*>(lds + 4 * tstride);   // [G]
-    float* l_lb = l_ls + G;                                      // [G]
-    float* l_red = l_lb + G;                                     // [2][NWV][4][4] partials (WPQ == 2 / SM 2)
+    const int GP = nst * 32;                                     // act groups of the padded steps (>= G)
+    float* l_ls = reinterpret_cast<float*>(lds + 4 * tstride);   // [GP]  (groups past K: 0)
+    float* l_lb = l_ls + GP;                                     // [GP]
+    float* l_red = l_lb + GP;                                    // [2][NWV][4][4] partials (WPQ == 2 / SM 2)
     float* l_scr = l_red + 2 * NWV * 16;                         // SM 2 build scratch: [NWV] maxima + [T/8] chunk sums
     const int total_q = a.m[a.nmat - 1].nb_end;                  // cumulative QUAD counts in this launch mode
 
@@ -342,6 +343,8 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
 #pragma unroll
         for (int j4 = 0; j4 < 4; ++j4)
             for (int u = nu + tid; u < nst * 64; u += FT) tab[j4 * tstride + u] = make_uint4(z, z, z, z);
+        if (SM != 2)
+            for (int i = G + tid; i < GP; i += FT) { l_ls[i] = 0.f; l_lb[i] = 0.f; }
     }
     QSTAMP(2);
     __syncthreads();
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
             const int ug = ub4 + 2 * gi;
-            if (ug < nu) {
+            {   // act groups past K have zero tables and zero LUT scale/bias: they add exactly 0, no guard needed
                 const int kk = ug >> 1;
                 const float ls = l_ls[kk], lb = l_lb[kk];
                 const bool first = (gi == 0) || (a.gs_shift >= 2);   // static register indices only: a run-time
@@ -460,7 +463,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
 #pragma unroll
                 for (int pl = 0; pl < BITS; ++pl) {
                     const int32_t ps = (gi == 0) ? (c[pl].x + c[pl].y) : (c[pl].z + c[pl].w);
-                    if (DUMP && a.dump && o < Mw_m) a.dump[((size_t)n * Mw_m * BITS + mrow(o, pl, BITS)) * G + kk] = ps;
+                    if (DUMP && a.dump && o < Mw_m && ug < nu) a.dump[((size_t)n * Mw_m * BITS + mrow(o, pl, BITS)) * G + kk] = ps;
                     const float v = (pl == 0) ? __fmaf_rn((float)ps, ls, lb) : __fmul_rn((float)ps, ls);
                     float cc = __fmaf_rn(v, sc, cacc[0][pl]);
                     if (ZP && pl == 0) cc = __fmaf_rn(zr, __fmul_rn(2.0f, lb), cc);
@@ -633,7 +636,7 @@ bool gemv_quad_supported(const Shape& s) {
 
 static size_t quad_lds_bytes(const Shape& s, int nwv) {
     const int nu = s.K / 32, nst = (nu + 63) / 64, G = s.K / s.ags;
-    return (size_t)4 * (nst * 64 + 1) * 16 + sizeof(float) * (2 * G + 2 * nwv * 16 + nwv + s.K / 32);
+    return (size_t)4 * (nst * 64 + 1) * 16 + sizeof(float) * (2 * (nst * 32 > G ? nst * 32 : G) + 2 * nwv * 16 + nwv + s.K / 32);
 }
 
 void fused_precompute(FusedArgs& a);   // tmac_fused.hip
@@ -679,6 +682,7 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
     //   while there are too few quads to give every wave of the chip one (<= 2048).
     const int nst = (a.s.K / 32 + 63) / 64;
     int best_ft = 512, best_wpq = (total_q <= 2048 && nst >= 2) ? 2 : 1;
+    if (total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || (SM != 2 && !a.acc_mfma))) { best_ft = 1024; best_wpq = 4; }   // long rows, few quads: 4 waves per quad
     double best = 0.0;
     if (a.s.K / 4 > 6 * 512 && !(a.dump || LUTSRC == 0 || (SM != 2 && !a.acc_mfma))) best_ft = 1024;   // LUT build: <= 6 tables per thread
     if (force_ft) best_ft = force_ft;

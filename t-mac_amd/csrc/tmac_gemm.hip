@@ -44,13 +44,13 @@ __device__ __forceinline__ void g_st(void* C, int f16, size_t i, float v) {
 }
 
 constexpr int GRT = 2;   // MFMA row tiles per wave (16 bit-plane rows each)
-constexpr int GNT = 4;   // MFMA n tiles per workgroup and wave (16 activation rows each)
 constexpr int GWV = 4;   // waves per workgroup (consecutive row blocks)
 constexpr int GCH = 4;   // units (8 tables = 32 activations each) per LDS chunk
 
 typedef float gv2f_t __attribute__((ext_vector_type(2)));
 
-template <int BITS, bool ZP, bool DUMP>
+// GNT: MFMA n tiles per workgroup and wave (16 activation rows each): 4, or 2 when that is needed to fill the chip
+template <int BITS, bool ZP, bool DUMP, int GNT>
 __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     constexpr int NJ = BITS;                               // uint4 per unit and quad in the QUAD layout
     constexpr int ORPT = 16 / BITS;                        // output rows per MFMA row tile
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     constexpr int QW = ORW / 4;                            // row quads per workgroup
     __shared__ uint4 bt[2][GCH][GNT * 16][4];              // [buffer][unit][n][j4]            2 x 16 KB
     __shared__ uint4 wt[2][GCH][QW][NJ];                   // [buffer][unit][quad][j]          2 x 2 KB
-    __shared__ float ep[2][2][4][64];                      // [buffer][act group][ls, lb, sc, zr][n | row]
+    __shared__ float ep[2][2][4][64];                      // [buffer][act group][ls, lb, sc, zr][n | row]  (n < GNT*16)
     __shared__ uint2 pat[16];                              // signed one-hot row of a recoded nibble c: byte (c & 7) = +1, or -1 if c & 8
     const Shape& s = a.s;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     const int w_ul = tid / (QW * NJ), w_ql = (tid / NJ) % QW, w_j = tid % NJ;
     const uint4* wsrc = reinterpret_cast<const uint4*>(a.W) + ((size_t)min(orow_wg / 4 + w_ql, nq - 1) * nst * NJ + w_j) * 64;
     // epilogue operands: e1 = ls / lb of column tid%64, e2 = scale / zero of row (tid/2)%64, act group tid/128
-    const int e_ag = tid >> 7, e1_which = (tid >> 6) & 1, e1_n = min(n0 + (tid & 63), a.N - 1);
+    const int e_ag = tid >> 7, e1_which = (tid >> 6) & 1, e1_n = min(n0 + (tid & (GNT * 16 - 1)), a.N - 1);
     const int e2_o = min(orow_wg + ((tid >> 1) & 63), s.Mw - 1), e2_which = tid & 1;
     const float* e1_src = (e1_which ? a.lut_biases : a.lut_scales) + (size_t)e1_n * G;
 
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     float e1, e2;
     auto fetch_chunk = [&](int c) {
 #pragma unroll
-        for (int ul = 0; ul < GCH; ++ul) bst[ul] = bsrc[min(c * GCH + ul, nu - 1)];   // tail units: clamped here, skipped below
+        for (int ul = 0; ul < GCH; ++ul)
+            if (tid < GNT * 64) bst[ul] = bsrc[min(c * GCH + ul, nu - 1)];   // tail units: clamped here, skipped below
         if (tid < GCH * QW * NJ) {
             const int u = min(c * GCH + w_ul, nu - 1);
             wst = wsrc[(size_t)(u >> 6) * NJ * 64 + (u & 63)];
@@ -103,8 +104,9 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     auto stage_chunk = [&](int buf) {       // biased -> signed table bytes on the way into LDS
 #pragma unroll
         for (int ul = 0; ul < GCH; ++ul)
-            bt[buf][ul][tid >> 2][tid & 3] = make_uint4(bst[ul].x ^ 0x80808080u, bst[ul].y ^ 0x80808080u,
-                                                        bst[ul].z ^ 0x80808080u, bst[ul].w ^ 0x80808080u);
+            if (tid < GNT * 64)
+                bt[buf][ul][tid >> 2][tid & 3] = make_uint4(bst[ul].x ^ 0x80808080u, bst[ul].y ^ 0x80808080u,
+                                                            bst[ul].z ^ 0x80808080u, bst[ul].w ^ 0x80808080u);
         if (tid < GCH * QW * NJ) wt[buf][w_ul][w_ql][w_j] = wst;
         ep[buf][e_ag][e1_which][tid & 63] = e1;
         ep[buf][e_ag][2 + e2_which][(tid >> 1) & 63] = e2;
@@ -134,6 +136,9 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
             facc[rt][nt][1] = (gv2f_t){0.f, 0.f};
         }
 
+    // The int32 accumulation starts from 0x4B400000 = bits of 1.5 * 2^23: with |PS| <= 16 * 127 the accumulator's bit
+    // pattern IS the float 12582912 + PS, so the int -> float conversion is one exact (packed) subtraction.
+    const gv4i_t cinit = {0x4B400000, 0x4B400000, 0x4B400000, 0x4B400000};
     fetch_chunk(0);
     stage_chunk(0);
     for (int ck = 0; ck < nchunk; ++ck) {
@@ -158,8 +163,8 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
                     const uint2 p1 = *reinterpret_cast<const uint2*>(pb + (__builtin_amdgcn_alignbit(w1, w1, a_sh[rt]) & 0x78u));
                     const gv4i_t av = {(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
 #pragma unroll
-                    for (int nt = 0; nt < GNT; ++nt)         // first unit of an act group starts from a zero accumulator operand
-                        c[rt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv[nt], (ul & 1) ? c[rt][nt] : (gv4i_t){0, 0, 0, 0}, 0, 0, 0);
+                    for (int nt = 0; nt < GNT; ++nt)         // first unit of an act group starts from the constant accumulator operand
+                        c[rt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv[nt], (ul & 1) ? c[rt][nt] : cinit, 0, 0, 0);
                 }
                 // ---- act group complete: fp32 scale-apply of the int32 tiles, then reset them --------------
                 if (ul & 1) {                                // ags = 64: units 2kk, 2kk+1
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
                                     const int o = orow_wg + (w * GRT + rt) * ORPT + (4 * g + r) / BITS, nn = n0 + nt * 16 + i16;
-                                    if (nn < a.N && o < s.Mw) a.dump[((size_t)nn * s.M() + mrow(o, r % BITS, BITS)) * G + kk] = c[rt][nt][r];
+                                    if (nn < a.N && o < s.Mw) a.dump[((size_t)nn * s.M() + mrow(o, r % BITS, BITS)) * G + kk] = c[rt][nt][r] - 0x4B400000;
                                 }
                             }
                             // rows 4g + 2pr, 4g + 2pr + 1 = planes (2pr) % BITS and the next one (never plane 0) of output
@@ -194,7 +199,8 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
                             for (int pr = 0; pr < 2; ++pr) {
                                 const int oo = (2 * pr) / BITS;
                                 const bool p0 = (2 * pr) % BITS == 0;
-                                const gv2f_t ps = {(float)c[rt][nt][2 * pr], (float)c[rt][nt][2 * pr + 1]};
+                                const gv2f_t ps = (gv2f_t){__int_as_float(c[rt][nt][2 * pr]), __int_as_float(c[rt][nt][2 * pr + 1])} -
+                                                  (gv2f_t){12582912.0f, 12582912.0f};
                                 const gv2f_t v = __builtin_elementwise_fma(ps, (gv2f_t){ls, ls}, (gv2f_t){p0 ? lb : 0.f, 0.f});
                                 gv2f_t acc = __builtin_elementwise_fma(v, (gv2f_t){sc[rt][oo], sc[rt][oo]}, facc[rt][nt][pr]);
                                 if (ZP && p0) acc = __builtin_elementwise_fma((gv2f_t){zr[rt][oo], 0.f}, (gv2f_t){lb2, lb2}, acc);
@@ -235,12 +241,18 @@ hipError_t launch_gemm_onehot(const GemmArgs& a, hipStream_t st) {
     if (!gemm_onehot_supported(a.s)) return hipErrorInvalidValue;
     const int bits = a.s.bits;
     const int rows_per_wg = GWV * GRT * 16 / bits;
-    dim3 g((a.s.Mw + rows_per_wg - 1) / rows_per_wg, (a.N + GNT * 16 - 1) / (GNT * 16)), b(64 * GWV);
-#define GL(B, Z) do { if (a.dump) hipLaunchKernelGGL((k_gemm_onehot<B, Z, true>), g, b, 0, st, a); \
-                      else hipLaunchKernelGGL((k_gemm_onehot<B, Z, false>), g, b, 0, st, a); } while (0)
+    const int gx = (a.s.Mw + rows_per_wg - 1) / rows_per_wg;
+    // 64-column tiles unless that leaves fewer than two workgroups (two waves per SIMD) per CU
+    const bool narrow = (long)gx * ((a.N + 63) / 64) < 2 * 256 && a.N > 32;
+    const int ncols = narrow ? 32 : 64;
+    dim3 g(gx, (a.N + ncols - 1) / ncols), b(64 * GWV);
+#define GL2(B, Z, D) do { if (narrow) hipLaunchKernelGGL((k_gemm_onehot<B, Z, D, 2>), g, b, 0, st, a); \
+                          else hipLaunchKernelGGL((k_gemm_onehot<B, Z, D, 4>), g, b, 0, st, a); } while (0)
+#define GL(B, Z) do { if (a.dump) GL2(B, Z, true); else GL2(B, Z, false); } while (0)
     if (bits == 2) { if (a.s.zero_point) GL(2, true); else GL(2, false); }
     else { if (a.s.zero_point) GL(4, true); else GL(4, false); }
 #undef GL
+#undef GL2
     return hipGetLastError();
 }
 

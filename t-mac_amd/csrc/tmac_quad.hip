@@ -110,7 +110,7 @@ __device__ __forceinline__ void load_q(QFrag<BITS>& f, const FusedArgs& a, const
             if (gi == 0) { r0 = v0; r1 = v1; } else { r2 = v0; r3 = v1; }
         }
     }
-    if ((SM == 0 && ACC == 1) || u < a.nu) {   // nst*64 lanes of every step exist in the QUAD layout (zero padded)
+    if (ACC == 1 || u < a.nu) {   // nst*64 lanes of every step exist in the QUAD layout (zero padded)
         const uint4* wp = M.W + (size_t)((uint32_t)(lq * nst + st) * (uint32_t)(NJ * 64)) + lane;   // uniform base + lane
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
         for (int j4 = 0; j4 < 4; ++j4)
             for (int u = tid; u < nu; u += FT) {
                 uint4 v = src[j4 * a.tstride + u];
-                if (ACC == 1 && SM != 2) { v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u; }
+                if (ACC == 1) { v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u; }
                 tab[j4 * tstride + u] = v;
             }
         if (SM == 2) { if (tid == 0) { l_ls[0] = a.lut_scales[n]; l_lb[0] = a.lut_biases[n]; } }
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                 // the sum's ulp is 1 and its low byte is q in two's complement; + 128 in the magic gives the biased byte).
                 // Half table j = 0..7 holds {-L15, L1, -L13, L3, -L11, L5, -L9, L7}: negated entries as magic - product.
                 const qv2f tt = {t_scales, t_scales};
-                const qv2f mg = {(ACC == 1 && SM != 2) ? 12582912.0f : 12583040.0f, 0.0f};
+                const qv2f mg = {(ACC == 1) ? 12582912.0f : 12583040.0f, 0.0f};
                 qv2f za, zb, zc, zd;
                 asm("v_pk_mul_f32 %0, %1, %2" : "=v"(za) : "v"(L31), "v"(tt));
                 asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zb) : "v"(L75), "v"(tt));
@@ -331,15 +331,25 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
         if (SM == 2) {
             __syncthreads();
             if (tid == 0) {
+                // lut_ctor.cc:157,218: one fp32 chain over the 8-table chunks in order; the LDS reads are batched (16-byte
+                // reads, unrolled) so that only the dependent adds are serial
                 float biases = 0.0f;
-                for (int c = 0; c < T / 8; ++c) biases = __fadd_rn(biases, l_scr[NWV + c]);
+                const float4* cs = reinterpret_cast<const float4*>(l_scr + NWV);
+                const int nc = T / 8;
+                int c = 0;
+#pragma unroll 4
+                for (; c + 4 <= nc; c += 4) {
+                    const float4 v4 = cs[c >> 2];
+                    biases = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(biases, v4.x), v4.y), v4.z), v4.w);
+                }
+                for (; c < nc; ++c) biases = __fadd_rn(biases, l_scr[NWV + c]);
                 l_ls[0] = gscale;
                 l_lb[0] = biases;
             }
         }
     }
     {   // zero tables for the units between K and the end of the last 64-unit step
-        const uint32_t z = (ACC == 1 && SM != 2) ? 0u : 0x80808080u;
+        const uint32_t z = (ACC == 1) ? 0u : 0x80808080u;
 #pragma unroll
         for (int j4 = 0; j4 < 4; ++j4)
             for (int u = nu + tid; u < nst * 64; u += FT) tab[j4 * tstride + u] = make_uint4(z, z, z, z);
@@ -442,6 +452,11 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                 c[pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8((qv4i_t){(int)pa, (int)ma, (int)pb, (int)mb}, bsel, c[pl], 0, 0, 0);
             }
         }
+        if (SM == 2) {      // unified scale: keep the exact integer sum of this lane's row (lane & 3), all units
+#pragma unroll
+            for (int pl = 0; pl < BITS; ++pl) iacc[pl][0] += (c[pl].x + c[pl].y) + (c[pl].z + c[pl].w);
+            return;
+        }
         const int ub4 = st * 64 + 4 * (lane & 12) + 4 * (lane >> 4);
         const int o = 4 * lq + (lane & 3);
 #pragma unroll
@@ -478,7 +493,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     int parity = 0;
     auto finish_quad = [&](bool have, const FusedMat& M, int lq) {
         float* red = l_red + parity * (NWV * 16);
-        if (ACC == 1 && SM != 2) {
+        if (ACC == 1 && SM != 2) {   // per-group scales: fp32 partials
             float acc = 0.f;
             if (have) {
                 acc = __fmul_rn(cacc[0][0], 0.5f);
@@ -541,15 +556,24 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
             int32_t tot[BITS];
 #pragma unroll
             for (int pl = 0; pl < BITS; ++pl) {
-                int32_t mine = 0;
+                if (ACC == 1) {       // every lane holds a partial of row lane & 3: rotate by 4, 8 within the row, then rows
+                    uint32_t v = have ? (uint32_t)iacc[pl][0] : 0u;
+                    v += qdpp_u<0x124>(v);
+                    v += qdpp_u<0x128>(v);
+                    v += (uint32_t)__shfl_xor((int)v, 16, 64);
+                    v += (uint32_t)__shfl_xor((int)v, 32, 64);
+                    tot[pl] = (int32_t)v;
+                } else {
+                    int32_t mine = 0;
 #pragma unroll
-                for (int be = 0; be < 4; ++be) {
-                    int32_t v = have ? iacc[pl][be] : 0;
+                    for (int be = 0; be < 4; ++be) {
+                        int32_t v = have ? iacc[pl][be] : 0;
 #pragma unroll
-                    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-                    if (lane == be) mine = v;
-                }
-                tot[pl] = mine;       // lane be (< 4) holds row be's integer sum of this wave
+                        for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+                        if (lane == be) mine = v;
+                    }
+                    tot[pl] = mine;
+                }                     // lane be (< 4) holds row be's integer sum of this wave
             }
             if (WPQ > 1) {
                 if (lane < 4)
@@ -601,7 +625,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
             if (have) locate(gq, mi, lq);                                                                     \
             c_st = h;                                                                                         \
         }                                                                                                     \
-        if (ACC == 1 && SM != 2) compute_mfma(F, c_st, a.m[mi].Mw, lq); else compute(F, c_st, a.m[mi].Mw, lq); \
+        if (ACC == 1) compute_mfma(F, c_st, a.m[mi].Mw, lq); else compute(F, c_st, a.m[mi].Mw, lq);             \
         issue(F);                                                                                             \
         c_st += WPQ;
         for (;;) {
@@ -653,12 +677,12 @@ static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t
     if (gx > cap) gx = cap;
     dim3 g(gx, N), b(FT);
     const int T = a.s.K / 4;
-    constexpr int A1 = (SM == 2) ? 0 : 1;   // the unified-scale path keeps the VALU accumulate
+    constexpr int A1 = 1;
 #define QL(NRV, DV, AV) hipLaunchKernelGGL((k_gemv_quad<BITS, ZP, SM, LUTSRC, NRV, FT, WPQ, DV, AV>), g, b, shmem, st, a)
     const bool two = (LUTSRC == 0 || T <= 2 * FT);
     if (!two && T > 6 * FT) return hipErrorInvalidValue;
     if constexpr (FT == 512) {
-        const int acc = (SM == 2) ? 0 : (a.acc_mfma ? 1 : 0);
+        const int acc = a.acc_mfma ? 1 : 0;
         if (a.dump) {
             if (acc) { if (two) QL(2, true, A1); else if constexpr (LUTSRC == 1) QL(6, true, A1); }
             else { if (two) QL(2, true, 0); else if constexpr (LUTSRC == 1) QL(6, true, 0); }
@@ -667,7 +691,7 @@ static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t
             else { if (two) QL(2, false, 0); else if constexpr (LUTSRC == 1) QL(6, false, 0); }
         }
     } else {
-        if (a.dump || LUTSRC == 0 || (SM != 2 && !a.acc_mfma)) return hipErrorInvalidValue;
+        if (a.dump || LUTSRC == 0 || !a.acc_mfma) return hipErrorInvalidValue;
         if constexpr (LUTSRC == 1) { if (two) QL(2, false, A1); else QL(6, false, A1); }
     }
 #undef QL
@@ -682,12 +706,12 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
     //   while there are too few quads to give every wave of the chip one (<= 2048).
     const int nst = (a.s.K / 32 + 63) / 64;
     int best_ft = 512, best_wpq = (total_q <= 2048 && nst >= 2) ? 2 : 1;
-    if (total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || (SM != 2 && !a.acc_mfma))) { best_ft = 1024; best_wpq = 4; }   // long rows, few quads: 4 waves per quad
+    if (total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) { best_ft = 1024; best_wpq = 4; }   // long rows, few quads: 4 waves per quad
     double best = 0.0;
-    if (a.s.K / 4 > 6 * 512 && !(a.dump || LUTSRC == 0 || (SM != 2 && !a.acc_mfma))) best_ft = 1024;   // LUT build: <= 6 tables per thread
+    if (a.s.K / 4 > 6 * 512 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) best_ft = 1024;   // LUT build: <= 6 tables per thread
     if (force_ft) best_ft = force_ft;
     if (force_wpq) best_wpq = force_wpq;
-    const bool need512 = a.dump || LUTSRC == 0 || (SM != 2 && !a.acc_mfma);
+    const bool need512 = a.dump || LUTSRC == 0 || !a.acc_mfma;
     if ((need512 && best_ft != 512) || (best_wpq == 4 && best_ft != 1024) || (best_ft != 512 && best_ft != 1024) ||
         (best_wpq != 1 && best_wpq != 2 && best_wpq != 4) || a.s.K / 4 > 6 * best_ft)
         best = 1e30;

@@ -177,16 +177,19 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     float* l_lb = l_ls + GP;                                     // [GP]
     float* l_red = l_lb + GP;                                    // [2][NWV][4][4] partials (WPQ == 2 / SM 2)
     float* l_scr = l_red + 2 * NWV * 16;                         // SM 2 build scratch: [NWV] maxima + [T/8] chunk sums
-    const int total_q = a.m[a.nmat - 1].nb_end;                  // cumulative QUAD counts in this launch mode
+    // The per-matrix fields are copied out of the kernel argument once: indexing a.m[] with a run-time matrix number
+    // makes every use a dependent s_load from the kernarg segment (several per step, each a scalar-cache round trip).
+    const int nmat = a.nmat;
+    const int qe0 = a.m[0].nb_end, qe1 = a.m[1].nb_end, qe2 = a.m[2].nb_end, qe3 = a.m[3].nb_end;
+    const FusedMat fm0 = a.m[0], fm1 = a.m[1], fm2 = a.m[2], fm3 = a.m[3];
+    const int total_q = nmat == 1 ? qe0 : (nmat == 2 ? qe1 : (nmat == 3 ? qe2 : qe3));   // cumulative QUAD counts
+    auto pick = [&](int mi) -> FusedMat { return mi == 0 ? fm0 : (mi == 1 ? fm1 : (mi == 2 ? fm2 : fm3)); };
 
 #define QSTAMP(i) do { if (a.stamps && lane == 0 && (w == 0 || w == NWV - 1)) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     QSTAMP(0);
     auto locate = [&](int gq, int& mi, int& lq) {
-        mi = 0;
-#pragma unroll
-        for (int i = 1; i < 4; ++i)
-            if (i < a.nmat && gq >= a.m[i - 1].nb_end) mi = i;
-        lq = gq - (mi ? a.m[mi - 1].nb_end : 0);
+        mi = (nmat > 1 && gq >= qe0) + (nmat > 2 && gq >= qe1) + (nmat > 3 && gq >= qe2);
+        lq = gq - (mi == 0 ? 0 : (mi == 1 ? qe0 : (mi == 2 ? qe1 : qe2)));
     };
 
     // ---- 1. activation loads for the LUT build (issued first: vmcnt retires in order) ----------
@@ -214,7 +217,8 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
         if (p_q < total_q && p_st < nst) {      // p_st >= nst: a wave without steps (WPQ > number of steps)
             int mi, lq;
             locate(p_q, mi, lq);
-            load_q<BITS, ZP, SM, ACC>(f, a, a.m[mi], lq, p_st, nst, lane);
+            const FusedMat M = pick(mi);
+            load_q<BITS, ZP, SM, ACC>(f, a, M, lq, p_st, nst, lane);
             p_st += WPQ;
             if (p_st >= nst) { p_st = h; p_q += stride; }
         }
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
 #define QSTEP(F)                                                                                              \
         while (!(have && c_st < nst)) {                                                                       \
             if (c_it == 0) QSTAMP(4);                                                                         \
-            finish_quad(have, a.m[mi], lq);                                                                   \
+            finish_quad(have, pick(mi), lq);                                                                  \
             if (c_it == 0) QSTAMP(5);                                                                         \
             ++c_it;                                                                                           \
             if (blockIdx.x * IPI + c_it * stride >= total_q) goto q_done;                                     \
@@ -625,7 +629,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
             if (have) locate(gq, mi, lq);                                                                     \
             c_st = h;                                                                                         \
         }                                                                                                     \
-        if (ACC == 1) compute_mfma(F, c_st, a.m[mi].Mw, lq); else compute(F, c_st, a.m[mi].Mw, lq);             \
+        if (ACC == 1) compute_mfma(F, c_st, pick(mi).Mw, lq); else compute(F, c_st, pick(mi).Mw, lq);           \
         issue(F);                                                                                             \
         c_st += WPQ;
         for (;;) {

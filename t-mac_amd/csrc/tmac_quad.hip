@@ -677,7 +677,7 @@ static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t
     constexpr int IPI = FT / 64 / WPQ;
     const size_t shmem = quad_lds_bytes(a.s, FT / 64);
     int gx = (total_q + IPI - 1) / IPI;
-    const int cap = (FT == 1024) ? 256 : 512;     // persistent: <= 1 (FT = 1024) / 2 (FT = 512) workgroups per CU
+    const int cap = (FT > 512) ? 256 : 512;       // persistent: <= 1 (FT = 768, 1024) / 2 (FT = 512) workgroups per CU
     if (gx > cap) gx = cap;
     dim3 g(gx, N), b(FT);
     const int T = a.s.K / 4;
@@ -705,17 +705,25 @@ static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t
 template <int BITS, bool ZP, int SM, int LUTSRC>
 static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_ft, int force_wpq, hipStream_t st) {
     // Configuration choice, from tools/tune_quad.py on MI355X (profiles/r01_tune_quad.txt, us per launch in a graph):
-    //   o 4096x4096: (512,2) 6.1 | qkv 12288x4096: (512,1) 9.7, (1024,1) 9.3 | gate_up 22016x4096: (512,1) 13.1,
-    //   (1024,1) 15.6 | down 4096x11008: (512,2) 11.0, (512,1) 14.9.  -> 512-thread workgroups; two waves per quad
-    //   while there are too few quads to give every wave of the chip one (<= 2048).
+    //   o 4096x4096: (512,2) 5.8, (768,3) 5.6 | qkv 12288x4096: (512,1) 9.0, (1024,1) 8.6 | gate_up 22016x4096:
+    //   (512,1) 11.8, (1024,1) 13.5 | down 4096x11008: (768,3) 8.6, (1024,4) 9.0, (512,2) 9.3, (512,1) 11.2.
+    //   -> 512-thread workgroups; two waves per quad while there are too few quads to give every wave of the chip
+    //   one (<= 2048); long rows with few quads: 3 waves per quad when that splits the steps evenly, else 4.
     const int nst = (a.s.K / 32 + 63) / 64;
     int best_ft = 512, best_wpq = (total_q <= 2048 && nst >= 2) ? 2 : 1;
-    if (total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) { best_ft = 1024; best_wpq = 4; }   // long rows, few quads: 4 waves per quad
+    if (total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
+        if (nst % 3 == 0 && a.s.K / 4 <= 6 * 768) { best_ft = 768; best_wpq = 3; }
+        else { best_ft = 1024; best_wpq = 4; }
+    }
     double best = 0.0;
-    if (a.s.K / 4 > 6 * 512 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) best_ft = 1024;   // LUT build: <= 6 tables per thread
-    if (force_ft) best_ft = force_ft;
+    if (a.s.K / 4 > 6 * 512 && best_ft == 512 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) best_ft = 1024;   // LUT build: <= 6 tables per thread
+    if (force_ft) { best_ft = force_ft; if (!force_wpq && best_wpq > 2) best_wpq = 2; }
     if (force_wpq) best_wpq = force_wpq;
     const bool need512 = a.dump || LUTSRC == 0 || !a.acc_mfma;
+    if (best_ft == 768 || best_wpq == 3) {        // 12 waves, 3 per quad: balanced when the row has 3k steps
+        if (best_ft != 768 || best_wpq != 3 || need512 || a.s.K / 4 > 6 * 768) return hipErrorInvalidValue;
+        return qlaunch_nr<BITS, ZP, SM, LUTSRC, 768, 3>(a, total_q, N, st);
+    }
     if ((need512 && best_ft != 512) || (best_wpq == 4 && best_ft != 1024) || (best_ft != 512 && best_ft != 1024) ||
         (best_wpq != 1 && best_wpq != 2 && best_wpq != 4) || a.s.K / 4 > 6 * best_ft)
         best = 1e30;

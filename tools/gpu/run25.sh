@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
+timeout 300 python tools/tune_quad.py > gpurun_out/tune25.txt 2>&1
+tail -4 gpurun_out/tune25.txt

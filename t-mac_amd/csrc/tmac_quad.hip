@@ -677,7 +677,7 @@ static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t
     constexpr int IPI = FT / 64 / WPQ;
     const size_t shmem = quad_lds_bytes(a.s, FT / 64);
     int gx = (total_q + IPI - 1) / IPI;
-    const int cap = (FT > 512) ? 256 : 512;       // persistent: <= 1 (FT = 768, 1024) / 2 (FT = 512) workgroups per CU
+    const int cap = (FT > 512) ? 256 : 512;       // persistent: <= 1 (FT = 768, 1024) / 2 (FT = 512) workgroups per CU (measured best)
     if (gx > cap) gx = cap;
     dim3 g(gx, N), b(FT);
     const int T = a.s.K / 4;
@@ -714,6 +714,8 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
     if (total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
         if (nst % 3 == 0 && a.s.K / 4 <= 6 * 768) { best_ft = 768; best_wpq = 3; }
         else { best_ft = 1024; best_wpq = 4; }
+    } else if (total_q > 2048 && total_q <= 4096 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
+        best_ft = 1024;   // one quad per wave fits one workgroup per CU: the LUT is built once per CU instead of twice
     }
     double best = 0.0;
     if (a.s.K / 4 > 6 * 512 && best_ft == 512 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) best_ft = 1024;   // LUT build: <= 6 tables per thread

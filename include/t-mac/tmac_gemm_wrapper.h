@@ -40,8 +40,17 @@ public:
   TMACGeMMWrapper(int n_threads, int act_group_size, const std::string& kcfg_file, const std::string& /*library_file*/)
       : _act_group_size(act_group_size), _allocated(false), _qlut(nullptr), _lut_scales(nullptr), _lut_biases(nullptr) {
     (void)n_threads;
-    // kcfg path: argument, else $TMAC_KCFG_FILE (reference: tmac_gemm_wrapper.h:40-56)
-    if (tmac_hip_load_kcfg(kcfg_file.empty() ? nullptr : kcfg_file.c_str()) != 0) {
+    // kcfg path: argument, else $TMAC_KCFG_FILE, else the TMAC_KCFG_FILE compile definition the CMake package sets
+    // (reference: tmac_gemm_wrapper.h:40-56)
+    const char* path = kcfg_file.empty() ? nullptr : kcfg_file.c_str();
+#ifdef TMAC_KCFG_FILE
+#define TMAC_STR2_(x) #x
+#define TMAC_STR_(x) TMAC_STR2_(x)
+    if (!path && !std::getenv("TMAC_KCFG_FILE")) path = TMAC_STR_(TMAC_KCFG_FILE);
+#undef TMAC_STR_
+#undef TMAC_STR2_
+#endif
+    if (tmac_hip_load_kcfg(path) != 0) {
       std::fprintf(stderr, "TMAC: %s\n", tmac_hip_last_error());
       std::abort();  // reference: LOG(FATAL) << "Please set TMAC_KCFG_FILE environment variable"
     }

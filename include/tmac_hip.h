@@ -38,6 +38,8 @@ extern "C" {
 
 typedef enum { TMAC_F32 = 0, TMAC_F16 = 1 } tmac_dtype_t;
 
+#define TMAC_HIP_ABI_VERSION 1   /* bumped when an exported signature changes */
+
 /* Mirrors TMAC::TMACGeMMConfig (include/t-mac/tmac_gemm_wrapper.h:26-35) plus the three facts the
  * reference bakes into the compiled kernel instead of kcfg.ini (zero_point, act_group_size,
  * m_groups: python/t_mac/ops/qgemm.py:16-96). */

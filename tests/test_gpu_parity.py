@@ -369,6 +369,8 @@ def test_quad_kernel_configurations(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, ft
     """every (threads per workgroup, waves per quad, accumulate) configuration of k_gemv_quad, LUT built
     in-kernel; the integer tap exists in the 512-thread configurations"""
     import torch
+    if variant == 7 and ft != 512:
+        pytest.skip("the v_mqsad accumulate is instantiated for 512-thread workgroups only")
     L = tm.lib()
     L.tmac_hip_debug_quad_config.argtypes = [C.c_int, C.c_int]
     case = orc.make_case(3 * Mw + K, Mw, K, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg)
@@ -381,8 +383,6 @@ def test_quad_kernel_configurations(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, ft
     Bt = torch.from_numpy(case["B"]).cuda()
     Ct = torch.empty((1, Mw), dtype=torch.float32, device="cuda")
     q, ls, lb, Cc, PSo = oracle_case(case, A, S, Mw, K, bits, bm, kf, gs, ags, zp, mg)
-    if variant == 7 and ft != 512:
-        pytest.skip("the v_mqsad accumulate is instantiated for 512-thread workgroups only")
     L.tmac_hip_debug_quad_config(ft, wpq)
     try:
         wr.fused([w], Bt, [Ct])
@@ -397,4 +397,39 @@ def test_quad_kernel_configurations(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, ft
     finally:
         L.tmac_hip_debug_quad_config(0, 0)
         L.tmac_hip_set_variant(0)
+    w.free()
+
+
+@pytest.mark.parametrize("Mw,K,bits,bm,zp,mg,ags", [
+    (4096, 14336, 2, 128, True, -1, 64),     # llama-3-8b down: 7 steps, 4 waves per quad, 1024-thread LUT build
+    (14336, 4096, 2, 256, True, -1, 64),     # llama-3-8b gate/up: one quad per wave
+    (1024, 4096, 2, 512, True, -1, 64),      # llama-3-8b k/v (GQA)
+    (5120, 13824, 2, 128, True, -1, 64),     # llama-2-13b down
+    (13824, 5120, 2, 128, True, -1, 64),     # llama-2-13b gate/up
+    (4096, 11008, 4, 256, True, -1, 64),     # llama-2-7b W4 down: 3 waves per quad, 2-deep fragment ring
+    (3200, 8640, 2, 128, False, 1, 8640),    # BitNet-3B down: unified scale, act group = K
+    (8640, 3200, 2, 128, False, 1, 3200),    # BitNet-3B gate/up
+])
+def test_model_shape_zoo(tm, Mw, K, bits, bm, zp, mg, ags):
+    """full-size shapes of the reference's preset models through the default (fused, auto-configured) path: every
+    launch-configuration branch of the quad kernel's heuristic against the oracle"""
+    import torch
+    gs = 128
+    tm.binding.check(tm.lib().tmac_hip_set_variant(0))
+    case = orc.make_case(Mw + K + bits, Mw, K, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg)
+    A = orc.preprocess_weights(case["w"], bits, bm, 16)
+    S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm) if mg == -1 else case["sc"]
+    wr = tm.TMACGeMMWrapper(act_group_size=ags)
+    wr.set_workspace(K, 1)
+    w = wr.register_weights(A, S, Mw, K, bits, tm.KCfg.make(Mw, K, bits, bm, 16, gs, ags, zp, mg))
+    Bt = torch.from_numpy(case["B"]).cuda()
+    Ct = torch.empty((1, Mw), dtype=torch.float32, device="cuda")
+    wr.fused([w], Bt, [Ct])
+    torch.cuda.synchronize()
+    q, ls, lb, Cc, PSo = oracle_case(case, A, S, Mw, K, bits, bm, 16, gs, ags, zp, mg)
+    assert rel_err(Ct.cpu().numpy(), Cc) <= 2e-5
+    C2 = torch.empty_like(Ct)
+    wr.fused([w], Bt, [C2])
+    torch.cuda.synchronize()
+    check_bits(Ct.cpu().numpy(), C2.cpu().numpy())
     w.free()

@@ -62,6 +62,10 @@ def parse():
                     help="fused: LUT build inside the GEMV kernel, q/k/v and gate/up batched (4 launches/layer); "
                          "split: preprocessor + one GEMV launch per matrix (11 launches/layer)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--eager-collectives", action="store_true",
+                    help="multi-GPU: launch eagerly instead of capturing the RCCL all-gathers into the hipGraph "
+                         "(~47 us of host time per launch + collective, 6 ms per token)")
+    ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # debugging: take the multi-GPU code path with 1 rank
     return ap.parse_args()
 
 
@@ -135,8 +139,11 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import tmac_amd
     from tmac_amd import KCfg, F16
@@ -199,31 +206,55 @@ def main():
                     for i in range(cnt):
                         wr.llama_cpp_compute(mats[name][i], outs[name][i], 1, out_dtype=F16)
                 # exchange step: the first output of the group becomes the next activation vector
-                if world > 1:
+                if dist_on:
                     dist.all_gather_into_tensor(gathered[name], outs[name][0])
                     x[nxt[name]] = gathered[name][:logical[name]]
                 else:
                     x[nxt[name]] = outs[name][0]
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # RCCL collectives inside a captured graph are not exercised on the 1-GPU development box: multi-GPU runs launch eagerly
-    use_graph = (not args.no_graph) and world == 1
+    # One step (128 launches + the all-gathers) is captured into a hipGraph and replayed.  With RCCL collectives inside,
+    # capture was exercised with one rank only on the development box (1.27 ms per step against 6.0 ms eager): if
+    # capture raises, the run falls back to eager launches; if the first replay does not finish, a watchdog ends the
+    # process instead of hanging the node.
+    use_graph = (not args.no_graph) and not (dist_on and args.eager_collectives)
     graph = None
     if use_graph:
-        # capture ONE step (352 launches on one stream) into a hipGraph; the timed region replays it
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            step(False)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            step(False)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step(False)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step(False)
+            if dist_on:
+                import threading
+                done = threading.Event()
+
+                def watchdog():
+                    if not done.wait(240.0):
+                        sys.stderr.write("bench.py: the captured step (with RCCL all-gathers) did not complete; "
+                                         "rerun with --eager-collectives\n")
+                        sys.stderr.flush()
+                        os._exit(3)
+                threading.Thread(target=watchdog, daemon=True).start()
+                graph.replay()
+                torch.cuda.synchronize()
+                done.set()
+        except Exception as e:   # capture not supported with this RCCL / torch build: measured eagerly instead
+            if not dist_on:
+                raise
+            sys.stderr.write(f"bench.py: graph capture with collectives failed ({e!r}); launching eagerly\n")
+            graph = None
+            use_graph = False
+            torch.cuda.synchronize()
 
     def run_step():
         if graph is not None:
@@ -239,7 +270,7 @@ def main():
         run_step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -315,7 +346,7 @@ def main():
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

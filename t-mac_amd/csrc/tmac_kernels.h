@@ -11,14 +11,14 @@ enum Dtype { F32 = 0, F16 = 1 };
 
 // GEMV kernel variants (A/B-able at run time through tmac_hip_set_variant)
 enum Variant {
-    V_AUTO = 0,
-    V_LO_MQSAD = 1,  // tiled kernel, v_mqsad_pk_u16_u8 accumulate
-    V_LO_SDWA = 2,   // tiled kernel, byte-select adds
-    V_REF_LAYOUT = 3,// generic kernel on the reference blobs
-    V_FUSED = 4,     // fused kernel (ts = 8 layout): LUT in LDS, multi-matrix launches, v_mqsad accumulate (default)
+    V_AUTO = 0,      // k_gemv_quad (V_QUAD) for 2/4-bit weights it supports, else the row-block fused kernel, else 1
+    V_LO_MQSAD = 1,  // two-kernel path: k_preprocess + tiled k_gemv_lo, v_mqsad_pk_u16_u8 accumulate
+    V_LO_SDWA = 2,   // same, byte-select adds
+    V_REF_LAYOUT = 3,// generic kernel on the reference blobs (reference float order)
+    V_FUSED = 4,     // row-block fused kernel k_gemv_fused (ts = 8 layout): LUT in LDS, v_mqsad accumulate
     V_FUSED_MFMA = 5,// same kernel with the matrix-pipe (v_mfma_i32_16x16x64_i8) accumulate
-    V_QUAD = 6,      // wave-owns-row-quad fused kernel (QUAD layout), MFMA accumulate (default)
-    V_QUAD_MQSAD = 7 // same with the v_mqsad_pk_u16_u8 accumulate
+    V_QUAD = 6,      // wave-owns-row-quad fused kernel k_gemv_quad (QUAD layout), MFMA accumulate
+    V_QUAD_MQSAD = 7 // same with the v_mqsad_pk_u16_u8 accumulate (512-thread workgroups)
 };
 
 struct FusedMat {

@@ -1,16 +1,17 @@
-// tmac_quad.hip — k_gemv_quad: the wave-owns-row-quad form of the fused LUT-build + GEMV kernel.
+// tmac_quad.hip — k_gemv_quad: fused LUT build + GEMV (N = 1 decode), a wave owns a row quad.  Production path.
 //
-// Same arithmetic as k_gemv_fused (tmac_fused.hip; lut_ctor.cc / tbl.cc citations there), different
-// work decomposition, chosen from the measured phase timeline of that kernel (profiles/r01_*):
-// its 8 waves split K for one 16-row block and meet at a barrier + LDS reduction per block, which
-// costs ~40 % of the block time.  Here a WAVE owns a row quad (4 output rows): its 64 lanes hold 64
-// consecutive 8-table units (QUAD layout, tmac_layout.h), so every weight instruction still reads 1 KiB
-// contiguous, the LUT in LDS is read conflict-free (lane u reads 16 B at u*16), and the reduction over
-// K is wave-local (DPP within rows of 16 lanes + 2 cross-row moves).  No barrier in the steady state.
-//   WPQ = 1 : one wave does all of K for its quad                     (large Mw: q/k/v, gate/up)
-//   WPQ = 2 : two waves split the K steps of a quad, combined in LDS  (Mw = 4096: o, down; better balance)
-// Workgroups are persistent (<= 1 per CU for FT = 1024), build the LUT once (bit-exact with k_preprocess)
-// while the first weight fragments are in flight, then stream quads.
+// Reference semantics: lut_ctor.cc:38-266 (LUT build, bit-exact), tbl.cc:435-529 / 586-628 (lookup, exact integer sums,
+// per-act-group fp32 scale-apply), qgemm.py:170-174,192-206 (bit-plane combine, scale-final).  Work decomposition:
+// a WAVE owns a row quad (4 output rows): its 64 lanes hold 64 consecutive 8-table units (QUAD layout,
+// tmac_layout.h), so every weight instruction reads 1 KiB contiguous, the LUT in LDS is read conflict-free (lane u
+// reads 16 B at u*16), and the reduction over K is wave-local (DPP within rows of 16 lanes + 2 cross-row moves).
+//   WPQ = 1     : one wave does all of K for its quad                       (many quads: q/k/v, gate/up)
+//   WPQ = 2,3,4 : that many waves split the K steps of a quad, combined in LDS  (few quads: o, down)
+// Workgroups (512 / 768 / 1024 threads) are persistent, build the LUT once while their first weight fragments are in
+// flight, then walk their (quad, step) list.  Template parameters: BITS 2|4; ZP zero points; SM 0 per-group scales /
+// 2 unified scale applied last (BitNet); LUTSRC 1 build the LUT in-kernel / 0 copy the image k_preprocess wrote;
+// NR tables built per thread; FT threads; WPQ waves per quad; DUMP integer tap; ACC 1 v_mfma_i32_16x16x64_i8
+// accumulate / 0 v_mqsad_pk_u16_u8 (A/B variant).  DESIGN.md 4.1, 4.2, 4.6.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -669,9 +670,8 @@ static size_t quad_lds_bytes(const Shape& s, int nwv) {
 
 void fused_precompute(FusedArgs& a);   // tmac_fused.hip
 
-// Instantiation policy (compile time): the v_mqsad accumulate (ACC 0) exists for the unified-scale path and, as an
-// A/B variant, for 512-thread workgroups; the prebuilt-LUT source (LUTSRC 0) and the integer tap (DUMP) only for
-// 512-thread workgroups.
+// Instantiation policy (compile time): the v_mqsad accumulate (ACC 0, A/B variant 7), the prebuilt-LUT source
+// (LUTSRC 0) and the integer tap (DUMP) exist for 512-thread workgroups only.
 template <int BITS, bool ZP, int SM, int LUTSRC, int FT, int WPQ>
 static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t st) {
     constexpr int IPI = FT / 64 / WPQ;

@@ -45,12 +45,13 @@ __device__ __forceinline__ void g_st(void* C, int f16, size_t i, float v) {
 
 constexpr int GRT = 2;   // MFMA row tiles per wave (16 bit-plane rows each)
 constexpr int GWV = 4;   // waves per workgroup (consecutive row blocks)
-constexpr int GCH = 4;   // units (8 tables = 32 activations each) per LDS chunk
 
 typedef float gv2f_t __attribute__((ext_vector_type(2)));
 
-// GNT: MFMA n tiles per workgroup and wave (16 activation rows each): 4, or 2 when that is needed to fill the chip
-template <int BITS, bool ZP, bool DUMP, int GNT>
+// GNT: MFMA n tiles per workgroup and wave (16 activation rows each): 4, or 2 when that is needed to fill the chip.
+// GCH: units (8 tables = 32 activations each) per LDS chunk: 4, or 8 with the narrow tile (longer chunks hide the
+// fetch latency when a CU holds few waves; 48 KB of LDS).
+template <int BITS, bool ZP, bool DUMP, int GNT, int GCH>
 __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     constexpr int NJ = BITS;                               // uint4 per unit and quad in the QUAD layout
     constexpr int ORPT = 16 / BITS;                        // output rows per MFMA row tile
@@ -58,7 +59,8 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     constexpr int QW = ORW / 4;                            // row quads per workgroup
     __shared__ uint4 bt[2][GCH][GNT * 16][4];              // [buffer][unit][n][j4]            2 x 16 KB
     __shared__ uint4 wt[2][GCH][QW][NJ];                   // [buffer][unit][quad][j]          2 x 2 KB
-    __shared__ float ep[2][2][4][64];                      // [buffer][act group][ls, lb, sc, zr][n | row]  (n < GNT*16)
+    constexpr int NAG = GCH / 2;                           // act groups (64 activations) per chunk
+    __shared__ float ep[2][NAG][4][64];                    // [buffer][act group][ls, lb, sc, zr][n | row]  (n < GNT*16)
     __shared__ uint2 pat[16];                              // signed one-hot row of a recoded nibble c: byte (c & 7) = +1, or -1 if c & 8
     const Shape& s = a.s;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -75,16 +77,16 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     // ---- staging roles of this thread -----------------------------------------------------------------------
     // B: activation row n0 + tid/4, j4 = tid%4, the chunk's GCH consecutive units
     const uint4* bsrc = reinterpret_cast<const uint4*>(a.qlut_lds) + ((size_t)min(n0 + (tid >> 2), a.N - 1) * 4 + (tid & 3)) * a.tstride;
-    // weights (tid < GCH*QW*NJ = 128): unit tid / (QW*NJ), quad (tid / NJ) % QW, uint4 j = tid % NJ
+    // weights (tid < GCH*QW*NJ = 128 | 256): unit tid / (QW*NJ), quad (tid / NJ) % QW, uint4 j = tid % NJ
     const int w_ul = tid / (QW * NJ), w_ql = (tid / NJ) % QW, w_j = tid % NJ;
     const uint4* wsrc = reinterpret_cast<const uint4*>(a.W) + ((size_t)min(orow_wg / 4 + w_ql, nq - 1) * nst * NJ + w_j) * 64;
-    // epilogue operands: e1 = ls / lb of column tid%64, e2 = scale / zero of row (tid/2)%64, act group tid/128
+    // epilogue operands: e1 = ls / lb of column tid%64, e2 = scale / zero of row (tid/2)%64, act groups tid/128 + 2k
     const int e_ag = tid >> 7, e1_which = (tid >> 6) & 1, e1_n = min(n0 + (tid & (GNT * 16 - 1)), a.N - 1);
     const int e2_o = min(orow_wg + ((tid >> 1) & 63), s.Mw - 1), e2_which = tid & 1;
     const float* e1_src = (e1_which ? a.lut_biases : a.lut_scales) + (size_t)e1_n * G;
 
     uint4 bst[GCH], wst;
-    float e1, e2;
+    float e1[NAG / 2], e2[NAG / 2];
     auto fetch_chunk = [&](int c) {
 #pragma unroll
         for (int ul = 0; ul < GCH; ++ul)
@@ -93,12 +95,15 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
             const int u = min(c * GCH + w_ul, nu - 1);
             wst = wsrc[(size_t)(u >> 6) * NJ * 64 + (u & 63)];
         }
-        const int kk = min(c * (GCH / 2) + e_ag, G - 1);
-        e1 = e1_src[kk];
-        e2 = 0.f;
-        if (ZP || !e2_which) {
-            const size_t si = quad_scale_index(s, e2_o >> 2, (kk * s.ags) / s.gs, e2_o & 3, e2_which);
-            e2 = a.sc_f16 ? __half2float(reinterpret_cast<const __half*>(a.SC)[si]) : reinterpret_cast<const float*>(a.SC)[si];
+#pragma unroll
+        for (int k = 0; k < NAG / 2; ++k) {
+            const int kk = min(c * NAG + e_ag + 2 * k, G - 1);
+            e1[k] = e1_src[kk];
+            e2[k] = 0.f;
+            if (ZP || !e2_which) {
+                const size_t si = quad_scale_index(s, e2_o >> 2, (kk * s.ags) / s.gs, e2_o & 3, e2_which);
+                e2[k] = a.sc_f16 ? __half2float(reinterpret_cast<const __half*>(a.SC)[si]) : reinterpret_cast<const float*>(a.SC)[si];
+            }
         }
     };
     auto stage_chunk = [&](int buf) {       // biased -> signed table bytes on the way into LDS
@@ -108,8 +113,11 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
                 bt[buf][ul][tid >> 2][tid & 3] = make_uint4(bst[ul].x ^ 0x80808080u, bst[ul].y ^ 0x80808080u,
                                                             bst[ul].z ^ 0x80808080u, bst[ul].w ^ 0x80808080u);
         if (tid < GCH * QW * NJ) wt[buf][w_ul][w_ql][w_j] = wst;
-        ep[buf][e_ag][e1_which][tid & 63] = e1;
-        ep[buf][e_ag][2 + e2_which][(tid >> 1) & 63] = e2;
+#pragma unroll
+        for (int k = 0; k < NAG / 2; ++k) {
+            ep[buf][e_ag + 2 * k][e1_which][tid & 63] = e1[k];
+            ep[buf][e_ag + 2 * k][2 + e2_which][(tid >> 1) & 63] = e2[k];
+        }
     };
 
     // ---- compute roles ----------------------------------------------------------------------------------------
@@ -145,27 +153,37 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
         __syncthreads();                                    // chunk ck is in LDS buffer ck & 1; buffer (ck+1) & 1 is free
         if (ck + 1 < nchunk) fetch_chunk(ck + 1);
         const int buf = ck & 1;
+        // operands of a unit: B tiles straight from LDS; A = signed one-hot rows, two dependent LDS reads (weight dwords,
+        // then the pattern table).  They are formed one unit ahead of the MFMAs that consume them.
+        auto operands = [&](int ul, gv4i_t (&av)[GRT], gv4i_t (&bv)[GNT]) {
+#pragma unroll
+            for (int nt = 0; nt < GNT; ++nt) {
+                const uint4 v = bt[buf][ul][nt * 16 + i16][g];
+                bv[nt] = (gv4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+            }
+#pragma unroll
+            for (int rt = 0; rt < GRT; ++rt) {
+                const uint32_t* wq = reinterpret_cast<const uint32_t*>(&wt[buf][ul][a_ql[rt]][0]);
+                const uint32_t w0 = wq[d0], w1 = wq[d0 + BITS / 2];
+                const char* pb = reinterpret_cast<const char*>(pat);     // byte offset = nibble * 8
+                const uint2 p0 = *reinterpret_cast<const uint2*>(pb + (__builtin_amdgcn_alignbit(w0, w0, a_sh[rt]) & 0x78u));
+                const uint2 p1 = *reinterpret_cast<const uint2*>(pb + (__builtin_amdgcn_alignbit(w1, w1, a_sh[rt]) & 0x78u));
+                av[rt] = (gv4i_t){(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
+            }
+        };
+        constexpr bool AHEAD = (GNT == 2);   // the 64-column tile has no registers to spare for a second operand set
+        gv4i_t avc[GRT], bvc[GNT], avn[GRT], bvn[GNT];
+        if (AHEAD) operands(0, avc, bvc);
 #pragma unroll
         for (int ul = 0; ul < GCH; ++ul) {
+            if (AHEAD) { if (ul + 1 < GCH) operands(ul + 1, avn, bvn); }
+            else operands(ul, avc, bvc);
             if (ck * GCH + ul < nu) {
-                gv4i_t bv[GNT];
 #pragma unroll
-                for (int nt = 0; nt < GNT; ++nt) {
-                    const uint4 v = bt[buf][ul][nt * 16 + i16][g];
-                    bv[nt] = (gv4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-                }
-#pragma unroll
-                for (int rt = 0; rt < GRT; ++rt) {
-                    const uint32_t* wq = reinterpret_cast<const uint32_t*>(&wt[buf][ul][a_ql[rt]][0]);
-                    const uint32_t w0 = wq[d0], w1 = wq[d0 + BITS / 2];
-                    const char* pb = reinterpret_cast<const char*>(pat);     // byte offset = nibble * 8
-                    const uint2 p0 = *reinterpret_cast<const uint2*>(pb + (__builtin_amdgcn_alignbit(w0, w0, a_sh[rt]) & 0x78u));
-                    const uint2 p1 = *reinterpret_cast<const uint2*>(pb + (__builtin_amdgcn_alignbit(w1, w1, a_sh[rt]) & 0x78u));
-                    const gv4i_t av = {(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
+                for (int rt = 0; rt < GRT; ++rt)
 #pragma unroll
                     for (int nt = 0; nt < GNT; ++nt)         // first unit of an act group starts from the constant accumulator operand
-                        c[rt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(av, bv[nt], (ul & 1) ? c[rt][nt] : cinit, 0, 0, 0);
-                }
+                        c[rt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(avc[rt], bvc[nt], (ul & 1) ? c[rt][nt] : cinit, 0, 0, 0);
                 // ---- act group complete: fp32 scale-apply of the int32 tiles, then reset them --------------
                 if (ul & 1) {                                // ags = 64: units 2kk, 2kk+1
                     const int ag = ul >> 1, kk = (ck * GCH + ul) >> 1;
@@ -210,6 +228,12 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
                     }
                 }
             }
+            if (AHEAD) {
+#pragma unroll
+                for (int rt = 0; rt < GRT; ++rt) avc[rt] = avn[rt];
+#pragma unroll
+                for (int nt = 0; nt < GNT; ++nt) bvc[nt] = bvn[nt];
+            }
         }
         if (ck + 1 < nchunk) stage_chunk((ck + 1) & 1);     // buffer (ck+1)&1 was last read in iteration ck-1, before this iteration's barrier
     }
@@ -246,8 +270,8 @@ hipError_t launch_gemm_onehot(const GemmArgs& a, hipStream_t st) {
     const bool narrow = (long)gx * ((a.N + 63) / 64) < 2 * 256 && a.N > 32;
     const int ncols = narrow ? 32 : 64;
     dim3 g(gx, (a.N + ncols - 1) / ncols), b(64 * GWV);
-#define GL2(B, Z, D) do { if (narrow) hipLaunchKernelGGL((k_gemm_onehot<B, Z, D, 2>), g, b, 0, st, a); \
-                          else hipLaunchKernelGGL((k_gemm_onehot<B, Z, D, 4>), g, b, 0, st, a); } while (0)
+#define GL2(B, Z, D) do { if (narrow) hipLaunchKernelGGL((k_gemm_onehot<B, Z, D, 2, 8>), g, b, 0, st, a); \
+                          else hipLaunchKernelGGL((k_gemm_onehot<B, Z, D, 4, 4>), g, b, 0, st, a); } while (0)
 #define GL(B, Z) do { if (a.dump) GL2(B, Z, true); else GL2(B, Z, false); } while (0)
     if (bits == 2) { if (a.s.zero_point) GL(2, true); else GL(2, false); }
     else { if (a.s.zero_point) GL(4, true); else GL(4, false); }

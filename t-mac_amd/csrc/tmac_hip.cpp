@@ -559,6 +559,7 @@ extern "C" int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const 
 }
 
 static unsigned long long* g_stamps = nullptr;   // debug: phase stamps of the next fused launches
+static int32_t* g_stamp_dump = nullptr;
 
 static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
                           void* const* C_list, tmac_dtype_t out_dtype, int N, int32_t* dump, float* lut_tap, hipStream_t st) {
@@ -582,6 +583,7 @@ static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const voi
     fa.B = B_dev; fa.act_f16 = act_dtype == TMAC_F16;
     fa.sc_f16 = wl[0]->sc_dtype == F16; fa.out_f16 = out_dtype == TMAC_F16; fa.dump = dump;
     fa.stamps = g_stamps;
+    if (g_stamps && !fa.dump) fa.dump = g_stamp_dump;   // the stamps live in the tap (DUMP) instantiation of the kernel
     fa.lut_tap = lut_tap;
     fa.acc_mfma = (fa.s.lay == 2) ? (g_variant != V_QUAD_MQSAD) : (g_variant == V_FUSED_MFMA);
     hipError_t e = (fa.s.lay == 2) ? launch_gemv_quad(fa, N, true, g_force_ft, g_force_wpq, st) : launch_gemv_fused(fa, N, true, st);
@@ -604,6 +606,7 @@ extern "C" int32_t tmac_hip_debug_quad_config(int force_ft, int force_wpq) {
 
 // debug/profiling: s_memtime phase stamps [nblocks][8] of the fused launches issued while enabled
 extern "C" int32_t tmac_hip_debug_stamps(unsigned long long* dev_buffer) {
+    if (dev_buffer && !g_stamp_dump) HIP_TRY(hipMalloc((void**)&g_stamp_dump, (size_t)256 << 20));   // scratch for the tap's stores
     g_stamps = dev_buffer;
     return TMAC_HIP_OK;
 }

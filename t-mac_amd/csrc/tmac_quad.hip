@@ -77,7 +77,7 @@ __device__ __forceinline__ float qfrag_scale(const uint32_t (&sraw)[4], int f16,
 }
 
 // weights of (local quad lq, step st) + the lane's scales (rows beta0, beta0+1 of its unit's scale group)
-template <int BITS, bool ZP, int SM, int ACC>
+template <int BITS, bool ZP, int SM, int ACC, bool SCF16>
 __device__ __forceinline__ void load_q(QFrag<BITS>& f, const FusedArgs& a, const FusedMat& M, int lq, int st, int nst, int lane) {
     constexpr int NJ = 8 * BITS / 8;
     constexpr int per = ZP ? 2 : 1;
@@ -98,7 +98,7 @@ __device__ __forceinline__ void load_q(QFrag<BITS>& f, const FusedArgs& a, const
             {
                 const int ug = min(ub4 + 2 * gi, a.nu - 1);
                 const uint32_t sidx = (((uint32_t)lq * (uint32_t)a.nsg + (uint32_t)(ug >> a.gs_shift)) * 4 + (lane & 3)) * per;
-                if (a.sc_f16) {
+                if (SCF16) {
                     const __half* ph = reinterpret_cast<const __half*>(M.SC) + sidx;
                     if (ZP) v0 = *reinterpret_cast<const uint32_t*>(ph);
                     else v0 = *reinterpret_cast<const unsigned short*>(ph);
@@ -122,7 +122,7 @@ __device__ __forceinline__ void load_q(QFrag<BITS>& f, const FusedArgs& a, const
             // rows beta0, beta0+1 of this unit's scale group: fp32 -> one word per element, f16 -> two per word
             const int sg = u >> a.gs_shift;
             const uint32_t sidx = (((uint32_t)lq * (uint32_t)a.nsg + (uint32_t)sg) * 4 + 2 * (lane & 1)) * per;
-            if (a.sc_f16) {
+            if (SCF16) {
                 const uint32_t* p32 = reinterpret_cast<const uint32_t*>(reinterpret_cast<const __half*>(M.SC) + sidx);
                 r0 = p32[0];
                 if (ZP) r1 = p32[1];
@@ -161,7 +161,7 @@ __device__ __forceinline__ void q_lookup4_pm(uint32_t w, uint32_t tab_lo, uint32
 // k_gemv_fused for the operand construction; with 64 lanes = 64 units of one quad, source lane l = 16g + i and
 // D[i][4g+beta] lands in lane l' = 16*(i/4) + 4g + beta, register i%4: lane l' owns output row beta and the four
 // units 16g + 4*(l'/16) .. +3 of the step (two act groups, one 128-wide scale group).
-template <int BITS, bool ZP, int SM, int LUTSRC, int NR, int FT, int WPQ, bool DUMP, int ACC>
+template <int BITS, bool ZP, int SM, int LUTSRC, int NR, int FT, int WPQ, bool DUMP, int ACC, bool SCF16>
 __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     extern __shared__ uint4 lds[];
     constexpr int NWV = FT / 64, IPI = NWV / WPQ;
@@ -178,20 +178,20 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     float* l_lb = l_ls + GP;                                     // [GP]
     float* l_red = l_lb + GP;                                    // [2][NWV][4][4] partials (WPQ == 2 / SM 2)
     float* l_scr = l_red + 2 * NWV * 16;                         // SM 2 build scratch: [NWV] maxima + [T/8] chunk sums
-    // The per-matrix fields are copied out of the kernel argument once: indexing a.m[] with a run-time matrix number
-    // makes every use a dependent s_load from the kernarg segment (several per step, each a scalar-cache round trip).
+    // Per-matrix fields: a cursor (one for the prefetch, one for the consumption) caches the current matrix' pointers
+    // and quad range in SGPRs and advances when a quad index leaves the range (quads only grow).  Looking the matrix
+    // up per step — run-time indexing of a.m[], or select chains over four copies — costs tens of scalar
+    // instructions per step, and the scalar pipe issues no faster than the vector pipe.
     const int nmat = a.nmat;
-    const int qe0 = a.m[0].nb_end, qe1 = a.m[1].nb_end, qe2 = a.m[2].nb_end, qe3 = a.m[3].nb_end;
-    const FusedMat fm0 = a.m[0], fm1 = a.m[1], fm2 = a.m[2], fm3 = a.m[3];
-    const int total_q = nmat == 1 ? qe0 : (nmat == 2 ? qe1 : (nmat == 3 ? qe2 : qe3));   // cumulative QUAD counts
-    auto pick = [&](int mi) -> FusedMat { return mi == 0 ? fm0 : (mi == 1 ? fm1 : (mi == 2 ? fm2 : fm3)); };
-
-#define QSTAMP(i) do { if (a.stamps && lane == 0 && (w == 0 || w == NWV - 1)) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    QSTAMP(0);
-    auto locate = [&](int gq, int& mi, int& lq) {
-        mi = (nmat > 1 && gq >= qe0) + (nmat > 2 && gq >= qe1) + (nmat > 3 && gq >= qe2);
-        lq = gq - (mi == 0 ? 0 : (mi == 1 ? qe0 : (mi == 2 ? qe1 : qe2)));
+    const int total_q = a.m[nmat - 1].nb_end;                    // cumulative QUAD counts
+    struct MatCur { FusedMat m; int base, mi; };
+    auto seek = [&](MatCur& c, int gq) {
+        while (gq >= c.m.nb_end && c.mi + 1 < nmat) { c.base = c.m.nb_end; ++c.mi; c.m = a.m[c.mi]; }
     };
+    MatCur pc = {a.m[0], 0, 0}, cc = {a.m[0], 0, 0};
+
+#define QSTAMP(i) do { if (DUMP && a.stamps && lane == 0 && (w == 0 || w == NWV - 1)) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+    QSTAMP(0);
 
     // ---- 1. activation loads for the LUT build (issued first: vmcnt retires in order) ----------
     uint32_t xr[NR][4];
@@ -216,10 +216,8 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     int p_q = slot0, p_st = h;    // prefetch cursor
     auto issue = [&](QFrag<BITS>& f) {
         if (p_q < total_q && p_st < nst) {      // p_st >= nst: a wave without steps (WPQ > number of steps)
-            int mi, lq;
-            locate(p_q, mi, lq);
-            const FusedMat M = pick(mi);
-            load_q<BITS, ZP, SM, ACC>(f, a, M, lq, p_st, nst, lane);
+            seek(pc, p_q);
+            load_q<BITS, ZP, SM, ACC, SCF16>(f, a, pc.m, p_q - pc.base, p_st, nst, lane);
             p_st += WPQ;
             if (p_st >= nst) { p_st = h; p_q += stride; }
         }
@@ -417,8 +415,8 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                     if (o < Mw_m) a.dump[((size_t)n * Mw_m * BITS + mrow(o, pl, BITS)) * G + kk] = ps;
                 }
                 const float v = (pl == 0) ? __fmaf_rn((float)ps, ls, lb) : __fmul_rn((float)ps, ls);
-                float c = __fmaf_rn(v, qfrag_scale<ZP>(f.sraw, a.sc_f16, i, 0), cacc[i][pl]);
-                if (ZP && pl == 0) c = __fmaf_rn(qfrag_scale<ZP>(f.sraw, a.sc_f16, i, 1), __fmul_rn(2.0f, lb), c);
+                float c = __fmaf_rn(v, qfrag_scale<ZP>(f.sraw, SCF16, i, 0), cacc[i][pl]);
+                if (ZP && pl == 0) c = __fmaf_rn(qfrag_scale<ZP>(f.sraw, SCF16, i, 1), __fmul_rn(2.0f, lb), c);
                 cacc[i][pl] = c;
             }
         }
@@ -472,7 +470,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                 const float ls = l_ls[kk], lb = l_lb[kk];
                 const bool first = (gi == 0) || (a.gs_shift >= 2);   // static register indices only: a run-time
                 float sc, zr = 0.f;                                   // subscript would put sraw in scratch memory
-                if (a.sc_f16) {
+                if (SCF16) {
                     const uint32_t wv = first ? f.sraw[0] : f.sraw[2];
                     sc = __half2float(__ushort_as_half((unsigned short)(wv & 0xffff)));
                     if (ZP) zr = __half2float(__ushort_as_half((unsigned short)(wv >> 16)));
@@ -614,23 +612,23 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     // position makes the compiler merge four control-flow paths with ~40 register copies per step).  A quad is
     // closed (reduce + store, workgroup barrier for WPQ > 1) when the cursor leaves it; every wave closes the
     // same number of quads, with or without work, so the barriers inside finish_quad stay matched.
-    int c_it = 0, c_st = h, mi = 0, lq = 0;
+    int c_it = 0, c_st = h, lq = 0;
     bool have = slot0 < total_q && h < nst;
-    if (have) locate(slot0, mi, lq);
+    if (have) { seek(cc, slot0); lq = slot0 - cc.base; }
     if (blockIdx.x * IPI < total_q) {      // uniform: this workgroup has at least one quad iteration
 #define QSTEP(F)                                                                                              \
         while (!(have && c_st < nst)) {                                                                       \
             if (c_it == 0) QSTAMP(4);                                                                         \
-            finish_quad(have, pick(mi), lq);                                                                  \
+            finish_quad(have, cc.m, lq);                                                                      \
             if (c_it == 0) QSTAMP(5);                                                                         \
             ++c_it;                                                                                           \
             if (blockIdx.x * IPI + c_it * stride >= total_q) goto q_done;                                     \
             const int gq = slot0 + c_it * stride;                                                             \
             have = gq < total_q && h < nst;                                                                   \
-            if (have) locate(gq, mi, lq);                                                                     \
+            if (have) { seek(cc, gq); lq = gq - cc.base; }                                                                   \
             c_st = h;                                                                                         \
         }                                                                                                     \
-        if (ACC == 1) compute_mfma(F, c_st, pick(mi).Mw, lq); else compute(F, c_st, pick(mi).Mw, lq);           \
+        if (ACC == 1) compute_mfma(F, c_st, cc.m.Mw, lq); else compute(F, c_st, cc.m.Mw, lq);                   \
         issue(F);                                                                                             \
         c_st += WPQ;
         for (;;) {
@@ -648,11 +646,12 @@ q_done:
 }
 
 // ---------------------------------------------------------------------------------------------
-#ifndef TMAC_QUAD_BITS
-#error "compile with -DTMAC_QUAD_BITS=2 or 4 (one translation unit per bit width keeps the build parallel)"
+#if !defined(TMAC_QUAD_BITS) || !defined(TMAC_QUAD_SCF16)
+#error "compile with -DTMAC_QUAD_BITS=2|4 -DTMAC_QUAD_SCF16=0|1 (one translation unit per combination keeps the build parallel)"
 #endif
+constexpr bool QSCF16 = TMAC_QUAD_SCF16 != 0;   // weight scales stored as fp16 (1) / fp32 (0): a kernel template parameter
 
-#if TMAC_QUAD_BITS == 2
+#if TMAC_QUAD_BITS == 2 && TMAC_QUAD_SCF16 == 0
 bool gemv_quad_supported(const Shape& s) {
     // instantiated for the shipped bit widths (W2, W4); W1 / W3 use the row-block fused kernel
     if ((s.bits != 2 && s.bits != 4) || s.K % 64 != 0 || s.K > 24576 || s.Mw % 4 != 0) return false;
@@ -682,7 +681,7 @@ static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t
     dim3 g(gx, N), b(FT);
     const int T = a.s.K / 4;
     constexpr int A1 = 1;
-#define QL(NRV, DV, AV) hipLaunchKernelGGL((k_gemv_quad<BITS, ZP, SM, LUTSRC, NRV, FT, WPQ, DV, AV>), g, b, shmem, st, a)
+#define QL(NRV, DV, AV) hipLaunchKernelGGL((k_gemv_quad<BITS, ZP, SM, LUTSRC, NRV, FT, WPQ, DV, AV, QSCF16>), g, b, shmem, st, a)
     const bool two = (LUTSRC == 0 || T <= 2 * FT);
     if (!two && T > 6 * FT) return hipErrorInvalidValue;
     if constexpr (FT == 512) {
@@ -739,25 +738,34 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
 
 template <int BITS, int LUTSRC>
 static hipError_t qlaunch_b(const FusedArgs& a, int total_q, int N, int fft, int fwpq, hipStream_t st) {
-    if (a.s.m_groups >= 1) return qlaunch_cfg<BITS, false, 2, LUTSRC>(a, total_q, N, fft, fwpq, st);
+    if (a.s.m_groups >= 1) {   // unified scale: one scalar read per output, dtype stays a run-time flag (fp32 TU only)
+        if constexpr (QSCF16) return hipErrorInvalidValue;
+        else return qlaunch_cfg<BITS, false, 2, LUTSRC>(a, total_q, N, fft, fwpq, st);
+    }
     return a.s.zero_point ? qlaunch_cfg<BITS, true, 0, LUTSRC>(a, total_q, N, fft, fwpq, st)
                           : qlaunch_cfg<BITS, false, 0, LUTSRC>(a, total_q, N, fft, fwpq, st);
 }
 
 // a.m[i].nb_end must hold cumulative QUAD counts.  force_ft / force_wpq: 0 = heuristic (A/B knobs)
-#if TMAC_QUAD_BITS == 2
-hipError_t launch_gemv_quad_b4(const FusedArgs& a, int total_q, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st);
+#define QENTRY_(b, h) launch_gemv_quad_b##b##_h##h
+#define QENTRY(b, h) QENTRY_(b, h)
+#define QENTRY_DECL(b, h) hipError_t QENTRY_(b, h)(const FusedArgs& a, int total_q, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st)
+QENTRY_DECL(2, 0); QENTRY_DECL(2, 1); QENTRY_DECL(4, 0); QENTRY_DECL(4, 1);
+hipError_t QENTRY(TMAC_QUAD_BITS, TMAC_QUAD_SCF16)(const FusedArgs& a, int total_q, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st) {
+    return build_lut ? qlaunch_b<TMAC_QUAD_BITS, 1>(a, total_q, N, force_ft, force_wpq, st)
+                     : qlaunch_b<TMAC_QUAD_BITS, 0>(a, total_q, N, force_ft, force_wpq, st);
+}
+#if TMAC_QUAD_BITS == 2 && TMAC_QUAD_SCF16 == 0
 hipError_t launch_gemv_quad(const FusedArgs& a_in, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st) {
     if (!gemv_quad_supported(a_in.s) || a_in.nmat < 1 || a_in.nmat > 4) return hipErrorInvalidValue;
     FusedArgs a = a_in;
     fused_precompute(a);
     const int total_q = a.m[a.nmat - 1].nb_end;
-    if (a.s.bits == 4) return launch_gemv_quad_b4(a, total_q, N, build_lut, force_ft, force_wpq, st);
-    return build_lut ? qlaunch_b<2, 1>(a, total_q, N, force_ft, force_wpq, st) : qlaunch_b<2, 0>(a, total_q, N, force_ft, force_wpq, st);
-}
-#else
-hipError_t launch_gemv_quad_b4(const FusedArgs& a, int total_q, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st) {
-    return build_lut ? qlaunch_b<4, 1>(a, total_q, N, force_ft, force_wpq, st) : qlaunch_b<4, 0>(a, total_q, N, force_ft, force_wpq, st);
+    const bool h = a.sc_f16 && a.s.m_groups < 1;
+    if (a.s.bits == 4) return h ? launch_gemv_quad_b4_h1(a, total_q, N, build_lut, force_ft, force_wpq, st)
+                                : launch_gemv_quad_b4_h0(a, total_q, N, build_lut, force_ft, force_wpq, st);
+    return h ? launch_gemv_quad_b2_h1(a, total_q, N, build_lut, force_ft, force_wpq, st)
+             : launch_gemv_quad_b2_h0(a, total_q, N, build_lut, force_ft, force_wpq, st);
 }
 #endif
 

@@ -91,19 +91,25 @@ __device__ __forceinline__ void load_q(QFrag<BITS>& f, const FusedArgs& a, const
         // sraw[2*gi], sraw[2*gi+1]: scale (, zero) of act-group pair gi; f16 packs both into sraw[2*gi]
         // Loads are unconditional with clamped indices (no exec-mask branches around them); units past K read zero
         // tables from LDS, so what the clamped lanes load never reaches a result.
-        const int ub4 = st * 64 + 4 * (lane & 12) + 4 * (lane >> 4);
+        // scale group of unit st*64 + c: st * (64 >> gs_shift) + (c >> gs_shift)  (a scale group never straddles a
+        // step: gs <= 2048); the lane part is loop-invariant, the step part scalar, the address a uniform base plus a
+        // 32-bit lane offset
+        const int c0 = 4 * (lane & 12) + 4 * (lane >> 4);
+        const uint32_t sg_step = (uint32_t)st * (64u >> a.gs_shift);
+        const uint32_t row0 = (uint32_t)lq * (uint32_t)a.nsg;
+        const char* scb = reinterpret_cast<const char*>(M.SC);
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
             uint32_t v0 = 0, v1 = 0;
             {
-                const int ug = min(ub4 + 2 * gi, a.nu - 1);
-                const uint32_t sidx = (((uint32_t)lq * (uint32_t)a.nsg + (uint32_t)(ug >> a.gs_shift)) * 4 + (lane & 3)) * per;
+                const uint32_t sg = min(sg_step + (uint32_t)((c0 + 2 * gi) >> a.gs_shift), (uint32_t)a.nsg - 1u);
+                const uint32_t sidx = ((row0 + sg) * 4 + (lane & 3)) * per;
                 if (SCF16) {
-                    const __half* ph = reinterpret_cast<const __half*>(M.SC) + sidx;
+                    const char* ph = scb + (size_t)(sidx * 2u);
                     if (ZP) v0 = *reinterpret_cast<const uint32_t*>(ph);
                     else v0 = *reinterpret_cast<const unsigned short*>(ph);
                 } else {
-                    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(M.SC) + sidx;
+                    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(scb + (size_t)(sidx * 4u));
                     v0 = p32[0];
                     if (ZP) v1 = p32[1];
                 }
@@ -184,11 +190,11 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     // instructions per step, and the scalar pipe issues no faster than the vector pipe.
     const int nmat = a.nmat;
     const int total_q = a.m[nmat - 1].nb_end;                    // cumulative QUAD counts
-    struct MatCur { FusedMat m; int base, mi; };
+    struct MatCur { FusedMat m; int base, mi, end; };          // end: first quad past this matrix (INT_MAX for the last)
     auto seek = [&](MatCur& c, int gq) {
-        while (gq >= c.m.nb_end && c.mi + 1 < nmat) { c.base = c.m.nb_end; ++c.mi; c.m = a.m[c.mi]; }
+        while (gq >= c.end) { c.base = c.m.nb_end; ++c.mi; c.m = a.m[c.mi]; c.end = (c.mi + 1 < nmat) ? c.m.nb_end : 0x7fffffff; }
     };
-    MatCur pc = {a.m[0], 0, 0}, cc = {a.m[0], 0, 0};
+    MatCur pc = {a.m[0], 0, 0, nmat > 1 ? a.m[0].nb_end : 0x7fffffff}, cc = pc;
 
 #define QSTAMP(i) do { if (DUMP && a.stamps && lane == 0 && (w == 0 || w == NWV - 1)) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     QSTAMP(0);
@@ -213,9 +219,9 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     const int slot0 = blockIdx.x * IPI + w / WPQ, h = w % WPQ, stride = gridDim.x * IPI;
     constexpr int RING = (BITS <= 2) ? 4 : 2;      // weight fragments in flight per wave (register budget)
     QFrag<BITS> f0, f1, f2, f3;
-    int p_q = slot0, p_st = h;    // prefetch cursor
+    int p_q = (h < nst) ? slot0 : total_q, p_st = h;    // prefetch cursor (a wave without steps, WPQ > nst, never issues)
     auto issue = [&](QFrag<BITS>& f) {
-        if (p_q < total_q && p_st < nst) {      // p_st >= nst: a wave without steps (WPQ > number of steps)
+        if (p_q < total_q) {
             seek(pc, p_q);
             load_q<BITS, ZP, SM, ACC, SCF16>(f, a, pc.m, p_q - pc.base, p_st, nst, lane);
             p_st += WPQ;

@@ -156,7 +156,7 @@ int32_t tmac_hip_selftest_mfma(const uint32_t* in_host, int32_t* out_host);
 int32_t tmac_hip_set_variant(int variant);
 /* tmac_hip_qgemm_dev with N >= n activation rows runs the one-hot MFMA GEMM (k_gemm_onehot: the table gather
  * written as an int8 contraction, same bit-exact integer sums) instead of looping the GEMV kernel over the
- * rows (qgemm.py:183-190); n = 0 disables it.  Default 40 (the measured crossover).  QUAD-layout weights (2/4-bit) only. */
+ * rows (qgemm.py:183-190); n = 0 disables it.  Default 32 (the measured crossover).  QUAD-layout weights (2/4-bit) only. */
 int32_t tmac_hip_set_gemm_min_n(int n);
 
 /* ---- (1) reference-named host-pointer entry points ---------------------------------------

@@ -204,7 +204,7 @@ extern "C" int32_t tmac_hip_set_variant(int variant) {
 }
 
 // N at and above which qgemm runs the one-hot MFMA GEMM instead of looping the GEMV kernel (0 = never)
-static int g_gemm_min_n = 40;   // measured crossover on MI355X (llama-2-7B W2 shapes): GEMV loop ~1.9 us per row, GEMM ~74 us per 64 rows
+static int g_gemm_min_n = 32;   // measured crossover on MI355X (llama-2-7B W2 shapes): GEMV loop ~1.7 us per row, GEMM 40-60 us up to 64 rows
 extern "C" int32_t tmac_hip_set_gemm_min_n(int n) {
     if (n < 0) return fail(TMAC_HIP_E_ARG, "gemm_min_n must be >= 0");
     g_gemm_min_n = n;

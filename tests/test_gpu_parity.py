@@ -66,7 +66,7 @@ def run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, m_groups=-1, N=1, varia
         out["PS"] = wr.partial_sums(w, N)
     w.free()
     L.tmac_hip_set_variant(0)
-    L.tmac_hip_set_gemm_min_n(40)
+    L.tmac_hip_set_gemm_min_n(32)
     return out
 
 

@@ -35,7 +35,7 @@ for name, Mw, K, cnt in [("qkv/o", 4096, 4096, 4), ("gate/up", 11008, 4096, 2), 
     t_gemm = timeit(lambda: wr.llama_cpp_compute(w, out, N))
     L.tmac_hip_set_gemm_min_n(0)
     t_loop = timeit(lambda: wr.llama_cpp_compute(w, out, N), reps=3)
-    L.tmac_hip_set_gemm_min_n(40)
+    L.tmac_hip_set_gemm_min_n(32)
     t_dense = timeit(lambda: torch.matmul(x, Wd.t()))
     ops = 2.0 * (Mw * 2) * (K / 4 * 16) * N
     print(f"{name:8s} Mw={Mw} K={K} N={N}: preprocessor {t_pre:8.1f} us | one-hot MFMA gemm {t_gemm:8.1f} us "

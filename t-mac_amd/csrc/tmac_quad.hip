@@ -163,6 +163,49 @@ __device__ __forceinline__ void q_lookup4_pm(uint32_t w, uint32_t tab_lo, uint32
     minus = __builtin_amdgcn_perm(rP, 0u, sel3);
 }
 
+// One LUT table from its 4 activations (lut_ctor.cc:120-215): the 8 distinct magnitudes ((x0 +- x1) +- x2) +- x3 in the
+// reference's association order, two per v_pk_add_f32; q = rne(L * t_scales) through the 1.5*2^23 magic add (|L * t_scales|
+// <= 127 for finite input, so the sum's ulp is 1 and its low byte is q in two's complement; + 128 in the magic gives the
+// biased byte).  Half table j = 0..7 holds {-L15, L1, -L13, L3, -L11, L5, -L9, L7}: negated entries as magic - product.
+// Returns the dwords [j0 j1 j2 j3], [j4 j5 j6 j7] and L15 (its negation is the table's LUT[0], summed into lut_biases).
+template <bool SIGNED>
+__device__ __forceinline__ void q_table8(float x0, float x1, float x2, float x3, float t_scales, uint32_t& lo, uint32_t& hi, float& L15) {
+    const qv2f x01 = {x0, x1}, x23 = {x2, x3};
+    qv2f apm, l2m, l2p, L31, L119, L75, L1513;
+    asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(apm) : "v"(x01));                      // {x0+x1, x0-x1}
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(l2m) : "v"(apm), "v"(x23)); // {a_p-x2, a_m-x2}
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(l2p) : "v"(apm), "v"(x23));                          // {a_p+x2, a_m+x2}
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(L31) : "v"(l2m), "v"(x23)); // {L3, L1}
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(L119) : "v"(l2m), "v"(x23));                         // {L11, L9}
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(L75) : "v"(l2p), "v"(x23)); // {L7, L5}
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(L1513) : "v"(l2p), "v"(x23));                        // {L15, L13}
+    L15 = L1513.x;
+    const qv2f tt = {t_scales, t_scales};
+    const qv2f mg = {SIGNED ? 12582912.0f : 12583040.0f, 0.0f};
+    qv2f za, zb, zc, zd;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(za) : "v"(L31), "v"(tt));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zb) : "v"(L75), "v"(tt));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zc) : "v"(L119), "v"(tt));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zd) : "v"(L1513), "v"(tt));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(za) : "v"(za), "v"(mg));                                  // j = 3 | 1
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(zb) : "v"(zb), "v"(mg));                                  // j = 7 | 5
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]" : "=v"(zc) : "v"(zc), "v"(mg));        // j = 4 | 6
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]" : "=v"(zd) : "v"(zd), "v"(mg));        // j = 0 | 2
+    lo = __builtin_amdgcn_perm(__float_as_uint(za.y), __float_as_uint(zd.x), 0x0c0c0400u) |
+         __builtin_amdgcn_perm(__float_as_uint(za.x), __float_as_uint(zd.y), 0x04000c0cu);
+    hi = __builtin_amdgcn_perm(__float_as_uint(zb.y), __float_as_uint(zc.x), 0x0c0c0400u) |
+         __builtin_amdgcn_perm(__float_as_uint(zb.x), __float_as_uint(zc.y), 0x04000c0cu);
+}
+
+// max over the 8 lanes of half a DPP row (the two quads of one act group when a lane holds two tables)
+__device__ __forceinline__ float q_half_allmax(float v) {
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v));
+    return v;
+}
+
 // ACC 0: v_mqsad_pk_u16_u8 accumulate (VALU).  ACC 1: v_mfma_i32_16x16x64_i8 accumulate (matrix pipe), see
 // k_gemv_fused for the operand construction; with 64 lanes = 64 units of one quad, source lane l = 16g + i and
 // D[i][4g+beta] lands in lane l' = 16*(i/4) + 4g + beta, register i%4: lane l' owns output row beta and the four
@@ -200,20 +243,39 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     QSTAMP(0);
 
     // ---- 1. activation loads for the LUT build (issued first: vmcnt retires in order) ----------
-    uint32_t xr[NR][4];
+    // A lane builds the two consecutive tables 2p, 2p+1 (8 activations, one 16-byte fp16 load) of pair p = r*FT + tid:
+    // one uint4 LDS store, and the act-group scale (abs-max over 8 lanes, two exact divisions) is computed once per two
+    // tables.
+    constexpr int NP = NR / 2;                                   // pairs per thread
+    const int P = T / 2;
+    uint32_t xr[NP][8];
     if (LUTSRC == 1) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int t = min(r * FT + tid, T - 1);     // clamped, not predicated (see load_q)
+        for (int r = 0; r < NP; ++r) {
+            const int p = min(r * FT + tid, P - 1);     // clamped, not predicated (see load_q)
             if (a.act_f16) {
-                const uint2 v = reinterpret_cast<const uint2*>(reinterpret_cast<const __half*>(a.B) + (size_t)n * s.K)[t];
-                xr[r][0] = v.x; xr[r][1] = v.y;
-            } else {
-                const uint4 v = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(a.B) + (size_t)n * s.K)[t];
+                const uint4 v = reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(a.B) + (size_t)n * s.K)[p];
                 xr[r][0] = v.x; xr[r][1] = v.y; xr[r][2] = v.z; xr[r][3] = v.w;
+            } else {
+                const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(a.B) + (size_t)n * s.K) + 2 * (size_t)p;
+                const uint4 v0 = src[0], v1 = src[1];
+                xr[r][0] = v0.x; xr[r][1] = v0.y; xr[r][2] = v0.z; xr[r][3] = v0.w;
+                xr[r][4] = v1.x; xr[r][5] = v1.y; xr[r][6] = v1.z; xr[r][7] = v1.w;
             }
         }
     }
+    auto unpack = [&](int r, float (&x)[8]) {
+        if (a.act_f16) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const __half2 hh = *reinterpret_cast<const __half2*>(&xr[r][i]);
+                x[2 * i] = __low2float(hh); x[2 * i + 1] = __high2float(hh);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = __uint_as_float(xr[r][i]);
+        }
+    };
 
     // ---- 2. this wave's work: quads slot, slot + stride, ...; steps h, h + WPQ, ... of each ------
     const int slot0 = blockIdx.x * IPI + w / WPQ, h = w % WPQ, stride = gridDim.x * IPI;
@@ -250,15 +312,12 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
         if (SM == 2) {
             float mx = 0.f;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int t = r * FT + tid;
-                if (t < T) {
-                    float x0, x1, x2, x3;
-                    if (a.act_f16) {
-                        const __half2 h0 = *reinterpret_cast<const __half2*>(&xr[r][0]), h1 = *reinterpret_cast<const __half2*>(&xr[r][1]);
-                        x0 = __low2float(h0); x1 = __high2float(h0); x2 = __low2float(h1); x3 = __high2float(h1);
-                    } else { x0 = __uint_as_float(xr[r][0]); x1 = __uint_as_float(xr[r][1]); x2 = __uint_as_float(xr[r][2]); x3 = __uint_as_float(xr[r][3]); }
-                    mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x0), fabsf(x1)), __fadd_rn(fabsf(x2), fabsf(x3))));
+            for (int r = 0; r < NP; ++r) {
+                if (r * FT + tid < P) {
+                    float x[8];
+                    unpack(r, x);
+                    mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3]))));
+                    mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x[4]), fabsf(x[5])), __fadd_rn(fabsf(x[6]), fabsf(x[7]))));
                 }
             }
             mx = q_row_allmax(mx);
@@ -274,65 +333,41 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
             __syncthreads();
         }
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int t = r * FT + tid;
-            if (t < T) {   // T % 16 == 0: a 16-lane act group is valid or invalid as a whole
-                float x0, x1, x2, x3;
-                if (a.act_f16) {
-                    const __half2 h0 = *reinterpret_cast<const __half2*>(&xr[r][0]), h1 = *reinterpret_cast<const __half2*>(&xr[r][1]);
-                    x0 = __low2float(h0); x1 = __high2float(h0); x2 = __low2float(h1); x3 = __high2float(h1);
-                } else { x0 = __uint_as_float(xr[r][0]); x1 = __uint_as_float(xr[r][1]); x2 = __uint_as_float(xr[r][2]); x3 = __uint_as_float(xr[r][3]); }
+        for (int r = 0; r < NP; ++r) {
+            const int p = r * FT + tid;
+            if (p < P) {   // T % 16 == 0: the 8 lanes of an act group are valid or invalid as a whole
+                float x[8];
+                unpack(r, x);
                 float scales, t_scales;
                 if (SM == 2) { scales = gscale; t_scales = gtinv; }
                 else {
-                    const float mx = q_row_allmax(__fadd_rn(__fadd_rn(fabsf(x0), fabsf(x1)), __fadd_rn(fabsf(x2), fabsf(x3))));
+                    const float s0 = __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3])));
+                    const float s1 = __fadd_rn(__fadd_rn(fabsf(x[4]), fabsf(x[5])), __fadd_rn(fabsf(x[6]), fabsf(x[7])));
+                    const float mx = q_half_allmax(fmaxf(s0, s1));
                     scales = div127(mx);
                     t_scales = (scales != 0.0f) ? rcp_exact(scales) : 0.0f;
                 }
-                // the 8 distinct magnitudes ((x0 +- x1) +- x2) +- x3 in the reference's association order
-                // (lut_ctor.cc:40-52), two per v_pk_add_f32
-                const qv2f x01 = {x0, x1}, x23 = {x2, x3};
-                qv2f apm, l2m, l2p, L31, L119, L75, L1513;
-                asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(apm) : "v"(x01));                      // {x0+x1, x0-x1}
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(l2m) : "v"(apm), "v"(x23)); // {a_p-x2, a_m-x2}
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(l2p) : "v"(apm), "v"(x23));                          // {a_p+x2, a_m+x2}
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(L31) : "v"(l2m), "v"(x23)); // {L3, L1}
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(L119) : "v"(l2m), "v"(x23));                         // {L11, L9}
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(L75) : "v"(l2p), "v"(x23)); // {L7, L5}
-                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(L1513) : "v"(l2p), "v"(x23));                        // {L15, L13}
-                const float L15 = L1513.x;
-                // quantise: q = rne(L * t_scales) via the 1.5*2^23 magic add (|L * t_scales| <= 127 for finite input, so
-                // the sum's ulp is 1 and its low byte is q in two's complement; + 128 in the magic gives the biased byte).
-                // Half table j = 0..7 holds {-L15, L1, -L13, L3, -L11, L5, -L9, L7}: negated entries as magic - product.
-                const qv2f tt = {t_scales, t_scales};
-                const qv2f mg = {(ACC == 1) ? 12582912.0f : 12583040.0f, 0.0f};
-                qv2f za, zb, zc, zd;
-                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(za) : "v"(L31), "v"(tt));
-                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zb) : "v"(L75), "v"(tt));
-                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zc) : "v"(L119), "v"(tt));
-                asm("v_pk_mul_f32 %0, %1, %2" : "=v"(zd) : "v"(L1513), "v"(tt));
-                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(za) : "v"(za), "v"(mg));                                  // j = 3 | 1
-                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(zb) : "v"(zb), "v"(mg));                                  // j = 7 | 5
-                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]" : "=v"(zc) : "v"(zc), "v"(mg));        // j = 4 | 6
-                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,0]" : "=v"(zd) : "v"(zd), "v"(mg));        // j = 0 | 2
-                // low bytes -> dwords [j0 j1 j2 j3], [j4 j5 j6 j7]
-                const uint32_t lo = __builtin_amdgcn_perm(__float_as_uint(za.y), __float_as_uint(zd.x), 0x0c0c0400u) |
-                                    __builtin_amdgcn_perm(__float_as_uint(za.x), __float_as_uint(zd.y), 0x04000c0cu);
-                const uint32_t hi = __builtin_amdgcn_perm(__float_as_uint(zb.y), __float_as_uint(zc.x), 0x0c0c0400u) |
-                                    __builtin_amdgcn_perm(__float_as_uint(zb.x), __float_as_uint(zc.y), 0x04000c0cu);
-                const int u = t >> 3, tl = t & 7;
-                reinterpret_cast<uint2*>(tab + (tl >> 1) * tstride + u)[tl & 1] = make_uint2(lo, hi);
-                float v = -L15;   // lut_ctor.cc:25-31 horizontal add; row_shl:n reads lane i+n
-                v = __fadd_rn(v, qdpp_f<0x104>(v));
-                v = __fadd_rn(v, qdpp_f<0x102>(v));
-                v = __fadd_rn(v, qdpp_f<0x101>(v));
+                uint32_t lo0, hi0, lo1, hi1;
+                float La, Lb;
+                q_table8<ACC == 1>(x[0], x[1], x[2], x[3], t_scales, lo0, hi0, La);
+                q_table8<ACC == 1>(x[4], x[5], x[6], x[7], t_scales, lo1, hi1, Lb);
+                // tables 2p, 2p+1 = the uint4 (j4 = p & 3) of unit p >> 2
+                tab[(p & 3) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
+                // lut_biases (lut_ctor.cc:25-31): per 8-table chunk ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)), v_i = LUT[0] of table i
+                // = -L15; the 4 lanes of a chunk hold (v0,v1), (v2,v3), (v4,v5), (v6,v7)
+                float va = -La, vb = -Lb;
+                va = __fadd_rn(va, qdpp_f<0x4E>(va));      // lane ^ 2: v0+v4 | v2+v6
+                vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));      //           v1+v5 | v3+v7
+                va = __fadd_rn(va, qdpp_f<0xB1>(va));      // lane ^ 1: (v0+v4)+(v2+v6)
+                vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));      //           (v1+v5)+(v3+v7)
+                const float v = __fadd_rn(va, vb);
                 if (SM == 2) {
-                    if ((t & 7) == 0) l_scr[NWV + (t >> 3)] = v;
+                    if ((p & 3) == 0) l_scr[NWV + (p >> 2)] = v;
                 } else {
-                    const float c1 = qdpp_f<0x108>(v);
-                    if ((t & 15) == 0) {
-                        l_ls[t >> 4] = scales;
-                        l_lb[t >> 4] = __fadd_rn(__fadd_rn(0.0f, v), c1);
+                    const float c1 = qdpp_f<0x104>(v);      // row_shl:4: the second chunk of the act group
+                    if ((p & 7) == 0) {
+                        l_ls[p >> 3] = scales;
+                        l_lb[p >> 3] = __fadd_rn(__fadd_rn(0.0f, v), c1);
                     }
                 }
             }

@@ -37,7 +37,7 @@ for name, Mw, K, cnt in [("qkv/o", 4096, 4096, 4), ("gate/up", 11008, 4096, 2), 
     t_loop = timeit(lambda: wr.llama_cpp_compute(w, out, N), reps=3)
     L.tmac_hip_set_gemm_min_n(32)
     t_dense = timeit(lambda: torch.matmul(x, Wd.t()))
-    ops = 2.0 * (Mw * 2) * (K / 4 * 16) * N
+    ops = 2.0 * (Mw * 2) * (K / 4 * 8) * N      # MFMA work actually issued: 8-entry half tables
     print(f"{name:8s} Mw={Mw} K={K} N={N}: preprocessor {t_pre:8.1f} us | one-hot MFMA gemm {t_gemm:8.1f} us "
           f"({ops / t_gemm * 1e-6:7.1f} int8 TOP/s, {2.0 * Mw * K * N / t_gemm * 1e-6:6.1f} dense-equivalent TFLOP/s) | "
           f"gemv loop {t_loop:9.1f} us | dense fp16 matmul {t_dense:7.1f} us")

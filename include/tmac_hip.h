@@ -117,7 +117,10 @@ int32_t tmac_hip_qgemm_dev(const tmac_hip_weights* w, const tmac_hip_workspace* 
  * matrices that consume the SAME activation rows (q/k/v, gate/up): the LUT is built inside the GEMV
  * kernel (bit-exact with tmac_hip_preprocessor_dev) and every matrix is covered by one launch.
  *   weights[i] : registered matrices sharing K, bits and quantisation config
- *   B_dev      : activations [N][K] (act_dtype);   C_dev[i] : [N][Mw_i] (out_dtype) */
+ *   B_dev      : activations [N][K] (act_dtype);   C_dev[i] : [N][Mw_i] (out_dtype)
+ * With N at or above the GEMM threshold (tmac_hip_set_gemm_min_n) the call runs the preprocessor once into a
+ * library-owned, per-stream workspace and the one-hot MFMA GEMM per matrix; the workspace is allocated on first use
+ * (call once outside any stream capture) and released by tmac_hip_cache_clear(). */
 int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weights, int nmat, const void* B_dev,
                                  tmac_dtype_t act_dtype, void* const* C_dev, tmac_dtype_t out_dtype, int N,
                                  void* stream);

@@ -561,9 +561,44 @@ extern "C" int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const 
 static unsigned long long* g_stamps = nullptr;   // debug: phase stamps of the next fused launches
 static int32_t* g_stamp_dump = nullptr;
 
+// Prefill through the fused entry point: one LUT build (k_preprocess) into a workspace owned by the library, one
+// one-hot MFMA GEMM per matrix.  The workspace is per stream (launches on one stream are ordered; two streams must not
+// share LUT buffers) and grows on demand; tmac_hip_cache_clear() releases them.
+static std::map<hipStream_t, tmac_hip_workspace*> g_fused_ws;
+
+static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
+                             void* const* C_list, tmac_dtype_t out_dtype, int N, hipStream_t st) {
+    const Shape& s0 = wl[0]->s;
+    tmac_hip_workspace* ws = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        tmac_hip_workspace*& slot = g_fused_ws[st];
+        if (slot && (slot->maxK < s0.K || slot->maxN < N)) {
+            // the old buffers may still be read by launches in flight on this stream
+            hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "stream sync: %s", hipGetErrorString(e));
+            tmac_hip_workspace_free(slot);
+            slot = nullptr;
+        }
+        if (!slot) {
+            int32_t rc = tmac_hip_workspace_create(&slot, s0.K, N);
+            if (rc) { slot = nullptr; return rc; }
+        }
+        ws = slot;
+    }
+    int32_t rc = tmac_hip_preprocessor_dev(ws, B_dev, act_dtype, s0.K, N, s0.ags, st);
+    for (int i = 0; i < nmat && rc == TMAC_HIP_OK; ++i) rc = tmac_hip_qgemm_dev(wl[i], ws, C_list[i], out_dtype, N, st);
+    return rc;
+}
+
 static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
                           void* const* C_list, tmac_dtype_t out_dtype, int N, int32_t* dump, float* lut_tap, hipStream_t st) {
     if (!wl || !C_list || !B_dev || nmat < 1 || nmat > 4 || N < 1) return fail(TMAC_HIP_E_ARG, "bad fused arguments (1..4 matrices)");
+    if (g_gemm_min_n > 0 && N >= g_gemm_min_n && !dump && !lut_tap) {
+        bool ok = true;
+        for (int i = 0; i < nmat; ++i) ok = ok && wl[i] && C_list[i] && gemm_onehot_supported(wl[i]->s) && wl[i]->s.K == wl[0]->s.K && wl[i]->s.ags == wl[0]->s.ags;
+        if (ok) return fused_prefill(wl, nmat, B_dev, act_dtype, C_list, out_dtype, N, st);
+    }
     FusedArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.nmat = nmat;
@@ -689,6 +724,8 @@ extern "C" int32_t tmac_hip_cache_clear(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (auto& kv : g_tiles) tmac_hip_free_weights(kv.second);
     g_tiles.clear();
+    for (auto& kv : g_fused_ws) tmac_hip_workspace_free(kv.second);
+    g_fused_ws.clear();
     return TMAC_HIP_OK;
 }
 

@@ -231,6 +231,27 @@ def test_onehot_mfma_gemm(tm, Mw, K, bits, bm, kf, gs, ags, zp, N):
     assert rel_err(r["C"], r2["C"]) <= 2e-6
 
 
+def test_fused_entry_point_prefill(tm):
+    """tmac_hip_qgemm_fused_dev with N above the GEMM threshold: library-owned LUT workspace + one-hot GEMM per matrix"""
+    import torch
+    Mw, K, bits, bm, kf, gs, ags, N = 512, 2048, 2, 128, 16, 128, 64, 48
+    case = orc.make_case(4242, Mw, K, N=N, bits=bits, gs=gs, ags=ags)
+    A = orc.preprocess_weights(case["w"], bits, bm, kf)
+    S = orc.preprocess_scales(case["sc"], case["zr"], bits, bm)
+    wr = tm.TMACGeMMWrapper(act_group_size=ags)
+    ws = [wr.register_weights(A, S, Mw, K, bits, tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, True, -1, N)) for _ in range(2)]
+    Bt = torch.from_numpy(case["B"]).cuda()
+    outs = [torch.empty((N, Mw), dtype=torch.float32, device="cuda") for _ in range(2)]
+    wr.fused(ws, Bt, outs, N)
+    torch.cuda.synchronize()
+    q, ls, lb, Cc, PS = oracle_case(case, A, S, Mw, K, bits, bm, kf, gs, ags, True, N=N)
+    for o in outs:
+        assert rel_err(o.cpu().numpy(), Cc) <= 2e-5
+    tm.binding.check(tm.lib().tmac_hip_cache_clear())
+    for w in ws:
+        w.free()
+
+
 def test_edge_activations(tm):
     """all-zero act groups (scale 0 -> t_scales 0), huge/small magnitudes, exact .5 ties"""
     Mw, K, bits, bm, kf, gs, ags = 128, 512, 2, 128, 16, 128, 64

@@ -35,9 +35,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per launch of the headline GEMV from rocprofv3 --pmc FETCH_SIZE (separate pass, x2 gfx950 correction,
-# MI355X_MICROARCH.md HBM section): profiles/r01_pmc_fetch_size.txt — 7017.5 KiB x 2 = 14.37 MB vs 12.73 MB algorithmic
+# MI355X_MICROARCH.md HBM section): profiles/r01_pmc_fetch_size.txt — 7011.5 KiB x 2 = 14.36 MB vs 12.73 MB algorithmic
 # (the x2 rule is calibrated for 16 B/lane streams; the 4-8 B/lane scale loads are probably double-counted by it)
-PMC_TRAFFIC_BYTES = 14371840
+PMC_TRAFFIC_BYTES = 14359552
 LAYERS = 32
 # (name, Mw, K, count per layer, input slot)
 MATS = [("qkv", 4096, 4096, 3, 0), ("o", 4096, 4096, 1, 1), ("gate_up", 11008, 4096, 2, 2), ("down", 4096, 11008, 1, 3)]
@@ -283,7 +283,7 @@ def main():
     if use_ev:
         xin = torch.randn(11008, device=dev, generator=gen).half()
         wr.llama_cpp_init(xin, 4096, 11008, 1, BITS, act_dtype=F16)
-        reps = 5
+        reps, skip = 10, 3            # the first replays run while the clocks settle after the timed region
         durs = []
 
         def headline_launches():
@@ -300,7 +300,7 @@ def main():
             rgraph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(rgraph):
                 headline_launches()
-        for r in range(reps + 1):
+        for r in range(reps + skip):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
             if rgraph is not None:
@@ -309,7 +309,7 @@ def main():
                 headline_launches()
             e1.record()
             torch.cuda.synchronize()
-            if r > 0:
+            if r >= skip:
                 durs.append(e0.elapsed_time(e1) * 1e-3 / args.layers)
         durs = np.array(durs)
         hb = algorithmic_bytes(shard_rows["down"], 11008)
@@ -318,7 +318,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES,
                 "algorithmic_bytes_per_launch": hb, "avg_launch_us": round(float(np.mean(durs)) * 1e6, 3),
                 "min_launch_us": round(float(np.min(durs)) * 1e6, 3), "launches_timed": reps * args.layers,
-                "timing": "hipEvent pair on the launch stream around %d back-to-back launches (distinct weights, %s), mean of 5" % (args.layers, "hipGraph replay" if use_graph else "eager")}
+                "timing": "hipEvent pair on the launch stream around %d back-to-back launches (distinct weights, %s), mean of 10" % (args.layers, "hipGraph replay" if use_graph else "eager")}
 
     if rank == 0:
         res = {

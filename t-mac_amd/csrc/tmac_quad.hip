@@ -214,6 +214,7 @@ __device__ __forceinline__ float q_half_allmax(float v) {
 template <int BITS, bool ZP, int SM, int LUTSRC, int NR, int FT, int WPQ, bool DUMP, int ACC, bool SCF16>
 __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     extern __shared__ uint4 lds[];
+    const unsigned long long t_entry = DUMP ? __builtin_amdgcn_s_memtime() : 0ull;   // before the first kernel-argument load
     constexpr int NWV = FT / 64, IPI = NWV / WPQ;
     const Shape& s = a.s;
     // the wave index is uniform but the compiler cannot prove it from threadIdx: readfirstlane moves every
@@ -242,6 +243,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
 
 #define QSTAMP(i) do { if (DUMP && a.stamps && lane == 0 && (w == 0 || w == NWV - 1)) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     QSTAMP(0);
+    if (DUMP && a.stamps && lane == 0 && (w == 0 || w == NWV - 1)) a.stamps[((size_t)blockIdx.x * 2 + (w ? 1 : 0)) * 8 + 7] = t_entry;
 
     // ---- 1. activation loads for the LUT build (issued first: vmcnt retires in order) ----------
     // A lane builds the two consecutive tables 2p, 2p+1 (8 activations, one 16-byte fp16 load) of pair p = r*FT + tid:

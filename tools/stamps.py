@@ -35,5 +35,6 @@ for name, Mw, K, cnt in [("o", 4096, 4096, 1), ("qkv", 4096, 4096, 3), ("gate_up
     print("   block start spread: min/median/max", rel[:, 0].min(), np.median(rel[:, 0]), rel[:, 0].max())
     print("   phase medians [issue loads, build LUT, barrier, first quad lookups, first quad reduce+store, remaining quads]:", np.median(d, axis=0))
     print("   phase p90:", np.percentile(d, 90, axis=0))
+    print("   kernel entry -> first kernel-argument value available (ticks), median/p90:", np.median(s[:, 0] - s[:, 7]), np.percentile(s[:, 0] - s[:, 7], 90))
     print("   workgroup duration median/max:", np.median(rel[:, 6] - rel[:, 0]), (rel[:, 6] - rel[:, 0]).max())
     for w in ws: w.free()

@@ -268,6 +268,43 @@ def test_edge_activations(tm):
     assert rel_err(r["C"], Cc) <= 2e-5
 
 
+@pytest.mark.parametrize("act_f16", [False, True])
+def test_edge_activations_fused_lut_build(tm, act_f16):
+    """the in-kernel LUT build (short exact divisions, magic-add rounding) on all-zero act groups, huge / tiny / denormal
+    magnitudes, exact .5 ties and an all-ones-significand scale: scales, biases and integer sums bit-exact"""
+    import torch
+    Mw, K, bits, bm, kf, gs, ags = 128, 1024, 2, 128, 16, 128, 64
+    case = orc.make_case(11, Mw, K, bits=bits)
+    B = case["B"]
+    B[0, :64] = 0
+    B[0, 64:128] *= (60000.0 / np.abs(B[0, 64:128]).max() / 4) if act_f16 else 1e20
+    B[0, 128:192] *= 1e-4 if act_f16 else 1e-20
+    B[0, 192:256] = np.tile(np.array([0.5, 1.5, 2.5, 127.0], np.float32), 16)
+    B[0, 256:320] = 0.0
+    # fp16 denormal / fp32 value whose scale (abs-sum / 127) is an fp32 denormal: below the fast-division range, IEEE path.
+    # (Smaller still, 1 / scale overflows and the reference itself saturates every entry to -128: outside the contract.)
+    B[0, 256] = np.float32(6e-8) if act_f16 else np.float32(1e-36)
+    B[0, 320:384] = 0.0
+    B[0, 320:324] = np.float32(127.0 * (2.0 - 2.0 ** -23) / 4) if not act_f16 else np.float32(31.75)   # abs-sum / 127 = all-ones significand (fp32)
+    if act_f16:
+        B = B.astype(np.float16).astype(np.float32)
+        case["B"] = B
+    A = orc.preprocess_weights(case["w"], bits, bm, kf)
+    S = orc.preprocess_scales(case["sc"], case["zr"], bits, bm)
+    wr = tm.TMACGeMMWrapper(act_group_size=ags)
+    w = wr.register_weights(A, S, Mw, K, bits, tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, True))
+    Bt = torch.from_numpy(B).cuda()
+    if act_f16:
+        Bt = Bt.half()
+    PS, Cf = wr.fused_partial_sums(w, Bt)
+    q, ls, lb, Cc, PSo = oracle_case(case, A, S, Mw, K, bits, bm, kf, gs, ags, True)
+    assert np.array_equal(PS, PSo)
+    check_bits(wr.last_fused_lut[:, 0, :], ls)
+    check_bits(wr.last_fused_lut[:, 1, :], lb)
+    assert rel_err(Cf, Cc) <= 2e-5
+    w.free()
+
+
 def test_headline_shape_properties(tm):
     """Full BASELINE headline shape (Mw=4096, K=11008, W2, zp): oracle comparison + size-independent
     properties: run-to-run determinism and row-shard consistency (the multi-GPU partitioning)."""

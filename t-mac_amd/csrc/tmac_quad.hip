@@ -754,7 +754,11 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
     //   one (<= 2048); long rows with few quads: 3 waves per quad when that splits the steps evenly, else 4.
     const int nst = (a.s.K / 32 + 63) / 64;
     int best_ft = 512, best_wpq = (total_q <= 2048 && nst >= 2) ? 2 : 1;
-    if (total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
+    if (BITS == 4) {
+        // W4 (tools/tune_quad.py 0 4): steps are twice as heavy, two waves per quad pay off up to one quad per wave slot:
+        // o (512,2) 5.9 | qkv (512,2) 10.2, (1024,1) 10.6 | gate_up (512,1) 13.8 | down (512,2) 10.3, (768,3) 10.8
+        best_wpq = (total_q <= 4096 && nst >= 2) ? 2 : 1;
+    } else if (total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
         if (nst % 3 == 0 && a.s.K / 4 <= 6 * 768) { best_ft = 768; best_wpq = 3; }
         else { best_ft = 1024; best_wpq = 4; }
     } else if (total_q > 2048 && total_q <= 4096 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {

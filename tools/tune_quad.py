@@ -11,15 +11,17 @@ dev = torch.device("cuda")
 wr = tmac_amd.TMACGeMMWrapper(act_group_size=64); wr.set_workspace(11008, 1)
 NSET = 12
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+BITS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+BM = 128 if BITS == 2 else 256
 L.tmac_hip_set_variant(variant)
 for name, Mw, K, cnt in [("o", 4096, 4096, 1), ("qkv", 4096, 4096, 3), ("gate_up", 11008, 4096, 2), ("down", 4096, 11008, 1)]:
     sets = []
     for _ in range(NSET):
         ws = []
         for _ in range(cnt):
-            A = torch.randint(0, 256, (Mw * 2 // 128, K // 4, 64), dtype=torch.uint8, device=dev)
-            S = (torch.randn((Mw * 2 // 128, K // 128, 8, 2, 8), device=dev) * 0.01).half().contiguous()
-            ws.append(tmac_amd.Weights(A, S, Mw, K, 2, KCfg.make(Mw, K, 2, 128), scales_dtype=F16, dev_dtype=F16, on_device=True))
+            A = torch.randint(0, 256, (Mw * BITS // BM, K // 4, BM // 2), dtype=torch.uint8, device=dev)
+            S = (torch.randn((Mw * BITS // BM, K // 128, BM // BITS // 8, 2, 8), device=dev) * 0.01).half().contiguous()
+            ws.append(tmac_amd.Weights(A, S, Mw, K, BITS, KCfg.make(Mw, K, BITS, BM), scales_dtype=F16, dev_dtype=F16, on_device=True))
         sets.append(ws)
     x = torch.randn(K, device=dev).half()
     outs = [torch.empty(Mw, dtype=torch.float16, device=dev) for _ in range(cnt)]

@@ -211,7 +211,7 @@ __device__ __forceinline__ float q_half_allmax(float v) {
 // k_gemv_fused for the operand construction; with 64 lanes = 64 units of one quad, source lane l = 16g + i and
 // D[i][4g+beta] lands in lane l' = 16*(i/4) + 4g + beta, register i%4: lane l' owns output row beta and the four
 // units 16g + 4*(l'/16) .. +3 of the step (two act groups, one 128-wide scale group).
-template <int BITS, bool ZP, int SM, int LUTSRC, int NR, int FT, int WPQ, bool DUMP, int ACC, bool SCF16>
+template <int BITS, bool ZP, int SM, int LUTSRC, int NR, int FT, int WPQ, bool DUMP, int ACC, bool SCF16, bool EARLY>
 __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     extern __shared__ uint4 lds[];
     const unsigned long long t_entry = DUMP ? __builtin_amdgcn_s_memtime() : 0ull;   // before the first kernel-argument load
@@ -293,9 +293,24 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
             if (p_st >= nst) { p_st = h; p_q += stride; }
         }
     };
-    issue(f0);
-    issue(f1);
-    if (RING == 4) { issue(f2); issue(f3); }
+    // When the weight loads are issued matters more than anything else in this kernel (measured, profiles/r01_tune_quad.txt):
+    // issued first, as a prefetch, they occupy the CU's 64 B/clk load path for 1-2 us while the VALU idles, and the LUT
+    // build cannot start before the wave's own loads have all returned (its s_waitcnt is vmcnt(0): loads sit under
+    // wave-dependent branches).  So: wait for the activation registers alone (the empty asm reads them, the compiler
+    // puts its s_waitcnt in front), THEN issue the fragments — the LUT build below is pure VALU and overlaps the weight
+    // stream — or, with two workgroups per CU competing for the load path, after the LUT build.
+    constexpr bool early = LUTSRC == 1 && EARLY;      // chosen by the launcher: at most one workgroup per CU
+    if (LUTSRC == 1) {
+#pragma unroll
+        for (int r = 0; r < NP; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < 4 || !a.act_f16) asm volatile("" :: "v"(xr[r][i]));
+    }
+    if (early) {
+        issue(f0); issue(f1);
+        if (RING == 4) { issue(f2); issue(f3); }
+    }
     QSTAMP(1);
 
     // ---- 3. LUT into LDS (all FT threads) ------------------------------------------------------
@@ -404,6 +419,10 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
             for (int i = G + tid; i < GP; i += FT) { l_ls[i] = 0.f; l_lb[i] = 0.f; }
     }
     QSTAMP(2);
+    if (!early) {
+        issue(f0); issue(f1);
+        if (RING == 4) { issue(f2); issue(f3); }
+    }
     __syncthreads();
     QSTAMP(3);
     if (a.lut_tap && blockIdx.x == 0) {
@@ -725,7 +744,9 @@ static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t
     dim3 g(gx, N), b(FT);
     const int T = a.s.K / 4;
     constexpr int A1 = 1;
-#define QL(NRV, DV, AV) hipLaunchKernelGGL((k_gemv_quad<BITS, ZP, SM, LUTSRC, NRV, FT, WPQ, DV, AV, QSCF16>), g, b, shmem, st, a)
+#define QLE(NRV, DV, AV, EV) hipLaunchKernelGGL((k_gemv_quad<BITS, ZP, SM, LUTSRC, NRV, FT, WPQ, DV, AV, QSCF16, EV>), g, b, shmem, st, a)
+#define QL(NRV, DV, AV) QLE(NRV, DV, AV, false)
+    const bool early = LUTSRC == 1 && gx <= 256;   // one workgroup per CU: overlap the weight stream with the LUT build (see the kernel)
     const bool two = (LUTSRC == 0 || T <= 2 * FT);
     if (!two && T > 6 * FT) return hipErrorInvalidValue;
     if constexpr (FT == 512) {
@@ -734,14 +755,19 @@ static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t
             if (acc) { if (two) QL(2, true, A1); else if constexpr (LUTSRC == 1) QL(6, true, A1); }
             else { if (two) QL(2, true, 0); else if constexpr (LUTSRC == 1) QL(6, true, 0); }
         } else {
-            if (acc) { if (two) QL(2, false, A1); else if constexpr (LUTSRC == 1) QL(6, false, A1); }
-            else { if (two) QL(2, false, 0); else if constexpr (LUTSRC == 1) QL(6, false, 0); }
+            if (acc) {
+                if constexpr (LUTSRC == 1) {
+                    if (early) { if (two) QLE(2, false, A1, true); else QLE(6, false, A1, true); }
+                    else { if (two) QL(2, false, A1); else QL(6, false, A1); }
+                } else QL(2, false, A1);
+            } else { if (two) QL(2, false, 0); else if constexpr (LUTSRC == 1) QL(6, false, 0); }
         }
     } else {
         if (a.dump || LUTSRC == 0 || !a.acc_mfma) return hipErrorInvalidValue;
-        if constexpr (LUTSRC == 1) { if (two) QL(2, false, A1); else QL(6, false, A1); }
+        if constexpr (LUTSRC == 1) { if (two) QLE(2, false, A1, true); else QLE(6, false, A1, true); }   // grids of these sizes never exceed one workgroup per CU
     }
 #undef QL
+#undef QLE
     return hipGetLastError();
 }
 

@@ -774,21 +774,16 @@ static hipError_t qlaunch_nr(const FusedArgs& a, int total_q, int N, hipStream_t
 template <int BITS, bool ZP, int SM, int LUTSRC>
 static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_ft, int force_wpq, hipStream_t st) {
     // Configuration choice, from tools/tune_quad.py on MI355X (profiles/r01_tune_quad.txt, us per launch in a graph):
-    //   o 4096x4096: (512,2) 5.8, (768,3) 5.6 | qkv 12288x4096: (512,1) 9.0, (1024,1) 8.6 | gate_up 22016x4096:
-    //   (512,1) 11.8, (1024,1) 13.5 | down 4096x11008: (768,3) 8.6, (1024,4) 9.0, (512,2) 9.3, (512,1) 11.2.
-    //   -> 512-thread workgroups; two waves per quad while there are too few quads to give every wave of the chip
-    //   one (<= 2048); long rows with few quads: 3 waves per quad when that splits the steps evenly, else 4.
+    //   W2: o 4096x4096: (512,2) 4.3 | qkv 12288x4096: (512,2) 6.5, (512,1) 6.6, (1024,1) 6.9 | gate_up 22016x4096:
+    //   (512,1) 9.2, (512,2) 10.2 | down 4096x11008: (768,3) 6.9, (1024,4) 7.2, (512,2) 7.3, (512,1) 8.8.
+    //   W4 (tune_quad.py 0 4): o (512,2) | qkv (512,2) | gate_up (512,1) | down (512,2).
     const int nst = (a.s.K / 32 + 63) / 64;
-    int best_ft = 512, best_wpq = (total_q <= 2048 && nst >= 2) ? 2 : 1;
-    if (BITS == 4) {
-        // W4 (tools/tune_quad.py 0 4): steps are twice as heavy, two waves per quad pay off up to one quad per wave slot:
-        // o (512,2) 5.9 | qkv (512,2) 10.2, (1024,1) 10.6 | gate_up (512,1) 13.8 | down (512,2) 10.3, (768,3) 10.8
-        best_wpq = (total_q <= 4096 && nst >= 2) ? 2 : 1;
-    } else if (total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
+    // two waves per quad up to one quad per wave slot of the chip (4096), one beyond
+    int best_ft = 512, best_wpq = (total_q <= 4096 && nst >= 2) ? 2 : 1;
+    if (BITS == 2 && total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
+        // long rows, few quads: 3 waves per quad when that splits the steps evenly, else 4
         if (nst % 3 == 0 && a.s.K / 4 <= 6 * 768) { best_ft = 768; best_wpq = 3; }
         else { best_ft = 1024; best_wpq = 4; }
-    } else if (total_q > 2048 && total_q <= 4096 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
-        best_ft = 1024;   // one quad per wave fits one workgroup per CU: the LUT is built once per CU instead of twice
     }
     double best = 0.0;
     if (a.s.K / 4 > 6 * 512 && best_ft == 512 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) best_ft = 1024;   // LUT build: <= 6 tables per thread

@@ -101,7 +101,7 @@ __device__ __forceinline__ void load_q(QFrag<BITS>& f, const FusedArgs& a, const
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
             uint32_t v0 = 0, v1 = 0;
-            {
+            if (gi == 0 || a.gs_shift < 2) {      // gs >= 128: both act-group pairs of the lane share the scale group (the epilogue reads pair 0)
                 const uint32_t sg = min(sg_step + (uint32_t)((c0 + 2 * gi) >> a.gs_shift), (uint32_t)a.nsg - 1u);
                 const uint32_t sidx = ((row0 + sg) * 4 + (lane & 3)) * per;
                 if (SCF16) {

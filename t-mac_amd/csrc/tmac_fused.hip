@@ -203,7 +203,7 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
         }
     }
 
-    // ---- 2. first two weight fragments (items = (row block, step) pairs in execution order) -------
+    // ---- 2. weight fragment ring (items = (row block, step) pairs in execution order); first issue after the LUT build --
     WFrag<BITS> f0, f1;
     int p_gb = blockIdx.x, p_step = 0;   // prefetch cursor
     auto issue = [&](WFrag<BITS>& f) {
@@ -215,9 +215,6 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
             if (++p_step == nsteps) { p_step = 0; p_gb += gridDim.x; }
         }
     };
-    issue(f0);
-    issue(f1);
-
     TMAC_STAMP(1);
     // ---- 3. LUT into LDS ----------------------------------------------------------------------
     if (LUTSRC == 0) {
@@ -318,6 +315,10 @@ __global__ __launch_bounds__(FT) void k_gemv_fused(FusedArgs a) {
             }
         }
     }
+    // the weight fragments are issued only now: up front they would occupy the CU's load path while the VALU idles and
+    // hold back the LUT build (measured on k_gemv_quad)
+    issue(f0);
+    issue(f1);
     TMAC_STAMP(2);
     __syncthreads();
     TMAC_STAMP(3);

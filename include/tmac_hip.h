@@ -154,12 +154,13 @@ int32_t tmac_hip_selftest_mfma(const uint32_t* in_host, int32_t* out_host);
 /* Select the GEMV kernel variant: 0 auto (fused layout where supported), 1/2 two-kernel tiled path
  * (mqsad / byte-add accumulate), 3 generic reference-layout kernel, 4 fused (v_mqsad accumulate),
  * 5 fused with the MFMA accumulate, 6 wave-per-row-quad kernel (QUAD layout, MFMA accumulate; what auto picks
- * for 2/4-bit weights), 7 the same with the v_mqsad accumulate.  Affects weights
+ * for 1- to 4-bit weights), 7 the same with the v_mqsad accumulate.  Affects weights
  * registered AFTER the call (the variant fixes their device layout).  For A/B benchmarking and tests. */
 int32_t tmac_hip_set_variant(int variant);
 /* tmac_hip_qgemm_dev with N >= n activation rows runs the one-hot MFMA GEMM (k_gemm_onehot: the table gather
  * written as an int8 contraction, same bit-exact integer sums) instead of looping the GEMV kernel over the
- * rows (qgemm.py:183-190); n = 0 disables it.  Default 32 (the measured crossover).  QUAD-layout weights (2/4-bit) only. */
+ * rows (qgemm.py:183-190); n = 0 disables it.  Default 32 (the measured crossover).  QUAD-layout weights of 2 or 4 bits only (1/3-bit
+ * weights loop the GEMV). */
 int32_t tmac_hip_set_gemm_min_n(int n);
 
 /* ---- (1) reference-named host-pointer entry points ---------------------------------------

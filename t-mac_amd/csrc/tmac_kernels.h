@@ -11,7 +11,7 @@ enum Dtype { F32 = 0, F16 = 1 };
 
 // GEMV kernel variants (A/B-able at run time through tmac_hip_set_variant)
 enum Variant {
-    V_AUTO = 0,      // k_gemv_quad (V_QUAD) for 2/4-bit weights it supports, else the row-block fused kernel, else 1
+    V_AUTO = 0,      // k_gemv_quad (V_QUAD) where it supports the configuration, else the row-block fused kernel, else 1
     V_LO_MQSAD = 1,  // two-kernel path: k_preprocess + tiled k_gemv_lo, v_mqsad_pk_u16_u8 accumulate
     V_LO_SDWA = 2,   // same, byte-select adds
     V_REF_LAYOUT = 3,// generic kernel on the reference blobs (reference float order)

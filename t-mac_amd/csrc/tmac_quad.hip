@@ -710,14 +710,13 @@ q_done:
 
 // ---------------------------------------------------------------------------------------------
 #if !defined(TMAC_QUAD_BITS) || !defined(TMAC_QUAD_SCF16)
-#error "compile with -DTMAC_QUAD_BITS=2|4 -DTMAC_QUAD_SCF16=0|1 (one translation unit per combination keeps the build parallel)"
+#error "compile with -DTMAC_QUAD_BITS=1..4 -DTMAC_QUAD_SCF16=0|1 (one translation unit per combination keeps the build parallel)"
 #endif
 constexpr bool QSCF16 = TMAC_QUAD_SCF16 != 0;   // weight scales stored as fp16 (1) / fp32 (0): a kernel template parameter
 
 #if TMAC_QUAD_BITS == 2 && TMAC_QUAD_SCF16 == 0
 bool gemv_quad_supported(const Shape& s) {
-    // instantiated for the shipped bit widths (W2, W4); W1 / W3 use the row-block fused kernel
-    if ((s.bits != 2 && s.bits != 4) || s.K % 64 != 0 || s.K > 24576 || s.Mw % 4 != 0) return false;
+    if (s.bits < 1 || s.bits > 4 || s.K % 64 != 0 || s.K > 24576 || s.Mw % 4 != 0) return false;
     if (s.m_groups >= 1) return s.ags == s.K && s.Mw % s.m_groups == 0;
     const int gu = s.gs / 32;
     return s.ags == 64 && s.gs >= 64 && s.gs % 64 == 0 && s.K % s.gs == 0 && (gu & (gu - 1)) == 0;
@@ -819,7 +818,7 @@ static hipError_t qlaunch_b(const FusedArgs& a, int total_q, int N, int fft, int
 #define QENTRY_(b, h) launch_gemv_quad_b##b##_h##h
 #define QENTRY(b, h) QENTRY_(b, h)
 #define QENTRY_DECL(b, h) hipError_t QENTRY_(b, h)(const FusedArgs& a, int total_q, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st)
-QENTRY_DECL(2, 0); QENTRY_DECL(2, 1); QENTRY_DECL(4, 0); QENTRY_DECL(4, 1);
+QENTRY_DECL(1, 0); QENTRY_DECL(1, 1); QENTRY_DECL(2, 0); QENTRY_DECL(2, 1); QENTRY_DECL(3, 0); QENTRY_DECL(3, 1); QENTRY_DECL(4, 0); QENTRY_DECL(4, 1);
 hipError_t QENTRY(TMAC_QUAD_BITS, TMAC_QUAD_SCF16)(const FusedArgs& a, int total_q, int N, bool build_lut, int force_ft, int force_wpq, hipStream_t st) {
     return build_lut ? qlaunch_b<TMAC_QUAD_BITS, 1>(a, total_q, N, force_ft, force_wpq, st)
                      : qlaunch_b<TMAC_QUAD_BITS, 0>(a, total_q, N, force_ft, force_wpq, st);
@@ -831,10 +830,15 @@ hipError_t launch_gemv_quad(const FusedArgs& a_in, int N, bool build_lut, int fo
     fused_precompute(a);
     const int total_q = a.m[a.nmat - 1].nb_end;
     const bool h = a.sc_f16 && a.s.m_groups < 1;
-    if (a.s.bits == 4) return h ? launch_gemv_quad_b4_h1(a, total_q, N, build_lut, force_ft, force_wpq, st)
-                                : launch_gemv_quad_b4_h0(a, total_q, N, build_lut, force_ft, force_wpq, st);
-    return h ? launch_gemv_quad_b2_h1(a, total_q, N, build_lut, force_ft, force_wpq, st)
-             : launch_gemv_quad_b2_h0(a, total_q, N, build_lut, force_ft, force_wpq, st);
+#define QDISP(B) return h ? launch_gemv_quad_b##B##_h1(a, total_q, N, build_lut, force_ft, force_wpq, st) \
+                          : launch_gemv_quad_b##B##_h0(a, total_q, N, build_lut, force_ft, force_wpq, st)
+    switch (a.s.bits) {
+        case 1: QDISP(1);
+        case 2: QDISP(2);
+        case 3: QDISP(3);
+        default: QDISP(4);
+    }
+#undef QDISP
 }
 #endif
 

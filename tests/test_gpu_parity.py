@@ -467,6 +467,8 @@ def test_quad_kernel_configurations(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, ft
     (4096, 11008, 4, 256, True, -1, 64),     # llama-2-7b W4 down: 3 waves per quad, 2-deep fragment ring
     (3200, 8640, 2, 128, False, 1, 8640),    # BitNet-3B down: unified scale, act group = K
     (8640, 3200, 2, 128, False, 1, 3200),    # BitNet-3B gate/up
+    (4096, 4096, 3, 192, True, -1, 64),      # W3: three uint4 per unit, 2-deep ring
+    (4096, 11008, 1, 128, True, -1, 64),     # W1
 ])
 def test_model_shape_zoo(tm, Mw, K, bits, bm, zp, mg, ags):
     """full-size shapes of the reference's preset models through the default (fused, auto-configured) path: every

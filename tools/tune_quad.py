@@ -12,7 +12,7 @@ wr = tmac_amd.TMACGeMMWrapper(act_group_size=64); wr.set_workspace(11008, 1)
 NSET = 12
 variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 BITS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-BM = 128 if BITS == 2 else 256
+BM = {1: 128, 2: 128, 3: 192, 4: 256}[BITS]
 L.tmac_hip_set_variant(variant)
 for name, Mw, K, cnt in [("o", 4096, 4096, 1), ("qkv", 4096, 4096, 3), ("gate_up", 11008, 4096, 2), ("down", 4096, 11008, 1)]:
     sets = []

@@ -162,6 +162,18 @@ int32_t tmac_hip_set_variant(int variant);
  * rows (qgemm.py:183-190); n = 0 disables it.  Default 32 (the measured crossover).  QUAD-layout weights of 2 or 4 bits only (1/3-bit
  * weights loop the GEMV). */
 int32_t tmac_hip_set_gemm_min_n(int n);
+/* Fast aggregation (the reference's `-fa` build option, deploy/compile.py:167-174,223): the
+ * looked-up bytes of an act group are folded by a tree of rounding-halving adds instead of being summed exactly
+ * (SignedHalvingAdder, tbl.cc:86-141,201-256), the result rescaled by the group's table count and corrected by the
+ * analytic bias (tbl.cc:301-318,474-477).  LOSSY; off by default as in every shipped reference configuration.
+ *   0  exact sums (default)
+ *   1  signed halving adds (vrhaddq_s8) -- the reference's ARM build, the one `-fa` is meant for
+ *   2  the reference's AVX2 build (_mm256_avg_epu8 applied to the signed bytes): kept so that the implementation can
+ *      be pinned bit for bit against reference code compiled on an x86 host; numerically meaningless
+ * A build-time property in the reference, a registration-time property here: applies to weights registered AFTER the
+ * call (they take the 16-table-segment layout and run the two-kernel path: preprocessor + qgemm).  Per-group-scale
+ * weights with act_group_size 32 or 64 only, as in the reference (no fast aggregation on its int32 path). */
+int32_t tmac_hip_set_fast_aggregation(int mode);
 
 /* ---- (1) reference-named host-pointer entry points ---------------------------------------
  * Signatures identical to the generated deploy/tuned/<set>/kernels.h.  `m` is bm for qgemm_lut

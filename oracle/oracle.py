@@ -134,6 +134,21 @@ def qgemm_float(A, qlut, scales, ls, lb, Mw, K, N, bits, bm, kfactor, gs, ags, z
     return Cout
 
 
+def qgemm_float_fa(A, qlut, scales, ls, lb, Mw, K, N, bits, bm, kfactor, gs, ags, zero_point, fa_mode):
+    """(a9) fast-aggregation flavour of the float path.  fa_mode 1: NEON signed rounding-halving adds,
+    2: what the reference's AVX2 build computes (tbl.cc:201-256).  Returns (C [N][Mw], tree results
+    int32 [N][M][K/ags])."""
+    A = _c(A, np.uint8); qlut = _c(qlut, np.int8); scales = _c(scales, np.float32)
+    ls = _c(ls, np.float32); lb = _c(lb, np.float32)
+    Cout = np.zeros((N, Mw), np.float32)
+    tap = np.zeros((N, Mw * bits, K // ags), np.int32)
+    rc = lib().oracle_qgemm_float_fa(_p(A), _p(qlut), _p(scales), _p(ls), _p(lb), _p(Cout), _p(tap), Mw, K, N,
+                                     bits, bm, kfactor, gs, ags, int(zero_point), int(fa_mode))
+    if rc != 0:
+        raise ValueError(f"oracle_qgemm_float_fa rc={rc}")
+    return Cout, tap
+
+
 def qgemm_scale_final(A, qlut, scales, ls, lb, Mw, K, N, bits, bm, kfactor, m_groups=1):
     A = _c(A, np.uint8); qlut = _c(qlut, np.int8); scales = _c(scales, np.float32)
     ls = _c(ls, np.float32); lb = _c(lb, np.float32)
@@ -178,8 +193,9 @@ def ref_preprocessor(B_row: np.ndarray, ags: int):
     return q, ls, lb
 
 
-def ref_cbits_float(A, qlut_row, scales_t, ls, lb, Mw, K, bits, bm, kfactor, gs, ags, zero_point):
-    """CBits fp32 [M] from the reference's tbl intrinsic, tile by tile."""
+def ref_cbits_float(A, qlut_row, scales_t, ls, lb, Mw, K, bits, bm, kfactor, gs, ags, zero_point, fa=False):
+    """CBits fp32 [M] from the reference's tbl intrinsic, tile by tile (fa: its FastAggregation = true
+    instantiation, AVX2 flavour)."""
     A = _c(A, np.uint8); q = _c(qlut_row, np.int8); S = _c(scales_t, np.float32)
     ls = _c(ls, np.float32); lb = _c(lb, np.float32)
     M = Mw * bits
@@ -187,8 +203,8 @@ def ref_cbits_float(A, qlut_row, scales_t, ls, lb, Mw, K, bits, bm, kfactor, gs,
     L = ref_lib()
     for tile in range(M // bm):
         cb = np.zeros(bm, np.float32)
-        rc = L.ref_tile_cbits_float(bits, kfactor, ags, int(zero_point), bm, K, gs, _p(A[tile]), _p(q),
-                                    _p(S[tile]), _p(ls), _p(lb), _p(cb))
+        fn = L.ref_tile_cbits_float_fa if fa else L.ref_tile_cbits_float
+        rc = fn(bits, kfactor, ags, int(zero_point), bm, K, gs, _p(A[tile]), _p(q), _p(S[tile]), _p(ls), _p(lb), _p(cb))
         if rc != 0:
             raise ValueError("no reference instantiation for this configuration")
         out[tile * bm:(tile + 1) * bm] = cb

@@ -31,6 +31,16 @@ tbl_g4_int8_float_update(true, 8, 2, 8, false, false, false)
 tbl_g4_int8_float_update(true, 8, 4, 8, false, true, false)
 tbl_g4_int8_float_update(true, 16, 2, 8, false, true, false)
 tbl_g4_int8_float_update(true, 16, 2, 8, false, false, false)
+// fast aggregation (a9): the AVX2 flavour of SignedHalvingAdder (tbl.cc:201-256)
+tbl_g4_int8_float_update(true, 16, 1, 16, true, true, false)
+tbl_g4_int8_float_update(true, 16, 2, 16, true, true, false)
+tbl_g4_int8_float_update(true, 16, 3, 16, true, true, false)
+tbl_g4_int8_float_update(true, 16, 4, 16, true, true, false)
+tbl_g4_int8_float_update(true, 16, 2, 16, true, false, false)
+tbl_g4_int8_float_update(true, 16, 3, 16, true, false, false)
+tbl_g4_int8_float_update(true, 16, 4, 16, true, false, false)
+tbl_g4_int8_float_update(true, 8, 2, 8, true, true, false)
+tbl_g4_int8_float_update(true, 16, 2, 8, true, true, false)
 // int32 aggregation (scale-final / BitNet on x86)
 tbl_g4_int8_int32_update(true, 16, 1, 16, false, false, false)
 tbl_g4_int8_int32_update(true, 16, 2, 16, false, false, false)
@@ -65,6 +75,21 @@ static tbl_float_fn pick_float(int kfactor, int bits, int actk, int zp) {
     return nullptr;
 }
 
+static tbl_float_fn pick_float_fa(int kfactor, int bits, int actk, int zp) {
+#define PICK(k, b, ak, z, fn) if (kfactor == k && bits == b && actk == ak && zp == z) return fn;
+    PICK(16, 1, 16, 1, tbl_g4_int8_float_update_strue_k16_b1_ak16_fatrue_ztrue_osfalse)
+    PICK(16, 2, 16, 1, tbl_g4_int8_float_update_strue_k16_b2_ak16_fatrue_ztrue_osfalse)
+    PICK(16, 3, 16, 1, tbl_g4_int8_float_update_strue_k16_b3_ak16_fatrue_ztrue_osfalse)
+    PICK(16, 4, 16, 1, tbl_g4_int8_float_update_strue_k16_b4_ak16_fatrue_ztrue_osfalse)
+    PICK(16, 2, 16, 0, tbl_g4_int8_float_update_strue_k16_b2_ak16_fatrue_zfalse_osfalse)
+    PICK(16, 3, 16, 0, tbl_g4_int8_float_update_strue_k16_b3_ak16_fatrue_zfalse_osfalse)
+    PICK(16, 4, 16, 0, tbl_g4_int8_float_update_strue_k16_b4_ak16_fatrue_zfalse_osfalse)
+    PICK(8, 2, 8, 1, tbl_g4_int8_float_update_strue_k8_b2_ak8_fatrue_ztrue_osfalse)
+    PICK(16, 2, 8, 1, tbl_g4_int8_float_update_strue_k16_b2_ak8_fatrue_ztrue_osfalse)
+#undef PICK
+    return nullptr;
+}
+
 static tbl_i32_fn pick_i32(int kfactor, int bits) {
     if (kfactor == 16 && bits == 1) return tbl_g4_int8_int32_update_strue_k16_b1_ak16_fafalse_zfalse_osfalse;
     if (kfactor == 16 && bits == 2) return tbl_g4_int8_int32_update_strue_k16_b2_ak16_fafalse_zfalse_osfalse;
@@ -78,11 +103,11 @@ extern "C" {
 
 // One M-tile of the float path: CBits[bm] (fp32) after the k_outer loop.  Pointers are the
 // per-tile pointers the llama.cpp caller would pass (tmac_gemm_wrapper.h:197-199).
-int32_t ref_tile_cbits_float(int bits, int kfactor, int ags, int zp, int bm, int K, int gs,
-                             void* A_tile, void* LUT, void* Scales_tile, void* LUT_Scales,
-                             void* LUT_Biases, float* CBits) {
+static int32_t tile_cbits_float(int fa, int bits, int kfactor, int ags, int zp, int bm, int K, int gs,
+                                void* A_tile, void* LUT, void* Scales_tile, void* LUT_Scales,
+                                void* LUT_Biases, float* CBits) {
     const int actk = (ags / 4 < kfactor) ? ags / 4 : kfactor;
-    tbl_float_fn fn = pick_float(kfactor, bits, actk, zp);
+    tbl_float_fn fn = fa ? pick_float_fa(kfactor, bits, actk, zp) : pick_float(kfactor, bits, actk, zp);
     if (!fn) return -1;
     const int sstride = bm / bits * (zp ? 2 : 1);
     tbl_float_reset(bm, CBits);
@@ -94,6 +119,18 @@ int32_t ref_tile_cbits_float(int bits, int kfactor, int ags, int zp, int bm, int
            (float*)LUT_Biases + k_outer * 4 * kfactor / ags);
     }
     return 0;
+}
+
+int32_t ref_tile_cbits_float(int bits, int kfactor, int ags, int zp, int bm, int K, int gs,
+                             void* A_tile, void* LUT, void* Scales_tile, void* LUT_Scales,
+                             void* LUT_Biases, float* CBits) {
+    return tile_cbits_float(0, bits, kfactor, ags, zp, bm, K, gs, A_tile, LUT, Scales_tile, LUT_Scales, LUT_Biases, CBits);
+}
+// same with the fast-aggregation instantiation of the intrinsic (FastAggregation = true)
+int32_t ref_tile_cbits_float_fa(int bits, int kfactor, int ags, int zp, int bm, int K, int gs,
+                                void* A_tile, void* LUT, void* Scales_tile, void* LUT_Scales,
+                                void* LUT_Biases, float* CBits) {
+    return tile_cbits_float(1, bits, kfactor, ags, zp, bm, K, gs, A_tile, LUT, Scales_tile, LUT_Scales, LUT_Biases, CBits);
 }
 
 // One M-tile of the int32 path: CBits32[bm] after the k_outer loop.

@@ -12,6 +12,10 @@
  * The one expression with no compiled x86 exemplar in the reference is the scale-final
  * epilogue (oracle_qgemm_scale_final, spec python/t_mac/ops/qgemm.py:170-174,192-206);
  * its integer part is pinned (tbl.cc:586-628), its last three float ops are "restated".
+ * Fast aggregation (oracle_qgemm_float_fa): fa_mode 2 (the reference's AVX2 build) is PINNED bit for
+ * bit against the reference's FastAggregation = true instantiation; fa_mode 1 (its NEON build,
+ * vrhaddq_s8) cannot be compiled on this x86 host: it shares the pinned tree/rescale/bias code and
+ * differs in the one averaging expression -- "restated", parity unpinned for that expression.
  *
  * Plain scalar C; every float op is individually rounded (compile with
  * -ffp-contract=off); fmaf() appears exactly where the reference uses _mm256_fmadd_ps.
@@ -154,16 +158,35 @@ int oracle_partial_sums(const uint8_t* A, const int8_t* qlut, int Mw, int K, int
  *   C       [N][Mw] float
  * one_scale follows the NEON branch (tbl.cc:417-423) — the AVX2 branch ignores OneScale
  * (tbl.cc:518-527), a known gap of the reference on x86. */
-int oracle_qgemm_float(const uint8_t* A, const int8_t* qlut, const float* scales,
+/* (a9) fast aggregation: the act group's ActK looked-up bytes are not summed exactly but folded by a
+ * balanced tree of rounding-halving adds, in table order (SignedHalvingAdder<N>, tbl.cc:86-141 NEON /
+ * :201-256 AVX2): H_2(v0,v1) = avg(v0,v1); H_N = avg(H_{N/2}(first half), H_{N/2}(second half)).
+ *   fa_mode 1: NEON  vrhaddq_s8  = (a + b + 1) >> 1 on SIGNED bytes          (tbl.cc:101,123)
+ *   fa_mode 2: AVX2  _mm256_avg_epu8 = (a + b + 1) >> 1 on the same bytes read as UNSIGNED, the result
+ *              sign-extended again (tbl.cc:218,237,226-231) -- what the reference's x86 build computes.
+ * The result stands for sum/ActK, so lut_s is multiplied by ActK and the expected rounding bias
+ * (log2(ActK)/4 in INTEGER arithmetic, times get_bias_scale(bits) = 2^bits - 1) is taken off lut_b
+ * (tbl.cc:301-318,369-372,474-477). */
+static int fa_tree(const int8_t* v, int n, int fa_mode) {
+    if (n == 1) return v[0];
+    const int a = fa_tree(v, n / 2, fa_mode), b = fa_tree(v + n / 2, n / 2, fa_mode);
+    if (fa_mode == 1) return (a + b + 1) >> 1;                           /* arithmetic shift: floor */
+    return (int8_t)(uint8_t)((((unsigned)(uint8_t)a) + ((unsigned)(uint8_t)b) + 1u) >> 1);
+}
+static int ilog2(int k) { int l = -1; while (k) { ++l; k /= 2; } return l; }  /* mylog2, tbl.cc:287-299 */
+
+static int qgemm_float_impl(const uint8_t* A, const int8_t* qlut, const float* scales,
                        const float* lut_scales, const float* lut_biases, float* C,
                        int Mw, int K, int N, int bits, int bm, int kfactor, int gs, int ags,
-                       int zero_point, int one_scale) {
+                       int zero_point, int one_scale, int fa_mode, int32_t* agg_tap) {
     const int M = Mw * bits;
+    if (fa_mode < 0 || fa_mode > 2) return -1;
     if (M % bm || bm % 32 || bm % bits || (bm / bits) % 8 || (K / 4) % kfactor) return -1;
     if (K % ags || (4 * kfactor) % ags) return -1;
     if (!one_scale && (K % gs || gs % (4 * kfactor))) return -1;
     const int G = K / ags, TG = ags / 4;
     const int ActK = TG < kfactor ? TG : kfactor;   /* tbl.py: min(ags/4, kfactor) */
+    if (fa_mode && (ActK > 64 || (ActK & (ActK - 1)) || ActK < 2)) return -1;
     const int groups_per_call = kfactor / ActK;
     const int ncalls = (K / 4) / kfactor;
     const int rows_per_tile = bm / bits;             /* output rows per tile */
@@ -187,13 +210,21 @@ int oracle_qgemm_float(const uint8_t* A, const int8_t* qlut, const float* scales
                 for (int j = 0; j < groups_per_call; ++j) {
                     const int kk = ko * groups_per_call + j;
                     int32_t s = 0; /* exact int16 sum in the reference (|s| <= 16*127) */
+                    int8_t looked[64];
                     for (int tl = 0; tl < ActK; ++tl) {
                         int t = ko * kfactor + j * ActK + tl;
-                        s += q[(size_t)t * 16 + ref_nibble(A, K, bm, kfactor, r, t)];
+                        looked[tl] = q[(size_t)t * 16 + ref_nibble(A, K, bm, kfactor, r, t)];
+                        s += looked[tl];
+                    }
+                    float lut_s = ls[kk], lut_b = lb[kk];
+                    partial_sum += lut_b;
+                    if (fa_mode) {
+                        s = fa_tree(looked, ActK, fa_mode);
+                        if (agg_tap && ActK == TG) agg_tap[((size_t)n * M + r) * G + kk] = s;
+                        lut_s = lut_s * (float)ActK;
+                        lut_b -= lut_s * (float)(ilog2(ActK) / 4 * ((1 << bits) - 1));
                     }
                     const float v = (float)s;
-                    const float lut_s = ls[kk], lut_b = lb[kk];
-                    partial_sum += lut_b;
                     /* lut_fma: plane 0 -> fmadd(v, lut_s, lut_b); else mul (tbl.cc:479-481) */
                     const float f = (plane == 0) ? fmaf(v, lut_s, lut_b) : v * lut_s;
                     vec_c = (j == 0) ? f : vec_c + f;
@@ -226,6 +257,24 @@ int oracle_qgemm_float(const uint8_t* A, const int8_t* qlut, const float* scales
     }
     free(cbits);
     return 0;
+}
+
+int oracle_qgemm_float(const uint8_t* A, const int8_t* qlut, const float* scales,
+                       const float* lut_scales, const float* lut_biases, float* C,
+                       int Mw, int K, int N, int bits, int bm, int kfactor, int gs, int ags,
+                       int zero_point, int one_scale) {
+    return qgemm_float_impl(A, qlut, scales, lut_scales, lut_biases, C, Mw, K, N, bits, bm, kfactor, gs, ags,
+                            zero_point, one_scale, 0, NULL);
+}
+
+/* fast-aggregation flavour; agg_tap (optional) receives the tree result per (n, M-space row, act group) */
+int oracle_qgemm_float_fa(const uint8_t* A, const int8_t* qlut, const float* scales,
+                          const float* lut_scales, const float* lut_biases, float* C, int32_t* agg_tap,
+                          int Mw, int K, int N, int bits, int bm, int kfactor, int gs, int ags,
+                          int zero_point, int fa_mode) {
+    if (fa_mode != 1 && fa_mode != 2) return -1;
+    return qgemm_float_impl(A, qlut, scales, lut_scales, lut_biases, C, Mw, K, N, bits, bm, kfactor, gs, ags,
+                            zero_point, 0, fa_mode, agg_tap);
 }
 
 /* ---- (a5): unified-scale (BitNet) path, int32 aggregation, scale applied last -------

@@ -83,6 +83,7 @@ def load_library() -> C.CDLL:
         "tmac_hip_qgemm_partial_sums": ([vp, vp, vp, C.c_int, vp], i32),
         "tmac_hip_set_variant": ([C.c_int], i32),
         "tmac_hip_set_gemm_min_n": ([C.c_int], i32),
+        "tmac_hip_set_fast_aggregation": ([C.c_int], i32),
         "tmac_hip_selftest": ([vp, vp, C.c_int], i32),
         "tmac_hip_selftest_mfma": ([vp, vp], i32),
         "tmac_hip_cache_clear": ([], i32),

@@ -13,6 +13,8 @@
 
 using namespace tmac;
 
+static uint32_t g_fa_xor = 0;   // MODE 2 (fast aggregation): 0 signed halving adds, 0x80808080 the AVX2 flavour
+
 template <int BITS, int MODE>
 static void run(const std::vector<uint32_t>& W, const std::vector<uint32_t>& QL, const Shape& s, int32_t* PS) {
     constexpr int NJ = TS * BITS / 8;
@@ -32,6 +34,7 @@ static void run(const std::vector<uint32_t>& W, const std::vector<uint32_t>& QL,
                     for (int a = 0; a < NA; ++a) {
                         SegAcc<BITS, MODE> acc;
                         acc.reset();
+                        if constexpr (MODE == 2) acc.xr = g_fa_xor;
                         if (TG == 16) accumulate_tables<BITS, 0, 16>(wd, tb, acc);
                         else if (a == 0) accumulate_tables<BITS, 0, 8>(wd, tb, acc);
                         else accumulate_tables<BITS, 8, 8>(wd, tb, acc);
@@ -185,10 +188,13 @@ extern "C" int emu_partial_sums(const uint8_t* A_ref, const int8_t* qlut_ref, in
     Shape s;
     memset(&s, 0, sizeof(s));
     s.Mw = Mw; s.K = K; s.bits = bits; s.bm = bm; s.kfactor = kfactor; s.gs = 128; s.ags = ags; s.m_groups = -1;
+    const int fa = mode == 5 ? 1 : mode == 6 ? 2 : 0;   // modes 5 / 6: two-kernel layout with fast aggregation (NEON / AVX2 flavour):
+    if (fa) mode = 0;                                   //   PS then holds the halving-tree results instead of sums
     s.ts = (mode >= 2) ? 8 : 16;     // mode 2 = fused-layout kernel (mqsad), 3 = fused-layout kernel (MFMA accumulate)
     s.lay = (mode == 4) ? 2 : 0;     // mode 4 = QUAD layout kernel
     if (K % 64 || (ags != 32 && ags != 64 && ags != K)) return -1;
     if (mode >= 2 && ags == 32) return -1;
+    if (fa && ags == K) return -1;
     std::vector<uint32_t> W(s.weight_u4() * 4);
     for (size_t i = 0; i < W.size(); ++i) W[i] = retile_dword(A_ref, s, i >> 2, (int)(i & 3));
     std::vector<uint32_t> QL(s.qlut_dev_u4() * 4, 0x80808080u);
@@ -256,7 +262,8 @@ extern "C" int emu_partial_sums(const uint8_t* A_ref, const int8_t* qlut_ref, in
         }
         return 0;
     }
-#define RUN(B) (mode == 0 ? run<B, 0>(W, QL, s, PS) : run<B, 1>(W, QL, s, PS))
+    g_fa_xor = fa == 2 ? 0x80808080u : 0u;
+#define RUN(B) (fa ? run<B, 2>(W, QL, s, PS) : mode == 0 ? run<B, 0>(W, QL, s, PS) : run<B, 1>(W, QL, s, PS))
     switch (bits) {
         case 1: RUN(1); break;
         case 2: RUN(2); break;

@@ -64,6 +64,17 @@ TMAC_HD uint64_t mqsad_acc(uint32_t r, uint64_t acc) {
 #endif
 }
 
+// v_lerp_u8 with rounding bits set: per byte (a + b + 1) >> 1, the unsigned rounding average
+TMAC_HD uint32_t avg_u8x4(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_lerp(a, b, 0x01010101u);
+#else
+    uint32_t out = 0;
+    for (int i = 0; i < 4; ++i) out |= ((((a >> (8 * i)) & 0xff) + ((b >> (8 * i)) & 0xff) + 1u) >> 1) << (8 * i);
+    return out;
+#endif
+}
+
 // 4 signed lookups (biased by +128) for the low (h=0) or high (h=1) nibbles of weight dword w.
 // tab = {U[0..3], U[4..7]} of the table these nibbles index.
 template <int H>
@@ -103,7 +114,7 @@ struct SegAcc<BITS, 0> {
 #pragma unroll
         for (int p = 0; p < BITS; ++p) a[p] = 0;
     }
-    TMAC_HD void add(int p, uint32_t r) { a[p] = mqsad_acc(r, a[p]); }
+    TMAC_HD void add(int p, uint32_t r, int = 0) { a[p] = mqsad_acc(r, a[p]); }
     // integer partial sum of (plane p, row beta) after `tables` lookups
     TMAC_HD int32_t ps(int p, int beta, int tables) const {
         return 127 * tables - (int32_t)((a[p] >> (16 * beta)) & 0xffff);
@@ -119,7 +130,7 @@ struct SegAcc<BITS, 1> {
 #pragma unroll
             for (int b = 0; b < 4; ++b) a[p][b] = 0;
     }
-    TMAC_HD void add(int p, uint32_t r) {
+    TMAC_HD void add(int p, uint32_t r, int = 0) {
         a[p][0] += r & 0xff;
         a[p][1] += (r >> 8) & 0xff;
         a[p][2] += (r >> 16) & 0xff;
@@ -127,6 +138,40 @@ struct SegAcc<BITS, 1> {
     }
     TMAC_HD int32_t ps(int p, int beta, int tables) const { return (int32_t)a[p][beta] - 128 * tables; }
 };
+
+// MODE 2: fast aggregation (a9; tbl.cc:86-141 NEON / :201-256 AVX2).  The act group's lookups are folded by a
+// balanced tree of rounding-halving adds in table order instead of being summed: push k merges, binary-counter
+// fashion, every completed pair of equal-sized subtrees.  The bytes arrive biased (V = value + 128), and
+//   signed rounding-halving add (vrhaddq_s8):  ((a + b + 1) >> 1) + 128 == (Va + Vb + 1) >> 1      -> xr = 0
+//   the AVX2 flavour (_mm256_avg_epu8 on the raw signed bytes): average V ^ 0x80 instead           -> xr = 0x80808080
+// both on v_lerp_u8.  ps() is the tree result as a signed byte (it stands for sum / tables).
+template <int BITS>
+struct SegAcc<BITS, 2> {
+    uint32_t lvl[BITS][4];
+    uint32_t res[BITS];
+    uint32_t xr;
+    TMAC_HD void reset() {}
+    TMAC_HD void add(int p, uint32_t r, int k) {
+        uint32_t cur = r ^ xr;
+        int l = 0;
+#pragma unroll
+        for (; l < 4; ++l) {
+            if (!((k >> l) & 1)) break;
+            cur = avg_u8x4(lvl[p][l], cur);
+        }
+        if (l < 4) lvl[p][l] = cur;
+        res[p] = cur;
+    }
+    TMAC_HD int32_t ps(int p, int beta, int) const {
+        return (int32_t)(((res[p] ^ xr) >> (8 * beta)) & 0xff) - 128;
+    }
+};
+
+TMAC_HD int fa_bias_factor(int tables, int bits) {   // mylog2<ActK>::value / 4 * get_bias_scale(Bits), tbl.cc:287-318
+    int l = -1;
+    for (int k = tables; k; k /= 2) ++l;
+    return l / 4 * ((1 << bits) - 1);
+}
 
 // Consume tables [TL0, TL0+NT) of a segment.  wd: the thread's TS*BITS/2 weight dwords of this
 // segment; tb: its TS half tables as (lo,hi) dword pairs.  Everything is compile-time indexed.
@@ -137,7 +182,7 @@ TMAC_HD void accumulate_tables(const WD& wd, const TB& tb, Acc& acc) {
         const int tl = q / BITS, p = q % BITS, d = q >> 1;
         const uint32_t r = (q & 1) ? lookup4<1>(wd[d], tb[2 * tl], tb[2 * tl + 1])
                                    : lookup4<0>(wd[d], tb[2 * tl], tb[2 * tl + 1]);
-        acc.add(p, r);
+        acc.add(p, r, tl - TL0);
     }
 }
 

@@ -55,6 +55,7 @@ struct tmac_hip_weights {
     void* S_ref = nullptr;
     Dtype ref_dtype = F32;
     bool lo_ok = false;
+    int fa = 0;             // fast-aggregation mode these weights were registered under (0 = exact)
     size_t w_bytes = 0, sc_bytes = 0;
 };
 
@@ -74,6 +75,7 @@ struct tmac_hip_workspace {
 static std::mutex g_mu;
 static int g_device = -1;
 static int g_variant = V_AUTO;
+static int g_fa_mode = 0;   // fast aggregation for weights registered from now on (tmac_hip_set_fast_aggregation)
 static int g_force_ft = 0, g_force_wpq = 0;   // A/B knobs of the quad kernel (0 = heuristic)
 static std::map<std::string, tmac_kcfg> g_kcfg;
 
@@ -197,6 +199,12 @@ extern "C" int32_t tmac_hip_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
+extern "C" int32_t tmac_hip_set_fast_aggregation(int mode) {
+    if (mode < 0 || mode > 2) return fail(TMAC_HIP_E_ARG, "unknown fast-aggregation mode %d", mode);
+    g_fa_mode = mode;
+    return TMAC_HIP_OK;
+}
+
 extern "C" int32_t tmac_hip_set_variant(int variant) {
     if (variant < 0 || variant > 7) return fail(TMAC_HIP_E_ARG, "unknown variant %d", variant);
     g_variant = variant;
@@ -282,6 +290,14 @@ static int32_t make_shape(Shape& s, int Mw, int K, int bits, const tmac_kcfg* cf
     s.ts = 8;
     s.lay = 0;
     const bool fused_ok = gemv_fused_supported(s), quad_ok = gemv_quad_supported(s);
+    if (g_fa_mode) {
+        // the reference has no fast aggregation on the int32 / unified-scale path (tbl.cc:534) and the halving tree
+        // needs a power-of-two number of tables per act group
+        if (s.m_groups >= 1) return fail(TMAC_HIP_E_NOMATCH, "fast aggregation is defined for per-group scales only");
+        if (s.ags != 32 && s.ags != 64) return fail(TMAC_HIP_E_NOMATCH, "fast aggregation needs act_group_size 32 or 64");
+        s.ts = 16;   // one act group's 16 (or 2 x 8) tables per lane: the tree stays inside a thread (k_gemv_lo)
+        return TMAC_HIP_OK;
+    }
     if ((g_variant == V_AUTO || g_variant == V_QUAD || g_variant == V_QUAD_MQSAD) && quad_ok) s.lay = 2;
     else if (g_variant == V_LO_MQSAD || g_variant == V_LO_SDWA || !fused_ok) s.ts = 16;
     return TMAC_HIP_OK;
@@ -307,6 +323,7 @@ static int32_t register_impl(tmac_hip_weights** out, const void* A_ref, const vo
     w->s = s;
     w->sc_dtype = (Dtype)dev_float;
     w->ref_dtype = (Dtype)host_float;
+    w->fa = g_fa_mode;
     w->lo_ok = (s.lay == 2) ? gemv_quad_supported(s) : (s.ts == 8) ? gemv_fused_supported(s) : gemv_lo_supported(s);
     const size_t ab = ref_weight_bytes(s), se = ref_scale_elems(s), sb = se * dt_size((Dtype)host_float);
     const bool keep_ref = !w->lo_ok || g_variant == V_REF_LAYOUT;
@@ -488,6 +505,8 @@ static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* w
         else if (w->s.ts == 8) v = V_FUSED;
         else if (v != V_LO_SDWA) v = V_LO_MQSAD;
     }
+    if (w->fa && v != V_REF_LAYOUT && v != V_LO_MQSAD && v != V_LO_SDWA)
+        return fail(TMAC_HIP_E_NOMATCH, "fast-aggregation weights run on the two-kernel path only");
     if (v == V_FUSED && g_gemm_min_n > 0 && N >= g_gemm_min_n && gemm_onehot_supported(w->s)) {
         GemmArgs ga;
         memset(&ga, 0, sizeof(ga));
@@ -516,6 +535,7 @@ static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* w
     a.s = w->s; a.N = N; a.qlut_dev = ws->qlut_dev; a.qlut_ref = ws->qlut_ref;
     a.lut_scales = ws->lut_scales; a.lut_biases = ws->lut_biases; a.C = C_dev; a.out_dtype = (Dtype)out_dtype;
     a.ps_dump = dump;
+    a.fa_mode = w->fa;
     if (v == V_REF_LAYOUT) {
         if (!w->A_ref) return fail(TMAC_HIP_E_NOMATCH, "reference-layout blobs were not kept for these weights (register them with variant 3 selected)");
         a.W = w->A_ref; a.SC = w->S_ref; a.sc_dtype = w->ref_dtype;

@@ -74,6 +74,7 @@ struct GemvArgs {
     Dtype out_dtype;
     int32_t* ps_dump;     // optional int32 tap (device)
     int N;
+    int fa_mode;          // 0 exact sums | 1, 2: fast aggregation (a9; see SegAcc<BITS, 2> in tmac_core.h)
 };
 
 hipError_t launch_selftest(const uint32_t* in, uint32_t* out, int n, hipStream_t st);

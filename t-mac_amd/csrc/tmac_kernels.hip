@@ -262,6 +262,7 @@ struct GemvPtrs {
     void* C;
     int32_t* dump;
     int out_f16;
+    uint32_t fa_xor;   // MODE 2 (fast aggregation): 0 = signed halving adds (NEON), 0x80808080 = the AVX2 flavour
 };
 
 template <int BITS, int TG, bool ZP, int SM, typename ST>
@@ -318,6 +319,7 @@ __device__ __forceinline__ void compute_frag(const Frag<BITS, TG, ZP, SM, ST>& f
     for (int a = 0; a < NA; ++a) {
         SegAcc<BITS, MODE> acc;
         acc.reset();
+        if constexpr (MODE == 2) acc.xr = p.fa_xor;
         if (a == 0) accumulate_tables<BITS, 0, NT>(f.wd, f.tb, acc);
         else accumulate_tables<BITS, (NA > 1 ? NT : 0), NT>(f.wd, f.tb, acc);
 #pragma unroll
@@ -334,7 +336,12 @@ __device__ __forceinline__ void compute_frag(const Frag<BITS, TG, ZP, SM, ST>& f
                             p.dump[((size_t)n * s.M() + mrow(o, pl, BITS)) * G + seg * NA + a] = ps;
                     }
                     // tbl.cc:479-492 (lut_fma) then :501-526 (scale, zero point)
-                    const float v = (pl == 0) ? __fmaf_rn((float)ps, f.ls[a], f.lb[a]) : __fmul_rn((float)ps, f.ls[a]);
+                    float lsa = f.ls[a], lba = f.lb[a];
+                    if constexpr (MODE == 2) {   // tbl.cc:474-477: the tree result stands for sum / ActK
+                        lsa = __fmul_rn(lsa, (float)NT);
+                        lba = __fsub_rn(lba, __fmul_rn(lsa, (float)fa_bias_factor(NT, BITS)));
+                    }
+                    const float v = (pl == 0) ? __fmaf_rn((float)ps, lsa, lba) : __fmul_rn((float)ps, lsa);
                     const float sc = (SM == 1) ? one_scale : f.sc[beta];
                     float c = __fmaf_rn(v, sc, cacc[beta][pl]);
                     if (ZP && pl == 0) c = __fmaf_rn(f.zr[beta], __fmul_rn(2.0f, f.lb[a]), c);
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(256) void k_gemv_lo(GemvPtrs p, Shape s) {
 template <typename ST>
 __global__ void k_gemv_ref_layout(const uint8_t* __restrict__ A, const int8_t* __restrict__ qlut, const ST* __restrict__ SC,
                                   const float* __restrict__ LS, const float* __restrict__ LB, void* C, int out_f16,
-                                  int32_t* dump, Shape s, int one_scale_per_group) {
+                                  int32_t* dump, Shape s, int one_scale_per_group, int fa_mode) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x, n = blockIdx.y;
     if (o >= s.Mw) return;
     const int bits = s.bits, G = s.ngroups(), TGr = s.ags / 4;
@@ -479,13 +486,32 @@ __global__ void k_gemv_ref_layout(const uint8_t* __restrict__ A, const int8_t* _
             for (int j = 0; j < gpc; ++j) {
                 const int kk = ko * gpc + j;
                 int32_t sum = 0;
-                for (int tl = 0; tl < ActK; ++tl) {
-                    const int t = ko * s.kfactor + j * ActK + tl;
-                    sum += q[(size_t)t * 16 + ref_nibble(A, s.K, s.bm, s.kfactor, r, t)];
+                float lsk = ls[kk], lbk = lb[kk];
+                partial_sum = __fadd_rn(partial_sum, lbk);
+                if (fa_mode) {
+                    // (a9) SignedHalvingAdder (tbl.cc:86-141,201-256): balanced tree of rounding-halving adds in table
+                    // order, kept as a binary counter of completed subtrees; mode 1 signed bytes, 2 the AVX2 flavour
+                    int lvl[6];
+                    for (int tl = 0; tl < ActK; ++tl) {
+                        const int t = ko * s.kfactor + j * ActK + tl;
+                        int cur = q[(size_t)t * 16 + ref_nibble(A, s.K, s.bm, s.kfactor, r, t)];
+                        int l = 0;
+                        for (; (tl >> l) & 1; ++l)
+                            cur = (fa_mode == 1) ? ((lvl[l] + cur + 1) >> 1)
+                                                 : (int)(int8_t)(((uint32_t)(uint8_t)lvl[l] + (uint32_t)(uint8_t)cur + 1u) >> 1);
+                        lvl[l] = cur;
+                        sum = cur;
+                    }
+                    lsk = __fmul_rn(lsk, (float)ActK);
+                    lbk = __fsub_rn(lbk, __fmul_rn(lsk, (float)fa_bias_factor(ActK, bits)));
+                } else {
+                    for (int tl = 0; tl < ActK; ++tl) {
+                        const int t = ko * s.kfactor + j * ActK + tl;
+                        sum += q[(size_t)t * 16 + ref_nibble(A, s.K, s.bm, s.kfactor, r, t)];
+                    }
                 }
                 if (dump && ActK == TGr) dump[((size_t)n * s.M() + r) * G + kk] = sum;
-                partial_sum = __fadd_rn(partial_sum, lb[kk]);
-                const float f = (pl == 0) ? __fmaf_rn((float)sum, ls[kk], lb[kk]) : __fmul_rn((float)sum, ls[kk]);
+                const float f = (pl == 0) ? __fmaf_rn((float)sum, lsk, lbk) : __fmul_rn((float)sum, lsk);
                 vec_c = (j == 0) ? f : __fadd_rn(vec_c, f);
             }
             if (one_scale_per_group) {
@@ -580,6 +606,7 @@ static hipError_t launch_lo_t(const GemvArgs& a, hipStream_t st) {
     GemvPtrs p;
     p.W = (const uint4*)a.W; p.QL = (const uint4*)a.qlut_dev; p.LS = a.lut_scales; p.LB = a.lut_biases;
     p.SC = a.SC; p.C = a.C; p.dump = a.ps_dump; p.out_f16 = a.out_dtype == F16;
+    p.fa_xor = a.fa_mode == 2 ? 0x80808080u : 0u;
     hipLaunchKernelGGL((k_gemv_lo<BITS, TG, ZP, SM, ST, MODE>), dim3(a.s.nb(), a.N), dim3(256), 0, st, p, a.s);
     return hipGetLastError();
 }
@@ -587,9 +614,13 @@ static hipError_t launch_lo_t(const GemvArgs& a, hipStream_t st) {
 template <int BITS, typename ST, int MODE>
 static hipError_t launch_lo_b(const GemvArgs& a, hipStream_t st) {
     const Shape& s = a.s;
-    if (s.m_groups >= 1 && s.ags == s.K) return launch_lo_t<BITS, 16, false, 2, ST, MODE>(a, st);
-    if (s.m_groups >= 1) return s.ags == 64 ? launch_lo_t<BITS, 16, false, 1, ST, MODE>(a, st)
-                                            : launch_lo_t<BITS, 8, false, 1, ST, MODE>(a, st);
+    if constexpr (MODE == 2) {   // fast aggregation exists for the per-group-scale float path only (tbl.cc:534 TODO)
+        if (s.m_groups >= 1) return hipErrorInvalidValue;
+    } else {
+        if (s.m_groups >= 1 && s.ags == s.K) return launch_lo_t<BITS, 16, false, 2, ST, MODE>(a, st);
+        if (s.m_groups >= 1) return s.ags == 64 ? launch_lo_t<BITS, 16, false, 1, ST, MODE>(a, st)
+                                                : launch_lo_t<BITS, 8, false, 1, ST, MODE>(a, st);
+    }
     if (s.ags == 64) return s.zero_point ? launch_lo_t<BITS, 16, true, 0, ST, MODE>(a, st)
                                          : launch_lo_t<BITS, 16, false, 0, ST, MODE>(a, st);
     return s.zero_point ? launch_lo_t<BITS, 8, true, 0, ST, MODE>(a, st)
@@ -611,16 +642,18 @@ hipError_t launch_gemv(const GemvArgs& a, Variant v, hipStream_t st) {
     if (v == V_REF_LAYOUT) {
         const Shape& s = a.s;
         const int one_scale_per_group = (s.m_groups >= 1 && s.ags != s.K) ? 1 : 0;
+        if (a.fa_mode && (s.m_groups >= 1 && s.ags == s.K)) return hipErrorInvalidValue;   // no fast aggregation on the int32 path
         dim3 g((s.Mw + 63) / 64, a.N), b(64);
         if (a.sc_dtype == F32)
             hipLaunchKernelGGL((k_gemv_ref_layout<float>), g, b, 0, st, (const uint8_t*)a.W, a.qlut_ref, (const float*)a.SC,
-                               a.lut_scales, a.lut_biases, a.C, a.out_dtype == F16, a.ps_dump, s, one_scale_per_group);
+                               a.lut_scales, a.lut_biases, a.C, a.out_dtype == F16, a.ps_dump, s, one_scale_per_group, a.fa_mode);
         else
             hipLaunchKernelGGL((k_gemv_ref_layout<__half>), g, b, 0, st, (const uint8_t*)a.W, a.qlut_ref, (const __half*)a.SC,
-                               a.lut_scales, a.lut_biases, a.C, a.out_dtype == F16, a.ps_dump, s, one_scale_per_group);
+                               a.lut_scales, a.lut_biases, a.C, a.out_dtype == F16, a.ps_dump, s, one_scale_per_group, a.fa_mode);
         return hipGetLastError();
     }
     if (!gemv_lo_supported(a.s)) return hipErrorInvalidValue;
+    if (a.fa_mode) return a.sc_dtype == F32 ? launch_lo_st<float, 2>(a, st) : launch_lo_st<__half, 2>(a, st);
     const bool sdwa = (v == V_LO_SDWA);
     if (a.sc_dtype == F32) return sdwa ? launch_lo_st<float, 1>(a, st) : launch_lo_st<float, 0>(a, st);
     return sdwa ? launch_lo_st<__half, 1>(a, st) : launch_lo_st<__half, 0>(a, st);

@@ -170,9 +170,17 @@ class TMACGeMMWrapper:
         check(B.lib().tmac_hip_set_kcfg(M, K, N, bits, C.byref(cfg)))
 
     def register_weights(self, A_ref, scales_ref, M: int, K: int, bits: int, cfg: Optional[KCfg] = None,
-                         scales_dtype=F32, dev_dtype=F32, on_device=False) -> Weights:
+                         scales_dtype=F32, dev_dtype=F32, on_device=False, fast_aggregation: int = 0) -> Weights:
+        """fast_aggregation: 0 exact (default) | 1 signed halving adds (the reference's ARM ``-fa`` build) | 2 its AVX2
+        build; the lossy aggregation of python/t_mac/ops/qgemm.py:30,86 — a property of the registered weights here."""
         cfg = cfg or self.get_kcfg(M, K, 1, bits)
-        return Weights(A_ref, scales_ref, M, K, bits, cfg, scales_dtype, dev_dtype, on_device)
+        if not fast_aggregation:
+            return Weights(A_ref, scales_ref, M, K, bits, cfg, scales_dtype, dev_dtype, on_device)
+        check(B.lib().tmac_hip_set_fast_aggregation(int(fast_aggregation)))
+        try:
+            return Weights(A_ref, scales_ref, M, K, bits, cfg, scales_dtype, dev_dtype, on_device)
+        finally:
+            B.lib().tmac_hip_set_fast_aggregation(0)
 
     def llama_cpp_init(self, B_dev, M: int, K: int, N: int, bits: int, act_group_size: Optional[int] = None,
                        act_dtype: Optional[int] = None, stream=None) -> None:

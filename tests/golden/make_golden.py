@@ -52,6 +52,19 @@ def gen(name, seed, Mw, K, bits, bm, kfactor, gs, ags, zp, m_groups=-1):
     print(name, {k: v.shape for k, v in out.items()})
 
 
+def gen_fa(name):
+    """(a9) the same inputs through the reference's FastAggregation = true instantiation of the tbl intrinsic (its AVX2
+    flavour, the one that runs on this host): tests/golden/fa/<name>.npz holds only the outputs."""
+    d = dict(np.load(os.path.join(HERE, name + ".npz")))
+    Mw, K, bits, bm, kfactor, gs, ags, zp, mg = [int(x) for x in d["meta"]]
+    cbits = orc.ref_cbits_float(d["A_ref"], d["qlut"], d["S_ref"], d["lut_scales"], d["lut_biases"], Mw, K, bits, bm,
+                                kfactor, gs, ags, bool(zp), fa=True)
+    os.makedirs(os.path.join(HERE, "fa"), exist_ok=True)
+    np.savez_compressed(os.path.join(HERE, "fa", name + ".npz"), cbits_fa=cbits, C_fa=orc.combine_planes(cbits, Mw, bits),
+                        meta=d["meta"])
+    print("fa/" + name)
+
+
 def gen_prebuilt(name, setname, seed, Mw, K, bits, bm, mname):
     """Through the checked-in prebuilt C-ABI kernels, driven tile by tile like llama.cpp."""
     L = orc.ref_lib(setname)
@@ -101,4 +114,6 @@ if __name__ == "__main__":
     gen("w3_nozp_g128_a64", 5, 128, 256, 3, 192, 16, 128, 64, False)
     gen("w2_zp_g128_a32_kf8", 6, 64, 512, 2, 128, 8, 128, 32, True)
     gen("bitnet_w2_int32_k640", 7, 160, 640, 2, 320, 16, 128, 640, False, m_groups=1)
+    for n in ("w2_zp_g128_a64", "w2_nozp_g128_a64", "w4_zp_g128_a64", "w1_zp_g128_a64", "w3_nozp_g128_a64", "w2_zp_g128_a32_kf8"):
+        gen_fa(n)
     gen_prebuilt("prebuilt_llama2_7b_w2_k4096", "aarch64-llama-2-7b-2bit", 0, 64, 4096, 2, 128, 8192)

@@ -71,3 +71,19 @@ def test_extreme_tables(emu):
         PSo = orc.partial_sums(A, q, Mw, K, bits, bm, kf, ags)
         for mode in (0, 1, 2, 3, 4):
             assert np.array_equal(run_emu(emu, A, q, Mw, K, bits, bm, kf, ags, mode), PSo)
+
+
+@pytest.mark.parametrize("bits,bm,kf,ags,Mw,K", [
+    (2, 128, 16, 64, 64, 11008), (4, 256, 16, 64, 64, 1024), (2, 128, 8, 32, 64, 1024), (3, 192, 16, 64, 64, 512),
+    (1, 128, 16, 32, 128, 512),
+])
+def test_emulation_fast_aggregation(emu, bits, bm, kf, ags, Mw, K):
+    """(a9) the halving-adder tree of tmac_core.h (SegAcc<BITS, 2>, v_lerp_u8 modelled on the host) == the oracle's tree,
+    both flavours"""
+    case = orc.make_case(bits * 10 + ags, Mw, K, bits=bits, ags=ags)
+    A = orc.preprocess_weights(case["w"], bits, bm, kf)
+    S = orc.preprocess_scales(case["sc"], case["zr"], bits, bm)
+    q, ls, lb = orc.preprocessor(case["B"], ags)
+    for fa in (1, 2):
+        _, tap = orc.qgemm_float_fa(A, q, S, ls, lb, Mw, K, 1, bits, bm, kf, 128, ags, True, fa)
+        assert np.array_equal(run_emu(emu, A, q[0], Mw, K, bits, bm, kf, ags, 4 + fa), tap[0])

@@ -36,7 +36,7 @@ def rel_err(c, ref):
 
 
 def run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, m_groups=-1, N=1, variant=0, scale_dtype=None, out_f16=False,
-             act_f16=False, want_ps=True, gemm_min_n=None):
+             act_f16=False, want_ps=True, gemm_min_n=None, fast_aggregation=0):
     """register + preprocess + gemv on the GPU; returns dict(q, ls, lb, C, PS)"""
     import torch
     L = tm.lib()
@@ -52,7 +52,7 @@ def run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, m_groups=-1, N=1, varia
     wr = tm.TMACGeMMWrapper(act_group_size=ags)
     wr.set_workspace(K, N)
     dev_dt = tm.F16 if scale_dtype == "f16" else tm.F32
-    w = wr.register_weights(A, S, Mw, K, bits, cfg, scales_dtype=tm.F32, dev_dtype=dev_dt)
+    w = wr.register_weights(A, S, Mw, K, bits, cfg, scales_dtype=tm.F32, dev_dtype=dev_dt, fast_aggregation=fast_aggregation)
     Bt = torch.from_numpy(case["B"]).cuda()
     if act_f16:
         Bt = Bt.half()
@@ -209,6 +209,83 @@ def test_multi_row_activations(tm):
     q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, kf, gs, ags, True, N=N)
     assert np.array_equal(r["q"], q) and np.array_equal(r["PS"], PS)
     assert rel_err(r["C"], Cc) <= 2e-5
+
+
+FA_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "fa", "*.npz")))
+
+
+@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("name", FA_CASES)
+def test_fast_aggregation_golden(tm, name, variant):
+    """(a9) the reference's own FastAggregation build (AVX2 flavour, tests/golden/fa/) through the GPU: mode 2"""
+    d = dict(np.load(os.path.join(GOLD, name + ".npz")))
+    g = dict(np.load(os.path.join(GOLD, "fa", name + ".npz")))
+    Mw, K, bits, bm, kf, gs, ags, zp, mg = [int(x) for x in d["meta"]]
+    case = dict(w=d["w"], sc=d["sc"], zr=d.get("zr"), B=d["B"])
+    r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, bool(zp), mg, variant=variant, fast_aggregation=2)
+    assert np.array_equal(r["q"][0], d["qlut"])
+    _, tap = orc.qgemm_float_fa(r["A"], r["q"], r["S"], r["ls"], r["lb"], Mw, K, 1, bits, bm, kf, gs, ags, bool(zp), 2)
+    assert np.array_equal(r["PS"], tap)          # the halving-tree results, bit for bit
+    if variant == 3:
+        check_bits(r["C"][0], g["C_fa"])         # generic kernel: the reference's float order
+    else:
+        assert np.abs(r["C"][0] - g["C_fa"]).max() <= 1e-4 * np.abs(g["C_fa"]).max()
+
+
+@pytest.mark.parametrize("variant", [0, 3])
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,N", [
+    (256, 4096, 2, 128, 16, 128, 64, True, 1), (128, 11008, 2, 128, 16, 128, 64, True, 2),
+    (256, 4096, 4, 256, 16, 128, 64, True, 1), (128, 2048, 3, 192, 16, 128, 64, False, 1),
+    (128, 2048, 1, 128, 16, 128, 64, True, 3), (128, 2048, 2, 128, 8, 128, 32, True, 1),
+    (64, 1024, 2, 128, 8, 64, 32, False, 1),
+])
+def test_fast_aggregation_vs_oracle(tm, Mw, K, bits, bm, kf, gs, ags, zp, N, mode, variant):
+    """(a9) both flavours of the halving-adder aggregation against the restatement: tree results bit-exact, outputs
+    within the fp tolerance; the signed flavour also stays close to the exact path (it is the usable one)"""
+    case = orc.make_case(1000 + Mw + K + bits, Mw, K, N=N, bits=bits, gs=gs, ags=ags, zero_point=zp)
+    r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, N=N, variant=variant, fast_aggregation=mode)
+    Cc, tap = orc.qgemm_float_fa(r["A"], r["q"], r["S"], r["ls"], r["lb"], Mw, K, N, bits, bm, kf, gs, ags, zp, mode)
+    assert np.array_equal(r["PS"], tap)
+    if variant == 3:
+        check_bits(r["C"], Cc)
+    elif mode == 1:
+        assert rel_err(r["C"], Cc) < REL_TOL
+        if ags == 64:
+            exact = orc.qgemm_float(r["A"], r["q"], r["S"], r["ls"], r["lb"], Mw, K, N, bits, bm, kf, gs, ags, zp)
+            assert np.mean((r["C"] - exact) ** 2) / np.mean(exact ** 2) < 5e-3
+    else:
+        assert np.abs(r["C"] - Cc).max() <= 1e-4 * np.abs(Cc).max()
+
+
+def test_fast_aggregation_rejections(tm):
+    """what the reference does not define stays undefined: no fast aggregation on the unified-scale / int32 path, and
+    fast-aggregation weights do not run through the fused entry point"""
+    import torch
+    L = tm.lib()
+    case = orc.make_case(5, 320, 640, bits=2, m_groups=1, ags=640)
+    A = orc.preprocess_weights(case["w"], 2, 320, 16)
+    cfg = tm.KCfg.make(320, 640, 2, 320, 16, 0, 640, False, 1, 1)
+    wr = tm.TMACGeMMWrapper(act_group_size=640)
+    with pytest.raises(Exception):
+        wr.register_weights(A, case["sc"], 320, 640, 2, cfg, fast_aggregation=1)
+    case = orc.make_case(6, 128, 1024, bits=2)
+    A = orc.preprocess_weights(case["w"], 2, 128, 16)
+    S = orc.preprocess_scales(case["sc"], case["zr"], 2, 128)
+    cfg = tm.KCfg.make(128, 1024, 2, 128, 16, 128, 64, True, -1, 1)
+    wr = tm.TMACGeMMWrapper(act_group_size=64)
+    wr.set_workspace(1024, 1)
+    w = wr.register_weights(A, S, 128, 1024, 2, cfg, fast_aggregation=1)
+    Bt = torch.from_numpy(case["B"]).cuda()
+    Ct = torch.empty((1, 128), dtype=torch.float32, device="cuda")
+    with pytest.raises(Exception):
+        wr.fused([w], Bt, [Ct], 1)
+    w.free()
+    # and the mode does not leak into later registrations
+    w2 = wr.register_weights(A, S, 128, 1024, 2, cfg)
+    wr.fused([w2], Bt, [Ct], 1)
+    torch.cuda.synchronize()
+    w2.free()
 
 
 @pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,N", [

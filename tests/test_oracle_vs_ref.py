@@ -98,6 +98,28 @@ def test_float_path_bit_exact_vs_reference_intrinsics(bits, bm, kfactor, gs, ags
     assert nmse < 5e-4
 
 
+FA_CFGS = [  # bits, bm, kfactor, gs, ags, zp  (the FastAggregation = true instantiations of oracle/ref_shim.cc)
+    (2, 128, 16, 128, 64, True), (2, 128, 16, 128, 64, False), (4, 256, 16, 128, 64, True), (4, 256, 16, 128, 64, False),
+    (1, 128, 16, 128, 64, True), (3, 192, 16, 128, 64, True), (2, 128, 8, 128, 32, True), (2, 128, 16, 128, 32, True),
+]
+
+
+@pytest.mark.parametrize("bits,bm,kfactor,gs,ags,zp", FA_CFGS)
+def test_fast_aggregation_bit_exact_vs_reference_intrinsics(bits, bm, kfactor, gs, ags, zp):
+    """(a9) the halving-adder tree, the ActK rescale and the analytic bias (tbl.cc:201-256,301-318,474-477):
+    fa_mode 2 of the restatement == the reference's own FastAggregation build on this x86 host, to the bit."""
+    Mw, K = bm // bits * 2, 1024
+    case = orc.make_case(5 * bits + ags + 1, Mw, K, bits=bits, gs=gs, ags=ags, zero_point=zp)
+    A = orc.preprocess_weights(case["w"], bits, bm, kfactor)
+    S = orc.preprocess_scales(case["sc"], case["zr"], bits, bm)
+    q, ls, lb = orc.preprocessor(case["B"], ags)
+    Cor, tap = orc.qgemm_float_fa(A, q, S, ls, lb, Mw, K, 1, bits, bm, kfactor, gs, ags, zp, fa_mode=2)
+    cbits = orc.ref_cbits_float(A, q[0], S, ls[0], lb[0], Mw, K, bits, bm, kfactor, gs, ags, zp, fa=True)
+    Cref = orc.combine_planes(cbits, Mw, bits)
+    assert np.array_equal(Cor[0].view(np.uint32), Cref.view(np.uint32))
+    assert tap.min() >= -128 and tap.max() <= 127
+
+
 def _call_prebuilt(setname, bm, K, bits, Mw_total_bits_name, case, gs=128, ags=64):
     """Drive a checked-in prebuilt kernel set exactly as llama.cpp would (per-tile pointers)."""
     L = orc.ref_lib(setname)

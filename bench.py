@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--path", choices=["fused", "split"], default="fused",
                     help="fused: LUT build inside the GEMV kernel, q/k/v and gate/up batched (4 launches/layer); "
                          "split: preprocessor + one GEMV launch per matrix (11 launches/layer)")
+    ap.add_argument("--autotune", action="store_true",
+                    help="measure the kernel's launch configurations on this rank's shard shapes before the run instead of "
+                         "trusting the built-in heuristic (tmac_hip_autotune_fused; outside the timed region)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--eager-collectives", action="store_true",
                     help="multi-GPU: launch eagerly instead of capturing the RCCL all-gathers into the hipGraph "
@@ -194,6 +197,15 @@ def main():
     logical = {"qkv": 4096, "o": 4096, "gate_up": 11008, "down": 4096}
     ev_pairs = []
     use_ev = not args.no_kernel_events
+
+    # launch-configuration tuning on this rank's shard shapes (one measurement per distinct matrix set; the table is keyed
+    # by shape, so layer 0 stands for all layers).  Outside the timed region, like the reference's offline autotvm tuning.
+    tuned = {}
+    if args.path == "fused" and args.autotune and args.variant == 0:
+        for name, Mw, K, cnt, slot in MATS:
+            r = wr.autotune(layers[0][name], F16, F16)
+            tuned[name] = [r["ft"], r["wpq"], round(r["us"], 2), round(r["heuristic_us"], 2)]
+        torch.cuda.synchronize()
 
     def step(record):
         for li in range(args.layers):
@@ -334,6 +346,7 @@ def main():
             "frac_of_hbm_peak": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
             "config": {"workload": "llama-2-7b-w2a8-decode-all-layers", "layers": args.layers,
                        "gemv_per_step": 7 * args.layers, "launches_per_step": (4 if args.path == "fused" else 11) * args.layers, "path": args.path,
+                       "autotune": tuned,
                        "algorithmic_bytes_per_step": bytes_per_step, "weights": "W2 g128 zero-point, act_group 64",
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
                        "kernel_variant": args.variant, "launch": "hipGraph replay" if use_graph else "eager"},

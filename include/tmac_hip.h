@@ -174,6 +174,21 @@ int32_t tmac_hip_set_gemm_min_n(int n);
  * call (they take the 16-table-segment layout and run the two-kernel path: preprocessor + qgemm).  Per-group-scale
  * weights with act_group_size 32 or 64 only, as in the reference (no fast aggregation on its int32 path). */
 int32_t tmac_hip_set_fast_aggregation(int mode);
+/* Launch-configuration tuner of the fused decode kernel (the role autotvm's grid search over
+ * (bm, kfactor, bn) plays for the reference's CPU kernels, python/t_mac/ops/base.py:84-127, qgemm.py:98-116).
+ * tmac_hip_autotune_fused times every (threads per workgroup, waves per row quad) configuration of k_gemv_quad on the
+ * given 1..4 registered matrices (the set that tmac_hip_qgemm_fused_dev will be called with, N = 1), on HBM-cold
+ * rotating copies of the weights inside a replayed hipGraph, and records the fastest when it beats the built-in
+ * heuristic by more than 2 %; later fused calls with the same (bits, K, rows, matrices, dtypes) use it.  Results do not
+ * change (same kernel, same arithmetic).  best_ft = 0 on return means "the heuristic stands".  Allocates and frees its
+ * own buffers (a few hundred MB); synchronous; not for use inside a stream capture.
+ * tmac_hip_tune_save / tmac_hip_tune_load persist the table as text (return the number of entries, or < 0);
+ * $TMAC_HIP_TUNE_FILE is loaded on the first fused call. */
+int32_t tmac_hip_autotune_fused(const tmac_hip_weights* const* weights, int nmat, tmac_dtype_t act_dtype,
+                                tmac_dtype_t out_dtype, int* best_ft, int* best_wpq, float* best_us, float* heuristic_us);
+int32_t tmac_hip_tune_save(const char* path);
+int32_t tmac_hip_tune_load(const char* path);
+int32_t tmac_hip_tune_clear(void);
 
 /* ---- (1) reference-named host-pointer entry points ---------------------------------------
  * Signatures identical to the generated deploy/tuned/<set>/kernels.h.  `m` is bm for qgemm_lut

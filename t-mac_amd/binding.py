@@ -84,6 +84,11 @@ def load_library() -> C.CDLL:
         "tmac_hip_set_variant": ([C.c_int], i32),
         "tmac_hip_set_gemm_min_n": ([C.c_int], i32),
         "tmac_hip_set_fast_aggregation": ([C.c_int], i32),
+        "tmac_hip_autotune_fused": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                     C.POINTER(C.c_float), C.POINTER(C.c_float)], i32),
+        "tmac_hip_tune_save": ([C.c_char_p], i32),
+        "tmac_hip_tune_load": ([C.c_char_p], i32),
+        "tmac_hip_tune_clear": ([], i32),
         "tmac_hip_selftest": ([vp, vp, C.c_int], i32),
         "tmac_hip_selftest_mfma": ([vp, vp], i32),
         "tmac_hip_cache_clear": ([], i32),
@@ -104,3 +109,10 @@ def lib() -> C.CDLL:
 def check(rc: int) -> None:
     if rc != 0:
         raise TMACHipError(rc, load_library().tmac_hip_last_error().decode())
+
+
+def check_count(rc: int) -> int:
+    """for entry points that return a count (>= 0) or an error code (< 0)"""
+    if rc < 0:
+        raise TMACHipError(rc, load_library().tmac_hip_last_error().decode())
+    return rc

@@ -779,6 +779,9 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
     const int nst = (a.s.K / 32 + 63) / 64;
     // two waves per quad up to one quad per wave slot of the chip (4096), one beyond
     int best_ft = 512, best_wpq = (total_q <= 4096 && nst >= 2) ? 2 : 1;
+    // ... except where two waves per quad would leave the chip between one and two workgroups per CU (shards of a
+    // row-split model: 3 x 2048 and 2 x 2752 rows measure 7 % faster with one, profiles/r01_autotune_shards.txt)
+    if (best_wpq == 2 && total_q > 1024 && total_q < 2048) best_wpq = 1;
     if (BITS == 2 && total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
         // long rows, few quads: 3 waves per quad when that splits the steps evenly, else 4
         if (nst % 3 == 0 && a.s.K / 4 <= 6 * 768) { best_ft = 768; best_wpq = 3; }

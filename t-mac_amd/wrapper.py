@@ -16,7 +16,7 @@ from typing import Optional
 import numpy as np
 
 from . import binding as B
-from .binding import KCfg, F16, F32, check
+from .binding import KCfg, F16, F32, check, check_count
 
 
 def _ptr(x) -> int:
@@ -213,6 +213,24 @@ class TMACGeMMWrapper:
             cache[key] = (wa, ca)
         wa, ca = cache[key]
         check(B.lib().tmac_hip_qgemm_fused_dev(wa, n, _ptr(B_dev), act_dtype, ca, out_dtype, N, _stream(stream)))
+
+    def autotune(self, weights_list, act_dtype=F16, out_dtype=F16):
+        """Measure the launch configurations of the fused decode kernel on these matrices (the list ``fused`` will be
+        called with) and keep the fastest: ``tmac_hip_autotune_fused``.  Returns dict(ft, wpq, us, heuristic_us);
+        ft == 0 means the built-in heuristic was kept."""
+        n = len(weights_list)
+        wa = (C.c_void_p * n)(*[w.handle.value for w in weights_list])
+        ft, wpq, us, hus = C.c_int(0), C.c_int(0), C.c_float(0), C.c_float(0)
+        check(B.lib().tmac_hip_autotune_fused(wa, n, act_dtype, out_dtype, C.byref(ft), C.byref(wpq), C.byref(us), C.byref(hus)))
+        return dict(ft=ft.value, wpq=wpq.value, us=us.value, heuristic_us=hus.value)
+
+    @staticmethod
+    def tune_save(path: str) -> int:
+        return check_count(B.lib().tmac_hip_tune_save(path.encode()))
+
+    @staticmethod
+    def tune_load(path: str) -> int:
+        return check_count(B.lib().tmac_hip_tune_load(path.encode()))
 
     def fused_partial_sums(self, weights: Weights, B_dev, N: int = 1, act_dtype: Optional[int] = None, stream=None):
         """Parity tap of the fused kernel: (int32 PS as partial_sums(), fp32 C [N][Mw]); the in-kernel LUT

@@ -258,6 +258,49 @@ def test_fast_aggregation_vs_oracle(tm, Mw, K, bits, bm, kf, gs, ags, zp, N, mod
         assert np.abs(r["C"] - Cc).max() <= 1e-4 * np.abs(Cc).max()
 
 
+def test_autotuner(tm, tmp_path):
+    """(N4) tmac_hip_autotune_fused: measures the launch configurations on the q/k/v-like set, may record one, and never
+    changes results; the table survives a save / clear / load cycle"""
+    import torch
+    L = tm.lib()
+    L.tmac_hip_tune_clear()
+    Mw, K, bits, bm = 1024, 4096, 2, 128
+    cfg = tm.KCfg.make(Mw, K, bits, bm, 16, 128, 64, True, -1, 1)
+    wr = tm.TMACGeMMWrapper(act_group_size=64)
+    ws, cases = [], []
+    for i in range(3):
+        case = orc.make_case(40 + i, Mw, K, bits=bits, fp16_values=True)
+        A = orc.preprocess_weights(case["w"], bits, bm, 16)
+        S = orc.preprocess_scales(case["sc"], case["zr"], bits, bm)
+        ws.append(wr.register_weights(A, S, Mw, K, bits, cfg, scales_dtype=tm.F32, dev_dtype=tm.F16))
+        cases.append(case)
+    Bt = torch.from_numpy(cases[0]["B"]).cuda().half()
+    Cs = [torch.empty((1, Mw), dtype=torch.float16, device="cuda") for _ in range(3)]
+    wr.fused(ws, Bt, Cs, 1)
+    torch.cuda.synchronize()
+    before = [c.clone() for c in Cs]
+    r = wr.autotune(ws, tm.F16, tm.F16)
+    assert r["heuristic_us"] > 0 and r["us"] > 0 and r["us"] <= r["heuristic_us"] * 1.0001
+    assert (r["ft"], r["wpq"]) in [(0, 0), (512, 1), (512, 2), (768, 3), (1024, 1), (1024, 2), (1024, 4)]
+    # force an entry so that the table lookup path is exercised whatever the measurement said
+    p = tmp_path / "t.txt"
+    p.write_text("2 4096 %d 3 13 1024 2 1.0\n" % (3 * Mw // 4))
+    assert wr.tune_load(str(p)) == 1
+    for c in Cs:
+        c.zero_()
+    wr.fused(ws, Bt, Cs, 1)
+    torch.cuda.synchronize()
+    for a, b in zip(before, Cs):          # same arithmetic; only the fp32 order across a row's waves may differ
+        assert rel_err(b.float().cpu().numpy(), a.float().cpu().numpy()) < REL_TOL
+    n = wr.tune_save(str(tmp_path / "o.txt"))
+    assert n >= 1
+    L.tmac_hip_tune_clear()
+    assert wr.tune_load(str(tmp_path / "o.txt")) == n
+    L.tmac_hip_tune_clear()
+    for w in ws:
+        w.free()
+
+
 def test_fast_aggregation_rejections(tm):
     """what the reference does not define stays undefined: no fast aggregation on the unified-scale / int32 path, and
     fast-aggregation weights do not run through the fused entry point"""

@@ -71,6 +71,28 @@ n_tile_num = 50
 """
 
 
+def test_tuning_table_file_round_trip(tmp_path):
+    """the launch-configuration table of the tuner is host state: save / load / reject malformed entries (no GPU needed)"""
+    L = tmac_amd.lib()
+    assert L.tmac_hip_tune_clear() == 0
+    p = tmp_path / "tune.txt"
+    p.write_text("# comment\n2 4096 3072 3 13 512 2 5.500\n2 11008 1024 1 13 768 3 6.250\n")
+    assert L.tmac_hip_tune_load(str(p).encode()) == 2
+    q = tmp_path / "out.txt"
+    assert L.tmac_hip_tune_save(str(q).encode()) == 2
+    rows = [l.split() for l in q.read_text().splitlines() if not l.startswith("#")]
+    assert [r[:7] for r in rows] == [["2", "4096", "3072", "3", "13", "512", "2"], ["2", "11008", "1024", "1", "13", "768", "3"]]
+    bad = tmp_path / "bad.txt"
+    bad.write_text("2 4096 3072 3 13 640 2 5.5\n")      # 640 threads is not a configuration of the kernel
+    assert L.tmac_hip_tune_load(str(bad).encode()) < 0
+    assert b"640" in L.tmac_hip_last_error()
+    bad.write_text("2 4096 oops\n")
+    assert L.tmac_hip_tune_load(str(bad).encode()) < 0
+    assert L.tmac_hip_tune_load(str(tmp_path / "missing.txt").encode()) < 0
+    assert L.tmac_hip_tune_clear() == 0
+    assert L.tmac_hip_tune_save(str(q).encode()) == 0
+
+
 def test_kcfg_ini_lookup(tmp_path):
     """same file format and section naming as deploy/compile.py:153-165 / tmac_gemm_wrapper.h:230-255"""
     p = tmp_path / "kcfg.ini"

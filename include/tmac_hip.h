@@ -179,7 +179,7 @@ int32_t tmac_hip_set_fast_aggregation(int mode);
  * tmac_hip_autotune_fused times every (threads per workgroup, waves per row quad) configuration of k_gemv_quad on the
  * given 1..4 registered matrices (the set that tmac_hip_qgemm_fused_dev will be called with, N = 1), on HBM-cold
  * rotating copies of the weights inside a replayed hipGraph, and records the fastest when it beats the built-in
- * heuristic by more than 2 %; later fused calls with the same (bits, K, rows, matrices, dtypes) use it.  Results do not
+ * heuristic by more than 4 %; later fused calls with the same (bits, K, rows, matrices, dtypes) use it.  Results do not
  * change (same kernel, same arithmetic).  best_ft = 0 on return means "the heuristic stands".  Allocates and frees its
  * own buffers (a few hundred MB); synchronous; not for use inside a stream capture.
  * tmac_hip_tune_save / tmac_hip_tune_load persist the table as text (return the number of entries, or < 0);

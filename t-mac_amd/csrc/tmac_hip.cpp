@@ -836,7 +836,7 @@ extern "C" int32_t tmac_hip_autotune_fused(const tmac_hip_weights* const* wl, in
     if (err != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "autotune: %s", hipGetErrorString(err));
     if (bestv.ft == 0) return fail(TMAC_HIP_E_NOMATCH, "no k_gemv_quad configuration for these matrices");
     // the heuristic's choice stands unless a candidate beats it by more than the run-to-run noise of the measurement
-    if (heur > 0.f && bestv.us > 0.98f * heur) {
+    if (heur > 0.f && bestv.us > 0.96f * heur) {
         bestv.us = heur;
         bestv.ft = 0;
     }

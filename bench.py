@@ -326,10 +326,40 @@ def main():
         durs = np.array(durs)
         hb = algorithmic_bytes(shard_rows["down"], 11008)
         ach = hb / float(np.mean(durs)) / 1e9
+        # floor of this launch structure, measured the same way: a kernel that only READS the same number of bytes
+        # (distinct buffers per launch, > MALL in total) and an empty kernel, as dependent nodes of a replayed graph
+        floor = None
+        if use_graph:
+            nb = (hb + 4095) // 4096 * 4096
+            bufs = [torch.empty(nb, dtype=torch.uint8, device=dev).fill_(0x5a) for _ in range(args.layers)]
+            sink = torch.zeros(4096, dtype=torch.uint8, device=dev)
+            cs = torch.cuda.current_stream().cuda_stream
+
+            def floor_time(nbytes):
+                def launches():
+                    for b in bufs:
+                        tmac_amd.binding.check(L.tmac_hip_debug_stream_read(b.data_ptr(), nbytes, sink.data_ptr(), cs))
+                launches(); torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    cs2 = torch.cuda.current_stream().cuda_stream
+                    for b in bufs:
+                        tmac_amd.binding.check(L.tmac_hip_debug_stream_read(b.data_ptr(), nbytes, sink.data_ptr(), cs2))
+                ts = []
+                for r in range(8):
+                    f0 = torch.cuda.Event(enable_timing=True); f1 = torch.cuda.Event(enable_timing=True)
+                    f0.record(); g.replay(); f1.record(); torch.cuda.synchronize()
+                    if r >= 3:
+                        ts.append(f0.elapsed_time(f1) * 1e-3 / len(bufs))
+                return float(np.mean(ts))
+            floor = {"pure_read_same_bytes_us": round(floor_time(hb // 16 * 16) * 1e6, 3),
+                     "near_empty_launch_us": round(floor_time(4096) * 1e6, 3)}
+            del bufs
         roof = {"bound": "hbm", "kernel": ("k_gemv_quad, LUT build fused" if args.path == "fused" else "k_gemv_quad, LUT prebuilt") + ", headline shape 4096x11008 W2 g128 zp", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES,
                 "algorithmic_bytes_per_launch": hb, "avg_launch_us": round(float(np.mean(durs)) * 1e6, 3),
                 "min_launch_us": round(float(np.min(durs)) * 1e6, 3), "launches_timed": reps * args.layers,
+                "launch_floor": floor,
                 "timing": "hipEvent pair on the launch stream around %d back-to-back launches (distinct weights, %s), mean of 10" % (args.layers, "hipGraph replay" if use_graph else "eager")}
 
     if rank == 0:

@@ -174,6 +174,10 @@ int32_t tmac_hip_set_gemm_min_n(int n);
  * call (they take the 16-table-segment layout and run the two-kernel path: preprocessor + qgemm).  Per-group-scale
  * weights with act_group_size 32 or 64 only, as in the reference (no fast aggregation on its int32 path). */
 int32_t tmac_hip_set_fast_aggregation(int mode);
+/* Measurement aid for bench.py: one launch that only reads `bytes` of device memory (non-temporal 16-byte loads) and
+ * keeps nothing -- the cost of streaming a matrix's bytes with no LUT build and no lookups, under the same launch
+ * mechanism as the GEMV it is compared with.  dev_sink: >= 4 KB of device scratch. */
+int32_t tmac_hip_debug_stream_read(const void* dev_src, size_t bytes, void* dev_sink, void* stream);
 /* Launch-configuration tuner of the fused decode kernel (the role autotvm's grid search over
  * (bm, kfactor, bn) plays for the reference's CPU kernels, python/t_mac/ops/base.py:84-127, qgemm.py:98-116).
  * tmac_hip_autotune_fused times every (threads per workgroup, waves per row quad) configuration of k_gemv_quad on the

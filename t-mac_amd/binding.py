@@ -84,6 +84,7 @@ def load_library() -> C.CDLL:
         "tmac_hip_set_variant": ([C.c_int], i32),
         "tmac_hip_set_gemm_min_n": ([C.c_int], i32),
         "tmac_hip_set_fast_aggregation": ([C.c_int], i32),
+        "tmac_hip_debug_stream_read": ([vp, sz, vp, vp], i32),
         "tmac_hip_autotune_fused": ([C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                      C.POINTER(C.c_float), C.POINTER(C.c_float)], i32),
         "tmac_hip_tune_save": ([C.c_char_p], i32),

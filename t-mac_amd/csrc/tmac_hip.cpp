@@ -860,6 +860,14 @@ extern "C" int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weigh
     return fused_impl(weights, nmat, B_dev, act_dtype, C_dev, out_dtype, N, nullptr, nullptr, (hipStream_t)stream);
 }
 
+// measurement aid: a launch that only reads `bytes` from dev_src (sink: >= 4 KB of device scratch, practically never written)
+extern "C" int32_t tmac_hip_debug_stream_read(const void* dev_src, size_t bytes, void* dev_sink, void* stream) {
+    if (!dev_src || !dev_sink || bytes < 16) return fail(TMAC_HIP_E_ARG, "bad stream_read arguments");
+    hipError_t e = launch_stream_read(dev_src, bytes, dev_sink, (hipStream_t)stream);
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "stream_read launch: %s", hipGetErrorString(e));
+    return TMAC_HIP_OK;
+}
+
 // A/B knobs of the quad kernel: threads per workgroup (512/1024) and waves per quad (1/2); 0 = heuristic
 extern "C" int32_t tmac_hip_debug_quad_config(int force_ft, int force_wpq) {
     g_force_ft = force_ft; g_force_wpq = force_wpq;

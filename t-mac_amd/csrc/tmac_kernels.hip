@@ -531,6 +531,27 @@ __global__ void k_gemv_ref_layout(const uint8_t* __restrict__ A, const int8_t* _
 }
 
 // ---------------------------------------------------------------------------------------------
+// Measurement aid (bench.py "floor" leg): a kernel that only READS n16 uint4 (non-temporal, every wave instruction
+// 1 KiB contiguous) and keeps nothing -- what a launch that streams the same bytes costs on this stack with no
+// LUT build and no lookups.  Not part of the compute path.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stream_read(const u32x4* __restrict__ src, size_t n16, uint32_t* __restrict__ sink) {
+    const size_t base = (size_t)blockIdx.x * 512 + threadIdx.x;
+    u32x4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    if (base < n16) a = __builtin_nontemporal_load(src + base);
+    if (base + 256 < n16) b = __builtin_nontemporal_load(src + base + 256);
+    a ^= b;
+    const uint32_t r = a.x ^ a.y ^ a.z ^ a.w;
+    if (r == 0x12345678u) sink[blockIdx.x & 1023] = r;   // practically never: keeps the loads alive without store traffic
+}
+
+hipError_t launch_stream_read(const void* src, size_t bytes, void* sink, hipStream_t st) {
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_stream_read, dim3((unsigned)((n16 + 511) / 512)), dim3(256), 0, st, (const u32x4*)src, n16, (uint32_t*)sink);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 hipError_t launch_selftest(const uint32_t* in, uint32_t* out, int n, hipStream_t st) {

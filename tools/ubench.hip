@@ -40,8 +40,60 @@ static void run(const char* tag, std::vector<u32x4*>& bufs, size_t bytes, int th
     printf("%-28s bytes=%8zu blocks=%5d thr=%4d NL=%2d nt=%d : %7.3f us/launch  %7.1f GB/s\n", tag, bytes, blocks, threads, NL, (int)NT, us, bytes / us * 1e-3);
 }
 
+// ---- the same floors as a replayed hipGraph of dependent kernel nodes (how bench.py launches the decode step) ----
+template <int NL>
+static double graph_chain(hipStream_t st, std::vector<u32x4*>& bufs, size_t bytes, int threads, uint32_t* out, bool empty) {
+    const size_t n4 = bytes / 16;
+    const int blocks = (int)(n4 / ((size_t)threads * NL));
+    hipGraph_t g; hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    for (auto b : bufs) {
+        if (empty) hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, (int*)nullptr);
+        else hipLaunchKernelGGL((k_stream<NL, true>), dim3(blocks), dim3(threads), 0, st, b, out);
+    }
+    CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    double best = 1e30;
+    for (int rep = 0; rep < 6; ++rep) {
+        CK(hipEventRecord(e0, st)); CK(hipGraphLaunch(ge, st)); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep && ms * 1e3 / bufs.size() < best) best = ms * 1e3 / bufs.size();
+    }
+    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    return best;
+}
+
+static int graph_main() {
+    // bytes per launch of the four llama-2-7B W2 decode launches (weights + scales/zeros)
+    struct { const char* name; size_t bytes; } L[] = {{"o        4096x4096      ", 4743424}, {"down     4096x11008     ", 12734128},
+                                                       {"qkv      3 x 4096x4096  ", 3 * 4743424}, {"gate_up  2 x 11008x4096 ", 2 * 12697600}};
+    hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    uint32_t* out; CK(hipMalloc((void**)&out, 1 << 20));
+    std::vector<u32x4*> one(64, nullptr);
+    printf("replayed hipGraph of dependent kernel nodes, per node:\n");
+    printf("  empty kernel (256 x 256 threads)            : %6.2f us\n", graph_chain<4>(st, one, 1 << 20, 256, out, true));
+    for (auto& l : L) {
+        const size_t bytes = (l.bytes + 65535) / 65536 * 65536;
+        const int nbuf = (int)((size_t)(800u << 20) / bytes) + 1;   // > 3 x the 256 MB MALL
+        std::vector<u32x4*> bufs(nbuf);
+        for (auto& b : bufs) { CK(hipMalloc((void**)&b, bytes)); CK(hipMemset(b, 0x5a, bytes)); }
+        CK(hipDeviceSynchronize());
+        double best = 1e30; int bt = 0, bn = 0;
+        const double a = graph_chain<4>(st, bufs, bytes, 256, out, false); if (a < best) { best = a; bt = 256; bn = 4; }
+        const double b8 = graph_chain<8>(st, bufs, bytes, 256, out, false); if (b8 < best) { best = b8; bt = 256; bn = 8; }
+        const double c = graph_chain<4>(st, bufs, bytes, 512, out, false); if (c < best) { best = c; bt = 512; bn = 4; }
+        const double d = graph_chain<8>(st, bufs, bytes, 512, out, false); if (d < best) { best = d; bt = 512; bn = 8; }
+        const double e = graph_chain<2>(st, bufs, bytes, 256, out, false); if (e < best) { best = e; bt = 256; bn = 2; }
+        printf("  pure read of %s %9zu B : %6.2f us  (%6.1f GB/s; best of 5 shapes: %d threads x %d uint4)\n", l.name, l.bytes, best, l.bytes / best * 1e-3, bt, bn);
+        for (auto b : bufs) CK(hipFree(b));
+    }
+    return 0;
+}
+
 int rate_main();
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'g') return graph_main();
     if (argc > 1) return rate_main();
     const size_t big = 12734128 / 16384 * 16384 + 16384, small = 4743424 / 16384 * 16384 + 16384;
     const int nbuf = 32;   // 32 x 12.7 MB = 407 MB > 256 MB MALL

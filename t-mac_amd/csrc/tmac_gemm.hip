@@ -123,18 +123,24 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     // ---- compute roles ----------------------------------------------------------------------------------------
     // A operand, lane (g, i16): bit-plane row (o, p) of row tile rt; tables 2g, 2g+1 of the unit are nibble quads
     // q = 2g*BITS + p and q + BITS -> dwords q >> 1 (and + BITS/2) of the unit's BITS uint4 (tmac_layout.h)
-    const int p_a = i16 % BITS;
+    // Row order inside a 16-row tile.  W4: [output][plane], the 4 accumulator rows of a lane are the planes of one output.
+    // W2: tile row 4q + r is plane r >> 1 of output 2q + (r & 1), so a lane's accumulator rows are (o0 p0, o1 p0, o0 p1,
+    // o1 p1): each packed-fp32 register pair holds ONE plane of the lane's two outputs and the planes combine pairwise.
+    const int p_a = (BITS == 2) ? ((i16 >> 1) & 1) : (i16 % BITS);
+    const int ol_t = (BITS == 2) ? (2 * (i16 >> 2) + (i16 & 1)) : (i16 / BITS);   // output row within the tile
     const int d0 = (2 * g * BITS + p_a) >> 1;              // BITS 2: 2g, 2g+1;  BITS 4: 4g + (p>>1), + 2
     int a_ql[GRT], a_sh[GRT];
 #pragma unroll
     for (int rt = 0; rt < GRT; ++rt) {
-        const int ol = (w * GRT + rt) * ORPT + i16 / BITS;  // output row within the workgroup
+        const int ol = (w * GRT + rt) * ORPT + ol_t;         // output row within the workgroup
         a_ql[rt] = ol >> 2;
         a_sh[rt] = (8 * (ol & 3) + 4 * (p_a & 1) + 29) & 31; // rotate-right count that puts the nibble (byte beta, half q & 1) at bits 3..6
     }
 
     gv4i_t c[GRT][GNT];
-    gv2f_t facc[GRT][GNT][2];                               // rows (4g, 4g+1), (4g+2, 4g+3) of the tile: v_pk_*_f32 operands
+    // W4: per-plane accumulators, rows (4g, 4g+1), (4g+2, 4g+3) of the tile as v_pk_*_f32 operands; combined at the end.
+    // W2: ONE pair per tile = the lane's two outputs, planes already combined (index [1] unused).
+    gv2f_t facc[GRT][GNT][2];
 #pragma unroll
     for (int rt = 0; rt < GRT; ++rt)
 #pragma unroll
@@ -199,20 +205,35 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
 #pragma unroll
                     for (int nt = 0; nt < GNT; ++nt) {
                         const float ls = ep[buf][ag][0][nt * 16 + i16], lb = ep[buf][ag][1][nt * 16 + i16];
-                        const float lb2 = __fmul_rn(2.0f, lb);
+                        const float lb2 = __fmul_rn(2.0f, lb), hlb = __fmul_rn(0.5f, lb);
 #pragma unroll
                         for (int rt = 0; rt < GRT; ++rt) {
                             if (DUMP) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) {
-                                    const int o = orow_wg + (w * GRT + rt) * ORPT + (4 * g + r) / BITS, nn = n0 + nt * 16 + i16;
-                                    if (nn < a.N && o < s.Mw) a.dump[((size_t)nn * s.M() + mrow(o, r % BITS, BITS)) * G + kk] = c[rt][nt][r] - 0x4B400000;
+                                    const int o = orow_wg + (w * GRT + rt) * ORPT + (BITS == 2 ? 2 * g + (r & 1) : (4 * g + r) / BITS), nn = n0 + nt * 16 + i16;
+                                    const int pl = (BITS == 2) ? (r >> 1) : (r % BITS);
+                                    if (nn < a.N && o < s.Mw) a.dump[((size_t)nn * s.M() + mrow(o, pl, BITS)) * G + kk] = c[rt][nt][r] - 0x4B400000;
                                 }
                             }
                             // rows 4g + 2pr, 4g + 2pr + 1 = planes (2pr) % BITS and the next one (never plane 0) of output
                             // row oo = 2pr / BITS.  tbl.cc: plane 0 takes v = fma(ps, ls, lb), the others v = ps * ls
                             // (= fma(ps, ls, +0) up to the sign of a zero), then acc = fma(v, scale, acc) and, plane 0 with
                             // zero points, acc = fma(zero, 2 lb, acc) (adding fma(0, 2 lb, acc) = acc to the odd lane).
+                            if constexpr (BITS == 2) {
+                                // planes first (exact: small integers and halves), then ONE scale chain per output:
+                                //   C += ((ps0/2 + ps1) * ls + lb/2) * scale + zero * lb
+                                // = alpha0 * [(ps0 ls + lb) scale + zero 2 lb] + alpha1 * [ps1 ls scale] of tbl.cc:479-526 +
+                                // kernels.cc:1068 with the roundings of the per-plane chains merged (fp32, <= 1e-3 contract)
+                                const gv2f_t m2 = {12582912.0f, 12582912.0f};
+                                const gv2f_t ps0 = (gv2f_t){__int_as_float(c[rt][nt][0]), __int_as_float(c[rt][nt][1])} - m2;
+                                const gv2f_t ps1 = (gv2f_t){__int_as_float(c[rt][nt][2]), __int_as_float(c[rt][nt][3])} - m2;
+                                const gv2f_t psc = __builtin_elementwise_fma(ps0, (gv2f_t){0.5f, 0.5f}, ps1);
+                                const gv2f_t v = __builtin_elementwise_fma(psc, (gv2f_t){ls, ls}, (gv2f_t){hlb, hlb});
+                                gv2f_t acc = __builtin_elementwise_fma(v, (gv2f_t){sc[rt][0], sc[rt][1]}, facc[rt][nt][0]);
+                                if (ZP) acc = __builtin_elementwise_fma((gv2f_t){zr[rt][0], zr[rt][1]}, (gv2f_t){lb, lb}, acc);
+                                facc[rt][nt][0] = acc;
+                            } else
 #pragma unroll
                             for (int pr = 0; pr < 2; ++pr) {
                                 const int oo = (2 * pr) / BITS;
@@ -248,9 +269,14 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
 #pragma unroll
             for (int oo = 0; oo < 4 / BITS; ++oo) {
                 const int o = orow_wg + (w * GRT + rt) * ORPT + (4 * g) / BITS + oo;
-                float acc = __fmul_rn(facc[rt][nt][(oo * BITS) >> 1][0], 0.5f);
+                float acc;
+                if constexpr (BITS == 2) {
+                    acc = facc[rt][nt][0][oo];
+                } else {
+                    acc = __fmul_rn(facc[rt][nt][(oo * BITS) >> 1][0], 0.5f);
 #pragma unroll
-                for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(facc[rt][nt][(oo * BITS + pl) >> 1][(oo * BITS + pl) & 1], g_alpha(pl)));
+                    for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(facc[rt][nt][(oo * BITS + pl) >> 1][(oo * BITS + pl) & 1], g_alpha(pl)));
+                }
                 if (o < s.Mw) g_st(a.C, a.out_f16, (size_t)n * s.Mw + o, acc);
             }
         }

@@ -133,6 +133,12 @@ def cpu_baseline(seconds=6.0):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Libraries underneath write banners to file descriptor 1 (RCCL prints its
+    # version block there under torchrun), so everything else that reaches fd 1 is sent to stderr and the original stdout
+    # is kept for the result line alone.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -244,29 +250,54 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step(False)
             if dist_on:
-                import threading
-                done = threading.Event()
-
-                def watchdog():
-                    if not done.wait(240.0):
-                        sys.stderr.write("bench.py: the captured step (with RCCL all-gathers) did not complete; "
-                                         "rerun with --eager-collectives\n")
-                        sys.stderr.flush()
-                        os._exit(3)
-                threading.Thread(target=watchdog, daemon=True).start()
-                graph.replay()
-                torch.cuda.synchronize()
-                done.set()
+                # ProcessGroupNCCL's watchdog thread polls the events of earlier collectives; under the default (global)
+                # capture mode such a query from another thread invalidates the capture and kills the process (seen on the
+                # development box).  Let it reap what has completed, then capture in thread-local mode, where only this
+                # thread's calls are policed.
+                time.sleep(1.0)
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    step(False)
+            else:
+                with torch.cuda.graph(graph):
+                    step(False)
         except Exception as e:   # capture not supported with this RCCL / torch build: measured eagerly instead
             if not dist_on:
                 raise
             sys.stderr.write(f"bench.py: graph capture with collectives failed ({e!r}); launching eagerly\n")
             graph = None
             use_graph = False
-            torch.cuda.synchronize()
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+
+    def first_step():
+        # every rank runs exactly one step here whether its capture succeeded or not, so that the ranks stay aligned on
+        # the number of collectives issued; a failed capture can leave a sticky HIP error behind, hence one retry
+        if graph is not None:
+            graph.replay()
+        else:
+            try:
+                step(False)
+            except tmac_amd.binding.TMACHipError:
+                torch.cuda.synchronize()
+                step(False)
+        torch.cuda.synchronize()
+
+    if dist_on:
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(240.0):
+                sys.stderr.write("bench.py: the first step with RCCL all-gathers did not complete; "
+                                 "rerun with --eager-collectives\n")
+                sys.stderr.flush()
+                os._exit(3)
+        threading.Thread(target=watchdog, daemon=True).start()
+        first_step()
+        done.set()
 
     def run_step():
         if graph is not None:
@@ -388,7 +419,8 @@ def main():
                 res["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"error": repr(e)}
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(res) + "\n").encode())
     if dist_on:
         dist.destroy_process_group()
 

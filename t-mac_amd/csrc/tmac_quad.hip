@@ -225,6 +225,10 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     const int tstride = nst * 64 + 1;                            // whole steps: units past K hold zero tables
     uint4* tab = lds;                                            // [4][tstride]
     const int GP = nst * 32;                                     // act groups of the padded steps (>= G)
+    // MFMA accumulate with per-group scales: the epilogue works on the plane-combined integer (see compute_mfma), which
+    // wants ls / 2 and lb / 2 -- stored halved (exact) instead of being halved per use
+    constexpr bool HALVES = (ACC == 1 && SM != 2);
+    constexpr float LSK = HALVES ? 0.5f : 1.0f;
     float* l_ls = reinterpret_cast<float*>(lds + 4 * tstride);   // [GP]  (groups past K: 0)
     float* l_lb = l_ls + GP;                                     // [GP]
     float* l_red = l_lb + GP;                                    // [2][NWV][4][4] partials (WPQ == 2 / SM 2)
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                 tab[j4 * tstride + u] = v;
             }
         if (SM == 2) { if (tid == 0) { l_ls[0] = a.lut_scales[n]; l_lb[0] = a.lut_biases[n]; } }
-        else for (int i = tid; i < G; i += FT) { l_ls[i] = a.lut_scales[(size_t)n * G + i]; l_lb[i] = a.lut_biases[(size_t)n * G + i]; }
+        else for (int i = tid; i < G; i += FT) { l_ls[i] = __fmul_rn(LSK, a.lut_scales[(size_t)n * G + i]); l_lb[i] = __fmul_rn(LSK, a.lut_biases[(size_t)n * G + i]); }
     } else {
         float gscale = 0.f, gtinv = 0.f;
         if (SM == 2) {
@@ -384,8 +388,8 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                 } else {
                     const float c1 = qdpp_f<0x104>(v);      // row_shl:4: the second chunk of the act group
                     if ((p & 7) == 0) {
-                        l_ls[p >> 3] = scales;
-                        l_lb[p >> 3] = __fadd_rn(__fadd_rn(0.0f, v), c1);
+                        l_ls[p >> 3] = __fmul_rn(LSK, scales);
+                        l_lb[p >> 3] = __fmul_rn(LSK, __fadd_rn(__fadd_rn(0.0f, v), c1));
                     }
                 }
             }
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     __syncthreads();
     QSTAMP(3);
     if (a.lut_tap && blockIdx.x == 0) {
-        for (int i = tid; i < (SM == 2 ? 1 : G); i += FT) { a.lut_tap[(size_t)n * 2 * G + i] = l_ls[i]; a.lut_tap[(size_t)n * 2 * G + G + i] = l_lb[i]; }
+        for (int i = tid; i < (SM == 2 ? 1 : G); i += FT) { a.lut_tap[(size_t)n * 2 * G + i] = __fmul_rn(1.0f / LSK, l_ls[i]); a.lut_tap[(size_t)n * 2 * G + G + i] = __fmul_rn(1.0f / LSK, l_lb[i]); }
     }
 
     // ---- 4. stream this wave's quads -----------------------------------------------------------
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
             const int ug = ub4 + 2 * gi;
             {   // act groups past K have zero tables and zero LUT scale/bias: they add exactly 0, no guard needed
                 const int kk = ug >> 1;
-                const float ls = l_ls[kk], lb = l_lb[kk];
+                const float hls = l_ls[kk], hlb = l_lb[kk];           // ls / 2, lb / 2 (HALVES)
                 const bool first = (gi == 0) || (a.gs_shift >= 2);   // static register indices only: a run-time
                 float sc, zr = 0.f;                                   // subscript would put sraw in scratch memory
                 if (SCF16) {
@@ -541,15 +545,21 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                     sc = __uint_as_float(first ? f.sraw[0] : f.sraw[2]);
                     if (ZP) zr = __uint_as_float(first ? f.sraw[1] : f.sraw[3]);
                 }
+                // Bit-planes are combined as integers before the one conversion and scale chain of the act group:
+                //   sum_p alpha_p [(ps_p ls + [p = 0] lb) scale + [p = 0] zero 2 lb]        (tbl.cc:479-526, kernels.cc:1068)
+                // = ((sum_p 2^p ps_p) (ls / 2) + lb / 2) scale + (2 zero) (lb / 2)          alpha_p = 2^(p-1); |sum| < 2^15
+                // -- the same real number with fewer roundings (fp32 contract 1e-3; the integer sums stay the tap).
+                int32_t comb = 0;
 #pragma unroll
-                for (int pl = 0; pl < BITS; ++pl) {
+                for (int pl = BITS - 1; pl >= 0; --pl) {
                     const int32_t ps = (gi == 0) ? (c[pl].x + c[pl].y) : (c[pl].z + c[pl].w);
                     if (DUMP && a.dump && o < Mw_m && ug < nu) a.dump[((size_t)n * Mw_m * BITS + mrow(o, pl, BITS)) * G + kk] = ps;
-                    const float v = (pl == 0) ? __fmaf_rn((float)ps, ls, lb) : __fmul_rn((float)ps, ls);
-                    float cc = __fmaf_rn(v, sc, cacc[0][pl]);
-                    if (ZP && pl == 0) cc = __fmaf_rn(zr, __fmul_rn(2.0f, lb), cc);
-                    cacc[0][pl] = cc;
+                    comb = (pl == BITS - 1) ? ps : (int32_t)(((uint32_t)comb << 1) + (uint32_t)ps);   // Horner: v_lshl_add_u32
                 }
+                const float v = __fmaf_rn((float)comb, hls, hlb);
+                float cc = __fmaf_rn(v, sc, cacc[0][0]);
+                if (ZP) cc = __fmaf_rn(__fadd_rn(zr, zr), hlb, cc);
+                cacc[0][0] = cc;
             }
         }
     };
@@ -562,9 +572,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
         if (ACC == 1 && SM != 2) {   // per-group scales: fp32 partials
             float acc = 0.f;
             if (have) {
-                acc = __fmul_rn(cacc[0][0], 0.5f);
-#pragma unroll
-                for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(cacc[0][pl], q_alpha(pl)));
+                acc = cacc[0][0];                             // planes already combined (compute_mfma)
                 acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // lanes with the same beta: rotate by 4, 8 within the row
                 acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
                 acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));

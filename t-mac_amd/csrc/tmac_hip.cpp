@@ -333,31 +333,36 @@ static int32_t register_impl(tmac_hip_weights** out, const void* A_ref, const vo
         tmac_hip_free_weights(w);
         return code;
     };
+#define REG_TRY(expr)                                                                                       \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) return cleanup(fail(TMAC_HIP_E_RUNTIME, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+    } while (0)
     if (src_on_device && !keep_ref) {
         dA = const_cast<void*>(A_ref);
         dS = const_cast<void*>(scales_ref);
     } else {
-        HIP_TRY(hipMalloc(&dA, ab));
-        HIP_TRY(hipMalloc(&dS, sb));
+        REG_TRY(hipMalloc(&dA, ab));
+        REG_TRY(hipMalloc(&dS, sb));
         const hipMemcpyKind kind = src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-        HIP_TRY(hipMemcpyAsync(dA, A_ref, ab, kind, st));
-        HIP_TRY(hipMemcpyAsync(dS, scales_ref, sb, kind, st));
+        REG_TRY(hipMemcpyAsync(dA, A_ref, ab, kind, st));
+        REG_TRY(hipMemcpyAsync(dS, scales_ref, sb, kind, st));
     }
     if (w->lo_ok) {
         w->w_bytes = s.weight_u4() * 16;
-        HIP_TRY(hipMalloc(&w->W, w->w_bytes));
+        REG_TRY(hipMalloc(&w->W, w->w_bytes));
         hipError_t e = launch_retile_weights((const uint8_t*)dA, w->W, s, st);
         if (e != hipSuccess) return cleanup(fail(TMAC_HIP_E_RUNTIME, "retile_weights: %s", hipGetErrorString(e)));
         const size_t de = s.m_groups >= 1 ? (size_t)s.m_groups : s.scale_elems();
         w->sc_bytes = de * dt_size(w->sc_dtype);
-        HIP_TRY(hipMalloc(&w->SC, w->sc_bytes));
+        REG_TRY(hipMalloc(&w->SC, w->sc_bytes));
         e = launch_retile_scales(dS, (Dtype)host_float, w->SC, w->sc_dtype, s, st);
         if (e != hipSuccess) return cleanup(fail(TMAC_HIP_E_RUNTIME, "retile_scales: %s", hipGetErrorString(e)));
     } else {
         w->w_bytes = ab;
         w->sc_bytes = sb;
     }
-    HIP_TRY(hipStreamSynchronize(st));
+    REG_TRY(hipStreamSynchronize(st));
     if (keep_ref) {
         w->A_ref = dA;
         w->S_ref = dS;
@@ -367,6 +372,7 @@ static int32_t register_impl(tmac_hip_weights** out, const void* A_ref, const vo
     }
     *out = w;
     return TMAC_HIP_OK;
+#undef REG_TRY
 }
 
 extern "C" int32_t tmac_hip_register_weights(tmac_hip_weights** out, const void* A_ref, const void* scales_ref, int Mw,
@@ -407,13 +413,19 @@ extern "C" int32_t tmac_hip_workspace_create(tmac_hip_workspace** out, int maxK,
     if (rc) return rc;
     auto* ws = new tmac_hip_workspace();
     ws->maxK = maxK; ws->maxN = maxN;
-    HIP_TRY(hipMalloc((void**)&ws->qlut_ref, (size_t)maxN * (maxK / 4) * 16));
-    HIP_TRY(hipMalloc(&ws->qlut_dev, (size_t)maxN * qdev_u4_for_K(maxK) * 16));
-    HIP_TRY(hipMemset(ws->qlut_dev, 0x80, (size_t)maxN * qdev_u4_for_K(maxK) * 16));
-    HIP_TRY(hipMalloc(&ws->qlut_lds, (size_t)maxN * qlut_lds_u4(maxK) * 16));
-    HIP_TRY(hipMemset(ws->qlut_lds, 0x80, (size_t)maxN * qlut_lds_u4(maxK) * 16));
-    HIP_TRY(hipMalloc((void**)&ws->lut_scales, sizeof(float) * (size_t)maxN * (maxK / 32)));
-    HIP_TRY(hipMalloc((void**)&ws->lut_biases, sizeof(float) * (size_t)maxN * (maxK / 32)));
+    const size_t nq = (size_t)maxN * (maxK / 4) * 16, nd = (size_t)maxN * qdev_u4_for_K(maxK) * 16, nl = (size_t)maxN * qlut_lds_u4(maxK) * 16;
+    const size_t ns = sizeof(float) * (size_t)maxN * (maxK / 32);
+    hipError_t e = hipMalloc((void**)&ws->qlut_ref, nq);
+    if (e == hipSuccess) e = hipMalloc(&ws->qlut_dev, nd);
+    if (e == hipSuccess) e = hipMemset(ws->qlut_dev, 0x80, nd);
+    if (e == hipSuccess) e = hipMalloc(&ws->qlut_lds, nl);
+    if (e == hipSuccess) e = hipMemset(ws->qlut_lds, 0x80, nl);
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->lut_scales, ns);
+    if (e == hipSuccess) e = hipMalloc((void**)&ws->lut_biases, ns);
+    if (e != hipSuccess) {   // nothing of a half-built workspace is left behind
+        tmac_hip_workspace_free(ws);
+        return fail(TMAC_HIP_E_RUNTIME, "workspace allocation (K=%d, N=%d): %s", maxK, maxN, hipGetErrorString(e));
+    }
     *out = ws;
     return TMAC_HIP_OK;
 }

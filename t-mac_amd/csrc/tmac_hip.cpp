@@ -618,7 +618,17 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
         }
         ws = slot;
     }
-    int32_t rc = tmac_hip_preprocessor_dev(ws, B_dev, act_dtype, s0.K, N, s0.ags, st);
+    int32_t rc;
+    if (s0.ags == 64 && g_variant != V_REF_LAYOUT) {
+        // only the one-hot GEMM reads this workspace: build the half-table image alone, two tables per lane
+        rc = check_lut_shape(ws, s0.K, N, s0.ags);
+        if (rc) return rc;
+        ws->K = s0.K; ws->N = N; ws->ags = s0.ags; ws->qdev_u4_per_row = qdev_u4_for_K(s0.K);
+        hipError_t e = launch_preprocess_pairs(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, s0.K, N, st);
+        if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
+    } else {
+        rc = tmac_hip_preprocessor_dev(ws, B_dev, act_dtype, s0.K, N, s0.ags, st);
+    }
     for (int i = 0; i < nmat && rc == TMAC_HIP_OK; ++i) rc = tmac_hip_qgemm_dev(wl[i], ws, C_list[i], out_dtype, N, st);
     return rc;
 }

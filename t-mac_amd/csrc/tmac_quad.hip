@@ -723,6 +723,68 @@ q_done:
 constexpr bool QSCF16 = TMAC_QUAD_SCF16 != 0;   // weight scales stored as fp16 (1) / fp32 (0): a kernel template parameter
 
 #if TMAC_QUAD_BITS == 2 && TMAC_QUAD_SCF16 == 0
+// ---------------------------------------------------------------------------------------------
+// Prefill LUT build for the fused entry point: the quad kernel's build phase as a kernel of its own.  One lane builds
+// the two tables of pair p (8 activations, one 16-byte fp16 load) of activation row n with the packed-fp32 sequence of
+// q_table8, the act group (64 activations = 8 lanes) shares its abs-max by DPP, and the result goes straight into the
+// unit-major half-table image the one-hot GEMM stages from (same bytes as k_preprocess writes there; QLUT, scales and
+// biases bit-identical to lut_ctor.cc by the same argument as in k_gemv_quad).  k_preprocess keeps one workgroup per
+// act group with 16 of 64 lanes building tables and writes three layouts; this one writes the image only.
+// ---------------------------------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(256) void k_preprocess_pairs(const void* __restrict__ B, uint4* __restrict__ qlut_lds,
+                                                          float* __restrict__ lut_scales, float* __restrict__ lut_biases,
+                                                          int K, int tstride) {
+    const int P = K / 8, G = K / 64, n = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;                     // P % 8 == 0: the 8 lanes of an act group leave together
+    float x[8];
+    if (F16) {
+        const uint4 v = reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(B) + (size_t)n * K)[p];
+        const uint32_t r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __half2 hh = *reinterpret_cast<const __half2*>(&r[i]);
+            x[2 * i] = __low2float(hh); x[2 * i + 1] = __high2float(hh);
+        }
+    } else {
+        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(B) + (size_t)n * K) + 2 * (size_t)p;
+        const float4 a0 = src[0], a1 = src[1];
+        x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
+    }
+    const float s0 = __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3])));
+    const float s1 = __fadd_rn(__fadd_rn(fabsf(x[4]), fabsf(x[5])), __fadd_rn(fabsf(x[6]), fabsf(x[7])));
+    const float mx = q_half_allmax(fmaxf(s0, s1));
+    const float scales = div127(mx);
+    const float t_scales = (scales != 0.0f) ? rcp_exact(scales) : 0.0f;
+    uint32_t lo0, hi0, lo1, hi1;
+    float La, Lb;
+    q_table8<false>(x[0], x[1], x[2], x[3], t_scales, lo0, hi0, La);     // biased bytes, as the image holds them
+    q_table8<false>(x[4], x[5], x[6], x[7], t_scales, lo1, hi1, Lb);
+    qlut_lds[((size_t)n * 4 + (p & 3)) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
+    float va = -La, vb = -Lb;               // lut_biases, lut_ctor.cc:25-31 (see k_gemv_quad)
+    va = __fadd_rn(va, qdpp_f<0x4E>(va));
+    vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));
+    va = __fadd_rn(va, qdpp_f<0xB1>(va));
+    vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));
+    const float v = __fadd_rn(va, vb);
+    const float c1 = qdpp_f<0x104>(v);
+    if ((p & 7) == 0) {
+        lut_scales[(size_t)n * G + (p >> 3)] = scales;
+        lut_biases[(size_t)n * G + (p >> 3)] = __fadd_rn(__fadd_rn(0.0f, v), c1);
+    }
+}
+
+hipError_t launch_preprocess_pairs(const void* B, int act_f16, void* qlut_lds, float* lut_scales, float* lut_biases, int K, int N,
+                                   hipStream_t st) {
+    if (K % 64 != 0 || N < 1) return hipErrorInvalidValue;
+    const int tstride = (((K / 32) + 15) & ~15) + 1;
+    dim3 g((K / 8 + 255) / 256, N), b(256);
+    if (act_f16) hipLaunchKernelGGL((k_preprocess_pairs<true>), g, b, 0, st, B, (uint4*)qlut_lds, lut_scales, lut_biases, K, tstride);
+    else hipLaunchKernelGGL((k_preprocess_pairs<false>), g, b, 0, st, B, (uint4*)qlut_lds, lut_scales, lut_biases, K, tstride);
+    return hipGetLastError();
+}
+
 bool gemv_quad_supported(const Shape& s) {
     if (s.bits < 1 || s.bits > 4 || s.K % 64 != 0 || s.K > 24576 || s.Mw % 4 != 0) return false;
     if (s.m_groups >= 1) return s.ags == s.K && s.Mw % s.m_groups == 0;

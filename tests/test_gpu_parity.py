@@ -351,22 +351,44 @@ def test_onehot_mfma_gemm(tm, Mw, K, bits, bm, kf, gs, ags, zp, N):
     assert rel_err(r["C"], r2["C"]) <= 2e-6
 
 
-def test_fused_entry_point_prefill(tm):
-    """tmac_hip_qgemm_fused_dev with N above the GEMM threshold: library-owned LUT workspace + one-hot GEMM per matrix"""
+@pytest.mark.parametrize("K,N,act_f16,edge", [(2048, 48, False, False), (11008, 40, True, False), (4096, 33, False, True),
+                                              (4096, 64, True, True)])
+def test_fused_entry_point_prefill(tm, K, N, act_f16, edge):
+    """tmac_hip_qgemm_fused_dev with N above the GEMM threshold: library-owned LUT workspace, the pair-wise LUT build
+    (k_preprocess_pairs: image only) and one one-hot GEMM per matrix.  A wrong table entry moves an output by ~1e-3 of
+    max|C|, far above the 2e-5 bound, so the outputs pin the LUT as well."""
     import torch
-    Mw, K, bits, bm, kf, gs, ags, N = 512, 2048, 2, 128, 16, 128, 64, 48
-    case = orc.make_case(4242, Mw, K, N=N, bits=bits, gs=gs, ags=ags)
+    Mw, bits, bm, kf, gs, ags = 512, 2, 128, 16, 128, 64
+    case = orc.make_case(4242 + K, Mw, K, N=N, bits=bits, gs=gs, ags=ags, fp16_values=act_f16)
+    if edge:   # all-zero act groups (scale 0 -> t_scales 0), huge / tiny magnitudes, exact .5 ties, as test_edge_activations
+        B = case["B"]
+        B[0, :64] = 0.0
+        B[1, 64:128] = 0.0
+        B[2, :] = 0.0
+        B[3, 128:192] *= (60000.0 / np.abs(B[3, 128:192]).max() / 4) if act_f16 else 1e20
+        B[4, 192:256] *= 1e-4 if act_f16 else 1e-20
+        B[5, 256:320] = np.tile(np.array([0.5, 1.5, 2.5, 127.0], np.float32), 16)
+        if act_f16:
+            case["B"] = B.astype(np.float16).astype(np.float32)
     A = orc.preprocess_weights(case["w"], bits, bm, kf)
     S = orc.preprocess_scales(case["sc"], case["zr"], bits, bm)
     wr = tm.TMACGeMMWrapper(act_group_size=ags)
     ws = [wr.register_weights(A, S, Mw, K, bits, tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, True, -1, N)) for _ in range(2)]
     Bt = torch.from_numpy(case["B"]).cuda()
+    if act_f16:
+        Bt = Bt.half()
     outs = [torch.empty((N, Mw), dtype=torch.float32, device="cuda") for _ in range(2)]
     wr.fused(ws, Bt, outs, N)
     torch.cuda.synchronize()
     q, ls, lb, Cc, PS = oracle_case(case, A, S, Mw, K, bits, bm, kf, gs, ags, True, N=N)
+    finite = np.isfinite(Cc)
     for o in outs:
-        assert rel_err(o.cpu().numpy(), Cc) <= 2e-5
+        got = o.cpu().numpy()
+        assert np.array_equal(np.isfinite(got), finite)
+        for nrow in range(N):          # per activation row: a huge row must not hide an error in the others
+            m = finite[nrow]
+            if m.any():
+                assert rel_err(got[nrow][m], Cc[nrow][m]) <= 2e-5
     tm.binding.check(tm.lib().tmac_hip_cache_clear())
     for w in ws:
         w.free()

@@ -36,14 +36,18 @@ for name, Mw, K, cnt in [("qkv/o", 4096, 4096, 4), ("gate/up", 11008, 4096, 2), 
     L.tmac_hip_set_gemm_min_n(0)
     t_loop = timeit(lambda: wr.llama_cpp_compute(w, out, N), reps=3)
     L.tmac_hip_set_gemm_min_n(32)
+    t_fused = timeit(lambda: wr.fused([w], x, [out], N))     # pair-wise LUT build (image only) + GEMM in one call
     t_dense = timeit(lambda: torch.matmul(x, Wd.t()))
     ops = 2.0 * (Mw * 2) * (K / 4 * 8) * N      # MFMA work actually issued: 8-entry half tables
     print(f"{name:8s} Mw={Mw} K={K} N={N}: preprocessor {t_pre:8.1f} us | one-hot MFMA gemm {t_gemm:8.1f} us "
           f"({ops / t_gemm * 1e-6:7.1f} int8 TOP/s, {2.0 * Mw * K * N / t_gemm * 1e-6:6.1f} dense-equivalent TFLOP/s) | "
-          f"gemv loop {t_loop:9.1f} us | dense fp16 matmul {t_dense:7.1f} us")
+          f"gemv loop {t_loop:9.1f} us | dense fp16 matmul {t_dense:7.1f} us | fused entry (LUT build + gemm) {t_fused:7.1f} us")
     tot["gemm"] += cnt * t_gemm; tot["loop"] += cnt * t_loop; tot["dense"] += cnt * t_dense
+    tot["fusedpre"] = tot.get("fusedpre", 0.0) + (t_fused - t_gemm) * (1 if name != "qkv/o" else 2)
     tot["pre"] += t_pre * (1 if name != "qkv/o" else 2)     # one LUT build per distinct activation tensor
     w.free()
+t = 32 * (tot["gemm"] + tot["fusedpre"])
+print(f"llama-2-7B prefill, {N} tokens, 32 layers of mpGEMMs, fused entry (pair-wise LUT build): {t * 1e-3:9.2f} ms  -> {N / t * 1e6:10.0f} tokens/s")
 for k in ("gemm", "loop", "dense"):
     t = 32 * (tot[k] + (tot["pre"] if k != "dense" else 0.0))
     print(f"llama-2-7B prefill, {N} tokens, 32 layers of mpGEMMs, {k:5s}: {t * 1e-3:9.2f} ms  -> {N / t * 1e6:10.0f} tokens/s")

@@ -178,6 +178,12 @@ int32_t tmac_hip_set_fast_aggregation(int mode);
  * keeps nothing -- the cost of streaming a matrix's bytes with no LUT build and no lookups, under the same launch
  * mechanism as the GEMV it is compared with.  dev_sink: >= 4 KB of device scratch. */
 int32_t tmac_hip_debug_stream_read(const void* dev_src, size_t bytes, void* dev_sink, void* stream);
+/* A/B and profiling knobs (tools/, tests/): force the decode kernel's launch configuration (0, 0 = heuristic / tuned
+ * table); s_memtime phase stamps [workgroups][2][8] of the next fused launches into a device buffer (NULL = off);
+ * activation rows from which tmac_hip_preprocessor_dev builds the LUT pair-wise (k_preprocess_pairs; default 2). */
+int32_t tmac_hip_debug_quad_config(int force_threads, int force_waves_per_quad);
+int32_t tmac_hip_debug_stamps(unsigned long long* dev_buffer);
+int32_t tmac_hip_debug_pairs_min_n(int n);
 /* Launch-configuration tuner of the fused decode kernel (the role autotvm's grid search over
  * (bm, kfactor, bn) plays for the reference's CPU kernels, python/t_mac/ops/base.py:84-127, qgemm.py:98-116).
  * tmac_hip_autotune_fused times every (threads per workgroup, waves per row quad) configuration of k_gemv_quad on the

@@ -75,6 +75,7 @@ struct tmac_hip_workspace {
 static std::mutex g_mu;
 static int g_device = -1;
 static int g_variant = V_AUTO;
+static int g_pairs_min_n = 2;   // tmac_hip_preprocessor_dev: rows from which the pair-wise LUT build is used (A/B: tmac_hip_debug_pairs_min_n)
 static int g_fa_mode = 0;   // fast aggregation for weights registered from now on (tmac_hip_set_fast_aggregation)
 static int g_force_ft = 0, g_force_wpq = 0;   // A/B knobs of the quad kernel (0 = heuristic)
 static std::map<std::string, tmac_kcfg> g_kcfg;
@@ -456,8 +457,13 @@ extern "C" int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void*
     if (rc) return rc;
     if (!B_dev) return fail(TMAC_HIP_E_ARG, "null activations");
     ws->K = K; ws->N = N; ws->ags = act_group_size; ws->qdev_u4_per_row = qdev_u4_for_K(K);
-    hipError_t e = launch_preprocess(B_dev, (Dtype)act_dtype, ws->qlut_ref, ws->qlut_dev, ws->qlut_lds, ws->lut_scales, ws->lut_biases,
-                                     K, N, act_group_size, ws->qdev_u4_per_row, (hipStream_t)stream);
+    // several activation rows with 64-activation groups: the pair-wise build (two tables per lane, all three layouts);
+    // otherwise one workgroup per act group (any act_group_size, and cheaper than it looks for a single row)
+    hipError_t e = (act_group_size == 64 && N >= g_pairs_min_n)
+        ? launch_preprocess_pairs(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, K, N, ws->qlut_ref,
+                                  ws->qlut_dev, ws->qdev_u4_per_row, (hipStream_t)stream)
+        : launch_preprocess(B_dev, (Dtype)act_dtype, ws->qlut_ref, ws->qlut_dev, ws->qlut_lds, ws->lut_scales, ws->lut_biases,
+                            K, N, act_group_size, ws->qdev_u4_per_row, (hipStream_t)stream);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
     return TMAC_HIP_OK;
 }
@@ -624,7 +630,8 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
         rc = check_lut_shape(ws, s0.K, N, s0.ags);
         if (rc) return rc;
         ws->K = s0.K; ws->N = N; ws->ags = s0.ags; ws->qdev_u4_per_row = qdev_u4_for_K(s0.K);
-        hipError_t e = launch_preprocess_pairs(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, s0.K, N, st);
+        hipError_t e = launch_preprocess_pairs(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, s0.K, N,
+                                               nullptr, nullptr, 0, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
     } else {
         rc = tmac_hip_preprocessor_dev(ws, B_dev, act_dtype, s0.K, N, s0.ags, st);
@@ -880,6 +887,12 @@ extern "C" int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weigh
                                             tmac_dtype_t act_dtype, void* const* C_dev, tmac_dtype_t out_dtype, int N,
                                             void* stream) {
     return fused_impl(weights, nmat, B_dev, act_dtype, C_dev, out_dtype, N, nullptr, nullptr, (hipStream_t)stream);
+}
+
+// A/B knob: activation rows from which tmac_hip_preprocessor_dev uses k_preprocess_pairs (a huge value = never)
+extern "C" int32_t tmac_hip_debug_pairs_min_n(int n) {
+    g_pairs_min_n = n < 1 ? 1 : n;
+    return TMAC_HIP_OK;
 }
 
 // measurement aid: a launch that only reads `bytes` from dev_src (sink: >= 4 KB of device scratch, practically never written)

@@ -85,9 +85,10 @@ hipError_t launch_retile_scales(const void* S_ref, Dtype in_dt, void* Sd, Dtype 
 hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, float* lut_scales,
                              float* lut_biases, int K, int N, int ags, size_t qdev_u4_per_row, hipStream_t st);
 hipError_t launch_qlut_ref_to_dev(const int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, int K, int N, size_t qdev_u4_per_row, hipStream_t st);
-// fast LUT build for the fused prefill path (tmac_quad.hip): writes the half-table image + LUT scales/biases only; ags = 64
+// pair-wise LUT build (tmac_quad.hip; ags = 64): the half-table image + LUT scales/biases, and -- when qlut_ref / qlut_dev are
+// given (both or neither) -- the other two layouts of the workspace as well
 hipError_t launch_preprocess_pairs(const void* B, int act_f16, void* qlut_lds, float* lut_scales, float* lut_biases, int K, int N,
-                                   hipStream_t st);
+                                   int8_t* qlut_ref, void* qlut_dev, size_t qdev_u4_per_row, hipStream_t st);
 hipError_t launch_stream_read(const void* src, size_t bytes, void* sink, hipStream_t st);   // measurement aid, see tmac_kernels.hip
 bool gemm_onehot_supported(const Shape& s);
 hipError_t launch_gemm_onehot(const GemmArgs& a, hipStream_t st);

@@ -731,10 +731,11 @@ constexpr bool QSCF16 = TMAC_QUAD_SCF16 != 0;   // weight scales stored as fp16 
 // biases bit-identical to lut_ctor.cc by the same argument as in k_gemv_quad).  k_preprocess keeps one workgroup per
 // act group with 16 of 64 lanes building tables and writes three layouts; this one writes the image only.
 // ---------------------------------------------------------------------------------------------
-template <bool F16>
+template <bool F16, bool ALL>
 __global__ __launch_bounds__(256) void k_preprocess_pairs(const void* __restrict__ B, uint4* __restrict__ qlut_lds,
                                                           float* __restrict__ lut_scales, float* __restrict__ lut_biases,
-                                                          int K, int tstride) {
+                                                          int K, int tstride, uint4* __restrict__ qlut_ref,
+                                                          uint2* __restrict__ qlut_dev, size_t qdev_u4_per_row) {
     const int P = K / 8, G = K / 64, n = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;                     // P % 8 == 0: the 8 lanes of an act group leave together
@@ -762,6 +763,20 @@ __global__ __launch_bounds__(256) void k_preprocess_pairs(const void* __restrict
     q_table8<false>(x[0], x[1], x[2], x[3], t_scales, lo0, hi0, La);     // biased bytes, as the image holds them
     q_table8<false>(x[4], x[5], x[6], x[7], t_scales, lo1, hi1, Lb);
     qlut_lds[((size_t)n * 4 + (p & 3)) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
+    if (ALL) {
+        // the other two layouts of the workspace (tmac_hip_preprocessor_dev serves every consumer):
+        // 16-table-segment half tables for k_gemv_lo -- tables 2p, 2p+1 are one uint4 of segment p >> 3
+        const int seg = p >> 3, j8 = p & 7;
+        *reinterpret_cast<uint4*>(qlut_dev + ((size_t)n * qdev_u4_per_row + qlut_dev_u4_index(seg, j8)) * 2) = make_uint4(lo0, hi0, lo1, hi1);
+        // and the reference's int8 [K/4][16]: entries 0..7 signed, 8..15 = -entry(15 - j) (lut_ctor.cc:152-155); on biased
+        // bytes U in [1, 255] the bytewise negation 256 - U is one word subtraction without borrows
+        const uint32_t sg = 0x80808080u, rev = 0x00010203u;
+        const uint32_t n0l = __builtin_amdgcn_perm(0u, 0x01010100u - lo0, rev), n0h = __builtin_amdgcn_perm(0u, 0x01010100u - hi0, rev);
+        const uint32_t n1l = __builtin_amdgcn_perm(0u, 0x01010100u - lo1, rev), n1h = __builtin_amdgcn_perm(0u, 0x01010100u - hi1, rev);
+        uint4* r = qlut_ref + ((size_t)n * (K / 4) + 2 * (size_t)p);
+        r[0] = make_uint4(lo0 ^ sg, hi0 ^ sg, n0h ^ sg, n0l ^ sg);
+        r[1] = make_uint4(lo1 ^ sg, hi1 ^ sg, n1h ^ sg, n1l ^ sg);
+    }
     float va = -La, vb = -Lb;               // lut_biases, lut_ctor.cc:25-31 (see k_gemv_quad)
     va = __fadd_rn(va, qdpp_f<0x4E>(va));
     vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));
@@ -776,12 +791,15 @@ __global__ __launch_bounds__(256) void k_preprocess_pairs(const void* __restrict
 }
 
 hipError_t launch_preprocess_pairs(const void* B, int act_f16, void* qlut_lds, float* lut_scales, float* lut_biases, int K, int N,
-                                   hipStream_t st) {
-    if (K % 64 != 0 || N < 1) return hipErrorInvalidValue;
+                                   int8_t* qlut_ref, void* qlut_dev, size_t qdev_u4_per_row, hipStream_t st) {
+    if (K % 64 != 0 || N < 1 || ((qlut_ref == nullptr) != (qlut_dev == nullptr))) return hipErrorInvalidValue;
     const int tstride = (((K / 32) + 15) & ~15) + 1;
     dim3 g((K / 8 + 255) / 256, N), b(256);
-    if (act_f16) hipLaunchKernelGGL((k_preprocess_pairs<true>), g, b, 0, st, B, (uint4*)qlut_lds, lut_scales, lut_biases, K, tstride);
-    else hipLaunchKernelGGL((k_preprocess_pairs<false>), g, b, 0, st, B, (uint4*)qlut_lds, lut_scales, lut_biases, K, tstride);
+#define PL(F, A) hipLaunchKernelGGL((k_preprocess_pairs<F, A>), g, b, 0, st, B, (uint4*)qlut_lds, lut_scales, lut_biases, K, tstride, \
+                                    (uint4*)qlut_ref, (uint2*)qlut_dev, qdev_u4_per_row)
+    if (qlut_ref) { if (act_f16) PL(true, true); else PL(false, true); }
+    else { if (act_f16) PL(true, false); else PL(false, false); }
+#undef PL
     return hipGetLastError();
 }
 

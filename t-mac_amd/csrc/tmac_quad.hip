@@ -332,14 +332,27 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
     } else {
         float gscale = 0.f, gtinv = 0.f;
         if (SM == 2) {
+            // One act group = the whole row: the scale needs a maximum over K, and lut_biases is ONE fp32 chain over the K/32
+            // 8-table chunk sums in order (lut_ctor.cc:157,218) -- 270 dependent adds for K = 8640, a microsecond of a single
+            // lane.  Neither the chunk sums nor the chain depend on the scale, so: pass 1 computes maxima AND chunk sums
+            // (LUT[0] of a table is -(((x0+x1)+x2)+x3), the same adds q_table8 performs), one barrier, then lane 0 of the last
+            // wave walks the chain while every other wave already builds its tables.
             float mx = 0.f;
 #pragma unroll
             for (int r = 0; r < NP; ++r) {
-                if (r * FT + tid < P) {
+                const int p = r * FT + tid;
+                if (p < P) {
                     float x[8];
                     unpack(r, x);
                     mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3]))));
                     mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x[4]), fabsf(x[5])), __fadd_rn(fabsf(x[6]), fabsf(x[7]))));
+                    float va = -__fadd_rn(__fadd_rn(__fadd_rn(x[0], x[1]), x[2]), x[3]);
+                    float vb = -__fadd_rn(__fadd_rn(__fadd_rn(x[4], x[5]), x[6]), x[7]);
+                    va = __fadd_rn(va, qdpp_f<0x4E>(va));      // lane ^ 2: v0+v4 | v2+v6      (lut_ctor.cc:25-31)
+                    vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));      //           v1+v5 | v3+v7
+                    va = __fadd_rn(va, qdpp_f<0xB1>(va));      // lane ^ 1: (v0+v4)+(v2+v6)
+                    vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));      //           (v1+v5)+(v3+v7)
+                    if ((p & 3) == 0) l_scr[NWV + (p >> 2)] = __fadd_rn(va, vb);
                 }
             }
             mx = q_row_allmax(mx);
@@ -352,7 +365,21 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
             for (int i = 1; i < NWV; ++i) mx = fmaxf(mx, l_scr[i]);
             gscale = __fdiv_rn(mx, 127.0f);
             gtinv = (gscale != 0.0f) ? __fdiv_rn(1.0f, gscale) : 0.0f;
-            __syncthreads();
+            if (tid == FT - 64) {   // the last wave holds the fewest pairs (none when K/8 <= FT - 64)
+                // the LDS reads are batched (16-byte reads, unrolled) so that only the dependent adds are serial
+                float biases = 0.0f;
+                const float4* cs = reinterpret_cast<const float4*>(l_scr + NWV);
+                const int nc = T / 8;
+                int c = 0;
+#pragma unroll 4
+                for (; c + 4 <= nc; c += 4) {
+                    const float4 v4 = cs[c >> 2];
+                    biases = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(biases, v4.x), v4.y), v4.z), v4.w);
+                }
+                for (; c < nc; ++c) biases = __fadd_rn(biases, l_scr[NWV + c]);
+                l_ls[0] = gscale;
+                l_lb[0] = biases;
+            }
         }
 #pragma unroll
         for (int r = 0; r < NP; ++r) {
@@ -383,34 +410,13 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                 va = __fadd_rn(va, qdpp_f<0xB1>(va));      // lane ^ 1: (v0+v4)+(v2+v6)
                 vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));      //           (v1+v5)+(v3+v7)
                 const float v = __fadd_rn(va, vb);
-                if (SM == 2) {
-                    if ((p & 3) == 0) l_scr[NWV + (p >> 2)] = v;
-                } else {
+                if (SM != 2) {
                     const float c1 = qdpp_f<0x104>(v);      // row_shl:4: the second chunk of the act group
                     if ((p & 7) == 0) {
                         l_ls[p >> 3] = __fmul_rn(LSK, scales);
                         l_lb[p >> 3] = __fmul_rn(LSK, __fadd_rn(__fadd_rn(0.0f, v), c1));
                     }
                 }
-            }
-        }
-        if (SM == 2) {
-            __syncthreads();
-            if (tid == 0) {
-                // lut_ctor.cc:157,218: one fp32 chain over the 8-table chunks in order; the LDS reads are batched (16-byte
-                // reads, unrolled) so that only the dependent adds are serial
-                float biases = 0.0f;
-                const float4* cs = reinterpret_cast<const float4*>(l_scr + NWV);
-                const int nc = T / 8;
-                int c = 0;
-#pragma unroll 4
-                for (; c + 4 <= nc; c += 4) {
-                    const float4 v4 = cs[c >> 2];
-                    biases = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(biases, v4.x), v4.y), v4.z), v4.w);
-                }
-                for (; c < nc; ++c) biases = __fadd_rn(biases, l_scr[NWV + c]);
-                l_ls[0] = gscale;
-                l_lb[0] = biases;
             }
         }
     }

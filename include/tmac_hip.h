@@ -184,6 +184,10 @@ int32_t tmac_hip_debug_stream_read(const void* dev_src, size_t bytes, void* dev_
 int32_t tmac_hip_debug_quad_config(int force_threads, int force_waves_per_quad);
 int32_t tmac_hip_debug_stamps(unsigned long long* dev_buffer);
 int32_t tmac_hip_debug_pairs_min_n(int n);
+/* host-pointer entry points: 1 (default) = tiles with contiguous weight / scale pointers are grouped into runs once they
+ * have been seen, and a run's output is computed in one launch per LUT and handed out tile by tile; 0 = every tile call is
+ * served on its own */
+int32_t tmac_hip_debug_host_runs(int on);
 /* Launch-configuration tuner of the fused decode kernel (the role autotvm's grid search over
  * (bm, kfactor, bn) plays for the reference's CPU kernels, python/t_mac/ops/base.py:84-127, qgemm.py:98-116).
  * tmac_hip_autotune_fused times every (threads per workgroup, waves per row quad) configuration of k_gemv_quad on the

@@ -6,6 +6,7 @@
 // GPU; there is no CPU compute path in this library.
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -79,6 +80,7 @@ static int g_pairs_min_n = 2;   // tmac_hip_preprocessor_dev: rows from which th
 static int g_fa_mode = 0;   // fast aggregation for weights registered from now on (tmac_hip_set_fast_aggregation)
 static int g_force_ft = 0, g_force_wpq = 0;   // A/B knobs of the quad kernel (0 = heuristic)
 static std::map<std::string, tmac_kcfg> g_kcfg;
+static unsigned long long g_kcfg_gen = 0;   // bumped whenever g_kcfg changes (memoised lookups check it)
 
 static size_t qdev_u4_for_K(int K) { return (size_t)((K / (4 * TS) + KL - 1) / KL) * 8 * KL; }
 
@@ -157,6 +159,7 @@ extern "C" int32_t tmac_hip_load_kcfg(const char* path) {
         c.n_tile_num = (int)r["n_tile_num"];
         derive_kcfg(c, m, k, n, b);
         g_kcfg[kv.first] = c;
+        ++g_kcfg_gen;
     }
     return TMAC_HIP_OK;
 }
@@ -165,6 +168,7 @@ extern "C" int32_t tmac_hip_set_kcfg(int M, int K, int N, int bits, const tmac_k
     if (!cfg) return fail(TMAC_HIP_E_ARG, "null cfg");
     std::lock_guard<std::mutex> lk(g_mu);
     g_kcfg[section_name(1, M * bits, K, N, bits)] = *cfg;
+    ++g_kcfg_gen;
     return TMAC_HIP_OK;
 }
 
@@ -956,15 +960,40 @@ struct TileKey {
         return bits < o.bits;
     }
 };
-static std::map<TileKey, tmac_hip_weights*> g_tiles;
+// The reference's caller (llama.cpp) walks the M-tiles of a matrix and calls qgemm_lut once per tile with the SAME LUT
+// (tmac_gemm_wrapper.h:197-228).  Served literally that is a PCIe staging and a synchronisation per 64 rows.  So the
+// host-pointer layer learns the matrices behind the tiles: tiles whose weight and scale pointers are contiguous (the
+// reference layout stores a matrix tile after tile) form a RUN; once a run has been seen whole, the first tile call
+// that arrives with a new LUT computes the run's entire output in one launch and the following tile calls are served
+// from that result as long as the LUT bytes they pass are the ones it was computed from (compared in full).
+struct HostRun {
+    tmac_hip_weights* w = nullptr;   // the run registered as one matrix
+    int ntile = 0, Mw_tile = 0;
+    std::vector<float> C;            // [ntile * Mw_tile] outputs for LUT generation `gen`
+    unsigned long long gen = 0;
+};
+struct TileInfo {
+    tmac_hip_weights* w = nullptr;   // the tile alone (first pass; released when a run takes over)
+    const void* S = nullptr;         // its scale pointer
+    HostRun* run = nullptr;
+    int idx = 0;                     // tile index inside the run
+};
+static std::map<TileKey, TileInfo> g_tiles;
+static std::vector<HostRun*> g_runs;
 static tmac_hip_workspace* g_ws = nullptr;
 static void* g_hostC = nullptr;  // device staging for C / B
 static size_t g_hostC_bytes = 0;
+// host copy of the LUT (qlut | lut_scales | lut_biases) that g_ws currently holds, and its generation
+static std::vector<unsigned char> g_lut_host;
+static int g_lut_k = 0, g_lut_n = 0, g_lut_ags = 0;
+static unsigned long long g_lut_gen = 0;
+static int g_host_runs = 1;      // A/B knob (tmac_hip_debug_host_runs)
 
 static int32_t host_ws(int K, int N) {
     if (g_ws && g_ws->maxK >= K && g_ws->maxN >= N) return TMAC_HIP_OK;
     if (g_ws) tmac_hip_workspace_free(g_ws);
     g_ws = nullptr;
+    g_lut_k = 0;                 // a new workspace holds no LUT
     return tmac_hip_workspace_create(&g_ws, K, N);
 }
 static int32_t host_stage(size_t bytes) {
@@ -976,8 +1005,32 @@ static int32_t host_stage(size_t bytes) {
     return TMAC_HIP_OK;
 }
 
-// first kcfg entry whose (k, n, b) match and, when bm_filter > 0, whose bm matches
+static bool lut_is_current(const void* q, const void* ls, const void* lb, int k, int n, int ags) {
+    if (g_lut_k != k || g_lut_n != n || g_lut_ags != ags) return false;
+    const size_t nq = (size_t)n * (k / 4) * 16, ns = sizeof(float) * (size_t)n * (k / ags);
+    if (g_lut_host.size() != nq + 2 * ns) return false;
+    return memcmp(g_lut_host.data(), q, nq) == 0 && memcmp(g_lut_host.data() + nq, ls, ns) == 0 &&
+           memcmp(g_lut_host.data() + nq + ns, lb, ns) == 0;
+}
+static void lut_remember(const void* q, const void* ls, const void* lb, int k, int n, int ags) {
+    const size_t nq = (size_t)n * (k / 4) * 16, ns = sizeof(float) * (size_t)n * (k / ags);
+    g_lut_host.resize(nq + 2 * ns);
+    memcpy(g_lut_host.data(), q, nq);
+    memcpy(g_lut_host.data() + nq, ls, ns);
+    memcpy(g_lut_host.data() + nq + ns, lb, ns);
+    g_lut_k = k; g_lut_n = n; g_lut_ags = ags;
+    ++g_lut_gen;
+}
+
+// first kcfg entry whose (k, n, b) match and, when bm_filter > 0, whose bm matches; looked up once per distinct key (the
+// per-tile entry points come here on every call) -- the memo is dropped when the table changes
 static bool find_cfg(int k, int n, int b, int bm_filter, int m_filter, tmac_kcfg* out) {
+    static std::map<std::array<int, 5>, tmac_kcfg> memo;
+    static unsigned long long memo_for = ~0ull;
+    if (memo_for != g_kcfg_gen) { memo.clear(); memo_for = g_kcfg_gen; }
+    const std::array<int, 5> mk = {k, n, b, bm_filter, m_filter};
+    auto mi = memo.find(mk);
+    if (mi != memo.end()) { *out = mi->second; return true; }
     for (auto& kv : g_kcfg) {
         int t, m, kk, nn, bb;
         if (sscanf(kv.first.c_str(), "qgemm_lut_t%d_int8_m%d_k%d_n%d_b%d", &t, &m, &kk, &nn, &bb) != 5) continue;
@@ -985,6 +1038,7 @@ static bool find_cfg(int k, int n, int b, int bm_filter, int m_filter, tmac_kcfg
         if (bm_filter > 0 && kv.second.bm != bm_filter) continue;
         if (m_filter > 0 && m != m_filter) continue;
         *out = kv.second;
+        memo[mk] = kv.second;
         return true;
     }
     return false;
@@ -992,10 +1046,19 @@ static bool find_cfg(int k, int n, int b, int bm_filter, int m_filter, tmac_kcfg
 
 extern "C" int32_t tmac_hip_cache_clear(void) {
     std::lock_guard<std::mutex> lk(g_mu);
-    for (auto& kv : g_tiles) tmac_hip_free_weights(kv.second);
+    for (auto& kv : g_tiles) if (kv.second.w) tmac_hip_free_weights(kv.second.w);
     g_tiles.clear();
+    for (HostRun* r : g_runs) { tmac_hip_free_weights(r->w); delete r; }
+    g_runs.clear();
     for (auto& kv : g_fused_ws) tmac_hip_workspace_free(kv.second);
     g_fused_ws.clear();
+    return TMAC_HIP_OK;
+}
+
+// A/B knob: 0 = serve every tile call on its own (the literal reading of the reference's ABI), 1 = whole runs (default)
+extern "C" int32_t tmac_hip_debug_host_runs(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_host_runs = on ? 1 : 0;
     return TMAC_HIP_OK;
 }
 
@@ -1011,9 +1074,47 @@ extern "C" int32_t preprocessor_int8(int m, int k, int n, int b, void* B, void* 
     if ((rc = host_ws(k, n))) return rc;
     if ((rc = host_stage(sizeof(float) * (size_t)n * k))) return rc;
     const int ags = cfg.act_group_size;
+    g_lut_k = 0;     // the workspace is about to change
     HIP_TRY(hipMemcpy(g_hostC, B, sizeof(float) * (size_t)n * k, hipMemcpyHostToDevice));
     if ((rc = tmac_hip_preprocessor_dev(g_ws, g_hostC, TMAC_F32, k, n, ags, nullptr))) return rc;
-    return tmac_hip_workspace_read(g_ws, (int8_t*)QLUT, (float*)LUT_Scales, (float*)LUT_Biases, k, n, ags, nullptr);
+    if ((rc = tmac_hip_workspace_read(g_ws, (int8_t*)QLUT, (float*)LUT_Scales, (float*)LUT_Biases, k, n, ags, nullptr))) return rc;
+    // the LUT the caller now holds is the one in the workspace: the qgemm calls that follow need not upload it again
+    lut_remember(QLUT, LUT_Scales, LUT_Biases, k, n, ags);
+    return TMAC_HIP_OK;
+}
+
+// the maximal run of registered, not yet grouped tiles around `key` with contiguous weight and scale pointers
+static HostRun* build_run(const TileKey& key, const tmac_kcfg& cfg, int Mw_tile, size_t a_bytes, size_t s_bytes) {
+    auto nb = [&](const TileKey& k, const TileInfo& ti, long d) -> std::map<TileKey, TileInfo>::iterator {
+        TileKey kk = k;
+        kk.A = (const char*)k.A + d * (long)a_bytes;
+        auto it = g_tiles.find(kk);
+        if (it == g_tiles.end() || it->second.run || !it->second.w) return g_tiles.end();
+        if ((const char*)it->second.S != (const char*)ti.S + d * (long)s_bytes) return g_tiles.end();
+        return it;
+    };
+    auto first = g_tiles.find(key);
+    int n = 1;
+    for (auto it = nb(first->first, first->second, -1); it != g_tiles.end(); it = nb(first->first, first->second, -1)) { first = it; ++n; }
+    auto last = g_tiles.find(key);
+    for (auto it = nb(last->first, last->second, +1); it != g_tiles.end(); it = nb(last->first, last->second, +1)) { last = it; ++n; }
+    if (n < 2) return nullptr;
+    tmac_kcfg rc = cfg;
+    if (rc.m_groups >= 1) rc.m_groups = 1;
+    tmac_hip_weights* w = nullptr;
+    if (register_impl(&w, first->first.A, first->second.S, false, n * Mw_tile, key.K, key.bits, &rc, TMAC_F32, TMAC_F32, nullptr) != TMAC_HIP_OK)
+        return nullptr;     // e.g. out of device memory: the tiles keep serving themselves
+    HostRun* r = new HostRun();
+    r->w = w; r->ntile = n; r->Mw_tile = Mw_tile;
+    g_runs.push_back(r);
+    TileKey kk = first->first;
+    for (int i = 0; i < n; ++i) {
+        TileInfo& ti = g_tiles[kk];
+        tmac_hip_free_weights(ti.w);
+        ti.w = nullptr; ti.run = r; ti.idx = i;
+        kk.A = (const char*)kk.A + a_bytes;
+    }
+    return r;
 }
 
 extern "C" int32_t qgemm_lut_int8(int m, int k, int n, int b, void* A, void* LUT, void* Scales, void* LUT_Scales,
@@ -1026,20 +1127,50 @@ extern "C" int32_t qgemm_lut_int8(int m, int k, int n, int b, void* A, void* LUT
     if (rc) return rc;
     const int Mw_tile = m / b;
     TileKey key{A, m, k, b};
-    tmac_hip_weights* w = nullptr;
     auto it = g_tiles.find(key);
-    if (it == g_tiles.end()) {
+    const bool known = it != g_tiles.end();
+    if (!known) {
         tmac_kcfg tc = cfg;
         if (tc.m_groups >= 1) tc.m_groups = 1;  // a tile sees one unified scale
-        if ((rc = register_impl(&w, A, Scales, false, Mw_tile, k, b, &tc, TMAC_F32, TMAC_F32, nullptr))) return rc;
-        g_tiles[key] = w;
-    } else {
-        w = it->second;
+        TileInfo ti;
+        if ((rc = register_impl(&ti.w, A, Scales, false, Mw_tile, k, b, &tc, TMAC_F32, TMAC_F32, nullptr))) return rc;
+        ti.S = Scales;
+        it = g_tiles.insert(std::make_pair(key, ti)).first;
+    } else if (it->second.S != Scales) {
+        return fail(TMAC_HIP_E_ARG, "qgemm_lut_int8: tile %p was registered with other scales (tiles are cached by pointer; "
+                                    "tmac_hip_cache_clear() after changing weights)", A);
     }
     if ((rc = host_ws(k, n))) return rc;
-    if ((rc = tmac_hip_workspace_write(g_ws, (const int8_t*)LUT, (const float*)LUT_Scales, (const float*)LUT_Biases, k, n,
-                                       cfg.act_group_size, nullptr)))
-        return rc;
+    if (!lut_is_current(LUT, LUT_Scales, LUT_Biases, k, n, cfg.act_group_size)) {
+        g_lut_k = 0;
+        if ((rc = tmac_hip_workspace_write(g_ws, (const int8_t*)LUT, (const float*)LUT_Scales, (const float*)LUT_Biases, k, n,
+                                           cfg.act_group_size, nullptr)))
+            return rc;
+        lut_remember(LUT, LUT_Scales, LUT_Biases, k, n, cfg.act_group_size);
+    }
+    TileInfo& ti = it->second;
+    // a tile that comes back (second GEMV on its matrix) with registered neighbours: group the run
+    if (g_host_runs && known && !ti.run && ti.w) {
+        const Shape& ts = ti.w->s;
+        const size_t s_bytes = ts.m_groups >= 1 ? 0 : ref_scale_elems(ts) * sizeof(float);
+        build_run(key, cfg, Mw_tile, ref_weight_bytes(ts), s_bytes);
+    }
+    if (ti.run) {
+        HostRun* r = ti.run;
+        const size_t Mw_run = (size_t)r->ntile * Mw_tile;
+        if (r->gen != g_lut_gen || r->C.size() != (size_t)n * Mw_run) {
+            r->C.resize((size_t)n * Mw_run);
+            const size_t bytes = sizeof(float) * r->C.size();
+            if ((rc = host_stage(bytes))) return rc;
+            if ((rc = qgemm_impl(r->w, g_ws, g_hostC, TMAC_F32, n, nullptr, nullptr))) return rc;
+            HIP_TRY(hipMemcpy(r->C.data(), g_hostC, bytes, hipMemcpyDeviceToHost));
+            r->gen = g_lut_gen;
+        }
+        for (int i = 0; i < n; ++i)   // C tile is [n][Mw_tile] (kernels.cc:1068: C + n * bm/bits)
+            memcpy((float*)C + (size_t)i * Mw_tile, r->C.data() + (size_t)i * Mw_run + (size_t)ti.idx * Mw_tile, sizeof(float) * Mw_tile);
+        return TMAC_HIP_OK;
+    }
+    tmac_hip_weights* w = ti.w;
     if ((rc = host_stage(sizeof(float) * (size_t)n * Mw_tile))) return rc;
     if ((rc = qgemm_impl(w, g_ws, g_hostC, TMAC_F32, n, nullptr, nullptr))) return rc;
     HIP_TRY(hipMemcpy(C, g_hostC, sizeof(float) * (size_t)n * Mw_tile, hipMemcpyDeviceToHost));

@@ -526,6 +526,64 @@ def test_host_pointer_cabi_matches_prebuilt_reference(tm, tmp_path):
     L.tmac_hip_cache_clear()
 
 
+def test_host_pointer_cabi_serves_whole_runs(tm, tmp_path):
+    """the per-tile host-pointer ABI driven like llama.cpp drives the reference (same LUT, tile after tile): from the second
+    GEMV on, the contiguous tiles are computed as one matrix and the tile calls are served from that result -- same values
+    as serving every tile on its own, for in-order and out-of-order tile calls, changing LUTs and two matrices of equal K"""
+    L = tm.lib()
+    L.tmac_hip_debug_host_runs.argtypes = [C.c_int]
+    Mw, K, bits, bm, kf, gs, ags = 512, 1024, 2, 128, 16, 128, 64
+    ntile, rpt = Mw * bits // bm, bm // bits
+    ini = tmp_path / "kcfg.ini"
+    ini.write_text(f"[qgemm_lut_t1_int8_m{Mw * bits}_k{K}_n1_b2]\nbm = {bm}\nsimd_n_in = 16\nsimd_n_out = 8\nkfactor = {kf}\n"
+                   f"group_size = {gs}\nlut_scales_size = {K // ags}\nscales_size = {Mw * K // gs * 2}\nn_tile_num = {ntile}\n")
+    tm.binding.check(L.tmac_hip_load_kcfg(str(ini).encode()))
+    L.tmac_hip_cache_clear()
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    mats = []
+    for seed in (1, 2):
+        case = orc.make_case(500 + seed, Mw, K, bits=bits, gs=gs, ags=ags)
+        A = np.ascontiguousarray(orc.preprocess_weights(case["w"], bits, bm, kf))       # [ntile][...]: tiles are contiguous
+        S = np.ascontiguousarray(orc.preprocess_scales(case["sc"], case["zr"], bits, bm))
+        mats.append((case, A, S))
+    luts = []
+    for seed in (11, 12, 13):
+        B = np.random.default_rng(seed).standard_normal((1, K)).astype(np.float32)
+        q = np.zeros((K // 4, 16), np.int8); ls = np.zeros(K // ags, np.float32); lb = np.zeros(K // ags, np.float32)
+        assert L.preprocessor_int8(Mw * bits, K, 1, bits, vp(B), vp(ls), vp(lb), vp(q)) == 0
+        qo, lso, lbo = orc.preprocessor(B, ags)
+        assert np.array_equal(q, qo[0]); check_bits(ls, lso[0]); check_bits(lb, lbo[0])
+        luts.append((q, ls, lb))
+
+    def gemv(mat, lut, order):
+        case, A, S = mat
+        q, ls, lb = lut
+        out = np.full(Mw, np.nan, np.float32)
+        for t in order:
+            c = np.zeros(rpt, np.float32)
+            assert L.qgemm_lut_int8(bm, K, 1, bits, vp(A[t]), vp(q), vp(S[t]), vp(ls), vp(lb), vp(c)) == 0, L.tmac_hip_last_error()
+            out[t * rpt:(t + 1) * rpt] = c
+        return out
+
+    def expect(mat, lut):
+        case, A, S = mat
+        q, ls, lb = lut
+        return orc.qgemm_float(A, q[None], S, ls[None], lb[None], Mw, K, 1, bits, bm, kf, gs, ags, True)[0]
+
+    fwd, rev = list(range(ntile)), [5, 0, 7, 2, 1, 6, 3, 4]
+    for runs in (1, 0):
+        L.tmac_hip_debug_host_runs(runs)
+        L.tmac_hip_cache_clear()
+        seq = [(0, 0, fwd), (1, 0, fwd), (0, 1, fwd), (1, 1, rev), (0, 2, rev), (0, 0, fwd), (1, 2, fwd[:3]), (0, 2, fwd)]
+        for mi, li, order in seq:
+            got = gemv(mats[mi], luts[li], order)
+            want = expect(mats[mi], luts[li])
+            idx = np.concatenate([np.arange(t * rpt, (t + 1) * rpt) for t in order])
+            assert rel_err(got[idx], want[idx]) <= 2e-5, (runs, mi, li)
+    L.tmac_hip_debug_host_runs(1)
+    L.tmac_hip_cache_clear()
+
+
 FUSED_CFGS = [c for c in CFGS if (c[6] == 64 and c[8] == -1) or c[6] == c[1]]
 
 

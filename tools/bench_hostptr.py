@@ -32,18 +32,28 @@ for Mw, K in [(4096, 4096), (4096, 11008)]:
     out = np.zeros(Mw, np.float32)
     p = lambda a: C.c_void_p(a.ctypes.data)
 
-    def gemv():
-        assert L.preprocessor_int8(Mw * bits, K, 1, bits, p(B), p(ls), p(lb), p(q)) == 0
-        for t in range(ntile):
-            assert L.qgemm_lut_int8(bm, K, 1, bits, p(A[t]), p(q), p(S[t]), p(ls), p(lb), C.c_void_p(out.ctypes.data + 4 * 64 * t)) == 0
+    # pointer objects made once: numpy's .ctypes.data costs more than a served tile call
+    pB, pls, plb, pq = p(B), p(ls), p(lb), p(q)
+    pA = [p(A[t]) for t in range(ntile)]; pS = [p(S[t]) for t in range(ntile)]
+    pC = [C.c_void_p(out.ctypes.data + 4 * 64 * t) for t in range(ntile)]
 
-    gemv()                      # uploads and caches the tiles
-    t0 = time.perf_counter()
-    reps = 5
-    for _ in range(reps):
-        gemv()
-    dt = (time.perf_counter() - t0) / reps
-    nbytes = Mw * K * bits // 8 + S.size * 2
-    print(f"host-pointer route {Mw}x{K} W2: {dt * 1e6:9.1f} us per GEMV ({ntile} tile calls, {dt * 1e6 / ntile:6.1f} us each) = "
-          f"{nbytes / dt / 1e9:6.2f} GB/s of weight bytes, PCIe staging and a synchronisation per call included")
+    def gemv():
+        assert L.preprocessor_int8(Mw * bits, K, 1, bits, pB, pls, plb, pq) == 0
+        for t in range(ntile):
+            assert L.qgemm_lut_int8(bm, K, 1, bits, pA[t], pq, pS[t], pls, plb, pC[t]) == 0
+
+    L.tmac_hip_debug_host_runs.argtypes = [C.c_int]
+    for runs in (0, 1):
+        L.tmac_hip_debug_host_runs(runs)
+        L.tmac_hip_cache_clear()
+        gemv(); gemv()              # uploads and caches the tiles; the second pass groups them into a run
+        reps = 5
+        t0 = time.perf_counter()
+        for r in range(reps):
+            B[:] = rng.standard_normal(K).astype(np.float32)     # a new activation vector per GEMV, as in a model
+            gemv()
+        dt = (time.perf_counter() - t0) / reps
+        nbytes = Mw * K * bits // 8 + S.size * 2
+        print(f"host-pointer route {Mw}x{K} W2, {'whole runs' if runs else 'tile by tile'}: {dt * 1e6:9.1f} us per GEMV ({ntile} tile calls, "
+              f"{dt * 1e6 / ntile:6.1f} us each) = {nbytes / dt / 1e9:6.2f} GB/s of weight bytes, PCIe staging and synchronisation included")
 L.tmac_hip_cache_clear()

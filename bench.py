@@ -386,6 +386,26 @@ def main():
             floor = {"pure_read_same_bytes_us": round(floor_time(hb // 16 * 16) * 1e6, 3),
                      "near_empty_launch_us": round(floor_time(4096) * 1e6, 3)}
             del bufs
+            # and of the whole step: the same 4 launches per layer, each only reading its matrices' bytes (distinct buffers)
+            sizes = [cnt * algorithmic_bytes(shard_rows[name], K) // 16 * 16 for name, Mw, K, cnt, slot in MATS]
+            sbufs = [[torch.empty(sz, dtype=torch.uint8, device=dev).fill_(0x5a) for sz in sizes] for _ in range(args.layers)]
+
+            def step_reads(stream):
+                for lb_ in sbufs:
+                    for b_, sz in zip(lb_, sizes):
+                        tmac_amd.binding.check(L.tmac_hip_debug_stream_read(b_.data_ptr(), sz, sink.data_ptr(), stream))
+            step_reads(cs); torch.cuda.synchronize()
+            sg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(sg):
+                step_reads(torch.cuda.current_stream().cuda_stream)
+            ts = []
+            for r in range(8):
+                f0 = torch.cuda.Event(enable_timing=True); f1 = torch.cuda.Event(enable_timing=True)
+                f0.record(); sg.replay(); f1.record(); torch.cuda.synchronize()
+                if r >= 3:
+                    ts.append(f0.elapsed_time(f1))
+            floor["pure_read_step_ms"] = round(float(np.mean(ts)), 4)
+            del sbufs, sg
         roof = {"bound": "hbm", "kernel": ("k_gemv_quad, LUT build fused" if args.path == "fused" else "k_gemv_quad, LUT prebuilt") + ", headline shape 4096x11008 W2 g128 zp", "achieved": round(ach, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES,
                 "algorithmic_bytes_per_launch": hb, "avg_launch_us": round(float(np.mean(durs)) * 1e6, 3),

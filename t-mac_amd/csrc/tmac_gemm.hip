@@ -65,8 +65,15 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     const Shape& s = a.s;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int g = lane >> 4, i16 = lane & 15;
-    const int G = s.K / s.ags, nu = s.K / 32, nst = (nu + 63) >> 6, nq = (s.Mw + 3) >> 2;
-    const int orow_wg = blockIdx.x * ORW;                  // first output row of this workgroup
+    // several matrices that share K, the quantisation config and the LUT (q/k/v, gate/up) in one launch: the workgroup
+    // index selects the matrix (uniform), the rest of the kernel sees one matrix
+    int mi = 0, bx = blockIdx.x;
+    while (mi + 1 < a.nmat && bx >= a.m[mi].wg_end) ++mi;
+    if (mi > 0) bx -= a.m[mi - 1].wg_end;
+    const GemmMat M = a.m[mi];
+    const int Mw = M.Mw;
+    const int G = s.K / s.ags, nu = s.K / 32, nst = (nu + 63) >> 6, nq = (Mw + 3) >> 2;
+    const int orow_wg = bx * ORW;                          // first output row of this workgroup
     const int n0 = blockIdx.y * (GNT * 16);                // first activation row of this workgroup
     const int nchunk = (nu + GCH - 1) / GCH;
 
@@ -79,10 +86,10 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     const uint4* bsrc = reinterpret_cast<const uint4*>(a.qlut_lds) + ((size_t)min(n0 + (tid >> 2), a.N - 1) * 4 + (tid & 3)) * a.tstride;
     // weights (tid < GCH*QW*NJ = 128 | 256): unit tid / (QW*NJ), quad (tid / NJ) % QW, uint4 j = tid % NJ
     const int w_ul = tid / (QW * NJ), w_ql = (tid / NJ) % QW, w_j = tid % NJ;
-    const uint4* wsrc = reinterpret_cast<const uint4*>(a.W) + ((size_t)min(orow_wg / 4 + w_ql, nq - 1) * nst * NJ + w_j) * 64;
+    const uint4* wsrc = reinterpret_cast<const uint4*>(M.W) + ((size_t)min(orow_wg / 4 + w_ql, nq - 1) * nst * NJ + w_j) * 64;
     // epilogue operands: e1 = ls / lb of column tid%64, e2 = scale / zero of row (tid/2)%64, act groups tid/128 + 2k
     const int e_ag = tid >> 7, e1_which = (tid >> 6) & 1, e1_n = min(n0 + (tid & (GNT * 16 - 1)), a.N - 1);
-    const int e2_o = min(orow_wg + ((tid >> 1) & 63), s.Mw - 1), e2_which = tid & 1;
+    const int e2_o = min(orow_wg + ((tid >> 1) & 63), Mw - 1), e2_which = tid & 1;
     const float* e1_src = (e1_which ? a.lut_biases : a.lut_scales) + (size_t)e1_n * G;
 
     uint4 bst[GCH], wst;
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
             e2[k] = 0.f;
             if (ZP || !e2_which) {
                 const size_t si = quad_scale_index(s, e2_o >> 2, (kk * s.ags) / s.gs, e2_o & 3, e2_which);
-                e2[k] = a.sc_f16 ? __half2float(reinterpret_cast<const __half*>(a.SC)[si]) : reinterpret_cast<const float*>(a.SC)[si];
+                e2[k] = a.sc_f16 ? __half2float(reinterpret_cast<const __half*>(M.SC)[si]) : reinterpret_cast<const float*>(M.SC)[si];
             }
         }
     };
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
                                 for (int r = 0; r < 4; ++r) {
                                     const int o = orow_wg + (w * GRT + rt) * ORPT + (BITS == 2 ? 2 * g + (r & 1) : (4 * g + r) / BITS), nn = n0 + nt * 16 + i16;
                                     const int pl = (BITS == 2) ? (r >> 1) : (r % BITS);
-                                    if (nn < a.N && o < s.Mw) a.dump[((size_t)nn * s.M() + mrow(o, pl, BITS)) * G + kk] = c[rt][nt][r] - 0x4B400000;
+                                    if (nn < a.N && o < Mw) a.dump[((size_t)nn * Mw * BITS + mrow(o, pl, BITS)) * G + kk] = c[rt][nt][r] - 0x4B400000;
                                 }
                             }
                             // rows 4g + 2pr, 4g + 2pr + 1 = planes (2pr) % BITS and the next one (never plane 0) of output
@@ -277,7 +284,7 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
 #pragma unroll
                     for (int pl = 1; pl < BITS; ++pl) acc = __fadd_rn(acc, __fmul_rn(facc[rt][nt][(oo * BITS + pl) >> 1][(oo * BITS + pl) & 1], g_alpha(pl)));
                 }
-                if (o < s.Mw) g_st(a.C, a.out_f16, (size_t)n * s.Mw + o, acc);
+                if (o < Mw) g_st(M.C, a.out_f16, (size_t)n * Mw + o, acc);
             }
         }
     }
@@ -287,11 +294,16 @@ bool gemm_onehot_supported(const Shape& s) {
     return s.lay == 2 && (s.bits == 2 || s.bits == 4) && s.m_groups < 0 && s.ags == 64 && s.gs % 64 == 0 && s.K % 64 == 0;
 }
 
-hipError_t launch_gemm_onehot(const GemmArgs& a, hipStream_t st) {
-    if (!gemm_onehot_supported(a.s)) return hipErrorInvalidValue;
+hipError_t launch_gemm_onehot(const GemmArgs& a_in, hipStream_t st) {
+    if (!gemm_onehot_supported(a_in.s) || a_in.nmat < 1 || a_in.nmat > 4 || (a_in.dump && a_in.nmat != 1)) return hipErrorInvalidValue;
+    GemmArgs a = a_in;
     const int bits = a.s.bits;
     const int rows_per_wg = GWV * GRT * 16 / bits;
-    const int gx = (a.s.Mw + rows_per_wg - 1) / rows_per_wg;
+    int gx = 0;
+    for (int i = 0; i < a.nmat; ++i) {
+        gx += (a.m[i].Mw + rows_per_wg - 1) / rows_per_wg;
+        a.m[i].wg_end = gx;
+    }
     // 64-column tiles unless that leaves fewer than two workgroups (two waves per SIMD) per CU
     const bool narrow = (long)gx * ((a.N + 63) / 64) < 2 * 256 && a.N > 32;
     const int ncols = narrow ? 32 : 64;

@@ -515,6 +515,22 @@ extern "C" int32_t tmac_hip_workspace_write(tmac_hip_workspace* ws, const int8_t
 // ---------------------------------------------------------------------------------------------
 // qgemm
 // ---------------------------------------------------------------------------------------------
+// one-hot MFMA GEMM over 1..4 matrices that share K, the quantisation config (checked by the callers) and the LUT in ws
+static int32_t gemm_multi(const tmac_hip_weights* const* wl, int nmat, const tmac_hip_workspace* ws, void* const* C_list,
+                          tmac_dtype_t out_dtype, int N, int32_t* dump, hipStream_t st) {
+    GemmArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    const tmac_hip_weights* w0 = wl[0];
+    ga.s = w0->s; ga.nmat = nmat;
+    for (int i = 0; i < nmat; ++i) { ga.m[i].W = wl[i]->W; ga.m[i].SC = wl[i]->SC; ga.m[i].C = C_list[i]; ga.m[i].Mw = wl[i]->s.Mw; }
+    ga.sc_f16 = w0->sc_dtype == F16; ga.out_f16 = out_dtype == TMAC_F16;
+    ga.qlut_lds = ws->qlut_lds; ga.tstride = (((w0->s.K / 32) + 15) & ~15) + 1; ga.lut_scales = ws->lut_scales; ga.lut_biases = ws->lut_biases;
+    ga.dump = dump; ga.N = N;
+    hipError_t e = launch_gemm_onehot(ga, st);
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "one-hot gemm launch: %s", hipGetErrorString(e));
+    return TMAC_HIP_OK;
+}
+
 static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* ws, void* C_dev, tmac_dtype_t out_dtype,
                           int N, int32_t* dump, hipStream_t st) {
     if (!w || !ws || !C_dev) return fail(TMAC_HIP_E_ARG, "null argument");
@@ -530,14 +546,8 @@ static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* w
     if (w->fa && v != V_REF_LAYOUT && v != V_LO_MQSAD && v != V_LO_SDWA)
         return fail(TMAC_HIP_E_NOMATCH, "fast-aggregation weights run on the two-kernel path only");
     if (v == V_FUSED && g_gemm_min_n > 0 && N >= g_gemm_min_n && gemm_onehot_supported(w->s)) {
-        GemmArgs ga;
-        memset(&ga, 0, sizeof(ga));
-        ga.s = w->s; ga.W = w->W; ga.SC = w->SC; ga.sc_f16 = w->sc_dtype == F16; ga.out_f16 = out_dtype == TMAC_F16;
-        ga.qlut_lds = ws->qlut_lds; ga.tstride = (((w->s.K / 32) + 15) & ~15) + 1; ga.lut_scales = ws->lut_scales; ga.lut_biases = ws->lut_biases;
-        ga.C = C_dev; ga.dump = dump; ga.N = N;
-        hipError_t e = launch_gemm_onehot(ga, st);
-        if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "one-hot gemm launch: %s", hipGetErrorString(e));
-        return TMAC_HIP_OK;
+        void* cl[1] = {C_dev};
+        return gemm_multi(&w, 1, ws, cl, out_dtype, N, dump, st);
     }
     if (v == V_FUSED) {
         FusedArgs fa;
@@ -640,6 +650,14 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
     } else {
         rc = tmac_hip_preprocessor_dev(ws, B_dev, act_dtype, s0.K, N, s0.ags, st);
     }
+    if (rc) return rc;
+    bool same = g_variant != V_REF_LAYOUT && g_gemm_min_n > 0 && N >= g_gemm_min_n;
+    for (int i = 0; i < nmat && same; ++i) {
+        const Shape &x = wl[i]->s, &y = s0;
+        same = x.lay == 2 && wl[i]->lo_ok && x.ts == 8 && x.bits == y.bits && x.gs == y.gs && x.zero_point == y.zero_point &&
+               x.m_groups == y.m_groups && wl[i]->sc_dtype == wl[0]->sc_dtype && !wl[i]->fa;
+    }
+    if (same) return gemm_multi(wl, nmat, ws, C_list, out_dtype, N, nullptr, st);   // q/k/v or gate/up: one launch fills the chip
     for (int i = 0; i < nmat && rc == TMAC_HIP_OK; ++i) rc = tmac_hip_qgemm_dev(wl[i], ws, C_list[i], out_dtype, N, st);
     return rc;
 }

@@ -46,18 +46,25 @@ struct FusedArgs {
     int nu, nsb, tstride, G, nsg, gs_shift;   // filled by launch_gemv_fused (host-side divides)
 };
 
-// one-hot MFMA GEMM for N > 1 activation rows (tmac_gemm.hip); weights in the QUAD layout
-struct GemmArgs {
-    Shape s;
+// one-hot MFMA GEMM for N > 1 activation rows (tmac_gemm.hip); weights in the QUAD layout; up to 4 matrices that share
+// K, the quantisation config and the LUT in one launch
+struct GemmMat {
     const void* W;            // QUAD layout weights
     const void* SC;           // QUAD layout scales
+    void* C;                  // [N][Mw]
+    int Mw;
+    int wg_end;               // cumulative workgroup count along x (filled by the launcher)
+};
+struct GemmArgs {
+    Shape s;                  // K, bits, gs, ags, zero_point (Mw unused)
+    GemmMat m[4];
+    int nmat;
     int sc_f16, out_f16;
     const void* qlut_lds;     // uint4 [N][4][tstride]: half tables, unit-major image written by k_preprocess
     int tstride;
     const float* lut_scales;  // fp32 [N][K/ags]
     const float* lut_biases;
-    void* C;                  // [N][Mw]
-    int32_t* dump;            // optional integer tap [N][M][K/ags]
+    int32_t* dump;            // optional integer tap [N][M][K/ags] (nmat == 1)
     int N;
 };
 

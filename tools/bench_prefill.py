@@ -37,6 +37,18 @@ for name, Mw, K, cnt in [("qkv/o", 4096, 4096, 4), ("gate/up", 11008, 4096, 2), 
     t_loop = timeit(lambda: wr.llama_cpp_compute(w, out, N), reps=3)
     L.tmac_hip_set_gemm_min_n(32)
     t_fused = timeit(lambda: wr.fused([w], x, [out], N))     # pair-wise LUT build (image only) + GEMM in one call
+    if cnt > 1:   # the matrices of a model that share this activation block (q/k/v: 3, gate/up: 2) in ONE fused call
+        nshare = 3 if name == "qkv/o" else cnt
+        ws_ = [w] + [tmac_amd.Weights(A, S, Mw, K, 2, KCfg.make(Mw, K, 2, 128), scales_dtype=F16, dev_dtype=F16, on_device=True) for _ in range(nshare - 1)]
+        outs_ = [out] + [torch.empty_like(out) for _ in range(nshare - 1)]
+        t_multi = timeit(lambda: wr.fused(ws_, x, outs_, N))
+        print(f"         {nshare} matrices sharing the activations in one fused call: {t_multi:8.1f} us = {t_multi / nshare:7.1f} us per matrix "
+              f"(single calls: {t_fused:7.1f} us each)")
+        tot["multi"] = tot.get("multi", 0.0) + t_multi + (t_fused if name == "qkv/o" else 0.0)   # q/k/v together + o alone
+        for w_ in ws_[1:]:
+            w_.free()
+    else:
+        tot["multi"] = tot.get("multi", 0.0) + t_fused
     t_dense = timeit(lambda: torch.matmul(x, Wd.t()))
     ops = 2.0 * (Mw * 2) * (K / 4 * 8) * N      # MFMA work actually issued: 8-entry half tables
     print(f"{name:8s} Mw={Mw} K={K} N={N}: preprocessor {t_pre:8.1f} us | one-hot MFMA gemm {t_gemm:8.1f} us "
@@ -46,6 +58,8 @@ for name, Mw, K, cnt in [("qkv/o", 4096, 4096, 4), ("gate/up", 11008, 4096, 2), 
     tot["fusedpre"] = tot.get("fusedpre", 0.0) + (t_fused - t_gemm) * (1 if name != "qkv/o" else 2)
     tot["pre"] += t_pre * (1 if name != "qkv/o" else 2)     # one LUT build per distinct activation tensor
     w.free()
+t = 32 * tot["multi"]
+print(f"llama-2-7B prefill, {N} tokens, 32 layers of mpGEMMs, fused entry with q/k/v and gate/up batched:  {t * 1e-3:9.2f} ms  -> {N / t * 1e6:10.0f} tokens/s")
 t = 32 * (tot["gemm"] + tot["fusedpre"])
 print(f"llama-2-7B prefill, {N} tokens, 32 layers of mpGEMMs, fused entry (pair-wise LUT build): {t * 1e-3:9.2f} ms  -> {N / t * 1e6:10.0f} tokens/s")
 for k in ("gemm", "loop", "dense"):

@@ -223,6 +223,14 @@ extern "C" int32_t tmac_hip_set_gemm_min_n(int n) {
     g_gemm_min_n = n;
     return TMAC_HIP_OK;
 }
+// GEMM or row loop for N activation rows on matrices with total_Mw output rows?  An explicitly set threshold is taken
+// literally; the default (32) also asks for a grid that fills the chip: with fewer than 128 workgroups of 128 bit-plane
+// rows the row loop is faster up to 64 rows (profiles/r01_small_n.txt: 4096 x 11008 at N = 32: 88 us against 152 us).
+static bool gemm_pays(const Shape& s, long total_Mw, int N) {
+    if (g_gemm_min_n <= 0 || N < g_gemm_min_n) return false;
+    if (g_gemm_min_n != 32) return true;
+    return N >= 64 || (total_Mw * s.bits + 127) / 128 >= 128;
+}
 
 extern "C" int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host, int n) {
     if (!in_host || !out_host || n <= 0) return fail(TMAC_HIP_E_ARG, "bad selftest arguments");
@@ -545,7 +553,7 @@ static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* w
     }
     if (w->fa && v != V_REF_LAYOUT && v != V_LO_MQSAD && v != V_LO_SDWA)
         return fail(TMAC_HIP_E_NOMATCH, "fast-aggregation weights run on the two-kernel path only");
-    if (v == V_FUSED && g_gemm_min_n > 0 && N >= g_gemm_min_n && gemm_onehot_supported(w->s)) {
+    if (v == V_FUSED && gemm_pays(w->s, w->s.Mw, N) && gemm_onehot_supported(w->s)) {
         void* cl[1] = {C_dev};
         return gemm_multi(&w, 1, ws, cl, out_dtype, N, dump, st);
     }
@@ -651,7 +659,7 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
         rc = tmac_hip_preprocessor_dev(ws, B_dev, act_dtype, s0.K, N, s0.ags, st);
     }
     if (rc) return rc;
-    bool same = g_variant != V_REF_LAYOUT && g_gemm_min_n > 0 && N >= g_gemm_min_n;
+    bool same = g_variant != V_REF_LAYOUT;      // (the caller has established that the GEMM pays for these matrices)
     for (int i = 0; i < nmat && same; ++i) {
         const Shape &x = wl[i]->s, &y = s0;
         same = x.lay == 2 && wl[i]->lo_ok && x.ts == 8 && x.bits == y.bits && x.gs == y.gs && x.zero_point == y.zero_point &&
@@ -751,8 +759,12 @@ static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const voi
     if (!wl || !C_list || !B_dev || nmat < 1 || nmat > 4 || N < 1) return fail(TMAC_HIP_E_ARG, "bad fused arguments (1..4 matrices)");
     if (g_gemm_min_n > 0 && N >= g_gemm_min_n && !dump && !lut_tap) {
         bool ok = true;
-        for (int i = 0; i < nmat; ++i) ok = ok && wl[i] && C_list[i] && gemm_onehot_supported(wl[i]->s) && wl[i]->s.K == wl[0]->s.K && wl[i]->s.ags == wl[0]->s.ags;
-        if (ok) return fused_prefill(wl, nmat, B_dev, act_dtype, C_list, out_dtype, N, st);
+        long rows = 0;
+        for (int i = 0; i < nmat; ++i) {
+            ok = ok && wl[i] && C_list[i] && gemm_onehot_supported(wl[i]->s) && wl[i]->s.K == wl[0]->s.K && wl[i]->s.ags == wl[0]->s.ags;
+            if (ok) rows += wl[i]->s.Mw;
+        }
+        if (ok && gemm_pays(wl[0]->s, rows, N)) return fused_prefill(wl, nmat, B_dev, act_dtype, C_list, out_dtype, N, st);
     }
     FusedArgs fa;
     memset(&fa, 0, sizeof(fa));

@@ -378,8 +378,16 @@ def test_fused_entry_point_prefill(tm, K, N, act_f16, edge):
     if act_f16:
         Bt = Bt.half()
     outs = [torch.empty((N, Mw), dtype=torch.float32, device="cuda") for _ in range(2)]
+    tm.binding.check(tm.lib().tmac_hip_set_gemm_min_n(16))     # explicit threshold: these small matrices take the GEMM
     wr.fused(ws, Bt, outs, N)
     torch.cuda.synchronize()
+    tm.lib().tmac_hip_set_gemm_min_n(32)
+    if not edge:   # the default threshold sends an under-filled grid below 64 rows through the row loop: same results
+        outs2 = [torch.empty_like(o) for o in outs]
+        wr.fused(ws, Bt, outs2, N)
+        torch.cuda.synchronize()
+        for a, b in zip(outs, outs2):
+            assert rel_err(b.cpu().numpy(), a.cpu().numpy()) <= 2e-6
     q, ls, lb, Cc, PS = oracle_case(case, A, S, Mw, K, bits, bm, kf, gs, ags, True, N=N)
     finite = np.isfinite(Cc)
     for o in outs:

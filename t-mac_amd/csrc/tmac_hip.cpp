@@ -710,7 +710,7 @@ extern "C" int32_t tmac_hip_tune_load(const char* path) {
         TuneKey k; TuneVal v;
         if (sscanf(line.c_str(), "%d %d %d %d %d %d %d %f", &k.bits, &k.K, &k.total_q, &k.nmat, &k.flavour, &v.ft, &v.wpq, &v.us) != 8)
             return fail(TMAC_HIP_E_ARG, "%s: malformed line '%s'", path, line.c_str());
-        const bool ok = (v.ft == 512 && (v.wpq == 1 || v.wpq == 2)) || (v.ft == 768 && v.wpq == 3) ||
+        const bool ok = (v.ft == 512 && (v.wpq == 1 || v.wpq == 2)) || (v.ft == 768 && v.wpq >= 1 && v.wpq <= 3) ||
                         (v.ft == 1024 && (v.wpq == 1 || v.wpq == 2 || v.wpq == 4));
         if (!ok) return fail(TMAC_HIP_E_ARG, "%s: (%d, %d) is not a launch configuration of k_gemv_quad", path, v.ft, v.wpq);
         g_tuned[k] = v;
@@ -882,7 +882,7 @@ extern "C" int32_t tmac_hip_autotune_fused(const tmac_hip_weights* const* wl, in
         us = best * 1000.f / R;
         return e;
     };
-    static const int cand[][2] = {{0, 0}, {512, 1}, {512, 2}, {768, 3}, {1024, 1}, {1024, 2}, {1024, 4}};
+    static const int cand[][2] = {{0, 0}, {512, 1}, {512, 2}, {768, 1}, {768, 2}, {768, 3}, {1024, 1}, {1024, 2}, {1024, 4}};
     TuneVal bestv{0, 0, 1e30f};
     float heur = 0.f;
     hipError_t err = hipSuccess;

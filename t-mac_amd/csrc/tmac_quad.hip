@@ -876,6 +876,11 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
     // ... except where two waves per quad would leave the chip between one and two workgroups per CU (shards of a
     // row-split model: 3 x 2048 and 2 x 2752 rows measure 7 % faster with one, profiles/r01_autotune_shards.txt)
     if (best_wpq == 2 && total_q > 1024 && total_q < 2048) best_wpq = 1;
+    // short rows whose quads are exactly one pass of twelve-wave workgroups over (most of) the chip: one quad per wave,
+    // every CU equally loaded, the LUT built once per CU (q/k/v of llama-2-7B, 3072 quads: 6.0 against 6.4 us)
+    if (nst <= 2 && total_q % 12 == 0 && total_q / 12 > 192 && total_q / 12 <= 256 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
+        best_ft = 768; best_wpq = 1;
+    }
     if (BITS == 2 && total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
         // long rows, few quads: 3 waves per quad when that splits the steps evenly, else 4
         if (nst % 3 == 0 && a.s.K / 4 <= 6 * 768) { best_ft = 768; best_wpq = 3; }
@@ -886,9 +891,12 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
     if (force_ft) { best_ft = force_ft; if (!force_wpq && best_wpq > 2) best_wpq = 2; }
     if (force_wpq) best_wpq = force_wpq;
     const bool need512 = a.dump || LUTSRC == 0 || !a.acc_mfma;
-    if (best_ft == 768 || best_wpq == 3) {        // 12 waves, 3 per quad: balanced when the row has 3k steps
-        if (best_ft != 768 || best_wpq != 3 || need512 || a.s.K / 4 > 6 * 768) return hipErrorInvalidValue;
-        return qlaunch_nr<BITS, ZP, SM, LUTSRC, 768, 3>(a, total_q, N, st);
+    if (best_ft == 768 || best_wpq == 3) {        // 12 waves: 3 per quad (balanced when the row has 3k steps), or 12 / 6 quads per workgroup
+        if (best_ft != 768 || need512 || a.s.K / 4 > 6 * 768) return hipErrorInvalidValue;
+        if (best_wpq == 3) return qlaunch_nr<BITS, ZP, SM, LUTSRC, 768, 3>(a, total_q, N, st);
+        if (best_wpq == 1) return qlaunch_nr<BITS, ZP, SM, LUTSRC, 768, 1>(a, total_q, N, st);
+        if (best_wpq == 2) return qlaunch_nr<BITS, ZP, SM, LUTSRC, 768, 2>(a, total_q, N, st);
+        return hipErrorInvalidValue;
     }
     if ((need512 && best_ft != 512) || (best_wpq == 4 && best_ft != 1024) || (best_ft != 512 && best_ft != 1024) ||
         (best_wpq != 1 && best_wpq != 2 && best_wpq != 4) || a.s.K / 4 > 6 * best_ft)

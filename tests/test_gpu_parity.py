@@ -281,7 +281,7 @@ def test_autotuner(tm, tmp_path):
     before = [c.clone() for c in Cs]
     r = wr.autotune(ws, tm.F16, tm.F16)
     assert r["heuristic_us"] > 0 and r["us"] > 0 and r["us"] <= r["heuristic_us"] * 1.0001
-    assert (r["ft"], r["wpq"]) in [(0, 0), (512, 1), (512, 2), (768, 3), (1024, 1), (1024, 2), (1024, 4)]
+    assert (r["ft"], r["wpq"]) in [(0, 0), (512, 1), (512, 2), (768, 1), (768, 2), (768, 3), (1024, 1), (1024, 2), (1024, 4)]
     # force an entry so that the table lookup path is exercised whatever the measurement said
     p = tmp_path / "t.txt"
     p.write_text("2 4096 %d 3 13 1024 2 1.0\n" % (3 * Mw // 4))
@@ -660,7 +660,7 @@ def test_fused_multi_matrix_launch(tm):
 
 
 @pytest.mark.parametrize("variant", [0, 7])
-@pytest.mark.parametrize("ft,wpq", [(512, 1), (512, 2), (768, 3), (1024, 1), (1024, 2), (1024, 4)])
+@pytest.mark.parametrize("ft,wpq", [(512, 1), (512, 2), (768, 1), (768, 2), (768, 3), (1024, 1), (1024, 2), (1024, 4)])
 @pytest.mark.parametrize("Mw,K,bits,bm,kf,gs,ags,zp,mg", [CFGS[0], CFGS[1], CFGS[3], CFGS[8]])
 def test_quad_kernel_configurations(tm, Mw, K, bits, bm, kf, gs, ags, zp, mg, ft, wpq, variant):
     """every (threads per workgroup, waves per quad, accumulate) configuration of k_gemv_quad, LUT built

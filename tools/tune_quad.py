@@ -26,7 +26,7 @@ for name, Mw, K, cnt in [("o", 4096, 4096, 1), ("qkv", 4096, 4096, 3), ("gate_up
     x = torch.randn(K, device=dev).half()
     outs = [torch.empty(Mw, dtype=torch.float16, device=dev) for _ in range(cnt)]
     res = {}
-    for ft, wpq in [(0, 0), (512, 1), (512, 2), (768, 3), (1024, 1), (1024, 2), (1024, 4)]:
+    for ft, wpq in [(0, 0), (512, 1), (512, 2), (768, 1), (768, 2), (768, 3), (1024, 1), (1024, 2), (1024, 4)]:
         L.tmac_hip_debug_quad_config(ft, wpq)
         try:
             for ws in sets[:2]: wr.fused(ws, x, outs, 1)

@@ -876,15 +876,22 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
     // ... except where two waves per quad would leave the chip between one and two workgroups per CU (shards of a
     // row-split model: 3 x 2048 and 2 x 2752 rows measure 7 % faster with one, profiles/r01_autotune_shards.txt)
     if (best_wpq == 2 && total_q > 1024 && total_q < 2048) best_wpq = 1;
-    // short rows whose quads are exactly one pass of twelve-wave workgroups over (most of) the chip: one quad per wave,
-    // every CU equally loaded, the LUT built once per CU (q/k/v of llama-2-7B, 3072 quads: 6.0 against 6.4 us)
-    if (nst <= 2 && total_q % 12 == 0 && total_q / 12 > 192 && total_q / 12 <= 256 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
-        best_ft = 768; best_wpq = 1;
-    }
     if (BITS == 2 && total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
         // long rows, few quads: 3 waves per quad when that splits the steps evenly, else 4
         if (nst % 3 == 0 && a.s.K / 4 <= 6 * 768) { best_ft = 768; best_wpq = 3; }
         else { best_ft = 1024; best_wpq = 4; }
+    }
+    // One balanced pass: if twelve-wave workgroups with 1, 2 or 3 waves per quad cover the quads in a single pass over
+    // 75-100 % of the CUs, every CU gets the same work, the LUT is built once per CU and the weights can be issued early.
+    // Matches every case the tuner found on the llama-2-7B shapes and their 2-/4-/8-way row shards
+    // (profiles/r01_autotune_shards.txt): q/k/v 3 x 4096 rows -> (768,1) 5.6 against 6.1 us; 3 x 2048 -> (768,2);
+    // gate/up 2 x 5504 -> (768,1) 5.45 against 5.9; 2 x 2752 -> (768,2); down 4096 x 11008 -> (768,3).
+    if (!(a.dump || LUTSRC == 0 || !a.acc_mfma) && a.s.K / 4 <= 6 * 768) {
+        for (int wq = 1; wq <= 3; ++wq) {
+            if (wq > nst || nst % wq || (wq == 3 && BITS > 2)) continue;   // (W4 long rows measure better on (512,2): tune_quad.py 0 4)
+            const int wgs = (total_q * wq + 11) / 12;
+            if (wgs > 192 && wgs <= 256) { best_ft = 768; best_wpq = wq; break; }
+        }
     }
     double best = 0.0;
     if (a.s.K / 4 > 6 * 512 && best_ft == 512 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) best_ft = 1024;   // LUT build: <= 6 tables per thread

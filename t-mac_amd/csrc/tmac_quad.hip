@@ -874,7 +874,7 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
     // two waves per quad up to one quad per wave slot of the chip (4096), one beyond
     int best_ft = 512, best_wpq = (total_q <= 4096 && nst >= 2) ? 2 : 1;
     // ... except where two waves per quad would leave the chip between one and two workgroups per CU (shards of a
-    // row-split model: 3 x 2048 and 2 x 2752 rows measure 7 % faster with one, profiles/r01_autotune_shards.txt)
+    // row-split model: 3 x 2048 and 2 x 2752 rows measured 7 % faster with one, profiles/history/r01_autotune_shards_before_heuristic.txt)
     if (best_wpq == 2 && total_q > 1024 && total_q < 2048) best_wpq = 1;
     if (BITS == 2 && total_q <= 1024 && nst >= 4 && !(a.dump || LUTSRC == 0 || !a.acc_mfma)) {
         // long rows, few quads: 3 waves per quad when that splits the steps evenly, else 4
@@ -884,7 +884,7 @@ static hipError_t qlaunch_cfg(const FusedArgs& a, int total_q, int N, int force_
     // One balanced pass: if twelve-wave workgroups with 1, 2 or 3 waves per quad cover the quads in a single pass over
     // 75-100 % of the CUs, every CU gets the same work, the LUT is built once per CU and the weights can be issued early.
     // Matches every case the tuner found on the llama-2-7B shapes and their 2-/4-/8-way row shards
-    // (profiles/r01_autotune_shards.txt): q/k/v 3 x 4096 rows -> (768,1) 5.6 against 6.1 us; 3 x 2048 -> (768,2);
+    // (profiles/history/r01_autotune_shards_before_heuristic.txt and the runs after it): q/k/v 3 x 4096 rows -> (768,1) 5.6 against 6.1 us; 3 x 2048 -> (768,2);
     // gate/up 2 x 5504 -> (768,1) 5.45 against 5.9; 2 x 2752 -> (768,2); down 4096 x 11008 -> (768,3).
     if (!(a.dump || LUTSRC == 0 || !a.acc_mfma) && a.s.K / 4 <= 6 * 768) {
         for (int wq = 1; wq <= 3; ++wq) {

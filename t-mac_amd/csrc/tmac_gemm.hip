@@ -184,7 +184,9 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
                 av[rt] = (gv4i_t){(int)p0.x, (int)p0.y, (int)p1.x, (int)p1.y};
             }
         };
-        constexpr bool AHEAD = (GNT == 2);   // the 64-column tile has no registers to spare for a second operand set
+        // operands one unit ahead of the MFMAs that consume them, where the registers allow: the 32-column tile, and the
+        // 64-column tile with W2 (one fp32 accumulator pair per tile since the planes are combined first: 150 VGPRs)
+        constexpr bool AHEAD = (GNT == 2) || (BITS == 2);
         gv4i_t avc[GRT], bvc[GNT], avn[GRT], bvn[GNT];
         if (AHEAD) operands(0, avc, bvc);
 #pragma unroll

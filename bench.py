@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per launch of the headline GEMV from rocprofv3 --pmc FETCH_SIZE (separate pass, x2 gfx950 correction,
 # MI355X_MICROARCH.md HBM section): profiles/r01_pmc_fetch_size.txt — 7013 KiB x 2 = 14.36 MB vs 12.73 MB algorithmic
 # (the x2 rule is calibrated for 16 B/lane streams; the 4-8 B/lane scale loads are probably double-counted by it)
-PMC_TRAFFIC_BYTES = 14362624
+PMC_TRAFFIC_BYTES = 14353408
 LAYERS = 32
 # (name, Mw, K, count per layer, input slot)
 MATS = [("qkv", 4096, 4096, 3, 0), ("o", 4096, 4096, 1, 1), ("gate_up", 11008, 4096, 2, 2), ("down", 4096, 11008, 1, 3)]

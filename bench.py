@@ -35,8 +35,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
 # HBM bytes per launch of the headline GEMV from rocprofv3 --pmc FETCH_SIZE (separate pass, x2 gfx950 correction,
-# MI355X_MICROARCH.md HBM section): profiles/r01_pmc_fetch_size.txt — 7013 KiB x 2 = 14.36 MB vs 12.73 MB algorithmic
-# (the x2 rule is calibrated for 16 B/lane streams; the 4-8 B/lane scale loads are probably double-counted by it)
+# MI355X_MICROARCH.md HBM section): profiles/r01_pmc_fetch_size.txt — 7008.5 KiB x 2 = 14.35 MB vs 12.73 MB algorithmic.
+# The excess is the zero padding of the device layout: K = 11008 is 5.4 steps of 64 units, stored (and read) as 6, i.e.
+# 12.58 MB of weight planes instead of 11.27 MB; the 4096-wide shapes read 1.01-1.04 x their algorithmic bytes.
 PMC_TRAFFIC_BYTES = 14353408
 LAYERS = 32
 # (name, Mw, K, count per layer, input slot)

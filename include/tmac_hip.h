@@ -161,7 +161,7 @@ int32_t tmac_hip_set_variant(int variant);
  * written as an int8 contraction, same bit-exact integer sums) instead of looping the GEMV kernel over the
  * rows (qgemm.py:183-190); n = 0 disables it.  Default 32 (the measured crossover); at the default the GEMM additionally waits for
  * N >= 64 when the matrices of the call have fewer than 128 x 64 output rows x bits / 2 (an under-filled grid), any other value is taken literally.  QUAD-layout weights of 2 or 4 bits only (1/3-bit
- * weights loop the GEMV). */
+ * weights loop the GEMV), per-group scales with act groups of 64 or the unified-scale (BitNet) flavour. */
 int32_t tmac_hip_set_gemm_min_n(int n);
 /* Fast aggregation (the reference's `-fa` build option, deploy/compile.py:167-174,223): the
  * looked-up bytes of an act group are folded by a tree of rounding-halving adds instead of being summed exactly

@@ -51,7 +51,10 @@ typedef float gv2f_t __attribute__((ext_vector_type(2)));
 // GNT: MFMA n tiles per workgroup and wave (16 activation rows each): 4, or 2 when that is needed to fill the chip.
 // GCH: units (8 tables = 32 activations each) per LDS chunk: 4, or 8 with the narrow tile (longer chunks hide the
 // fetch latency when a CU holds few waves; 48 KB of LDS).
-template <int BITS, bool ZP, bool DUMP, int GNT, int GCH>
+// US: unified-scale flavour (BitNet: m_groups >= 1, act group = K; tbl_g4_int8_int32_update + qgemm.py:170-174): the int32
+// tiles accumulate over the whole K, nothing is scaled per act group, and the epilogue is
+//   C = ((sum_p float(cb_p) alpha_p) * lut_scale[n] + lut_bias[n] / 2) * scale[o / (Mw / m_groups)]      bit-exact
+template <int BITS, bool ZP, bool DUMP, int GNT, int GCH, bool US>
 __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
     constexpr int NJ = BITS;                               // uint4 per unit and quad in the QUAD layout
     constexpr int ORPT = 16 / BITS;                        // output rows per MFMA row tile
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < NAG / 2; ++k) {
+            if (US) continue;                               // no per-act-group operands
             const int kk = min(c * NAG + e_ag + 2 * k, G - 1);
             e1[k] = e1_src[kk];
             e2[k] = 0.f;
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
         if (tid < GCH * QW * NJ) wt[buf][w_ul][w_ql][w_j] = wst;
 #pragma unroll
         for (int k = 0; k < NAG / 2; ++k) {
+            if (US) continue;
             ep[buf][e_ag + 2 * k][e1_which][tid & 63] = e1[k];
             ep[buf][e_ag + 2 * k][2 + e2_which][(tid >> 1) & 63] = e2[k];
         }
@@ -198,9 +203,9 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
                 for (int rt = 0; rt < GRT; ++rt)
 #pragma unroll
                     for (int nt = 0; nt < GNT; ++nt)         // first unit of an act group starts from the constant accumulator operand
-                        c[rt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(avc[rt], bvc[nt], (ul & 1) ? c[rt][nt] : cinit, 0, 0, 0);
+                        c[rt][nt] = __builtin_amdgcn_mfma_i32_16x16x64_i8(avc[rt], bvc[nt], (US || (ul & 1)) ? c[rt][nt] : cinit, 0, 0, 0);
                 // ---- act group complete: fp32 scale-apply of the int32 tiles, then reset them --------------
-                if (ul & 1) {                                // ags = 64: units 2kk, 2kk+1
+                if (!US && (ul & 1)) {                       // ags = 64: units 2kk, 2kk+1
                     const int ag = ul >> 1, kk = (ck * GCH + ul) >> 1;
                     float sc[GRT][4 / BITS], zr[GRT][4 / BITS];
 #pragma unroll
@@ -279,7 +284,22 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
             for (int oo = 0; oo < 4 / BITS; ++oo) {
                 const int o = orow_wg + (w * GRT + rt) * ORPT + (4 * g) / BITS + oo;
                 float acc;
-                if constexpr (BITS == 2) {
+                if constexpr (US) {
+                    // accumulator rows of the lane: W2 (o0 p0, o1 p0, o0 p1, o1 p1), W4 planes 0..3 of one output
+                    float t = 0.f;
+#pragma unroll
+                    for (int pl = 0; pl < BITS; ++pl) {
+                        const int r = (BITS == 2) ? (2 * pl + oo) : pl;
+                        const int32_t cb = c[rt][nt][r];
+                        if (DUMP && o < Mw) a.dump[(size_t)n * Mw * BITS + mrow(o, pl, BITS)] = cb;
+                        const float tp = __fmul_rn((float)cb, g_alpha(pl));
+                        t = (pl == 0) ? tp : __fadd_rn(t, tp);
+                    }
+                    const float v = __fadd_rn(__fmul_rn(t, a.lut_scales[n]), __fmul_rn(a.lut_biases[n], 0.5f));
+                    const int sgi = o < Mw ? o / (Mw / s.m_groups) : 0;
+                    const float scv = a.sc_f16 ? __half2float(reinterpret_cast<const __half*>(M.SC)[sgi]) : reinterpret_cast<const float*>(M.SC)[sgi];
+                    acc = __fmul_rn(v, scv);
+                } else if constexpr (BITS == 2) {
                     acc = facc[rt][nt][0][oo];
                 } else {
                     acc = __fmul_rn(facc[rt][nt][(oo * BITS) >> 1][0], 0.5f);
@@ -293,7 +313,9 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
 }
 
 bool gemm_onehot_supported(const Shape& s) {
-    return s.lay == 2 && (s.bits == 2 || s.bits == 4) && s.m_groups < 0 && s.ags == 64 && s.gs % 64 == 0 && s.K % 64 == 0;
+    if (s.lay != 2 || (s.bits != 2 && s.bits != 4) || s.K % 64 != 0) return false;
+    if (s.m_groups >= 1) return s.ags == s.K && s.Mw % s.m_groups == 0;      // unified scale (BitNet): int32 over the whole K
+    return s.ags == 64 && s.gs % 64 == 0;
 }
 
 hipError_t launch_gemm_onehot(const GemmArgs& a_in, hipStream_t st) {
@@ -310,10 +332,13 @@ hipError_t launch_gemm_onehot(const GemmArgs& a_in, hipStream_t st) {
     const bool narrow = (long)gx * ((a.N + 63) / 64) < 2 * 256 && a.N > 32;
     const int ncols = narrow ? 32 : 64;
     dim3 g(gx, (a.N + ncols - 1) / ncols), b(64 * GWV);
-#define GL2(B, Z, D) do { if (narrow) hipLaunchKernelGGL((k_gemm_onehot<B, Z, D, 2, 8>), g, b, 0, st, a); \
-                          else hipLaunchKernelGGL((k_gemm_onehot<B, Z, D, 4, 4>), g, b, 0, st, a); } while (0)
-#define GL(B, Z) do { if (a.dump) GL2(B, Z, true); else GL2(B, Z, false); } while (0)
-    if (bits == 2) { if (a.s.zero_point) GL(2, true); else GL(2, false); }
+#define GL2(B, Z, D, U) do { if (narrow) hipLaunchKernelGGL((k_gemm_onehot<B, Z, D, 2, 8, U>), g, b, 0, st, a); \
+                             else hipLaunchKernelGGL((k_gemm_onehot<B, Z, D, 4, 4, U>), g, b, 0, st, a); } while (0)
+#define GL(B, Z) do { if (a.dump) GL2(B, Z, true, false); else GL2(B, Z, false, false); } while (0)
+    if (a.s.m_groups >= 1) {
+        if (bits == 2) { if (a.dump) GL2(2, false, true, true); else GL2(2, false, false, true); }
+        else { if (a.dump) GL2(4, false, true, true); else GL2(4, false, false, true); }
+    } else if (bits == 2) { if (a.s.zero_point) GL(2, true); else GL(2, false); }
     else { if (a.s.zero_point) GL(4, true); else GL(4, false); }
 #undef GL
 #undef GL2

@@ -351,6 +351,20 @@ def test_onehot_mfma_gemm(tm, Mw, K, bits, bm, kf, gs, ags, zp, N):
     assert rel_err(r["C"], r2["C"]) <= 2e-6
 
 
+@pytest.mark.parametrize("Mw,K,bits,bm,N", [(320, 3200, 2, 320, 5), (320, 3200, 2, 320, 40), (160, 640, 2, 320, 33),
+                                            (128, 1024, 4, 256, 20), (3200, 8640, 2, 128, 34)])
+def test_onehot_mfma_gemm_unified_scale(tm, Mw, K, bits, bm, N):
+    """the BitNet flavour (m_groups = 1, act group = K) through k_gemm_onehot: int32 totals over the whole K bit-exact,
+    outputs bit-identical to the GEMV loop's (same scale-final expression on the same integers) and to the oracle"""
+    case = orc.make_case(300 + N + K, Mw, K, N=N, bits=bits, ags=K, zero_point=False, m_groups=1)
+    r = run_case(tm, case, Mw, K, bits, bm, 16, 128, K, False, m_groups=1, N=N, gemm_min_n=1)
+    q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, 16, 128, K, False, m_groups=1, N=N)
+    assert np.array_equal(r["q"], q) and np.array_equal(r["PS"], PS)
+    check_bits(r["C"], Cc)
+    r2 = run_case(tm, case, Mw, K, bits, bm, 16, 128, K, False, m_groups=1, N=N, gemm_min_n=0, want_ps=False)
+    check_bits(r["C"], r2["C"])
+
+
 @pytest.mark.parametrize("K,N,act_f16,edge", [(2048, 48, False, False), (11008, 40, True, False), (4096, 33, False, True),
                                               (4096, 64, True, True)])
 def test_fused_entry_point_prefill(tm, K, N, act_f16, edge):

@@ -58,3 +58,38 @@ print(f"llama-2-7B W4A16-style decode: {32 * t * 1e-3:.3f} ms/token of GEMV laun
 t, b = run("bitnet-3b", [("o", 3200, 3200, 1, 1), ("qkv", 3200, 3200, 3, 1), ("gate_up", 8640, 3200, 2, 1), ("down", 3200, 8640, 1, 1)],
            2, 128, 128, lambda K: K, False, 1)
 print(f"BitNet-b1.58-3B decode: {26 * t * 1e-3:.3f} ms/token of GEMV launches, {b / t * 1e-3:.0f} GB/s")
+
+# ---- BitNet prefill: the unified-scale flavour of the one-hot GEMM against the GEMV row loop (fused entry point) ----
+def bitnet_prefill(N):
+    L = tmac_amd.lib()
+    tot = {"gemm": 0.0, "loop": 0.0}
+    for name, Mw, K, cnt in [("o", 3200, 3200, 1), ("qkv", 3200, 3200, 3), ("gate_up", 8640, 3200, 2), ("down", 3200, 8640, 1)]:
+        wr = tmac_amd.TMACGeMMWrapper(act_group_size=K); wr.set_workspace(K, N)
+        cfg = KCfg.make(Mw, K, 2, 128, 16, 128, K, False, 1, N)
+        ws = []
+        for _ in range(cnt):
+            A = torch.randint(0, 256, (Mw * 2 // 128, K // 4, 64), dtype=torch.uint8, device=dev)
+            S = torch.full((1,), 0.01, device=dev, dtype=torch.float32)
+            ws.append(tmac_amd.Weights(A, S, Mw, K, 2, cfg, scales_dtype=F32, dev_dtype=F32, on_device=True))
+        x = torch.randn(N, K, device=dev).half()
+        outs = [torch.empty(N, Mw, dtype=torch.float16, device=dev) for _ in range(cnt)]
+        res = {}
+        for tag, mn in (("gemm", 16), ("loop", 0)):
+            L.tmac_hip_set_gemm_min_n(mn)
+            wr.fused(ws, x, outs, N); torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(3):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5): wr.fused(ws, x, outs, N)
+                e1.record(); torch.cuda.synchronize()
+                best = min(best, e0.elapsed_time(e1) * 1e3 / 5)
+            res[tag] = best; tot[tag] += best
+        L.tmac_hip_set_gemm_min_n(32)
+        print(f"bitnet-3b prefill N={N} {name:8s} Mw={Mw}x{cnt} K={K}: LUT build + one-hot GEMM {res['gemm']:8.1f} us | LUT build + GEMV row loop {res['loop']:8.1f} us")
+        for w in ws: w.free()
+        L.tmac_hip_cache_clear()
+    print(f"BitNet-b1.58-3B prefill, {N} tokens, 26 layers of mpGEMMs: GEMM {26 * tot['gemm'] * 1e-3:.2f} ms ({N / (26 * tot['gemm']) * 1e6:.0f} tokens/s), "
+          f"row loop {26 * tot['loop'] * 1e-3:.2f} ms ({N / (26 * tot['loop']) * 1e6:.0f} tokens/s)")
+
+bitnet_prefill(256)

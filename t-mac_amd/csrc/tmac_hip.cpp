@@ -474,6 +474,9 @@ extern "C" int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void*
     hipError_t e = (act_group_size == 64 && N >= g_pairs_min_n)
         ? launch_preprocess_pairs(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, K, N, ws->qlut_ref,
                                   ws->qlut_dev, ws->qdev_u4_per_row, (hipStream_t)stream)
+        : (act_group_size == K && K <= 12288 && N >= g_pairs_min_n)
+        ? launch_preprocess_pairs_row(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, K, N, ws->qlut_ref,
+                                      ws->qlut_dev, ws->qdev_u4_per_row, (hipStream_t)stream)
         : launch_preprocess(B_dev, (Dtype)act_dtype, ws->qlut_ref, ws->qlut_dev, ws->qlut_lds, ws->lut_scales, ws->lut_biases,
                             K, N, act_group_size, ws->qdev_u4_per_row, (hipStream_t)stream);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
@@ -647,13 +650,14 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
         ws = slot;
     }
     int32_t rc;
-    if (s0.ags == 64 && g_variant != V_REF_LAYOUT) {
+    if ((s0.ags == 64 || (s0.ags == s0.K && s0.K <= 12288)) && g_variant != V_REF_LAYOUT) {
         // only the one-hot GEMM reads this workspace: build the half-table image alone, two tables per lane
         rc = check_lut_shape(ws, s0.K, N, s0.ags);
         if (rc) return rc;
         ws->K = s0.K; ws->N = N; ws->ags = s0.ags; ws->qdev_u4_per_row = qdev_u4_for_K(s0.K);
-        hipError_t e = launch_preprocess_pairs(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, s0.K, N,
-                                               nullptr, nullptr, 0, st);
+        hipError_t e = s0.ags == 64
+            ? launch_preprocess_pairs(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, s0.K, N, nullptr, nullptr, 0, st)
+            : launch_preprocess_pairs_row(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, s0.K, N, nullptr, nullptr, 0, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
     } else {
         rc = tmac_hip_preprocessor_dev(ws, B_dev, act_dtype, s0.K, N, s0.ags, st);

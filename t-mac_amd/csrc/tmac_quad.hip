@@ -796,6 +796,106 @@ __global__ __launch_bounds__(256) void k_preprocess_pairs(const void* __restrict
     }
 }
 
+// The same for one act group per row (act_group_size = K, the unified-scale / BitNet flavour): a workgroup owns an
+// activation row.  Pass 1: abs-max of the row and the 8-table chunk sums of lut_biases (neither depends on the scale);
+// then one lane walks the reference's sequential fp32 chain over the chunk sums (lut_ctor.cc:157,218) while the other
+// waves quantise their tables -- the build phase of k_gemv_quad's SM == 2 path as a kernel of its own.
+template <bool F16, bool ALL, int PT>
+__global__ __launch_bounds__(PT) void k_preprocess_pairs_row(const void* __restrict__ B, uint4* __restrict__ qlut_lds,
+                                                               float* __restrict__ lut_scales, float* __restrict__ lut_biases,
+                                                               int K, int tstride, uint4* __restrict__ qlut_ref,
+                                                               uint2* __restrict__ qlut_dev, size_t qdev_u4_per_row) {
+    extern __shared__ float prs[];          // [PT/64] wave maxima | [K/32] chunk sums
+    constexpr int NWV = PT / 64;
+    const int P = K / 8, n = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    float* l_mx = prs;
+    float* l_cs = prs + NWV;
+    constexpr int NPR = 3;                   // pairs per thread: K <= 24 * PT
+    float x[NPR][8];
+    float mx = 0.f;
+#pragma unroll
+    for (int r = 0; r < NPR; ++r) {
+        const int p = r * PT + tid;
+        if (p < P) {
+            if (F16) {
+                const uint4 v = reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(B) + (size_t)n * K)[p];
+                const uint32_t rr[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const __half2 hh = *reinterpret_cast<const __half2*>(&rr[i]);
+                    x[r][2 * i] = __low2float(hh); x[r][2 * i + 1] = __high2float(hh);
+                }
+            } else {
+                const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(B) + (size_t)n * K) + 2 * (size_t)p;
+                const float4 a0 = src[0], a1 = src[1];
+                x[r][0] = a0.x; x[r][1] = a0.y; x[r][2] = a0.z; x[r][3] = a0.w; x[r][4] = a1.x; x[r][5] = a1.y; x[r][6] = a1.z; x[r][7] = a1.w;
+            }
+            mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x[r][0]), fabsf(x[r][1])), __fadd_rn(fabsf(x[r][2]), fabsf(x[r][3]))));
+            mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x[r][4]), fabsf(x[r][5])), __fadd_rn(fabsf(x[r][6]), fabsf(x[r][7]))));
+            float va = -__fadd_rn(__fadd_rn(__fadd_rn(x[r][0], x[r][1]), x[r][2]), x[r][3]);
+            float vb = -__fadd_rn(__fadd_rn(__fadd_rn(x[r][4], x[r][5]), x[r][6]), x[r][7]);
+            va = __fadd_rn(va, qdpp_f<0x4E>(va));
+            vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));
+            va = __fadd_rn(va, qdpp_f<0xB1>(va));
+            vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));
+            if ((p & 3) == 0) l_cs[p >> 2] = __fadd_rn(va, vb);
+        }
+    }
+    mx = q_row_allmax(mx);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (lane == 0) l_mx[w] = mx;
+    __syncthreads();
+    mx = l_mx[0];
+#pragma unroll
+    for (int i = 1; i < NWV; ++i) mx = fmaxf(mx, l_mx[i]);
+    const float gscale = __fdiv_rn(mx, 127.0f);
+    const float gtinv = (gscale != 0.0f) ? __fdiv_rn(1.0f, gscale) : 0.0f;
+    if (tid == PT - 64) {
+        float biases = 0.0f;
+        const int nc = K / 32;
+        for (int c = 0; c < nc; ++c) biases = __fadd_rn(biases, l_cs[c]);
+        lut_scales[n] = gscale;
+        lut_biases[n] = biases;
+    }
+#pragma unroll
+    for (int r = 0; r < NPR; ++r) {
+        const int p = r * PT + tid;
+        if (p < P) {
+            uint32_t lo0, hi0, lo1, hi1;
+            float La, Lb;
+            q_table8<false>(x[r][0], x[r][1], x[r][2], x[r][3], gtinv, lo0, hi0, La);
+            q_table8<false>(x[r][4], x[r][5], x[r][6], x[r][7], gtinv, lo1, hi1, Lb);
+            qlut_lds[((size_t)n * 4 + (p & 3)) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
+            if (ALL) {
+                const int seg = p >> 3, j8 = p & 7;
+                *reinterpret_cast<uint4*>(qlut_dev + ((size_t)n * qdev_u4_per_row + qlut_dev_u4_index(seg, j8)) * 2) = make_uint4(lo0, hi0, lo1, hi1);
+                const uint32_t sg = 0x80808080u, rev = 0x00010203u;
+                const uint32_t n0l = __builtin_amdgcn_perm(0u, 0x01010100u - lo0, rev), n0h = __builtin_amdgcn_perm(0u, 0x01010100u - hi0, rev);
+                const uint32_t n1l = __builtin_amdgcn_perm(0u, 0x01010100u - lo1, rev), n1h = __builtin_amdgcn_perm(0u, 0x01010100u - hi1, rev);
+                uint4* rp = qlut_ref + ((size_t)n * (K / 4) + 2 * (size_t)p);
+                rp[0] = make_uint4(lo0 ^ sg, hi0 ^ sg, n0h ^ sg, n0l ^ sg);
+                rp[1] = make_uint4(lo1 ^ sg, hi1 ^ sg, n1h ^ sg, n1l ^ sg);
+            }
+        }
+    }
+}
+
+hipError_t launch_preprocess_pairs_row(const void* B, int act_f16, void* qlut_lds, float* lut_scales, float* lut_biases, int K, int N,
+                                       int8_t* qlut_ref, void* qlut_dev, size_t qdev_u4_per_row, hipStream_t st) {
+    constexpr int PT = 512;
+    if (K % 64 != 0 || N < 1 || K > 24 * PT || ((qlut_ref == nullptr) != (qlut_dev == nullptr))) return hipErrorInvalidValue;
+    const int tstride = (((K / 32) + 15) & ~15) + 1;
+    const size_t shmem = sizeof(float) * (PT / 64 + K / 32);
+    dim3 g(N), b(PT);
+#define PLR(F, A) hipLaunchKernelGGL((k_preprocess_pairs_row<F, A, PT>), g, b, shmem, st, B, (uint4*)qlut_lds, lut_scales, lut_biases, K, tstride, \
+                                     (uint4*)qlut_ref, (uint2*)qlut_dev, qdev_u4_per_row)
+    if (qlut_ref) { if (act_f16) PLR(true, true); else PLR(false, true); }
+    else { if (act_f16) PLR(true, false); else PLR(false, false); }
+#undef PLR
+    return hipGetLastError();
+}
+
 hipError_t launch_preprocess_pairs(const void* B, int act_f16, void* qlut_lds, float* lut_scales, float* lut_biases, int K, int N,
                                    int8_t* qlut_ref, void* qlut_dev, size_t qdev_u4_per_row, hipStream_t st) {
     if (K % 64 != 0 || N < 1 || ((qlut_ref == nullptr) != (qlut_dev == nullptr))) return hipErrorInvalidValue;

@@ -360,6 +360,7 @@ def test_onehot_mfma_gemm_unified_scale(tm, Mw, K, bits, bm, N):
     r = run_case(tm, case, Mw, K, bits, bm, 16, 128, K, False, m_groups=1, N=N, gemm_min_n=1)
     q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, 16, 128, K, False, m_groups=1, N=N)
     assert np.array_equal(r["q"], q) and np.array_equal(r["PS"], PS)
+    check_bits(r["ls"], ls); check_bits(r["lb"], lb)      # the row-wise pair build (k_preprocess_pairs_row) from N = 2 on
     check_bits(r["C"], Cc)
     r2 = run_case(tm, case, Mw, K, bits, bm, 16, 128, K, False, m_groups=1, N=N, gemm_min_n=0, want_ps=False)
     check_bits(r["C"], r2["C"])

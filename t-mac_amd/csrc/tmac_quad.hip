@@ -530,7 +530,14 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
         }
         if (SM == 2) {      // unified scale: keep the exact integer sum of this lane's row (lane & 3), all units
 #pragma unroll
-            for (int pl = 0; pl < BITS; ++pl) iacc[pl][0] += (c[pl].x + c[pl].y) + (c[pl].z + c[pl].w);
+            for (int pl = 0; pl < BITS; ++pl) {
+                // The MFMA result must have landed before a VALU instruction reads it (no hardware interlock: up to 18 wait
+                // states after an 8-pass MFMA).  With one bit-plane nothing else separates the last MFMA of the step from this
+                // sum, and the compiler's hazard recogniser left them 1 wait state apart across the loop branch (W1
+                // unified-scale results were wrong); the dependency through this asm puts the wait in explicitly.
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[pl]));
+                iacc[pl][0] += (c[pl].x + c[pl].y) + (c[pl].z + c[pl].w);
+            }
             return;
         }
         const int ub4 = st * 64 + 4 * (lane & 12) + 4 * (lane >> 4);

@@ -160,6 +160,9 @@ CFGS = [  # Mw, K, bits, bm, kf, gs, ags, zp, m_groups
     (256, 1024, 2, 128, 8, 128, 32, True, -1),       # act_group 32
     (256, 1024, 4, 256, 16, 64, 64, False, -1),      # group_size 64
     (320, 3200, 2, 320, 16, 128, 3200, False, 1),    # BitNet x86: unified scale, int32 aggregation (config #4)
+    (128, 1024, 1, 128, 16, 128, 1024, False, 1),    # ... with 1-bit weights: one MFMA chain per step, its result read right
+    (256, 576, 1, 128, 8, 64, 576, False, 1),        #     behind the loop branch (a missing wait state was found here)
+    (128, 2048, 3, 192, 16, 128, 2048, False, 1), (128, 1024, 4, 256, 16, 128, 1024, False, 1),
     (320, 8640, 2, 128, 16, 128, 8640, False, 1),
     (320, 3200, 2, 128, 16, 128, 64, False, 1),      # BitNet ARM flavour: one weight scale, per-group LUT scales
 ]
@@ -187,6 +190,54 @@ def test_reference_layout_kernel_is_bit_exact(tm, Mw, K, bits, bm, kf, gs, ags, 
     q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, kf, gs, ags, zp, mg)
     assert np.array_equal(r["PS"], PS)
     check_bits(r["C"], Cc)
+
+
+def _random_configs(n, seed):
+    """valid (Mw, K, bits, bm, kf, gs, ags, zp, m_groups, N) tuples drawn from the reference's knob space
+    (qgemm.py:98-129: bm % 32 == 0, (bm / bits) % 8 == 0, 4 kfactor % ags == 0, gs % (4 kfactor) == 0, K % gs == 0)"""
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        bits = int(rng.integers(1, 5))
+        bm = int(rng.choice([192, 384] if bits == 3 else [128, 256, 512, 320, 640]))
+        if bm % bits or (bm // bits) % 8:
+            continue
+        kf = int(rng.choice([8, 16]))
+        flavour = int(rng.integers(0, 4))         # 0, 1: per-group scales (zp on/off); 2: unified scale; 3: one scale + per-group LUT
+        gs = int(rng.choice([64, 128, 256]))
+        if gs % (4 * kf):
+            continue
+        K = gs * int(rng.integers(2, 12))
+        if (K // 4) % kf:
+            continue
+        ags = int(rng.choice([32, 64]))
+        if (4 * kf) % ags:
+            continue
+        mg = -1
+        zp = flavour == 0
+        if flavour == 2:
+            ags, mg, zp = K, 1, False
+        elif flavour == 3:
+            mg, zp = 1, False
+        Mw = (bm // bits) * int(rng.integers(1, 5))
+        N = int(rng.choice([1, 1, 1, 2, 3, 37]))
+        out.append((Mw, K, bits, bm, kf, gs, ags, zp, mg, N))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_configs(48, 20260924), ids=lambda c: "-".join(str(int(x)) for x in c))
+def test_random_configurations(tm, cfg):
+    """48 configurations drawn from the reference's whole knob space (1-4 bits, every legal bm / kfactor, group sizes,
+    act groups 32 / 64 / K, zero points, unified and single scales, 1-37 activation rows), whatever kernel the dispatcher
+    picks for them: QLUT, LUT scales / biases and integer sums bit-exact, outputs within the fp32 bound"""
+    Mw, K, bits, bm, kf, gs, ags, zp, mg, N = cfg
+    case = orc.make_case(sum(cfg), Mw, K, N=N, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg)
+    r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, mg, N=N)
+    q, ls, lb, Cc, PS = oracle_case(case, r["A"], r["S"], Mw, K, bits, bm, kf, gs, ags, zp, mg, N=N)
+    assert np.array_equal(r["q"], q)
+    check_bits(r["ls"], ls); check_bits(r["lb"], lb)
+    assert np.array_equal(np.asarray(r["PS"]).reshape(PS.shape), PS)
+    assert rel_err(r["C"], Cc) <= 2e-5
 
 
 def test_fp16_storage_path(tm):

@@ -240,6 +240,62 @@ def test_random_configurations(tm, cfg):
     assert rel_err(r["C"], Cc) <= 2e-5
 
 
+def _random_fused(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        bits = int(rng.integers(1, 5))
+        bm = int(rng.choice([192, 384] if bits == 3 else [128, 256, 512, 320, 640]))
+        if bm % bits or (bm // bits) % 8:
+            continue
+        gs = int(rng.choice([64, 128, 256]))
+        K = gs * int(rng.integers(2, 40))
+        unified = bool(rng.integers(0, 4) == 0)
+        zp = (not unified) and bool(rng.integers(0, 2))
+        nmat = int(rng.integers(1, 4))
+        Mws = [(bm // bits) * int(rng.integers(1, 6)) for _ in range(nmat)]
+        N = int(rng.choice([1, 1, 2, 40, 70]))
+        out.append((tuple(Mws), K, bits, bm, gs, zp, unified, N, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_fused(40, 99), ids=lambda c: "-".join(str(x) for x in c).replace(" ", ""))
+def test_random_fused_calls(tm, cfg):
+    """40 random calls of the fused entry point (1-3 matrices sharing the activations, 1-4 bits, per-group or unified scale,
+    fp16 / fp32 activations, scales and outputs, 1-70 activation rows: decode kernel, row loop or pair-wise LUT build +
+    batched GEMM, whatever the dispatcher picks) against the oracle"""
+    import torch
+    Mws, K, bits, bm, gs, zp, unified, N, act_f16, sc_f16, out_f16 = cfg
+    ags, mg, kf = (K, 1, 16) if unified else (64, -1, 16)
+    wr = tm.TMACGeMMWrapper(act_group_size=ags)
+    B = np.random.default_rng(sum(Mws) + K).standard_normal((N, K)).astype(np.float32)
+    if act_f16:
+        B = B.astype(np.float16).astype(np.float32)
+    ws, cases, outs = [], [], []
+    for i, Mw in enumerate(Mws):
+        case = orc.make_case(1000 * i + K + bits, Mw, K, N=N, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg, fp16_values=sc_f16)
+        case["B"] = B
+        A = orc.preprocess_weights(case["w"], bits, bm, kf)
+        S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm) if mg == -1 else case["sc"]
+        cfgk = tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, zp, mg, N)
+        ws.append(wr.register_weights(A, S, Mw, K, bits, cfgk, scales_dtype=tm.F32,
+                                      dev_dtype=tm.F16 if (sc_f16 and mg == -1) else tm.F32))
+        cases.append((case, A, S))
+        outs.append(torch.empty((N, Mw), dtype=torch.float16 if out_f16 else torch.float32, device="cuda"))
+    Bt = torch.from_numpy(B).cuda()
+    if act_f16:
+        Bt = Bt.half()
+    wr.fused(ws, Bt, outs, N)
+    torch.cuda.synchronize()
+    for (case, A, S), o, Mw in zip(cases, outs, Mws):
+        _, _, _, Cc, _ = oracle_case(case, A, S, Mw, K, bits, bm, kf, gs, ags, zp, mg, N=N)
+        got = o.float().cpu().numpy()
+        assert rel_err(got, Cc) <= (REL_TOL if out_f16 else 2e-5)
+    tm.lib().tmac_hip_cache_clear()
+    for w in ws:
+        w.free()
+
+
 def test_fp16_storage_path(tm):
     """fp16 activations, fp16 scales on the device, fp16 output — exact w.r.t. the oracle fed the same
     fp16-representable values, up to the final rounding to fp16."""

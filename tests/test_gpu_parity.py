@@ -233,6 +233,15 @@ def test_random_configurations(tm, cfg):
     Mw, K, bits, bm, kf, gs, ags, zp, mg, N = cfg
     case = orc.make_case(sum(cfg), Mw, K, N=N, bits=bits, gs=gs, ags=ags, zero_point=zp, m_groups=mg)
     variant = int(os.environ.get("TMAC_FUZZ_VARIANT", "0"))     # tools/gpu/fuzz.sh sweeps the A/B variants too
+    fa = int(os.environ.get("TMAC_FUZZ_FA", "0"))               # ... and the two fast-aggregation flavours
+    if fa:
+        if mg != -1:
+            pytest.skip("fast aggregation is defined for per-group scales only")
+        r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, mg, N=N, variant=variant, fast_aggregation=fa)
+        Cc, tap = orc.qgemm_float_fa(r["A"], r["q"], r["S"], r["ls"], r["lb"], Mw, K, N, bits, bm, kf, gs, ags, zp, fa)
+        assert np.array_equal(np.asarray(r["PS"]).reshape(tap.shape), tap)
+        assert np.abs(r["C"] - Cc).max() <= (1e-3 if fa == 1 else 1e-4) * np.abs(Cc).max()
+        return
     try:
         r = run_case(tm, case, Mw, K, bits, bm, kf, gs, ags, zp, mg, N=N, variant=variant)
     except tm.binding.TMACHipError as e:

@@ -258,6 +258,7 @@ def test_random_configurations(tm, cfg):
 
 def _random_fused(n, seed):
     rng = np.random.default_rng(seed)
+    big = int(os.environ.get("TMAC_FUZZ_BIG", "0"))      # tools/gpu/fuzz.sh: matrices large enough for every launch configuration
     out = []
     while len(out) < n:
         bits = int(rng.integers(1, 5))
@@ -265,12 +266,14 @@ def _random_fused(n, seed):
         if bm % bits or (bm // bits) % 8:
             continue
         gs = int(rng.choice([64, 128, 256]))
-        K = gs * int(rng.integers(2, 40))
+        K = gs * int(rng.integers(2, 96 if big else 40))
+        if K > 24576:
+            continue
         unified = bool(rng.integers(0, 4) == 0)
         zp = (not unified) and bool(rng.integers(0, 2))
         nmat = int(rng.integers(1, 4))
-        Mws = [(bm // bits) * int(rng.integers(1, 6)) for _ in range(nmat)]
-        N = int(rng.choice([1, 1, 2, 40, 70]))
+        Mws = [(bm // bits) * int(rng.integers(1, 160 if big else 6)) for _ in range(nmat)]
+        N = int(rng.choice([1, 1, 1, 1, 2] if big else [1, 1, 2, 40, 70]))
         out.append((tuple(Mws), K, bits, bm, gs, zp, unified, N, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
     return out
 

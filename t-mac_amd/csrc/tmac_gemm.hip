@@ -45,6 +45,7 @@ __device__ __forceinline__ void g_st(void* C, int f16, size_t i, float v) {
 
 constexpr int GRT = 2;   // MFMA row tiles per wave (16 bit-plane rows each)
 constexpr int GWV = 4;   // waves per workgroup (consecutive row blocks)
+constexpr bool W4COMB = true;   // W4: integer plane combine + one scale chain per output (false: the per-plane packed chains, A/B)
 
 typedef float gv2f_t __attribute__((ext_vector_type(2)));
 
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
         };
         // operands one unit ahead of the MFMAs that consume them, where the registers allow: the 32-column tile, and the
         // 64-column tile with W2 (one fp32 accumulator pair per tile since the planes are combined first: 150 VGPRs)
-        constexpr bool AHEAD = (GNT == 2) || (BITS == 2);
+        constexpr bool AHEAD = (GNT == 2) || (BITS == 2) || (BITS == 4 && W4COMB);
         gv4i_t avc[GRT], bvc[GNT], avn[GRT], bvn[GNT];
         if (AHEAD) operands(0, avc, bvc);
 #pragma unroll
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
 #pragma unroll
                     for (int nt = 0; nt < GNT; ++nt) {
                         const float ls = ep[buf][ag][0][nt * 16 + i16], lb = ep[buf][ag][1][nt * 16 + i16];
-                        const float lb2 = __fmul_rn(2.0f, lb), hlb = __fmul_rn(0.5f, lb);
+                        const float lb2 = __fmul_rn(2.0f, lb), hlb = __fmul_rn(0.5f, lb), hls = __fmul_rn(0.5f, ls);
 #pragma unroll
                         for (int rt = 0; rt < GRT; ++rt) {
                             if (DUMP) {
@@ -247,6 +248,19 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
                                 gv2f_t acc = __builtin_elementwise_fma(v, (gv2f_t){sc[rt][0], sc[rt][1]}, facc[rt][nt][0]);
                                 if (ZP) acc = __builtin_elementwise_fma((gv2f_t){zr[rt][0], zr[rt][1]}, (gv2f_t){lb, lb}, acc);
                                 facc[rt][nt][0] = acc;
+                            } else if constexpr (BITS == 4 && W4COMB) {
+                                // the lane's four accumulator rows are the planes of ONE output: combine them as integers
+                                // (Horner on the accumulator bits, each 0x4B400000 + ps; the 15 offsets leave in one add),
+                                // one conversion and one scale chain: sum_p 2^p ps_p * (ls / 2) + lb / 2, as in k_gemv_quad
+                                uint32_t h = (uint32_t)c[rt][nt][3];
+                                h = (h << 1) + (uint32_t)c[rt][nt][2];
+                                h = (h << 1) + (uint32_t)c[rt][nt][1];
+                                h = (h << 1) + (uint32_t)c[rt][nt][0];
+                                const int32_t comb = (int32_t)(h - 15u * 0x4B400000u);
+                                const float v = __fmaf_rn((float)comb, hls, hlb);
+                                float acc = __fmaf_rn(v, sc[rt][0], facc[rt][nt][0][0]);
+                                if (ZP) acc = __fmaf_rn(zr[rt][0], lb, acc);
+                                facc[rt][nt][0][0] = acc;
                             } else
 #pragma unroll
                             for (int pr = 0; pr < 2; ++pr) {
@@ -301,6 +315,8 @@ __global__ __launch_bounds__(64 * GWV) void k_gemm_onehot(GemmArgs a) {
                     acc = __fmul_rn(v, scv);
                 } else if constexpr (BITS == 2) {
                     acc = facc[rt][nt][0][oo];
+                } else if constexpr (BITS == 4 && W4COMB) {
+                    acc = facc[rt][nt][0][0];
                 } else {
                     acc = __fmul_rn(facc[rt][nt][(oo * BITS) >> 1][0], 0.5f);
 #pragma unroll

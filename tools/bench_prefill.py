@@ -9,6 +9,8 @@ from tmac_amd import KCfg, F16
 L = tmac_amd.lib()
 dev = torch.device("cuda")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+BITS = int(sys.argv[2]) if len(sys.argv) > 2 else 2          # 2 or 4
+BM = 128 if BITS == 2 else 256
 wr = tmac_amd.TMACGeMMWrapper(act_group_size=64); wr.set_workspace(11008, N)
 
 def timeit(fn, reps=10):
@@ -24,13 +26,13 @@ def timeit(fn, reps=10):
 
 tot = {"gemm": 0.0, "loop": 0.0, "pre": 0.0, "dense": 0.0}
 for name, Mw, K, cnt in [("qkv/o", 4096, 4096, 4), ("gate/up", 11008, 4096, 2), ("down", 4096, 11008, 1)]:
-    A = torch.randint(0, 256, (Mw * 2 // 128, K // 4, 64), dtype=torch.uint8, device=dev)
-    S = (torch.randn((Mw * 2 // 128, K // 128, 8, 2, 8), device=dev) * 0.01).half().contiguous()
-    w = tmac_amd.Weights(A, S, Mw, K, 2, KCfg.make(Mw, K, 2, 128), scales_dtype=F16, dev_dtype=F16, on_device=True)
+    A = torch.randint(0, 256, (Mw * BITS // BM, K // 4, BM // 2), dtype=torch.uint8, device=dev)
+    S = (torch.randn((Mw * BITS // BM, K // 128, BM // BITS // 8, 2, 8), device=dev) * 0.01).half().contiguous()
+    w = tmac_amd.Weights(A, S, Mw, K, BITS, KCfg.make(Mw, K, BITS, BM), scales_dtype=F16, dev_dtype=F16, on_device=True)
     x = torch.randn(N, K, device=dev).half()
     out = torch.empty(N, Mw, dtype=torch.float16, device=dev)
     Wd = torch.randn(Mw, K, device=dev).half()
-    t_pre = timeit(lambda: wr.llama_cpp_init(x, Mw, K, N, 2))
+    t_pre = timeit(lambda: wr.llama_cpp_init(x, Mw, K, N, BITS))
     L.tmac_hip_set_gemm_min_n(1)
     t_gemm = timeit(lambda: wr.llama_cpp_compute(w, out, N))
     L.tmac_hip_set_gemm_min_n(0)
@@ -39,7 +41,7 @@ for name, Mw, K, cnt in [("qkv/o", 4096, 4096, 4), ("gate/up", 11008, 4096, 2), 
     t_fused = timeit(lambda: wr.fused([w], x, [out], N))     # pair-wise LUT build (image only) + GEMM in one call
     if cnt > 1:   # the matrices of a model that share this activation block (q/k/v: 3, gate/up: 2) in ONE fused call
         nshare = 3 if name == "qkv/o" else cnt
-        ws_ = [w] + [tmac_amd.Weights(A, S, Mw, K, 2, KCfg.make(Mw, K, 2, 128), scales_dtype=F16, dev_dtype=F16, on_device=True) for _ in range(nshare - 1)]
+        ws_ = [w] + [tmac_amd.Weights(A, S, Mw, K, BITS, KCfg.make(Mw, K, BITS, BM), scales_dtype=F16, dev_dtype=F16, on_device=True) for _ in range(nshare - 1)]
         outs_ = [out] + [torch.empty_like(out) for _ in range(nshare - 1)]
         t_multi = timeit(lambda: wr.fused(ws_, x, outs_, N))
         print(f"         {nshare} matrices sharing the activations in one fused call: {t_multi:8.1f} us = {t_multi / nshare:7.1f} us per matrix "
@@ -50,8 +52,8 @@ for name, Mw, K, cnt in [("qkv/o", 4096, 4096, 4), ("gate/up", 11008, 4096, 2), 
     else:
         tot["multi"] = tot.get("multi", 0.0) + t_fused
     t_dense = timeit(lambda: torch.matmul(x, Wd.t()))
-    ops = 2.0 * (Mw * 2) * (K / 4 * 8) * N      # MFMA work actually issued: 8-entry half tables
-    print(f"{name:8s} Mw={Mw} K={K} N={N}: preprocessor {t_pre:8.1f} us | one-hot MFMA gemm {t_gemm:8.1f} us "
+    ops = 2.0 * (Mw * BITS) * (K / 4 * 8) * N      # MFMA work actually issued: 8-entry half tables
+    print(f"{name:8s} Mw={Mw} K={K} N={N} W{BITS}: preprocessor {t_pre:8.1f} us | one-hot MFMA gemm {t_gemm:8.1f} us "
           f"({ops / t_gemm * 1e-6:7.1f} int8 TOP/s, {2.0 * Mw * K * N / t_gemm * 1e-6:6.1f} dense-equivalent TFLOP/s) | "
           f"gemv loop {t_loop:9.1f} us | dense fp16 matmul {t_dense:7.1f} us | fused entry (LUT build + gemm) {t_fused:7.1f} us")
     tot["gemm"] += cnt * t_gemm; tot["loop"] += cnt * t_loop; tot["dense"] += cnt * t_dense

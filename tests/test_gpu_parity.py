@@ -543,6 +543,60 @@ def test_fused_entry_point_prefill(tm, K, N, act_f16, edge):
         w.free()
 
 
+def _random_prefill(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        bits = int(rng.choice([2, 4]))
+        bm = 128 if bits == 2 else 256
+        out.append((tuple((bm // bits) * int(rng.integers(4, 40)) for _ in range(int(rng.integers(1, 4)))), 128 * int(rng.integers(8, 70)),
+                    bits, bm, bool(rng.integers(0, 2)), int(rng.integers(64, 400)), bool(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("cfg", _random_prefill(8, 5), ids=lambda c: "-".join(str(x) for x in c).replace(" ", ""))
+def test_random_prefill_sampled_rows(tm, cfg):
+    """random prefill calls at sizes the oracle cannot cover whole (1-3 matrices of 256-2500 rows, K up to 8960, 64-400
+    activation rows, W2 / W4, zero points on / off): three sampled activation rows against the oracle, every 23rd against the
+    decode kernel run on that row alone"""
+    import torch
+    Mws, K, bits, bm, zp, N, act_f16 = cfg
+    kf, gs, ags = 16, 128, 64
+    wr = tm.TMACGeMMWrapper(act_group_size=ags)
+    B = np.random.default_rng(K + N).standard_normal((N, K)).astype(np.float32)
+    if act_f16:
+        B = B.astype(np.float16).astype(np.float32)
+    ws, cases, outs = [], [], []
+    for i, Mw in enumerate(Mws):
+        case = orc.make_case(50 * i + K, Mw, K, N=1, bits=bits, gs=gs, ags=ags, zero_point=zp, fp16_values=True)
+        A = orc.preprocess_weights(case["w"], bits, bm, kf)
+        S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm)
+        ws.append(wr.register_weights(A, S, Mw, K, bits, tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, zp, -1, N), scales_dtype=tm.F32, dev_dtype=tm.F16))
+        cases.append((case, A, S))
+        outs.append(torch.empty((N, Mw), dtype=torch.float32, device="cuda"))
+    Bt = torch.from_numpy(B).cuda()
+    if act_f16:
+        Bt = Bt.half()
+    wr.fused(ws, Bt, outs, N)
+    torch.cuda.synchronize()
+    rows = [0, N // 2, N - 1]
+    ones = [torch.empty((1, Mw), dtype=torch.float32, device="cuda") for Mw in Mws]
+    gots = [o.cpu().numpy() for o in outs]
+    for (case, A, S), got, Mw in zip(cases, gots, Mws):
+        sub = dict(case, B=B[rows])
+        _, _, _, Cc, _ = oracle_case(sub, A, S, Mw, K, bits, bm, kf, gs, ags, zp, N=len(rows))
+        for i, r in enumerate(rows):
+            assert rel_err(got[r], Cc[i]) <= 2e-5
+    for r in range(0, N, 23):
+        wr.fused(ws, Bt[r:r + 1].contiguous(), ones, 1)
+        torch.cuda.synchronize()
+        for got, one in zip(gots, ones):
+            assert rel_err(got[r], one.cpu().numpy()[0]) <= 2e-5
+    tm.lib().tmac_hip_cache_clear()
+    for w in ws:
+        w.free()
+
+
 @pytest.mark.parametrize("Mw,K", [(4096, 4096), (4096, 11008)])
 def test_prefill_full_size_sampled_rows(tm, Mw, K):
     """BASELINE configs[4] shape (llama-2-7B W2, N = 256) at full size through the fused entry point (pair-wise LUT build +

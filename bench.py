@@ -34,11 +34,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM bytes per launch of the headline GEMV from rocprofv3 --pmc FETCH_SIZE (separate pass, x2 gfx950 correction,
-# MI355X_MICROARCH.md HBM section): profiles/r01_pmc_fetch_size.txt — 7008.5 KiB x 2 = 14.35 MB vs 12.73 MB algorithmic.
-# The excess is the zero padding of the device layout: K = 11008 is 5.4 steps of 64 units, stored (and read) as 6, i.e.
-# 12.58 MB of weight planes instead of 11.27 MB; the 4096-wide shapes read 1.01-1.04 x their algorithmic bytes.
-PMC_TRAFFIC_BYTES = 14353408
 LAYERS = 32
 # (name, Mw, K, count per layer, input slot)
 MATS = [("qkv", 4096, 4096, 3, 0), ("o", 4096, 4096, 1, 1), ("gate_up", 11008, 4096, 2, 2), ("down", 4096, 11008, 1, 3)]
@@ -59,9 +54,14 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="GEMV kernel variant (0 auto, 1 mqsad, 2 sdwa)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the headline GEMV with events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--path", choices=["fused", "split"], default="fused",
-                    help="fused: LUT build inside the GEMV kernel, q/k/v and gate/up batched (4 launches/layer); "
-                         "split: preprocessor + one GEMV launch per matrix (11 launches/layer)")
+    ap.add_argument("--path", choices=["chain", "fused", "split"], default="chain",
+                    help="chain: the token's 128 fused calls recorded once and executed by ONE persistent launch "
+                         "(k_decode_chain: in-kernel hand-off of the activation vectors, weights of the next call streaming "
+                         "in behind the current one); fused: LUT build inside the GEMV kernel, q/k/v and gate/up batched "
+                         "(4 launches/layer, hipGraph replay); split: preprocessor + one GEMV launch per matrix (11 launches/layer)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the check of one layer's outputs (the launches being timed, at full size) against the oracle")
+    ap.add_argument("--stamps", action="store_true", help="chain path: report per-call times from in-kernel s_memtime stamps")
     ap.add_argument("--autotune", action="store_true",
                     help="measure the kernel's launch configurations on this rank's shard shapes before the run instead of "
                          "trusting the built-in heuristic (tmac_hip_autotune_fused; outside the timed region)")
@@ -150,6 +150,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dist_on = world > 1 or args.force_dist
+    if dist_on and args.path == "chain":
+        args.path = "fused"            # the persistent chain is a single-GPU launch; row shards exchange through RCCL between launches
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if "MASTER_ADDR" not in os.environ:
@@ -168,6 +170,7 @@ def main():
     # ---- synthetic, row-sharded weights, registered (re-tiled on the GPU) once --------------------
     rpt = BM // BITS                                  # 64 output rows per reference tile
     layers = []
+    host_l0 = {}
     bytes_per_step = 0
     shard_rows = {}
     for name, Mw, K, cnt, slot in MATS:
@@ -181,14 +184,20 @@ def main():
         for name, Mw, K, cnt, slot in MATS:
             Mloc = shard_rows[name]
             cfg = KCfg.make(Mloc, K, BITS, BM, KF, GS, AGS, True)
-            c = 1.0 / np.sqrt(2.5 * K)
+            c = 1.0 / np.sqrt(2.25 * K)           # E[((w - 1.5) s - n)^2] = (1.25 + 1) c^2 for w uniform in 0..3: unit gain per GEMV
             ws = []
             for _ in range(cnt):
                 A = torch.randint(0, 256, (Mloc * BITS // BM, K // 4, BM // 2), dtype=torch.uint8, device=dev, generator=gen)
                 S = (torch.randn((Mloc * BITS // BM, K // GS, rpt // 8, 2, 8), device=dev, generator=gen) * c)
                 S[:, :, :, 0, :].abs_()
+                # zero = (mean weight level - 2^(b-1)) * scale + noise: the real weight (w - 2^(b-1)) * scale - zero has mean 0, so
+                # a common component of the activations is not amplified from layer to layer (it grew 16x per GEMV and the
+                # chained vectors overflowed fp16 after a few layers)
+                S[:, :, :, 1, :] += S[:, :, :, 0, :] * ((2 ** BITS - 1) / 2.0 - 2 ** (BITS - 1))
                 S = S.half().contiguous()
                 ws.append(tmac_amd.Weights(A, S, Mloc, K, BITS, cfg, scales_dtype=F16, dev_dtype=F16, on_device=True))
+                if li == 0 and not args.no_verify:
+                    host_l0.setdefault(name, []).append((A.cpu().numpy(), S.float().cpu().numpy().reshape(Mloc * BITS // BM, K // GS, -1)))
                 del A, S
             mats[name] = ws
         layers.append(mats)
@@ -214,11 +223,13 @@ def main():
             tuned[name] = [r["ft"], r["wpq"], round(r["us"], 2), round(r["heuristic_us"], 2)]
         torch.cuda.synchronize()
 
+    fused_calls = args.path in ("chain", "fused")
+
     def step(record):
         for li in range(args.layers):
             mats = layers[li]
             for name, Mw, K, cnt, slot in MATS:
-                if args.path == "fused":
+                if fused_calls:
                     wr.fused(mats[name], x[slot], outs[name], 1, act_dtype=F16, out_dtype=F16)
                 else:
                     wr.llama_cpp_init(x[slot], Mw, K, 1, BITS, act_dtype=F16)
@@ -240,8 +251,19 @@ def main():
     # capture was exercised with one rank only on the development box (1.27 ms per step against 6.0 ms eager): if
     # capture raises, the run falls back to eager launches; if the first replay does not finish, a watchdog ends the
     # process instead of hanging the node.
-    use_graph = (not args.no_graph) and not (dist_on and args.eager_collectives)
+    use_graph = (not args.no_graph) and not (dist_on and args.eager_collectives) and args.path != "chain"
     graph = None
+    chain = None
+    if args.path == "chain":
+        # record the token's calls once (they are not launched while recording); one launch per step from here on
+        step(False)                                  # leaves x[0] = the down projection's output, as in a decode loop
+        torch.cuda.synchronize()
+        with wr.record_chain() as rec:
+            step(False)
+        chain = rec.chain
+        if args.stamps:
+            stamp_buf = torch.zeros(chain.nops * chain.grid * 8, dtype=torch.int64, device=dev)
+            chain.set_stamps(stamp_buf)
     if use_graph:
         try:
             side = torch.cuda.Stream()
@@ -301,7 +323,9 @@ def main():
         done.set()
 
     def run_step():
-        if graph is not None:
+        if chain is not None:
+            chain.launch()
+        elif graph is not None:
             graph.replay()
         else:
             step(False)
@@ -309,11 +333,17 @@ def main():
     for _ in range(args.warmup):
         run_step()
     barrier()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for _ in range(args.steps):
         run_step()
+    ev1.record()
     barrier()
     dt = time.perf_counter() - t0
+    ev_ms_per_step = ev0.elapsed_time(ev1) / args.steps      # hipEvent pair on the launch stream around the timed region
+    if chain is not None and chain.status() != 0:
+        raise SystemExit("bench.py: a hand-off inside the decode chain timed out; outputs invalid")
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -324,7 +354,50 @@ def main():
     # hipEvent pair (on the launch stream) around back-to-back launches of that kernel over all layers'
     # distinct weights (32 x 11.3 MB > MALL), so the figure includes the inter-kernel boundary.
     roof = None
-    if use_ev:
+    traffic, traffic_src = None, None
+    try:    # HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            tj = json.load(f)
+        ent = tj.get("k_decode_chain" if args.path == "chain" else "k_gemv_quad_headline")
+        if ent and (args.path != "chain" or ent.get("layers") == args.layers):
+            traffic, traffic_src = ent["bytes_per_launch"], ent.get("source")
+    except Exception:
+        pass
+    if args.path == "chain":
+        ach = bytes_per_step / (ev_ms_per_step * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "k_decode_chain: one persistent launch per decoded token (all %d GEMVs, LUT builds and "
+                                          "in-kernel hand-offs of the llama-2-7B W2 g128 zp layer stack)" % (7 * args.layers),
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": bytes_per_step, "avg_launch_us": round(ev_ms_per_step * 1e3, 2),
+                "launches_timed": args.steps,
+                "timing": "hipEvent pair on the launch stream around the %d timed launches" % args.steps}
+        if args.stamps:
+            raw = stamp_buf.cpu().numpy().reshape(chain.nops, chain.grid, 8)
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                np.save(os.path.join(ROOT, "gpurun_out", "chain_stamps.npy"), raw)
+            except Exception:
+                pass
+            st = raw[:, :, :7].astype(np.float64) * 0.01                     # s_memrealtime: 100 MHz -> us (wave 0 of every workgroup)
+            names = [m[0] for m in MATS]
+            ends = st[:, :, 5].max(axis=1)                                    # a call is complete when its last row quad is published
+            dur = ends - np.concatenate([[st[0, :, 0].min()], ends[:-1]])
+            per = {}
+            for k, name in enumerate(names):
+                sel = st[k::4]
+                per[name] = {"us": round(float(np.mean(dur[k::4])), 3),
+                             "wait_input_us": round(float(np.mean(sel[:, :, 1] - sel[:, :, 0])), 3),
+                             "lut_build_us": round(float(np.mean(sel[:, :, 2] - sel[:, :, 1])), 3),
+                             "wait_weights_us": round(float(np.mean(sel[:, :, 3] - sel[:, :, 2])), 3),
+                             "lookups_us": round(float(np.mean(sel[:, :, 5] - sel[:, :, 3])), 3),
+                             "polls": round(float(np.mean(raw[k::4, :, 7])), 2)}
+            hb = algorithmic_bytes(4096, 11008)
+            roof["per_call_from_stamps"] = per
+            roof["headline_gemv"] = {"shape": "4096x11008 W2 g128 zp (the down projection inside the launch)", "us": per["down"]["us"],
+                                     "GBps": round(hb / (per["down"]["us"] * 1e-6) / 1e9, 1) if per["down"]["us"] > 0 else None,
+                                     "frac": round(hb / (per["down"]["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if per["down"]["us"] > 0 else None}
+    elif use_ev:
         xin = torch.randn(11008, device=dev, generator=gen).half()
         wr.llama_cpp_init(xin, 4096, 11008, 1, BITS, act_dtype=F16)
         reps, skip = 10, 3            # the first replays run while the clocks settle after the timed region
@@ -408,11 +481,51 @@ def main():
             floor["pure_read_step_ms"] = round(float(np.mean(ts)), 4)
             del sbufs, sg
         roof = {"bound": "hbm", "kernel": ("k_gemv_quad, LUT build fused" if args.path == "fused" else "k_gemv_quad, LUT prebuilt") + ", headline shape 4096x11008 W2 g128 zp", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": hb, "avg_launch_us": round(float(np.mean(durs)) * 1e6, 3),
                 "min_launch_us": round(float(np.min(durs)) * 1e6, 3), "launches_timed": reps * args.layers,
                 "launch_floor": floor,
                 "timing": "hipEvent pair on the launch stream around %d back-to-back launches (distinct weights, %s), mean of 10" % (args.layers, "hipGraph replay" if use_graph else "eager")}
+
+    # ---- verification (outside the timed region): the launches being timed, at full size, against the oracle ----------
+    verified = None
+    if not args.no_verify and world == 1 and host_l0:
+        from oracle import oracle as orc
+        vx = torch.randn(4096, device=dev, generator=gen).half()
+        vouts = {name: [torch.zeros(Mw, dtype=torch.float16, device=dev) for _ in range(cnt)] for name, Mw, K, cnt, slot in MATS}
+        vin = {"qkv": vx, "o": vouts["qkv"][0], "gate_up": vouts["o"][0], "down": vouts["gate_up"][0]}
+
+        def vcalls():
+            for name, Mw, K, cnt, slot in MATS:
+                if fused_calls:
+                    wr.fused(layers[0][name], vin[name], vouts[name], 1, act_dtype=F16, out_dtype=F16)
+                else:
+                    wr.llama_cpp_init(vin[name], Mw, K, 1, BITS, act_dtype=F16)
+                    for i in range(cnt):
+                        wr.llama_cpp_compute(layers[0][name][i], vouts[name][i], 1, out_dtype=F16)
+        if args.path == "chain":
+            with wr.record_chain() as vrec:
+                vcalls()
+            vrec.chain.launch()
+            torch.cuda.synchronize()
+            ok = vrec.chain.status() == 0
+            vrec.chain.free()
+        else:
+            vcalls()
+            torch.cuda.synchronize()
+            ok = True
+        worst = 0.0
+        for name, Mw, K, cnt, slot in MATS:
+            q, ls, lb = orc.preprocessor(vin[name].float().cpu().numpy()[None, :], AGS)
+            for i in range(cnt):
+                A, S = host_l0[name][i]
+                ref = orc.qgemm_float(A, q, S, ls, lb, Mw, K, 1, BITS, BM, KF, GS, AGS, True)[0]
+                got = vouts[name][i].float().cpu().numpy()
+                worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)))
+        verified = {"ok": bool(ok and worst <= 1e-3), "max_rel_err": float("%.3g" % worst), "tolerance": 1e-3,
+                    "what": "layer 0's seven GEMVs (q/k/v, o, gate/up, down at full size, chained) through the timed path vs oracle/ (fp16 outputs)"}
+        if not verified["ok"]:
+            sys.stderr.write("bench.py: VERIFICATION FAILED: %r\n" % (verified,))
 
     if rank == 0:
         res = {
@@ -427,12 +540,14 @@ def main():
             "tokens_per_s": round(1e3 / ms_per_step, 1),
             "frac_of_hbm_peak": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
             "config": {"workload": "llama-2-7b-w2a8-decode-all-layers", "layers": args.layers,
-                       "gemv_per_step": 7 * args.layers, "launches_per_step": (4 if args.path == "fused" else 11) * args.layers, "path": args.path,
+                       "gemv_per_step": 7 * args.layers, "launches_per_step": 1 if args.path == "chain" else (4 if args.path == "fused" else 11) * args.layers, "path": args.path,
                        "autotune": tuned,
                        "algorithmic_bytes_per_step": bytes_per_step, "weights": "W2 g128 zero-point, act_group 64",
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
-                       "kernel_variant": args.variant, "launch": "hipGraph replay" if use_graph else "eager"},
+                       "kernel_variant": args.variant, "launch": "one persistent launch per step" if args.path == "chain" else ("hipGraph replay" if use_graph else "eager")},
             "roofline": roof,
+            "verified": verified,
+            "event_ms_per_step": round(ev_ms_per_step, 4),
             "cpu_baseline": None,
         }
         if world == 1 and not args.no_cpu_baseline:

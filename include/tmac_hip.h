@@ -125,6 +125,43 @@ int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weights, int nma
                                  tmac_dtype_t act_dtype, void* const* C_dev, tmac_dtype_t out_dtype, int N,
                                  void* stream);
 
+/* ---- persistent decode chain ---------------------------------------------------------------
+ * The fused calls of one decoded token (llama.cpp issues the same tmac_hip_qgemm_fused_dev sequence for every token:
+ * llama_cpp_init + llama_cpp_compute per projection, tmac_gemm_wrapper.h:170-228) recorded ONCE and executed by ONE
+ * persistent kernel launch (k_decode_chain): one workgroup per CU walks the whole list, weights of the next call stream in
+ * while the current one computes, and an output that a later call takes as its activations is handed over inside the
+ * launch (self-tagged fp16 granules, no kernel boundary).  Recording works like stream capture:
+ *     tmac_hip_chain_begin();
+ *     ... the thread's usual tmac_hip_qgemm_fused_dev(..., N = 1, ...) calls: noted, not launched ...
+ *     tmac_hip_chain_end(&chain);
+ *     tmac_hip_chain_launch(chain, stream);      // per token; outputs land in the C_dev buffers given while recording
+ * Data flow is inferred from pointer identity: a call whose B_dev equals an earlier call's C_dev[i] consumes that output
+ * inside the launch; any other B_dev must hold its activations when the launch starts.  Calls execute in recorded order.
+ * An output buffer may be written by several calls (a decoder reuses its buffers layer after layer); the last one wins.
+ * Scope: 2- or 4-bit QUAD-layout weights, per-group scales (group size >= 128) with act groups of 64, fp16 activations;
+ * chained outputs fp16; one scale dtype and zero-point setting per chain.  Anything else: -1 from tmac_hip_chain_end and
+ * the caller keeps launching the calls one by one.  Results are bit-identical to tmac_hip_qgemm_fused_dev with
+ * 768-thread workgroups and the same number of waves per row quad (tmac_hip_debug_quad_config(768, wpq)).
+ * A chain must not be launched concurrently with itself; the GPU must be able to hold one workgroup per CU (true unless
+ * other work occupies CUs for the whole duration: every wait inside the kernel is bounded and reports through
+ * tmac_hip_chain_status instead of hanging). */
+typedef struct tmac_hip_chain tmac_hip_chain;
+int32_t tmac_hip_chain_begin(void);
+int32_t tmac_hip_chain_end(tmac_hip_chain** out);
+int32_t tmac_hip_chain_launch(tmac_hip_chain* chain, void* stream);
+/* after synchronising the stream: *error_word == 0 means every hand-off completed; otherwise (bit 31 | op << 8 | wave of
+ * the first wave that gave up) the outputs of that launch are invalid.  Clears the word and re-arms the chain. */
+int32_t tmac_hip_chain_status(tmac_hip_chain* chain, uint32_t* error_word);
+/* number of recorded calls, waves per row quad chosen for call `op`, workgroups, weight + scale bytes one launch streams
+ * (any pointer may be NULL) */
+int32_t tmac_hip_chain_info(const tmac_hip_chain* chain, int op, int32_t* nops, int32_t* wpq, int32_t* grid, size_t* bytes);
+int32_t tmac_hip_chain_free(tmac_hip_chain* chain);
+/* profiling / A-B knobs: s_memrealtime stamps (100 MHz) [calls][workgroups][8] of wave 0 (0 call entry, 1 activations complete, 2 LUT
+ * built, 3 weights of the call landed, 5 last row quad published, 6 all loads landed, 7 number of polls) into a device buffer (NULL = off); waves per row quad forced for chains built from now on (0 = per-call
+ * choice) and the poll limit of a hand-off (0 = keep) */
+int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* chain, unsigned long long* dev_buffer);
+int32_t tmac_hip_debug_chain_config(int force_waves_per_quad, unsigned spin_limit);
+
 /* Raw device pointers of the workspace, for collectives (RCCL all-gather of the LUT over xGMI):
  *   qlut_dev  : kernel-layout half tables, nbytes_qlut per activation row
  *   lut_scales/lut_biases : fp32 [N][K/act_group_size] */

@@ -11,7 +11,7 @@ Importable as ``tmac_amd`` (the directory name carries a hyphen for historical r
 """
 from .binding import (TMACHipError, KCfg, lib, lib_path, F32, F16, load_library, build_library)  # noqa: F401
 from .weights import preprocess_weights  # noqa: F401
-from .wrapper import TMACGeMMWrapper, Weights, Workspace  # noqa: F401
+from .wrapper import TMACGeMMWrapper, Weights, Workspace, DecodeChain  # noqa: F401
 from . import convert, weights, sharding, binding  # noqa: F401
 
 __version__ = "0.1.0"

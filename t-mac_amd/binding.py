@@ -90,6 +90,15 @@ def load_library() -> C.CDLL:
         "tmac_hip_tune_save": ([C.c_char_p], i32),
         "tmac_hip_tune_load": ([C.c_char_p], i32),
         "tmac_hip_tune_clear": ([], i32),
+        "tmac_hip_chain_begin": ([], i32),
+        "tmac_hip_chain_end": ([C.POINTER(vp)], i32),
+        "tmac_hip_chain_launch": ([vp, vp], i32),
+        "tmac_hip_chain_status": ([vp, C.POINTER(C.c_uint32)], i32),
+        "tmac_hip_chain_info": ([vp, C.c_int, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)], i32),
+        "tmac_hip_chain_free": ([vp], i32),
+        "tmac_hip_chain_set_stamps": ([vp, vp], i32),
+        "tmac_hip_debug_chain_config": ([C.c_int, C.c_uint], i32),
+        "tmac_hip_debug_quad_config": ([C.c_int, C.c_int], i32),
         "tmac_hip_selftest": ([vp, vp, C.c_int], i32),
         "tmac_hip_selftest_mfma": ([vp, vp], i32),
         "tmac_hip_cache_clear": ([], i32),

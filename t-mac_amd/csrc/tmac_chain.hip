@@ -1,0 +1,434 @@
+// tmac_chain.hip — k_decode_chain: a recorded sequence of fused decode GEMV groups (N = 1) as ONE persistent launch.
+//
+// Why: a decoded token of llama-2-7B is 128 dependent launches of 4.7-25 MB each; as separate launches every one of them
+// pays the dependent-dispatch gap, fetches its activations, builds its LUT and only then starts its weight stream, so HBM
+// idles through most of a launch (0.78 ms per token against 0.45 ms for launches that merely read the
+// bytes).  Here one workgroup per CU walks the whole op list:
+//   * weights do not depend on the previous op, so every wave keeps the fragments of its NEXT op's first work items in
+//     flight (second register ring) while it computes the current op and while it waits for the hand-off;
+//   * the hand-off is in-kernel: an op's outputs are published as self-tagged 8-byte granules {generation, 2 x fp16}
+//     with write-through (sc1) stores; the consumers' LUT build reads exactly those granules with sc1 loads and spins
+//     until every tag carries this launch's generation (data is the flag: no counter, no fence, no drain of the weight
+//     loads in flight).  cdna_hip_programming.md Guideline 16, recipe R2;
+//   * no dispatch gap, no grid barrier: a workgroup only ever waits for data it needs.
+// Arithmetic is that of k_gemv_quad (tmac_quad.hip) — same LUT build (lut_ctor.cc:120-215), same lookup + MFMA adder
+// (tbl.cc:445-462), same per-act-group scale chain (tbl.cc:479-526), same lane/wave decomposition for a given number of
+// waves per quad — so results are bit-identical to the per-launch path with 768-thread workgroups.
+// Scope: per-group scales with act groups of 64 and scale groups >= 128 (the GPTQ-style path), fp16 activations.
+// Deadlock freedom: workgroups process ops in order and producers never wait for consumers, so by induction over the op
+// index everything completes provided all workgroups are resident; the grid is one workgroup per CU and the kernel's
+// register / LDS footprint admits exactly one.  Every spin is bounded (ChainArgs::spin_limit) and reports through ctl[2].
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "tmac_quad_core.h"
+#include "tmac_chain.h"
+
+namespace tmac {
+
+typedef const ChainOp __attribute__((address_space(4))) * cop_ptr;   // descriptors through the scalar cache
+
+template <int BITS>
+struct CFrag {
+    uint32_t wd[4 * BITS];
+    uint32_t s0, s1;     // the lane's scale (, zero) of the step's scale group: fp16 pair in s0, or fp32 in s0 (, s1)
+};
+
+__device__ __forceinline__ void c_seek(cop_ptr d, int gq, int& mi, int& base) {
+    mi = 0; base = 0;
+    const int nm = d->nmat;
+    while (mi + 1 < nm && gq >= d->m[mi].q_end) { base = d->m[mi].q_end; ++mi; }
+}
+
+// weights of (global quad gq, step st) of op d + the lane's scale: the epilogue role of a lane is row lane & 3, units
+// st*64 + 16g + 4*lg .. +3 (see k_gemv_quad); scale groups span >= 4 units, so one scale group per lane and step.
+// Lanes whose unit lies past K skip the weight load (their LUT entries are zero tables: whatever the registers hold
+// contributes exactly 0) -- the zero padding of the last step is stored but never fetched.
+template <int BITS, bool ZP, bool SCF16>
+__device__ __forceinline__ void c_issue(CFrag<BITS>& f, cop_ptr d, int gq, int st, int lane) {
+    constexpr int per = ZP ? 2 : 1;
+    int mi, base;
+    c_seek(d, gq, mi, base);
+    const int lq = gq - base;
+    const uint4* W = d->m[mi].W;
+    const char* scb = reinterpret_cast<const char*>(d->m[mi].SC);
+    const int nsg = d->nsg, gsh = d->gs_shift, nst = d->nst, nu = d->nu;
+    const int c0 = 4 * (lane & 12) + 4 * (lane >> 4);
+    const uint32_t sg = min((uint32_t)st * (64u >> gsh) + (uint32_t)(c0 >> gsh), (uint32_t)nsg - 1u);
+    const uint32_t sidx = (((uint32_t)lq * (uint32_t)nsg + sg) * 4 + (lane & 3)) * per;
+    uint32_t r0 = 0, r1 = 0;
+    if (SCF16) {
+        const char* ph = scb + (size_t)(sidx * 2u);
+        if (ZP) r0 = *reinterpret_cast<const uint32_t*>(ph);
+        else r0 = *reinterpret_cast<const unsigned short*>(ph);
+    } else {
+        const uint32_t* p32 = reinterpret_cast<const uint32_t*>(scb + (size_t)(sidx * 4u));
+        r0 = p32[0];
+        if (ZP) r1 = p32[1];
+    }
+    f.s0 = r0; f.s1 = r1;
+    if (st * 64 + lane < nu) {
+        const uint4* wp = W + (size_t)((uint32_t)(lq * nst + st) * (uint32_t)(BITS * 64)) + lane;
+#pragma unroll
+        for (int j = 0; j < BITS; ++j) {
+            const u32x4q v = __builtin_nontemporal_load(reinterpret_cast<const u32x4q*>(wp + (size_t)j * 64));
+            f.wd[4 * j] = v.x; f.wd[4 * j + 1] = v.y; f.wd[4 * j + 2] = v.z; f.wd[4 * j + 3] = v.w;
+        }
+    }
+}
+
+// One 64-unit step of a row quad: lookups (v_perm_b32 on the half tables), v_mfma_i32_16x16x64_i8 as the adder, then the
+// two act groups of the lane's output row through the fp32 scale chain (compute_mfma of k_gemv_quad, SM = 0).
+template <int BITS, bool ZP, bool SCF16>
+__device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab, int tstride, const float* l_ls, const float* l_lb,
+                                          int st, int lane, qv4i_t bsel, uint32_t k3, float& cacc) {
+    const int u = st * 64 + lane;
+    uint32_t tb[16];
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+        const uint4 v = tab[j4 * tstride + u];            // units past K read the zero tables: no contribution
+        tb[4 * j4] = v.x; tb[4 * j4 + 1] = v.y; tb[4 * j4 + 2] = v.z; tb[4 * j4 + 3] = v.w;
+    }
+    qv4i_t c[BITS];
+#pragma unroll
+    for (int pl = 0; pl < BITS; ++pl) c[pl] = (qv4i_t){0, 0, 0, 0};
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+        for (int pl = 0; pl < BITS; ++pl) {
+            uint32_t pa, ma, pb, mb;
+            const int qa = (2 * tp) * BITS + pl, qb = (2 * tp + 1) * BITS + pl;
+            if (qa & 1) q_lookup4_pm<1>(f.wd[qa >> 1], tb[4 * tp], tb[4 * tp + 1], k3, pa, ma);
+            else q_lookup4_pm<0>(f.wd[qa >> 1], tb[4 * tp], tb[4 * tp + 1], k3, pa, ma);
+            if (qb & 1) q_lookup4_pm<1>(f.wd[qb >> 1], tb[4 * tp + 2], tb[4 * tp + 3], k3, pb, mb);
+            else q_lookup4_pm<0>(f.wd[qb >> 1], tb[4 * tp + 2], tb[4 * tp + 3], k3, pb, mb);
+            c[pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8((qv4i_t){(int)pa, (int)ma, (int)pb, (int)mb}, bsel, c[pl], 0, 0, 0);
+        }
+    }
+    float sc, zr = 0.f;
+    if (SCF16) {
+        sc = __half2float(__ushort_as_half((unsigned short)(f.s0 & 0xffff)));
+        if (ZP) zr = __half2float(__ushort_as_half((unsigned short)(f.s0 >> 16)));
+    } else {
+        sc = __uint_as_float(f.s0);
+        if (ZP) zr = __uint_as_float(f.s1);
+    }
+    const int ub4 = st * 64 + 4 * (lane & 12) + 4 * (lane >> 4);
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const int kk = (ub4 + 2 * gi) >> 1;
+        const float hls = l_ls[kk], hlb = l_lb[kk];           // ls / 2, lb / 2; groups past K hold zeros
+        // sum_p alpha_p [(ps_p ls + [p = 0] lb) scale + [p = 0] zero 2 lb] = ((sum_p 2^p ps_p)(ls / 2) + lb / 2) scale + (2 zero)(lb / 2)
+        int32_t comb = 0;
+#pragma unroll
+        for (int pl = BITS - 1; pl >= 0; --pl) {
+            const int32_t ps = (gi == 0) ? (c[pl].x + c[pl].y) : (c[pl].z + c[pl].w);
+            comb = (pl == BITS - 1) ? ps : (int32_t)(((uint32_t)comb << 1) + (uint32_t)ps);
+        }
+        const float v = __fmaf_rn((float)comb, hls, hlb);
+        float cc = __fmaf_rn(v, sc, cacc);
+        if (ZP) cc = __fmaf_rn(__fadd_rn(zr, zr), hlb, cc);
+        cacc = cc;
+    }
+}
+
+// four hand-off granules of two consecutive row quads = the 8 activations of LUT pair p; both loads and their wait in
+// one statement (cdna_hip_programming.md 5.7, form (i)): sc1 loads bypass this CU's L1
+__device__ __forceinline__ void c_poll2(const uint4* p, u32x4q& v0, u32x4q& v1) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1) : "v"(p) : "memory");
+}
+
+template <int BITS, bool ZP, bool SCF16>
+__global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    constexpr int FT = CHAIN_FT, NWV = CHAIN_NWV;
+    constexpr int RING = (BITS <= 2) ? 4 : 2;       // fragments per ring; two rings (current op / next op)
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int bx = blockIdx.x, gx = gridDim.x;
+    const cop_ptr ops = (cop_ptr)a.ops;
+    const unsigned gen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][4] partials of split quads
+    bool aborted = false;                                                   // a hand-off timed out somewhere: stop waiting
+
+    // stamps: s_memrealtime (100 MHz, one clock for the whole device; s_memtime counts per XCD with unrelated offsets)
+#define CSTAMPV(i, k, v) do { if (a.stamps && tid == 0) a.stamps[((size_t)(i) * gx + bx) * 8 + (k)] = (v); } while (0)
+#define CSTAMP(i, k) CSTAMPV(i, k, __builtin_amdgcn_s_memrealtime())
+
+    qv4i_t bsel;
+    {
+        const int jrel = (lane & 15) - 4 * (lane >> 4);
+        const uint32_t be = (jrel >= 0 && jrel < 4) ? (0x01u << (8 * jrel)) : 0u, bo = (jrel >= 0 && jrel < 4) ? (0xfeu << (8 * jrel)) : 0u;   // +1 | -2
+        bsel = (qv4i_t){(int)be, (int)bo, (int)be, (int)bo};
+    }
+    uint32_t k3 = 0x03020100u;
+    asm volatile("" : "+v"(k3));
+
+    // per-op role of this wave: quads slot0, slot0 + stride, ...; steps h, h + wpq, ... of each
+    struct Role { int slot0, stride, h, wpq, nst, total_q, my_iter; };
+    auto role_of = [&](cop_ptr d) __attribute__((always_inline)) {
+        Role r;
+        r.wpq = d->wpq;
+        const int ipi = d->ipi;
+        const int qs = (w * d->wpq_inv) >> 16;                          // w / wpq for w < 12
+        r.h = w - qs * r.wpq;
+        r.slot0 = bx * ipi + qs;
+        r.stride = gx * ipi;
+        r.nst = d->nst;
+        r.total_q = d->total_q;
+        r.my_iter = d->it_full + ((bx * ipi < d->it_rem) ? 1 : 0);
+        return r;
+    };
+
+    CFrag<BITS> ra[RING], rb[RING];
+    int pf_it = 0, pf_st = 0;        // item cursor of the op whose first RING items are in its ring: where its refills resume
+
+    // issue the first RING work items of op e into ring r
+    auto prefetch = [&](CFrag<BITS> (&r)[RING], cop_ptr e) __attribute__((always_inline)) {
+        const Role ro = role_of(e);
+        int it = 0, st = ro.h;
+#pragma unroll
+        for (int k = 0; k < RING; ++k) {
+            const int gq = ro.slot0 + it * ro.stride;
+            if (it < ro.my_iter && gq < ro.total_q && ro.h < ro.nst) c_issue<BITS, ZP, SCF16>(r[k], e, gq, st, lane);
+            st += ro.wpq;
+            if (st >= ro.nst) { st = ro.h; ++it; }
+        }
+        pf_it = it; pf_st = st;
+    };
+
+    int parity = 0;
+    auto phase = [&](int i, CFrag<BITS> (&cur)[RING], CFrag<BITS> (&nxt)[RING]) __attribute__((always_inline)) {
+        const cop_ptr d = ops + i;
+        CSTAMP(i, 0);
+        const int tstride = d->tstride, nu = d->nu, nst = d->nst, G = d->G, GP = d->GP;
+        uint4* tab = lds + (size_t)(i & 1) * a.buf_u4;                // [4][tstride]
+        float* l_ls = reinterpret_cast<float*>(tab + 4 * tstride);   // [GP] ls / 2 (groups past K: 0)
+        float* l_lb = l_ls + GP;                                     // [GP] lb / 2
+        const int P = d->K / 8;                                      // LUT pairs: tables 2p, 2p+1 from activations 8p .. 8p+7
+
+        // ---- 1. this op's activations: poll the producer's granules (or read the external vector), build the LUT ----
+        const bool gran = d->in_gran != 0;
+        unsigned long long polls = 0;
+        for (int r0 = 0; r0 * FT < P; ++r0) {
+            const int p = r0 * FT + tid;
+            const bool need = p < P;            // K % 64 == 0: the 8 lanes of an act group are valid or invalid together
+            uint32_t xw[4] = {0, 0, 0, 0};
+            if (gran) {
+                const uint4* g = reinterpret_cast<const uint4*>(d->in) + 2 * (size_t)min(p, P - 1);
+                bool ok = !need;
+                unsigned spins = 0;
+                for (;;) {
+                    ++polls;
+                    if (!ok) {
+                        u32x4q v0, v1;
+                        c_poll2(g, v0, v1);
+                        ok = (v0.x == gen) & (v0.z == gen) & (v1.x == gen) & (v1.z == gen);
+                        xw[0] = v0.y; xw[1] = v0.w; xw[2] = v1.y; xw[3] = v1.w;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                    if (aborted) break;
+                    ++spins;
+                    if ((spins & 1023u) == 0u) {      // something is slow or broken: look at the error word, give up past the limit
+                        const unsigned err = __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (err != 0u || spins >= a.spin_limit) {
+                            if (err == 0u && lane == 0) atomicOr(a.ctl + 2, 0x80000000u | ((unsigned)i << 8) | (unsigned)w);
+                            aborted = true;
+                        }
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            } else if (need) {
+                const uint4 v = reinterpret_cast<const uint4*>(d->in)[p];
+                xw[0] = v.x; xw[1] = v.y; xw[2] = v.z; xw[3] = v.w;
+            }
+            if (need) {
+                float x[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const __half2 hh = *reinterpret_cast<const __half2*>(&xw[q]);
+                    x[2 * q] = __low2float(hh); x[2 * q + 1] = __high2float(hh);
+                }
+                const float s0 = __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3])));
+                const float s1 = __fadd_rn(__fadd_rn(fabsf(x[4]), fabsf(x[5])), __fadd_rn(fabsf(x[6]), fabsf(x[7])));
+                const float mx = q_half_allmax(fmaxf(s0, s1));
+                const float scales = div127(mx);
+                const float t_scales = (scales != 0.0f) ? rcp_exact(scales) : 0.0f;
+                uint32_t lo0, hi0, lo1, hi1;
+                float La, Lb;
+                q_table8<true>(x[0], x[1], x[2], x[3], t_scales, lo0, hi0, La);
+                q_table8<true>(x[4], x[5], x[6], x[7], t_scales, lo1, hi1, Lb);
+                tab[(p & 3) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
+                // lut_biases (lut_ctor.cc:25-31): per 8-table chunk ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)), v_i = -L15 of table i
+                float va = -La, vb = -Lb;
+                va = __fadd_rn(va, qdpp_f<0x4E>(va));
+                vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));
+                va = __fadd_rn(va, qdpp_f<0xB1>(va));
+                vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));
+                const float v = __fadd_rn(va, vb);
+                const float c1 = qdpp_f<0x104>(v);      // row_shl:4: the second chunk of the act group
+                if ((p & 7) == 0) {
+                    l_ls[p >> 3] = __fmul_rn(0.5f, scales);
+                    l_lb[p >> 3] = __fmul_rn(0.5f, __fadd_rn(__fadd_rn(0.0f, v), c1));
+                }
+            }
+        }
+        CSTAMP(i, 1);
+        CSTAMPV(i, 7, polls);
+        {   // zero tables / zero LUT scales for the units between K and the end of the last 64-unit step
+#pragma unroll
+            for (int j4 = 0; j4 < 4; ++j4)
+                for (int u = nu + tid; u < nst * 64; u += FT) tab[j4 * tstride + u] = make_uint4(0u, 0u, 0u, 0u);
+            for (int g = G + tid; g < GP; g += FT) { l_ls[g] = 0.f; l_lb[g] = 0.f; }
+        }
+        __syncthreads();
+        CSTAMP(i, 2);
+
+        // ---- 2. next op's first fragments into the other ring (they stream in during this op's lookups and the next wait) ----
+        int r_it = pf_it, r_st = pf_st;               // refill cursor of THIS op (its first RING items were issued a phase ago)
+        // The current ring's loads were issued a phase ago.  Reading its registers here makes the compiler place its wait
+        // for them HERE, in front of the next ring's loads -- otherwise the wait lands at the first lookup below, behind
+        // loads whose number it cannot count, as s_waitcnt vmcnt(0): a full memory latency before the first lookup.
+#pragma unroll
+        for (int k = 0; k < RING; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4 * BITS; ++j) asm volatile("" :: "v"(cur[k].wd[j]));
+            asm volatile("" :: "v"(cur[k].s0), "v"(cur[k].s1));
+        }
+        CSTAMP(i, 3);
+        if (i + 1 < a.nops) prefetch(nxt, ops + i + 1);
+
+        // ---- 3. this wave's (quad, step) items ----
+        const Role ro = role_of(d);
+        const int wpq = ro.wpq, h = ro.h;
+        auto finish = [&](bool have, int gq, float cacc) __attribute__((always_inline)) {
+            float acc = 0.f;
+            if (have) {
+                acc = cacc;
+                acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // lanes with the same row: rotate by 4, 8 within the DPP row
+                acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
+                acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));
+                acc = __fadd_rn(acc, __shfl_xor(acc, 32, 64));
+            }
+            const bool owner = have && h == 0;
+            float t = acc;
+            if (wpq > 1) {
+                float* red = l_red + parity * (NWV * 4);
+                if (lane < 4) red[w * 4 + lane] = acc;
+                __syncthreads();
+                if (owner && lane < 4) {
+                    t = red[w * 4 + lane];
+                    for (int ww = 1; ww < wpq; ++ww) t = __fadd_rn(t, red[(w + ww) * 4 + lane]);
+                }
+                parity ^= 1;
+            }
+            if (owner) {
+                int mi, base;
+                c_seek(d, gq, mi, base);
+                const int lq = gq - base;
+                if (lane < 4) q_st_out(d->m[mi].C, a.out_f16, (size_t)(4 * lq + lane), t);
+                unsigned long long* gr = reinterpret_cast<unsigned long long*>(d->m[mi].GR);
+                if (gr) {
+                    // granule = {generation, fp16 row | fp16 next row << 16}: lanes 0 and 2 each store one (8 bytes, write-through)
+                    const uint32_t hb = (uint32_t)__half_as_ushort(__float2half_rn(t));
+                    const uint32_t nb = qdpp_u<0xB1>(hb);            // quad_perm [1,0,3,2]: the neighbour's value
+                    if (lane == 0 || lane == 2)
+                        __hip_atomic_store(gr + 2 * (size_t)lq + (lane >> 1), ((unsigned long long)(hb | (nb << 16)) << 32) | gen,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        };
+
+        // Items are consumed in issue order, ring slot = item ordinal mod RING (static register roles: the loop is unrolled
+        // over the ring).  A quad is closed -- reduce, combine, publish -- right behind its last step, before the loop's
+        // back edge (where the compiler waits for every load in flight, refills and the next op's fragments included).
+        // Every wave closes my_iter quads, with or without work, so the barriers inside finish() stay matched.
+        int c_it = 0, c_st = h;
+        int gq = ro.slot0;
+        float cacc = 0.f;
+        if (ro.my_iter > 0 && gq < ro.total_q && h < nst) {
+            bool done = false;
+            while (!done) {
+#pragma unroll
+                for (int k = 0; k < RING; ++k) {
+                    c_compute<BITS, ZP, SCF16>(cur[k], tab, tstride, l_ls, l_lb, c_st, lane, bsel, k3, cacc);
+                    {   // refill this slot with the op's item RING places ahead, if there is one
+                        const int rq = ro.slot0 + r_it * ro.stride;
+                        if (r_it < ro.my_iter && rq < ro.total_q) {
+                            c_issue<BITS, ZP, SCF16>(cur[k], d, rq, r_st, lane);
+                            r_st += wpq;
+                            if (r_st >= nst) { r_st = h; ++r_it; }
+                        }
+                    }
+                    c_st += wpq;
+                    if (c_st >= nst) {
+                        finish(true, gq, cacc);
+                        cacc = 0.f;
+                        ++c_it;
+                        gq = ro.slot0 + c_it * ro.stride;
+                        c_st = h;
+                        if (c_it >= ro.my_iter || gq >= ro.total_q) { done = true; break; }
+                    }
+                }
+            }
+        }
+        CSTAMP(i, 5);
+        for (; c_it < ro.my_iter; ++c_it) finish(false, 0, 0.f);
+        if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CSTAMP(i, 6); }
+    };
+
+    prefetch(ra, ops);
+    for (int i = 0; i < a.nops; i += 2) {
+        phase(i, ra, rb);
+        if (i + 1 < a.nops) phase(i + 1, rb, ra);
+    }
+#undef CSTAMP
+#undef CSTAMPV
+
+    // the last workgroup out advances the generation: every workgroup has read it by then
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == (unsigned)gx - 1u) {
+            __hip_atomic_store(a.ctl + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.ctl, gen + 1u == 0u ? 1u : gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int chain_buf_u4(int K) {
+    const int nu = K / 32, nst = (nu + 63) / 64;
+    return 4 * (nst * 64 + 1) + (2 * nst * 32 * 4 + 15) / 16;      // [4][tstride] tables + [2][GP] floats
+}
+size_t chain_lds_bytes(int buf_u4) { return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4; }
+
+hipError_t launch_decode_chain(const ChainArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st) {
+    if (a.nops < 1 || grid < 1) return hipErrorInvalidValue;
+    dim3 g(grid), b(CHAIN_FT);
+#define CL(B, Z, H)                                                                                                                  \
+    do {                                                                                                                             \
+        if (lds_bytes > 64 * 1024) {                                                                                                 \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_chain<B, Z, H>),                             \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                         \
+            if (e_ != hipSuccess) return e_;                                                                                         \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((k_decode_chain<B, Z, H>), g, b, lds_bytes, st, a);                                                       \
+        return hipGetLastError();                                                                                                    \
+    } while (0)
+#define CLZ(B)                                                                  \
+    do {                                                                        \
+        if (zp) { if (sc_f16) CL(B, true, true); else CL(B, true, false); }     \
+        else { if (sc_f16) CL(B, false, true); else CL(B, false, false); }      \
+    } while (0)
+    switch (bits) {
+        case 2: CLZ(2);
+        case 4: CLZ(4);
+        default: return hipErrorInvalidValue;
+    }
+#undef CLZ
+#undef CL
+}
+
+}  // namespace tmac

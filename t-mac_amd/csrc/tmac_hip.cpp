@@ -20,6 +20,7 @@
 
 #include "../../include/tmac_hip.h"
 #include "tmac_kernels.h"
+#include "tmac_chain.h"
 
 using namespace tmac;
 
@@ -758,9 +759,233 @@ static void tuned_config(const FusedArgs& fa, int total_q, int& ft, int& wpq) {
     if (it != g_tuned.end()) { ft = it->second.ft; wpq = it->second.wpq; }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Persistent decode chain (tmac_chain.hip): the fused calls of one decoded token recorded once, then executed by ONE
+// launch.  Recording mirrors stream capture: between tmac_hip_chain_begin() and tmac_hip_chain_end() the calling thread's
+// tmac_hip_qgemm_fused_dev calls (N = 1) are noted instead of launched; data flow is inferred from pointer identity (an
+// op whose activation pointer equals an earlier op's output pointer consumes that output inside the launch).
+// ---------------------------------------------------------------------------------------------
+struct ChainRecOp {
+    std::vector<const tmac_hip_weights*> w;
+    const void* B;
+    std::vector<void*> C;
+    tmac_dtype_t act, out;
+};
+static thread_local std::vector<ChainRecOp>* g_chain_rec = nullptr;
+static int g_chain_wpq = 0;          // A/B knob: waves per row quad for every op of chains built from now on (0 = per-op choice)
+static unsigned g_chain_spin_limit = 1u << 21;
+
+struct tmac_hip_chain {
+    std::vector<ChainOp> ops;
+    ChainOp* d_ops = nullptr;
+    unsigned* ctl = nullptr;
+    std::vector<void*> grans;
+    int bits = 0, zp = 0, sc_f16 = 0, out_f16 = 0;
+    int grid = 0, buf_u4 = 0;
+    size_t lds_bytes = 0;
+    unsigned long long* stamps = nullptr;
+    size_t bytes = 0;                 // algorithmic weight + scale bytes of one launch
+};
+
+static int32_t chain_record(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
+                            void* const* C_list, tmac_dtype_t out_dtype, int N) {
+    if (N != 1) return fail(TMAC_HIP_E_NOMATCH, "a decode chain records N = 1 calls only");
+    ChainRecOp op;
+    for (int i = 0; i < nmat; ++i) {
+        if (!wl[i] || !C_list[i]) return fail(TMAC_HIP_E_ARG, "null matrix or output");
+        op.w.push_back(wl[i]);
+        op.C.push_back(C_list[i]);
+    }
+    op.B = B_dev; op.act = act_dtype; op.out = out_dtype;
+    g_chain_rec->push_back(op);
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_chain_begin(void) {
+    if (g_chain_rec) return fail(TMAC_HIP_E_ARG, "a chain is already being recorded on this thread");
+    g_chain_rec = new std::vector<ChainRecOp>();
+    return TMAC_HIP_OK;
+}
+
+static int chain_pick_wpq(int total_q, int nst, int grid) {
+    int best = 1;
+    long best_cost = 1L << 60;
+    for (int wpq = 1; wpq <= 3; ++wpq) {          // the combinations k_gemv_quad is instantiated for with 768 threads
+        if (wpq > 1 && wpq > nst) continue;
+        const long ipi = CHAIN_NWV / wpq;
+        const long iters = (total_q + (long)grid * ipi - 1) / ((long)grid * ipi);
+        const long steps = (nst + wpq - 1) / wpq;
+        if (iters * steps < best_cost) { best_cost = iters * steps; best = wpq; }     // ties: fewer waves per quad (no LDS combine)
+    }
+    return best;
+}
+
+extern "C" int32_t tmac_hip_chain_free(tmac_hip_chain* c) {
+    if (!c) return TMAC_HIP_OK;
+    for (void* p : c->grans) (void)hipFree(p);
+    if (c->d_ops) (void)hipFree(c->d_ops);
+    if (c->ctl) (void)hipFree(c->ctl);
+    delete c;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
+    if (!g_chain_rec) return fail(TMAC_HIP_E_ARG, "no chain is being recorded on this thread");
+    std::vector<ChainRecOp> rec;
+    rec.swap(*g_chain_rec);
+    delete g_chain_rec;
+    g_chain_rec = nullptr;
+    if (!out) return fail(TMAC_HIP_E_ARG, "null argument");
+    *out = nullptr;
+    if (rec.empty()) return fail(TMAC_HIP_E_ARG, "nothing was recorded");
+    int32_t rc = ensure_device();
+    if (rc) return rc;
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus < 1) return fail(TMAC_HIP_E_RUNTIME, "no compute units reported");
+    auto* c = new tmac_hip_chain();
+    c->grid = cus;                                  // one workgroup per CU: all resident by construction
+    const tmac_hip_weights* w0 = rec[0].w[0];
+    c->bits = w0->s.bits; c->zp = w0->s.zero_point; c->sc_f16 = w0->sc_dtype == F16; c->out_f16 = rec[0].out == TMAC_F16;
+    auto bail = [&](int32_t code) { tmac_hip_chain_free(c); return code; };
+    if (c->bits != 2 && c->bits != 4) return bail(fail(TMAC_HIP_E_NOMATCH, "the decode chain is built for 2- and 4-bit weights"));
+    int maxK = 0;
+    // which outputs are consumed later in the chain (pointer identity, most recent writer)
+    struct Src { int op, mat; };
+    std::vector<Src> src(rec.size(), Src{-1, -1});
+    std::vector<std::vector<char>> consumed(rec.size());
+    for (size_t i = 0; i < rec.size(); ++i) consumed[i].assign(rec[i].w.size(), 0);
+    for (size_t i = 0; i < rec.size(); ++i) {
+        for (size_t j = i; j-- > 0 && src[i].op < 0;)
+            for (size_t m = 0; m < rec[j].C.size(); ++m)
+                if (rec[j].C[m] == rec[i].B) { src[i] = Src{(int)j, (int)m}; consumed[j][m] = 1; break; }
+    }
+    c->ops.resize(rec.size());
+    std::vector<std::vector<void*>> gr(rec.size());
+    for (size_t i = 0; i < rec.size(); ++i) {
+        const ChainRecOp& r = rec[i];
+        ChainOp& o = c->ops[i];
+        memset(&o, 0, sizeof(o));
+        const Shape& s0 = r.w[0]->s;
+        if (r.act != TMAC_F16) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the decode chain takes fp16 activations", i));
+        if ((r.out == TMAC_F16) != (c->out_f16 != 0)) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: one output dtype per chain", i));
+        int gu = s0.gs / 32;
+        if (s0.m_groups >= 1 || s0.ags != 64 || s0.gs < 128 || (gu & (gu - 1)) || s0.K % s0.gs || s0.K % 64)
+            return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the decode chain covers per-group scales (group >= 128, power of two) with act groups of 64", i));
+        int nq = 0;
+        for (size_t m = 0; m < r.w.size(); ++m) {
+            const tmac_hip_weights* w = r.w[m];
+            const Shape& a = w->s;
+            if (a.lay != 2 || !w->lo_ok || w->fa) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu matrix %zu is not registered in the QUAD layout", i, m));
+            if (a.K != s0.K || a.bits != c->bits || a.gs != s0.gs || a.ags != s0.ags || a.zero_point != c->zp || a.m_groups != s0.m_groups ||
+                (w->sc_dtype == F16) != (c->sc_f16 != 0))
+                return bail(fail(TMAC_HIP_E_ARG, "op %zu: the matrices of a chain share bits, zero points and scale dtype; those of an op also K and group size", i));
+            nq += a.nquads();
+            o.m[m].W = (const uint4*)w->W; o.m[m].SC = w->SC; o.m[m].C = r.C[m]; o.m[m].Mw = a.Mw; o.m[m].q_end = nq;
+            o.m[m].GR = nullptr;
+            if (consumed[i][m]) {
+                if (r.out != TMAC_F16) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: outputs consumed inside the chain must be fp16", i));
+                void* g = nullptr;
+                const size_t gb = (size_t)a.nquads() * 16;
+                if (hipMalloc(&g, gb) != hipSuccess || hipMemset(g, 0, gb) != hipSuccess)
+                    return bail(fail(TMAC_HIP_E_RUNTIME, "hand-off buffer allocation failed"));
+                c->grans.push_back(g);
+                o.m[m].GR = (uint4*)g;
+            }
+            c->bytes += w->w_bytes + w->sc_bytes;
+        }
+        o.nmat = (int)r.w.size();
+        o.K = s0.K; o.nu = s0.K / 32; o.nst = (o.nu + 63) / 64; o.tstride = o.nst * 64 + 1;
+        o.G = s0.K / 64; o.GP = o.nst * 32; o.nsg = s0.K / s0.gs;
+        o.gs_shift = 0;
+        for (int g = gu; g > 1; g >>= 1) ++o.gs_shift;
+        o.total_q = nq;
+        o.wpq = g_chain_wpq ? g_chain_wpq : chain_pick_wpq(nq, o.nst, c->grid);
+        if (CHAIN_NWV % o.wpq) return bail(fail(TMAC_HIP_E_ARG, "waves per quad must divide %d", CHAIN_NWV));
+        o.ipi = CHAIN_NWV / o.wpq;
+        o.wpq_inv = (65536 + o.wpq - 1) / o.wpq;
+        const int stride = c->grid * o.ipi;
+        o.it_full = nq / stride; o.it_rem = nq % stride;
+        if (src[i].op >= 0) {
+            const ChainOp& po = c->ops[src[i].op];
+            if (po.m[src[i].mat].Mw != o.K) return bail(fail(TMAC_HIP_E_ARG, "op %zu reads an output of %d rows as %d activations", i, po.m[src[i].mat].Mw, o.K));
+            o.in = po.m[src[i].mat].GR; o.in_gran = 1;
+        } else {
+            o.in = r.B; o.in_gran = 0;
+        }
+        if (o.K > maxK) maxK = o.K;
+    }
+    c->buf_u4 = chain_buf_u4(maxK);
+    c->lds_bytes = chain_lds_bytes(c->buf_u4);
+    if (c->lds_bytes > 160 * 1024) return bail(fail(TMAC_HIP_E_NOMATCH, "K = %d needs %zu bytes of LDS", maxK, c->lds_bytes));
+    if (hipMalloc((void**)&c->d_ops, sizeof(ChainOp) * c->ops.size()) != hipSuccess ||
+        hipMemcpy(c->d_ops, c->ops.data(), sizeof(ChainOp) * c->ops.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(TMAC_HIP_E_RUNTIME, "descriptor upload failed"));
+    const unsigned ctl0[4] = {1u, 0u, 0u, 0u};
+    if (hipMalloc((void**)&c->ctl, sizeof(ctl0)) != hipSuccess || hipMemcpy(c->ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(TMAC_HIP_E_RUNTIME, "control word allocation failed"));
+    *out = c;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
+    if (!c) return fail(TMAC_HIP_E_ARG, "null chain");
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ops = c->d_ops; a.nops = (int)c->ops.size(); a.ctl = c->ctl; a.out_f16 = c->out_f16;
+    a.spin_limit = g_chain_spin_limit; a.buf_u4 = c->buf_u4; a.stamps = c->stamps;
+    hipError_t e = launch_decode_chain(a, c->bits, c->zp != 0, c->sc_f16 != 0, c->grid, c->lds_bytes, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no decode-chain kernel for this configuration");
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "decode chain launch: %s", hipGetErrorString(e));
+    return TMAC_HIP_OK;
+}
+
+// After the stream has been synchronised: 0 = every hand-off completed; otherwise the error word of the first wave that
+// gave up (bit 31 | op << 8 | wave) -- the outputs are then invalid.  Clears the word and re-arms the chain.
+extern "C" int32_t tmac_hip_chain_status(tmac_hip_chain* c, uint32_t* error_word) {
+    if (!c || !error_word) return fail(TMAC_HIP_E_ARG, "null argument");
+    unsigned ctl[4];
+    HIP_TRY(hipMemcpy(ctl, c->ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+    *error_word = ctl[2];
+    if (ctl[2] || ctl[1]) {
+        // a launch that gave up may not have advanced the generation: do it here and clear the partial state
+        const unsigned fresh[4] = {ctl[0] + 2u ? ctl[0] + 2u : 1u, 0u, 0u, 0u};
+        HIP_TRY(hipMemcpy(c->ctl, fresh, sizeof(fresh), hipMemcpyHostToDevice));
+    }
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_chain_info(const tmac_hip_chain* c, int op, int32_t* nops, int32_t* wpq, int32_t* grid, size_t* bytes) {
+    if (!c) return fail(TMAC_HIP_E_ARG, "null chain");
+    if (nops) *nops = (int32_t)c->ops.size();
+    if (grid) *grid = c->grid;
+    if (bytes) *bytes = c->bytes;
+    if (wpq) {
+        if (op < 0 || op >= (int)c->ops.size()) return fail(TMAC_HIP_E_ARG, "op index out of range");
+        *wpq = c->ops[op].wpq;
+    }
+    return TMAC_HIP_OK;
+}
+
+// profiling aid: s_memrealtime stamps [ops][workgroups][8] of wave 0 (layout: tmac_chain.h)
+extern "C" int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* c, unsigned long long* dev_buffer) {
+    if (!c) return fail(TMAC_HIP_E_ARG, "null chain");
+    c->stamps = dev_buffer;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_debug_chain_config(int force_wpq, unsigned spin_limit) {
+    if (force_wpq < 0 || (force_wpq && CHAIN_NWV % force_wpq)) return fail(TMAC_HIP_E_ARG, "waves per quad must divide %d", CHAIN_NWV);
+    g_chain_wpq = force_wpq;
+    if (spin_limit) g_chain_spin_limit = spin_limit;
+    return TMAC_HIP_OK;
+}
+
 static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
                           void* const* C_list, tmac_dtype_t out_dtype, int N, int32_t* dump, float* lut_tap, hipStream_t st) {
     if (!wl || !C_list || !B_dev || nmat < 1 || nmat > 4 || N < 1) return fail(TMAC_HIP_E_ARG, "bad fused arguments (1..4 matrices)");
+    if (g_chain_rec && !dump && !lut_tap) return chain_record(wl, nmat, B_dev, act_dtype, C_list, out_dtype, N);
     if (g_gemm_min_n > 0 && N >= g_gemm_min_n && !dump && !lut_tap) {
         bool ok = true;
         long rows = 0;

@@ -67,6 +67,7 @@ class Weights:
         check(fn(C.byref(self._h), _ptr(A_ref), _ptr(scales_ref), Mw, K, bits, C.byref(cfg), scales_dtype, dev_dtype,
                  _stream(stream)))
         self._keep = None
+        self._caches = []          # fused-call caches holding this handle (TMACGeMMWrapper.fused)
 
     @property
     def handle(self):
@@ -77,6 +78,11 @@ class Weights:
 
     def free(self):
         if self._h:
+            hv = self._h.value
+            for cache in getattr(self, "_caches", []):     # no cached call may keep the freed native handle
+                for key in [k for k in cache if hv in k[0]]:
+                    del cache[key]
+            self._caches = []
             B.lib().tmac_hip_free_weights(self._h)
             self._h = C.c_void_p()
 
@@ -130,6 +136,68 @@ class Workspace:
             self.free()
         except Exception:
             pass
+
+
+class DecodeChain:
+    """A recorded sequence of ``TMACGeMMWrapper.fused`` calls (N = 1) executed by ONE persistent kernel launch
+    (tmac_hip_chain_*, include/tmac_hip.h).  Built by ``TMACGeMMWrapper.record_chain``."""
+
+    def __init__(self, handle, keep):
+        self._h = handle
+        self._keep = keep          # weights / tensors the chain points into
+        n, g, b = C.c_int32(0), C.c_int32(0), C.c_size_t(0)
+        check(B.lib().tmac_hip_chain_info(self._h, 0, C.byref(n), None, C.byref(g), C.byref(b)))
+        self.nops, self.grid, self.weight_bytes = n.value, g.value, b.value
+
+    def launch(self, stream=None) -> None:
+        check(B.lib().tmac_hip_chain_launch(self._h, _stream(stream)))
+
+    def status(self) -> int:
+        """after a stream synchronisation: 0 if every in-kernel hand-off of the last launches completed"""
+        w = C.c_uint32(0)
+        check(B.lib().tmac_hip_chain_status(self._h, C.byref(w)))
+        return w.value
+
+    def wpq(self, op: int) -> int:
+        w = C.c_int32(0)
+        check(B.lib().tmac_hip_chain_info(self._h, op, None, C.byref(w), None, None))
+        return w.value
+
+    def set_stamps(self, dev_buffer) -> None:
+        check(B.lib().tmac_hip_chain_set_stamps(self._h, _ptr(dev_buffer)))
+        self._stamps = dev_buffer
+
+    def free(self):
+        if self._h:
+            B.lib().tmac_hip_chain_free(self._h)
+            self._h = C.c_void_p()
+        self._keep = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _ChainRecorder:
+    def __init__(self, wrapper):
+        self.wr = wrapper
+        self.chain: Optional[DecodeChain] = None
+
+    def __enter__(self):
+        check(B.lib().tmac_hip_chain_begin())
+        self.wr._recording = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        keep, self.wr._recording = self.wr._recording, None
+        h = C.c_void_p()
+        rc = B.lib().tmac_hip_chain_end(C.byref(h))
+        if et is None:
+            check(rc)
+            self.chain = DecodeChain(h, keep)
+        return False
 
 
 class TMACGeMMWrapper:
@@ -205,14 +273,28 @@ class TMACGeMMWrapper:
             act_dtype = _dtype_code(B_dev)
         if out_dtype is None:
             out_dtype = _dtype_code(C_list[0])
-        key = (tuple(id(w) for w in weights_list), tuple(_ptr(c) for c in C_list))
+        # keyed by the native handle VALUES (an id() can be reused once a Weights object is collected); the arrays
+        # hold raw handles, so an entry is dropped when any of its weights is freed (see Weights.free / _forget)
+        key = (tuple(w.handle.value for w in weights_list), tuple(_ptr(c) for c in C_list))
         cache = self.__dict__.setdefault("_fused_cache", {})
         if key not in cache:   # the ctypes pointer arrays are reused across calls (cheap host path)
+            if len(cache) > 4096:
+                cache.clear()
             wa = (C.c_void_p * n)(*[w.handle.value for w in weights_list])
             ca = (C.c_void_p * n)(*[_ptr(c) for c in C_list])
             cache[key] = (wa, ca)
+            for w in weights_list:
+                w._caches.append(cache)
         wa, ca = cache[key]
+        rec = getattr(self, "_recording", None)
+        if rec is not None:
+            rec.append((list(weights_list), B_dev, list(C_list)))
         check(B.lib().tmac_hip_qgemm_fused_dev(wa, n, _ptr(B_dev), act_dtype, ca, out_dtype, N, _stream(stream)))
+
+    def record_chain(self) -> "_ChainRecorder":
+        """``with wr.record_chain() as rec: <the token's wr.fused(...) calls>`` — the calls are noted instead of launched;
+        afterwards ``rec.chain.launch()`` executes all of them in ONE persistent kernel launch (tmac_hip_chain_*)."""
+        return _ChainRecorder(self)
 
     def autotune(self, weights_list, act_dtype=F16, out_dtype=F16):
         """Measure the launch configurations of the fused decode kernel on these matrices (the list ``fused`` will be

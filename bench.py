@@ -389,8 +389,7 @@ def main():
                 per[name] = {"us": round(float(np.mean(dur[k::4])), 3),
                              "wait_input_us": round(float(np.mean(sel[:, :, 1] - sel[:, :, 0])), 3),
                              "lut_build_us": round(float(np.mean(sel[:, :, 2] - sel[:, :, 1])), 3),
-                             "wait_weights_us": round(float(np.mean(sel[:, :, 3] - sel[:, :, 2])), 3),
-                             "lookups_us": round(float(np.mean(sel[:, :, 5] - sel[:, :, 3])), 3),
+                             "lookups_us": round(float(np.mean(sel[:, :, 5] - sel[:, :, 2])), 3),
                              "polls": round(float(np.mean(raw[k::4, :, 7])), 2)}
             hb = algorithmic_bytes(4096, 11008)
             roof["per_call_from_stamps"] = per

@@ -4,8 +4,8 @@
 // pays the dependent-dispatch gap, fetches its activations, builds its LUT and only then starts its weight stream, so HBM
 // idles through most of a launch (0.78 ms per token against 0.45 ms for launches that merely read the
 // bytes).  Here one workgroup per CU walks the whole op list:
-//   * weights do not depend on the previous op, so every wave keeps the fragments of its NEXT op's first work items in
-//     flight (second register ring) while it computes the current op and while it waits for the hand-off;
+//   * no dependent dispatch, no ramp-up and drain per op, activations read once (the poll that detects them IS the load);
+//     an op's weights are issued the moment its activations are complete and stream in during the LUT build;
 //   * the hand-off is in-kernel: an op's outputs are published as self-tagged 8-byte granules {generation, 2 x fp16}
 //     with write-through (sc1) stores; the consumers' LUT build reads exactly those granules with sc1 loads and spins
 //     until every tag carries this launch's generation (data is the flag: no counter, no fence, no drain of the weight
@@ -46,7 +46,7 @@ __device__ __forceinline__ void c_seek(cop_ptr d, int gq, int& mi, int& base) {
 // Lanes whose unit lies past K skip the weight load (their LUT entries are zero tables: whatever the registers hold
 // contributes exactly 0) -- the zero padding of the last step is stored but never fetched.
 template <int BITS, bool ZP, bool SCF16>
-__device__ __forceinline__ void c_issue(CFrag<BITS>& f, cop_ptr d, int gq, int st, int lane) {
+__device__ __forceinline__ void c_issue(CFrag<BITS>& f, cop_ptr d, int gq, int st, int lane, uint32_t lane16) {
     constexpr int per = ZP ? 2 : 1;
     int mi, base;
     c_seek(d, gq, mi, base);
@@ -69,10 +69,16 @@ __device__ __forceinline__ void c_issue(CFrag<BITS>& f, cop_ptr d, int gq, int s
     }
     f.s0 = r0; f.s1 = r1;
     if (st * 64 + lane < nu) {
-        const uint4* wp = W + (size_t)((uint32_t)(lq * nst + st) * (uint32_t)(BITS * 64)) + lane;
+        // Buffer loads: resource (matrix base) and the fragment's byte offset in SGPRs, the lane's byte offset in a VGPR of
+        // its own (lane16, made opaque at kernel entry).  No VALU instruction takes part: when the address arithmetic
+        // (a rematerialised lane << 4, or a 64-bit add) lands in a dead ring register, that VALU write makes the
+        // compiler wait for every earlier load that might still target the register -- it serialised the fragments of a
+        // ring, one full memory latency each (1.4-2.8 us per op, profiles/r02_chain_prefetch_ab.txt B).
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(W), (short)0, 0x7fffffff, 0x00020000);
+        const int soff = (lq * nst + st) * (BITS * 1024);
 #pragma unroll
         for (int j = 0; j < BITS; ++j) {
-            const u32x4q v = __builtin_nontemporal_load(reinterpret_cast<const u32x4q*>(wp + (size_t)j * 64));
+            const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane16, soff + j * 1024, 2 /* nt */);
             f.wd[4 * j] = v.x; f.wd[4 * j + 1] = v.y; f.wd[4 * j + 2] = v.z; f.wd[4 * j + 3] = v.w;
         }
     }
@@ -166,6 +172,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     }
     uint32_t k3 = 0x03020100u;
     asm volatile("" : "+v"(k3));
+    uint32_t lane16 = (uint32_t)lane * 16u;
+    asm volatile("" : "+v"(lane16));
 
     // per-op role of this wave: quads slot0, slot0 + stride, ...; steps h, h + wpq, ... of each
     struct Role { int slot0, stride, h, wpq, nst, total_q, my_iter; };
@@ -183,25 +191,9 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         return r;
     };
 
-    CFrag<BITS> ra[RING], rb[RING];
-    int pf_it = 0, pf_st = 0;        // item cursor of the op whose first RING items are in its ring: where its refills resume
-
-    // issue the first RING work items of op e into ring r
-    auto prefetch = [&](CFrag<BITS> (&r)[RING], cop_ptr e) __attribute__((always_inline)) {
-        const Role ro = role_of(e);
-        int it = 0, st = ro.h;
-#pragma unroll
-        for (int k = 0; k < RING; ++k) {
-            const int gq = ro.slot0 + it * ro.stride;
-            if (it < ro.my_iter && gq < ro.total_q && ro.h < ro.nst) c_issue<BITS, ZP, SCF16>(r[k], e, gq, st, lane);
-            st += ro.wpq;
-            if (st >= ro.nst) { st = ro.h; ++it; }
-        }
-        pf_it = it; pf_st = st;
-    };
-
+    CFrag<BITS> ring[RING];
     int parity = 0;
-    auto phase = [&](int i, CFrag<BITS> (&cur)[RING], CFrag<BITS> (&nxt)[RING]) __attribute__((always_inline)) {
+    for (int i = 0; i < a.nops; ++i) {
         const cop_ptr d = ops + i;
         CSTAMP(i, 0);
         const int tstride = d->tstride, nu = d->nu, nst = d->nst, G = d->G, GP = d->GP;
@@ -209,47 +201,84 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         float* l_ls = reinterpret_cast<float*>(tab + 4 * tstride);   // [GP] ls / 2 (groups past K: 0)
         float* l_lb = l_ls + GP;                                     // [GP] lb / 2
         const int P = d->K / 8;                                      // LUT pairs: tables 2p, 2p+1 from activations 8p .. 8p+7
+        const Role ro = role_of(d);
+        const int wpq = ro.wpq, h = ro.h;
 
-        // ---- 1. this op's activations: poll the producer's granules (or read the external vector), build the LUT ----
+        // ---- 1. this op's activations.  The CU's vector-memory queue is empty here (the previous op's lookups consumed
+        // everything it had in flight): a poll costs one round trip, not the drain time of a weight stream.  Measured the
+        // other way round -- next op's weights prefetched behind the current op's lookups -- every publish and every poll
+        // sat behind 20-100 KB of queued weight loads per CU: 3-4 us per hand-off (profiles/r02_chain_prefetch_ab.txt). ----
         const bool gran = d->in_gran != 0;
+        const int nr = (P + FT - 1) / FT;                            // rounds of FT pairs (<= NRMAX, checked on the host)
+        constexpr int NRMAX = 3;
+        uint32_t xw[NRMAX][4];
         unsigned long long polls = 0;
-        for (int r0 = 0; r0 * FT < P; ++r0) {
-            const int p = r0 * FT + tid;
-            const bool need = p < P;            // K % 64 == 0: the 8 lanes of an act group are valid or invalid together
-            uint32_t xw[4] = {0, 0, 0, 0};
-            if (gran) {
-                const uint4* g = reinterpret_cast<const uint4*>(d->in) + 2 * (size_t)min(p, P - 1);
-                bool ok = !need;
-                unsigned spins = 0;
-                for (;;) {
-                    ++polls;
-                    if (!ok) {
-                        u32x4q v0, v1;
-                        c_poll2(g, v0, v1);
-                        ok = (v0.x == gen) & (v0.z == gen) & (v1.x == gen) & (v1.z == gen);
-                        xw[0] = v0.y; xw[1] = v0.w; xw[2] = v1.y; xw[3] = v1.w;
-                    }
-                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                    if (aborted) break;
-                    ++spins;
-                    if ((spins & 1023u) == 0u) {      // something is slow or broken: look at the error word, give up past the limit
-                        const unsigned err = __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (err != 0u || spins >= a.spin_limit) {
-                            if (err == 0u && lane == 0) atomicOr(a.ctl + 2, 0x80000000u | ((unsigned)i << 8) | (unsigned)w);
-                            aborted = true;
+#pragma unroll
+        for (int r = 0; r < NRMAX; ++r) {
+            xw[r][0] = xw[r][1] = xw[r][2] = xw[r][3] = 0u;
+            if (r < nr) {
+                const int p = r * FT + tid;
+                const bool need = p < P;        // K % 64 == 0: the 8 lanes of an act group are valid or invalid together
+                if (gran) {
+                    const uint4* g = reinterpret_cast<const uint4*>(d->in) + 2 * (size_t)min(p, P - 1);
+                    bool ok = !need;
+                    unsigned spins = 0;
+                    for (;;) {
+                        ++polls;
+                        if (!ok) {
+                            u32x4q v0, v1;
+                            c_poll2(g, v0, v1);
+                            ok = (v0.x == gen) & (v0.z == gen) & (v1.x == gen) & (v1.z == gen);
+                            xw[r][0] = v0.y; xw[r][1] = v0.w; xw[r][2] = v1.y; xw[r][3] = v1.w;
                         }
+                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                        if (aborted) break;
+                        ++spins;
+                        if ((spins & 1023u) == 0u) {      // something is slow or broken: look at the error word, give up past the limit
+                            const unsigned err = __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (err != 0u || spins >= a.spin_limit) {
+                                if (err == 0u && lane == 0) atomicOr(a.ctl + 2, 0x80000000u | ((unsigned)i << 8) | (unsigned)w);
+                                aborted = true;
+                            }
+                        }
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    __builtin_amdgcn_s_sleep(1);
+                } else if (need) {
+                    // plain activations in memory since before the launch; load and wait in one statement so that the
+                    // compiler never sees xw as pending (it would wait for the weights issued below before the LUT build)
+                    u32x4q v;
+                    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(reinterpret_cast<const uint4*>(d->in) + p) : "memory");
+                    xw[r][0] = v.x; xw[r][1] = v.y; xw[r][2] = v.z; xw[r][3] = v.w;
                 }
-            } else if (need) {
-                const uint4 v = reinterpret_cast<const uint4*>(d->in)[p];
-                xw[0] = v.x; xw[1] = v.y; xw[2] = v.z; xw[3] = v.w;
             }
-            if (need) {
+        }
+        CSTAMP(i, 1);
+        CSTAMPV(i, 7, polls);
+        // Nothing is in flight here (the polls carry their own waits, invisible to the compiler).  Saying so with a wait
+        // the compiler SEES resets its scoreboard: otherwise every register that was a load destination anywhere in the
+        // op loop counts as possibly pending, and VALU writes to such registers (LUT build temporaries, store operands)
+        // get conservative s_waitcnt vmcnt(n) in front of them -- waits for this op's weights in the middle of the LUT build.
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt / lgkmcnt untouched
+
+        // ---- 2. this wave's first RING (quad, step) items: the weights stream in during the LUT build ----
+        int r_it = 0, r_st = h;
+#pragma unroll
+        for (int k = 0; k < RING; ++k) {
+            const int rq = ro.slot0 + r_it * ro.stride;
+            if (r_it < ro.my_iter && rq < ro.total_q && h < nst) c_issue<BITS, ZP, SCF16>(ring[k], d, rq, r_st, lane, lane16);
+            r_st += wpq;
+            if (r_st >= nst) { r_st = h; ++r_it; }
+        }
+
+        // ---- 3. LUT into LDS (lut_ctor.cc:120-215, as in k_gemv_quad) ----
+#pragma unroll
+        for (int r = 0; r < NRMAX; ++r) {
+            const int p = r * FT + tid;
+            if (r < nr && p < P) {
                 float x[8];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const __half2 hh = *reinterpret_cast<const __half2*>(&xw[q]);
+                    const __half2 hh = *reinterpret_cast<const __half2*>(&xw[r][q]);
                     x[2 * q] = __low2float(hh); x[2 * q + 1] = __high2float(hh);
                 }
                 const float s0 = __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3])));
@@ -276,8 +305,6 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 }
             }
         }
-        CSTAMP(i, 1);
-        CSTAMPV(i, 7, polls);
         {   // zero tables / zero LUT scales for the units between K and the end of the last 64-unit step
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4)
@@ -287,24 +314,14 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         __syncthreads();
         CSTAMP(i, 2);
 
-        // ---- 2. next op's first fragments into the other ring (they stream in during this op's lookups and the next wait) ----
-        int r_it = pf_it, r_st = pf_st;               // refill cursor of THIS op (its first RING items were issued a phase ago)
-        // The current ring's loads were issued a phase ago.  Reading its registers here makes the compiler place its wait
-        // for them HERE, in front of the next ring's loads -- otherwise the wait lands at the first lookup below, behind
-        // loads whose number it cannot count, as s_waitcnt vmcnt(0): a full memory latency before the first lookup.
-#pragma unroll
-        for (int k = 0; k < RING; ++k) {
-#pragma unroll
-            for (int j = 0; j < 4 * BITS; ++j) asm volatile("" :: "v"(cur[k].wd[j]));
-            asm volatile("" :: "v"(cur[k].s0), "v"(cur[k].s1));
-        }
-        CSTAMP(i, 3);
-        if (i + 1 < a.nops) prefetch(nxt, ops + i + 1);
-
-        // ---- 3. this wave's (quad, step) items ----
-        const Role ro = role_of(d);
-        const int wpq = ro.wpq, h = ro.h;
-        auto finish = [&](bool have, int gq, float cacc) __attribute__((always_inline)) {
+        // ---- 4. lookups.  Items are consumed in issue order, ring slot = item ordinal mod RING (static register roles:
+        // the loop is unrolled over the ring).  A workgroup iteration (ipi consecutive quads) is closed by finish(): every
+        // wave leaves its quad's partial sums in LDS, one barrier, and wave 0 combines the wpq partials of each quad (in wave
+        // order, as k_gemv_quad does), stores the outputs and publishes the granules of all ipi quads with ONE store
+        // instruction -- a granule line is then written by one or two stores, not by sixteen 8-byte write-throughs that each
+        // invalidate the line in every polling XCD.  Every wave closes my_iter iterations, with or without work. ----
+        int c_it = 0;
+        auto finish = [&](bool have, float cacc) __attribute__((always_inline)) {
             float acc = 0.f;
             if (have) {
                 acc = cacc;
@@ -313,40 +330,46 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));
                 acc = __fadd_rn(acc, __shfl_xor(acc, 32, 64));
             }
-            const bool owner = have && h == 0;
-            float t = acc;
-            if (wpq > 1) {
-                float* red = l_red + parity * (NWV * 4);
-                if (lane < 4) red[w * 4 + lane] = acc;
-                __syncthreads();
-                if (owner && lane < 4) {
-                    t = red[w * 4 + lane];
-                    for (int ww = 1; ww < wpq; ++ww) t = __fadd_rn(t, red[(w + ww) * 4 + lane]);
+            float* red = l_red + parity * (NWV * 4);
+            if (lane < 4) red[w * 4 + lane] = acc;
+            __syncthreads();
+            if (w == 0) {
+                const int qs = lane >> 2, row = lane & 3;
+                const int g0 = bx * d->ipi + c_it * ro.stride;           // first quad of this workgroup iteration
+                const int gql = g0 + qs;
+                const bool mine = qs < d->ipi && gql < ro.total_q;      // the 4 lanes of a quad decide together
+                float t = 0.f;
+                if (mine) {
+                    t = red[(qs * wpq) * 4 + row];
+                    for (int ww = 1; ww < wpq; ++ww) t = __fadd_rn(t, red[(qs * wpq + ww) * 4 + row]);
                 }
-                parity ^= 1;
-            }
-            if (owner) {
-                int mi, base;
-                c_seek(d, gq, mi, base);
-                const int lq = gq - base;
-                if (lane < 4) q_st_out(d->m[mi].C, a.out_f16, (size_t)(4 * lq + lane), t);
-                unsigned long long* gr = reinterpret_cast<unsigned long long*>(d->m[mi].GR);
-                if (gr) {
-                    // granule = {generation, fp16 row | fp16 next row << 16}: lanes 0 and 2 each store one (8 bytes, write-through)
-                    const uint32_t hb = (uint32_t)__half_as_ushort(__float2half_rn(t));
-                    const uint32_t nb = qdpp_u<0xB1>(hb);            // quad_perm [1,0,3,2]: the neighbour's value
-                    if (lane == 0 || lane == 2)
-                        __hip_atomic_store(gr + 2 * (size_t)lq + (lane >> 1), ((unsigned long long)(hb | (nb << 16)) << 32) | gen,
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // granule = {generation, fp16 row | fp16 next row << 16}, 8 bytes, write-through: even rows store
+                const uint32_t hb = (uint32_t)__half_as_ushort(__float2half_rn(t));
+                const uint32_t nb = qdpp_u<0xB1>(hb);                    // quad_perm [1,0,3,2]: the neighbour's value
+                // matrices in a uniform loop (descriptor fields through the scalar cache): a per-lane descriptor lookup
+                // is a vector load, and waiting for it waits for every weight load in flight as well
+                int base = 0;
+                const int nm = d->nmat;
+                for (int mi = 0; mi < nm; ++mi) {
+                    const int qe = d->m[mi].q_end;
+                    if (g0 < qe && g0 + d->ipi > base) {
+                        if (mine && gql >= base && gql < qe) {
+                            const int lq = gql - base;
+                            q_st_out(d->m[mi].C, a.out_f16, (size_t)(4 * lq + row), t);
+                            unsigned long long* gr = reinterpret_cast<unsigned long long*>(d->m[mi].GR);
+                            if (gr && !(row & 1))
+                                __hip_atomic_store(gr + 2 * (size_t)lq + (row >> 1), ((unsigned long long)(hb | (nb << 16)) << 32) | gen,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    base = qe;
                 }
             }
+            parity ^= 1;
+            ++c_it;
         };
 
-        // Items are consumed in issue order, ring slot = item ordinal mod RING (static register roles: the loop is unrolled
-        // over the ring).  A quad is closed -- reduce, combine, publish -- right behind its last step, before the loop's
-        // back edge (where the compiler waits for every load in flight, refills and the next op's fragments included).
-        // Every wave closes my_iter quads, with or without work, so the barriers inside finish() stay matched.
-        int c_it = 0, c_st = h;
+        int c_st = h;
         int gq = ro.slot0;
         float cacc = 0.f;
         if (ro.my_iter > 0 && gq < ro.total_q && h < nst) {
@@ -354,20 +377,19 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             while (!done) {
 #pragma unroll
                 for (int k = 0; k < RING; ++k) {
-                    c_compute<BITS, ZP, SCF16>(cur[k], tab, tstride, l_ls, l_lb, c_st, lane, bsel, k3, cacc);
+                    c_compute<BITS, ZP, SCF16>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane, bsel, k3, cacc);
                     {   // refill this slot with the op's item RING places ahead, if there is one
                         const int rq = ro.slot0 + r_it * ro.stride;
                         if (r_it < ro.my_iter && rq < ro.total_q) {
-                            c_issue<BITS, ZP, SCF16>(cur[k], d, rq, r_st, lane);
+                            c_issue<BITS, ZP, SCF16>(ring[k], d, rq, r_st, lane, lane16);
                             r_st += wpq;
                             if (r_st >= nst) { r_st = h; ++r_it; }
                         }
                     }
                     c_st += wpq;
                     if (c_st >= nst) {
-                        finish(true, gq, cacc);
+                        finish(true, cacc);
                         cacc = 0.f;
-                        ++c_it;
                         gq = ro.slot0 + c_it * ro.stride;
                         c_st = h;
                         if (c_it >= ro.my_iter || gq >= ro.total_q) { done = true; break; }
@@ -376,14 +398,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             }
         }
         CSTAMP(i, 5);
-        for (; c_it < ro.my_iter; ++c_it) finish(false, 0, 0.f);
+        while (c_it < ro.my_iter) finish(false, 0.f);
         if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CSTAMP(i, 6); }
-    };
-
-    prefetch(ra, ops);
-    for (int i = 0; i < a.nops; i += 2) {
-        phase(i, ra, rb);
-        if (i + 1 < a.nops) phase(i + 1, rb, ra);
     }
 #undef CSTAMP
 #undef CSTAMPV

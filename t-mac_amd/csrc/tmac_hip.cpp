@@ -871,6 +871,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         if (r.act != TMAC_F16) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the decode chain takes fp16 activations", i));
         if ((r.out == TMAC_F16) != (c->out_f16 != 0)) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: one output dtype per chain", i));
         int gu = s0.gs / 32;
+        if (s0.K > 8 * 3 * CHAIN_FT) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: K = %d beyond the decode chain's %d", i, s0.K, 8 * 3 * CHAIN_FT));
         if (s0.m_groups >= 1 || s0.ags != 64 || s0.gs < 128 || (gu & (gu - 1)) || s0.K % s0.gs || s0.K % 64)
             return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the decode chain covers per-group scales (group >= 128, power of two) with act groups of 64", i));
         int nq = 0;

@@ -21,6 +21,7 @@ struct ChainMat {
 
 struct ChainOp {
     ChainMat m[4];
+    int q_end[4];        // m[k].q_end again, contiguous (one scalar load), INT_MAX from the last matrix on
     const void* in;      // in_gran: the hand-off image (uint4 [K/4]) written earlier in this launch; else activations [K] fp16
     int in_gran;
     int nmat;
@@ -29,21 +30,26 @@ struct ChainOp {
     int wpq_inv;         // ceil(65536 / wpq): wave / wpq = (wave * wpq_inv) >> 16
     int total_q;
     int it_full, it_rem; // total_q = it_full * (grid * ipi) + it_rem: iterations every workgroup runs / quads of the last, partial one
+    int pad_[2];         // sizeof == 256: the kernel keeps a copy of all descriptors in LDS (uint4 copies)
 };
+static_assert(sizeof(ChainOp) == 256, "ChainOp is copied to LDS in 16-byte pieces");
 
 struct ChainArgs {
-    const ChainOp* ops;            // device memory, read through the scalar cache (constant address space)
+    const ChainOp* ops;            // device memory; every workgroup copies them to LDS at kernel entry (a descriptor field read through
+                                   // the scalar cache misses it -- 128 x 256 B per token, once each -- and costs ~0.4 us on the critical path)
     int nops;
     unsigned* ctl;                 // [0] generation (tag of this launch), [1] workgroups finished, [2] error word
     int out_f16;
     unsigned spin_limit;           // polls of one hand-off before a wave gives up and sets ctl[2]
     int buf_u4;                    // uint4 per LDS LUT buffer (two buffers, by op parity)
+    int poll_sleep;                // s_sleep between two polls of a hand-off (A/B knob)
+    int issue_first;               // A/B knob: issue an op's weights before polling for its activations
     unsigned long long* stamps;    // optional [nops][grid][8] of wave 0, s_memrealtime (100 MHz): 0 op entry, 1 activations complete, 2 LUT built
                                    // (barrier passed), 3 current ring landed, 5 last quad published, 6 everything in flight landed, 7 polls
 };
 
 hipError_t launch_decode_chain(const ChainArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st);
-size_t chain_lds_bytes(int buf_u4);
+size_t chain_lds_bytes(int buf_u4, int nops);
 int chain_buf_u4(int K);
 
 }  // namespace tmac

@@ -27,7 +27,21 @@
 
 namespace tmac {
 
-typedef const ChainOp __attribute__((address_space(4))) * cop_ptr;   // descriptors through the scalar cache
+typedef const ChainOp* cop_ptr;   // descriptors: the workgroup's copy in LDS
+// Pointers read from the LDS copy are generic to the compiler: without the explicit global address space it emits flat
+// loads / stores, which also count on lgkmcnt -- every LDS wait would then wait for global memory.
+#define TMAC_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ TMAC_GLOBAL T* as_global(T* p) { return (TMAC_GLOBAL T*)p; }
+// A value read from the LDS copy is the same in every lane, but the compiler treats an LDS load as divergent: it
+// computes with it in VGPRs and wraps buffer resources in waterfall loops.  readfirstlane states the uniformity.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+template <typename T>
+__device__ __forceinline__ T* uni(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
 
 template <int BITS>
 struct CFrag {
@@ -35,35 +49,24 @@ struct CFrag {
     uint32_t s0, s1;     // the lane's scale (, zero) of the step's scale group: fp16 pair in s0, or fp32 in s0 (, s1)
 };
 
-__device__ __forceinline__ void c_seek(cop_ptr d, int gq, int& mi, int& base) {
-    mi = 0; base = 0;
-    const int nm = d->nmat;
-    while (mi + 1 < nm && gq >= d->m[mi].q_end) { base = d->m[mi].q_end; ++mi; }
-}
-
-// weights of (global quad gq, step st) of op d + the lane's scale: the epilogue role of a lane is row lane & 3, units
+// weights of (global quad gq, step st) + the lane's scale: the epilogue role of a lane is row lane & 3, units
 // st*64 + 16g + 4*lg .. +3 (see k_gemv_quad); scale groups span >= 4 units, so one scale group per lane and step.
 // Lanes whose unit lies past K skip the weight load (their LUT entries are zero tables: whatever the registers hold
 // contributes exactly 0) -- the zero padding of the last step is stored but never fetched.
 template <int BITS, bool ZP, bool SCF16>
-__device__ __forceinline__ void c_issue(CFrag<BITS>& f, cop_ptr d, int gq, int st, int lane, uint32_t lane16) {
+__device__ __forceinline__ void c_issue(CFrag<BITS>& f, __amdgpu_buffer_rsrc_t rs, int woff, const TMAC_GLOBAL char* scq, int nsg, int gsh, int nu,
+                                        int st, int lane, uint32_t lane16) {
     constexpr int per = ZP ? 2 : 1;
-    int mi, base;
-    c_seek(d, gq, mi, base);
-    const int lq = gq - base;
-    const uint4* W = d->m[mi].W;
-    const char* scb = reinterpret_cast<const char*>(d->m[mi].SC);
-    const int nsg = d->nsg, gsh = d->gs_shift, nst = d->nst, nu = d->nu;
+    constexpr int esz = SCF16 ? 2 : 4;
     const int c0 = 4 * (lane & 12) + 4 * (lane >> 4);
     const uint32_t sg = min((uint32_t)st * (64u >> gsh) + (uint32_t)(c0 >> gsh), (uint32_t)nsg - 1u);
-    const uint32_t sidx = (((uint32_t)lq * (uint32_t)nsg + sg) * 4 + (lane & 3)) * per;
+    const uint32_t boff = (sg * 4 + (lane & 3)) * (per * esz);          // scq already points at the quad's first scale group
     uint32_t r0 = 0, r1 = 0;
     if (SCF16) {
-        const char* ph = scb + (size_t)(sidx * 2u);
-        if (ZP) r0 = *reinterpret_cast<const uint32_t*>(ph);
-        else r0 = *reinterpret_cast<const unsigned short*>(ph);
+        if (ZP) r0 = *reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq + boff);
+        else r0 = *reinterpret_cast<const TMAC_GLOBAL unsigned short*>(scq + boff);
     } else {
-        const uint32_t* p32 = reinterpret_cast<const uint32_t*>(scb + (size_t)(sidx * 4u));
+        const TMAC_GLOBAL uint32_t* p32 = reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq + boff);
         r0 = p32[0];
         if (ZP) r1 = p32[1];
     }
@@ -74,8 +77,7 @@ __device__ __forceinline__ void c_issue(CFrag<BITS>& f, cop_ptr d, int gq, int s
         // (a rematerialised lane << 4, or a 64-bit add) lands in a dead ring register, that VALU write makes the
         // compiler wait for every earlier load that might still target the register -- it serialised the fragments of a
         // ring, one full memory latency each (1.4-2.8 us per op, profiles/r02_chain_prefetch_ab.txt B).
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(W), (short)0, 0x7fffffff, 0x00020000);
-        const int soff = (lq * nst + st) * (BITS * 1024);
+        const int soff = woff + st * (BITS * 1024);
 #pragma unroll
         for (int j = 0; j < BITS; ++j) {
             const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane16, soff + j * 1024, 2 /* nt */);
@@ -139,13 +141,40 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
     }
 }
 
-// four hand-off granules of two consecutive row quads = the 8 activations of LUT pair p; both loads and their wait in
-// one statement (cdna_hip_programming.md 5.7, form (i)): sc1 loads bypass this CU's L1
-__device__ __forceinline__ void c_poll2(const uint4* p, u32x4q& v0, u32x4q& v1) {
+// The hand-off granules of up to three LUT pairs (two consecutive row quads = 8 activations each), all rounds of a thread
+// in flight together; loads and their wait in one statement (cdna_hip_programming.md 5.7, form (i)); sc1 loads bypass
+// this CU's L1
+__device__ __forceinline__ void c_poll1(const uint4* p0, u32x4q (&v)[6]) {
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
                  "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1) : "v"(p) : "memory");
+                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(p0) : "memory");
+}
+__device__ __forceinline__ void c_poll2(const uint4* p0, const uint4* p1, u32x4q (&v)[6]) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off sc1\n\t"
+                 "global_load_dwordx4 %3, %5, off offset:16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p0), "v"(p1) : "memory");
+}
+__device__ __forceinline__ void c_poll3(const uint4* p0, const uint4* p1, const uint4* p2, u32x4q (&v)[6]) {
+    asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
+                 "global_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %7, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %4, %8, off sc1\n\t"
+                 "global_load_dwordx4 %5, %8, off offset:16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]) : "v"(p0), "v"(p1), "v"(p2) : "memory");
+}
+// the same for plain activations (in memory since before the launch)
+__device__ __forceinline__ void c_ext3(const uint4* p0, const uint4* p1, const uint4* p2, u32x4q (&v)[6]) {
+    asm volatile("global_load_dwordx4 %0, %3, off\n\t"
+                 "global_load_dwordx4 %1, %4, off\n\t"
+                 "global_load_dwordx4 %2, %5, off\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(p0), "v"(p1), "v"(p2) : "memory");
 }
 
 template <int BITS, bool ZP, bool SCF16>
@@ -155,9 +184,16 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     constexpr int RING = (BITS <= 2) ? 4 : 2;       // fragments per ring; two rings (current op / next op)
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int bx = blockIdx.x, gx = gridDim.x;
-    const cop_ptr ops = (cop_ptr)a.ops;
     const unsigned gen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][4] partials of split quads
+    // all op descriptors into LDS (16 uint4 each): a field is then a ds_read away instead of a scalar-cache miss
+    uint4* l_ops = lds + 2 * (size_t)a.buf_u4 + (2 * NWV * 4 * sizeof(float)) / 16;
+    {
+        const uint4* gsrc = reinterpret_cast<const uint4*>(a.ops);
+        for (int idx = tid; idx < a.nops * 16; idx += FT) l_ops[idx] = gsrc[idx];
+        __syncthreads();
+    }
+    const cop_ptr ops = reinterpret_cast<cop_ptr>(l_ops);
     bool aborted = false;                                                   // a hand-off timed out somewhere: stop waiting
 
     // stamps: s_memrealtime (100 MHz, one clock for the whole device; s_memtime counts per XCD with unrelated offsets)
@@ -176,18 +212,22 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     asm volatile("" : "+v"(lane16));
 
     // per-op role of this wave: quads slot0, slot0 + stride, ...; steps h, h + wpq, ... of each
-    struct Role { int slot0, stride, h, wpq, nst, total_q, my_iter; };
+    // per-op role of this wave: quads slot0, slot0 + stride, ...; steps h, h + wpq, ... of each
+    struct Role { int slot0, stride, h, wpq, nst, total_q, my_iter, nquads, nsteps; };
     auto role_of = [&](cop_ptr d) __attribute__((always_inline)) {
         Role r;
-        r.wpq = d->wpq;
-        const int ipi = d->ipi;
-        const int qs = (w * d->wpq_inv) >> 16;                          // w / wpq for w < 12
+        r.wpq = uni(d->wpq);
+        const int ipi = uni(d->ipi), inv = uni(d->wpq_inv);
+        const int qs = (w * inv) >> 16;                                  // w / wpq for w < 12
         r.h = w - qs * r.wpq;
         r.slot0 = bx * ipi + qs;
         r.stride = gx * ipi;
-        r.nst = d->nst;
-        r.total_q = d->total_q;
-        r.my_iter = d->it_full + ((bx * ipi < d->it_rem) ? 1 : 0);
+        r.nst = uni(d->nst);
+        r.total_q = uni(d->total_q);
+        const int itf = uni(d->it_full), itr = uni(d->it_rem);
+        r.my_iter = itf + ((bx * ipi < itr) ? 1 : 0);                    // iterations the WORKGROUP runs (barriers)
+        r.nquads = itf + ((r.slot0 < itr) ? 1 : 0);                      // quads this wave works on: its slot exists in every full iteration
+        r.nsteps = r.h < r.nst ? ((r.nst - r.h + r.wpq - 1) * inv) >> 16 : 0;   // steps h, h + wpq, ... < nst
         return r;
     };
 
@@ -196,60 +236,99 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     for (int i = 0; i < a.nops; ++i) {
         const cop_ptr d = ops + i;
         CSTAMP(i, 0);
-        const int tstride = d->tstride, nu = d->nu, nst = d->nst, G = d->G, GP = d->GP;
+        const int tstride = uni(d->tstride), nu = uni(d->nu), nst = uni(d->nst), G = uni(d->G), GP = uni(d->GP);
         uint4* tab = lds + (size_t)(i & 1) * a.buf_u4;                // [4][tstride]
         float* l_ls = reinterpret_cast<float*>(tab + 4 * tstride);   // [GP] ls / 2 (groups past K: 0)
         float* l_lb = l_ls + GP;                                     // [GP] lb / 2
-        const int P = d->K / 8;                                      // LUT pairs: tables 2p, 2p+1 from activations 8p .. 8p+7
+        const int P = uni(d->K) / 8;                                      // LUT pairs: tables 2p, 2p+1 from activations 8p .. 8p+7
         const Role ro = role_of(d);
         const int wpq = ro.wpq, h = ro.h;
+        const int nsg = uni(d->nsg), gsh = uni(d->gs_shift), ipi = uni(d->ipi), nm = uni(d->nmat);
+        // Work items of this wave in this op: nquads quads x nsteps steps, walked by an issue cursor and a lookup cursor.
+        // What depends on the quad alone -- its matrix (compares against the op's cumulative quad counts), the buffer
+        // resource of that matrix, the byte offset of the quad's weights, its first scale group -- is resolved when the
+        // cursor enters the quad, not per item: scalar instructions are issued by ONE unit per CU, and 12 waves x ~60 of
+        // them per fragment were 0.4 us per fragment issued (profiles/r02_chain_prefetch_ab.txt C).
+        const int qe0 = uni(d->q_end[0]), qe1 = uni(d->q_end[1]), qe2 = uni(d->q_end[2]);
+        const int n_items = ro.nquads * ro.nsteps;
+        __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint4*>(nullptr), (short)0, 0, 0x00020000);
+        const TMAC_GLOBAL char* q_sc = nullptr;
+        int q_woff = 0, q_res = -1;
+        int i_it = 0, i_st = h, issued = 0;
+        auto issue_next = [&](CFrag<BITS>& f) __attribute__((always_inline)) {
+            if (issued < n_items) {
+                if (q_res != i_it) {
+                    const int gqi = ro.slot0 + i_it * ro.stride;
+                    const int mi = (gqi >= qe0 ? 1 : 0) + (gqi >= qe1 ? 1 : 0) + (gqi >= qe2 ? 1 : 0);
+                    const int lq = gqi - (gqi >= qe2 ? qe2 : (gqi >= qe1 ? qe1 : (gqi >= qe0 ? qe0 : 0)));
+                    q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(uni(d->m[mi].W)), (short)0, 0x7fffffff, 0x00020000);
+                    q_sc = as_global(uni(reinterpret_cast<const char*>(d->m[mi].SC))) + (size_t)lq * (size_t)(nsg * 4 * (ZP ? 2 : 1) * (SCF16 ? 2 : 4));
+                    q_woff = lq * nst * (BITS * 1024);
+                    q_res = i_it;
+                }
+                c_issue<BITS, ZP, SCF16>(f, q_rs, q_woff, q_sc, nsg, gsh, nu, i_st, lane, lane16);
+                ++issued;
+                i_st += wpq;
+                if (i_st >= nst) { i_st = h; ++i_it; }
+            }
+        };
 
         // ---- 1. this op's activations.  The CU's vector-memory queue is empty here (the previous op's lookups consumed
         // everything it had in flight): a poll costs one round trip, not the drain time of a weight stream.  Measured the
         // other way round -- next op's weights prefetched behind the current op's lookups -- every publish and every poll
         // sat behind 20-100 KB of queued weight loads per CU: 3-4 us per hand-off (profiles/r02_chain_prefetch_ab.txt). ----
-        const bool gran = d->in_gran != 0;
+        if (a.issue_first) {       // A/B: weights first, the polls queue behind them
+#pragma unroll
+            for (int k = 0; k < RING; ++k) issue_next(ring[k]);
+        }
+        const bool gran = uni(d->in_gran) != 0;
         const int nr = (P + FT - 1) / FT;                            // rounds of FT pairs (<= NRMAX, checked on the host)
         constexpr int NRMAX = 3;
         uint32_t xw[NRMAX][4];
         unsigned long long polls = 0;
-#pragma unroll
-        for (int r = 0; r < NRMAX; ++r) {
-            xw[r][0] = xw[r][1] = xw[r][2] = xw[r][3] = 0u;
-            if (r < nr) {
-                const int p = r * FT + tid;
-                const bool need = p < P;        // K % 64 == 0: the 8 lanes of an act group are valid or invalid together
-                if (gran) {
-                    const uint4* g = reinterpret_cast<const uint4*>(d->in) + 2 * (size_t)min(p, P - 1);
-                    bool ok = !need;
-                    unsigned spins = 0;
-                    for (;;) {
-                        ++polls;
-                        if (!ok) {
-                            u32x4q v0, v1;
-                            c_poll2(g, v0, v1);
-                            ok = (v0.x == gen) & (v0.z == gen) & (v1.x == gen) & (v1.z == gen);
-                            xw[r][0] = v0.y; xw[r][1] = v0.w; xw[r][2] = v1.y; xw[r][3] = v1.w;
-                        }
-                        if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
-                        if (aborted) break;
-                        ++spins;
-                        if ((spins & 1023u) == 0u) {      // something is slow or broken: look at the error word, give up past the limit
-                            const unsigned err = __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (err != 0u || spins >= a.spin_limit) {
-                                if (err == 0u && lane == 0) atomicOr(a.ctl + 2, 0x80000000u | ((unsigned)i << 8) | (unsigned)w);
-                                aborted = true;
-                            }
-                        }
-                        __builtin_amdgcn_s_sleep(1);
+        {
+            // pair of round r: p = r * FT + tid; past the end the address is clamped and the result ignored
+            const uint4* in4 = uni(reinterpret_cast<const uint4*>(d->in));
+            const int p0 = min(tid, P - 1), p1 = min(FT + tid, P - 1), p2 = min(2 * FT + tid, P - 1);
+            const bool n0 = tid < P, n1 = FT + tid < P, n2 = 2 * FT + tid < P;
+            u32x4q v[6];
+            if (gran) {
+                const uint4 *g0 = in4 + 2 * (size_t)p0, *g1 = in4 + 2 * (size_t)p1, *g2 = in4 + 2 * (size_t)p2;
+                unsigned spins = 0;
+                for (;;) {
+                    ++polls;
+                    bool ok;
+                    if (nr == 1) {
+                        c_poll1(g0, v);
+                        ok = !n0 || ((v[0].x == gen) & (v[0].z == gen) & (v[1].x == gen) & (v[1].z == gen));
+                    } else if (nr == 2) {
+                        c_poll2(g0, g1, v);
+                        ok = (!n0 || ((v[0].x == gen) & (v[0].z == gen) & (v[1].x == gen) & (v[1].z == gen))) &
+                             (!n1 || ((v[2].x == gen) & (v[2].z == gen) & (v[3].x == gen) & (v[3].z == gen)));
+                    } else {
+                        c_poll3(g0, g1, g2, v);
+                        ok = (!n0 || ((v[0].x == gen) & (v[0].z == gen) & (v[1].x == gen) & (v[1].z == gen))) &
+                             (!n1 || ((v[2].x == gen) & (v[2].z == gen) & (v[3].x == gen) & (v[3].z == gen))) &
+                             (!n2 || ((v[4].x == gen) & (v[4].z == gen) & (v[5].x == gen) & (v[5].z == gen)));
                     }
-                } else if (need) {
-                    // plain activations in memory since before the launch; load and wait in one statement so that the
-                    // compiler never sees xw as pending (it would wait for the weights issued below before the LUT build)
-                    u32x4q v;
-                    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(reinterpret_cast<const uint4*>(d->in) + p) : "memory");
-                    xw[r][0] = v.x; xw[r][1] = v.y; xw[r][2] = v.z; xw[r][3] = v.w;
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                    if (aborted) break;
+                    ++spins;
+                    if ((spins & 1023u) == 0u) {      // something is slow or broken: look at the error word, give up past the limit
+                        const unsigned err = __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (err != 0u || spins >= a.spin_limit) {
+                            if (err == 0u && lane == 0) atomicOr(a.ctl + 2, 0x80000000u | ((unsigned)i << 8) | (unsigned)w);
+                            aborted = true;
+                        }
+                    }
+                    if (a.poll_sleep) __builtin_amdgcn_s_sleep(1);
                 }
+#pragma unroll
+                for (int r = 0; r < NRMAX; ++r) { xw[r][0] = v[2 * r].y; xw[r][1] = v[2 * r].w; xw[r][2] = v[2 * r + 1].y; xw[r][3] = v[2 * r + 1].w; }
+            } else {
+                c_ext3(in4 + p0, in4 + p1, in4 + p2, v);
+#pragma unroll
+                for (int r = 0; r < NRMAX; ++r) { xw[r][0] = v[r].x; xw[r][1] = v[r].y; xw[r][2] = v[r].z; xw[r][3] = v[r].w; }
             }
         }
         CSTAMP(i, 1);
@@ -261,14 +340,12 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt / lgkmcnt untouched
 
         // ---- 2. this wave's first RING (quad, step) items: the weights stream in during the LUT build ----
-        int r_it = 0, r_st = h;
+        if (!a.issue_first) {
 #pragma unroll
-        for (int k = 0; k < RING; ++k) {
-            const int rq = ro.slot0 + r_it * ro.stride;
-            if (r_it < ro.my_iter && rq < ro.total_q && h < nst) c_issue<BITS, ZP, SCF16>(ring[k], d, rq, r_st, lane, lane16);
-            r_st += wpq;
-            if (r_st >= nst) { r_st = h; ++r_it; }
+            for (int k = 0; k < RING; ++k) issue_next(ring[k]);
         }
+
+        CSTAMP(i, 3);
 
         // ---- 3. LUT into LDS (lut_ctor.cc:120-215, as in k_gemv_quad) ----
 #pragma unroll
@@ -311,6 +388,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 for (int u = nu + tid; u < nst * 64; u += FT) tab[j4 * tstride + u] = make_uint4(0u, 0u, 0u, 0u);
             for (int g = G + tid; g < GP; g += FT) { l_ls[g] = 0.f; l_lb[g] = 0.f; }
         }
+        CSTAMP(i, 4);
         __syncthreads();
         CSTAMP(i, 2);
 
@@ -335,9 +413,9 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             __syncthreads();
             if (w == 0) {
                 const int qs = lane >> 2, row = lane & 3;
-                const int g0 = bx * d->ipi + c_it * ro.stride;           // first quad of this workgroup iteration
+                const int g0 = bx * ipi + c_it * ro.stride;           // first quad of this workgroup iteration
                 const int gql = g0 + qs;
-                const bool mine = qs < d->ipi && gql < ro.total_q;      // the 4 lanes of a quad decide together
+                const bool mine = qs < ipi && gql < ro.total_q;      // the 4 lanes of a quad decide together
                 float t = 0.f;
                 if (mine) {
                     t = red[(qs * wpq) * 4 + row];
@@ -349,14 +427,15 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 // matrices in a uniform loop (descriptor fields through the scalar cache): a per-lane descriptor lookup
                 // is a vector load, and waiting for it waits for every weight load in flight as well
                 int base = 0;
-                const int nm = d->nmat;
                 for (int mi = 0; mi < nm; ++mi) {
-                    const int qe = d->m[mi].q_end;
-                    if (g0 < qe && g0 + d->ipi > base) {
+                    const int qe = uni(d->m[mi].q_end);
+                    if (g0 < qe && g0 + ipi > base) {
                         if (mine && gql >= base && gql < qe) {
                             const int lq = gql - base;
-                            q_st_out(d->m[mi].C, a.out_f16, (size_t)(4 * lq + row), t);
-                            unsigned long long* gr = reinterpret_cast<unsigned long long*>(d->m[mi].GR);
+                            const size_t oi = (size_t)(4 * lq + row);
+                            if (a.out_f16) as_global(reinterpret_cast<unsigned short*>(uni(d->m[mi].C)))[oi] = __half_as_ushort(__float2half_rn(t));
+                            else as_global(reinterpret_cast<float*>(uni(d->m[mi].C)))[oi] = t;
+                            TMAC_GLOBAL unsigned long long* gr = as_global(reinterpret_cast<unsigned long long*>(uni(d->m[mi].GR)));
                             if (gr && !(row & 1))
                                 __hip_atomic_store(gr + 2 * (size_t)lq + (row >> 1), ((unsigned long long)(hb | (nb << 16)) << 32) | gen,
                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -370,30 +449,21 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         };
 
         int c_st = h;
-        int gq = ro.slot0;
         float cacc = 0.f;
-        if (ro.my_iter > 0 && gq < ro.total_q && h < nst) {
-            bool done = false;
-            while (!done) {
+        if (n_items > 0) {
+            int left = n_items;
+            while (left > 0) {
 #pragma unroll
                 for (int k = 0; k < RING; ++k) {
                     c_compute<BITS, ZP, SCF16>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane, bsel, k3, cacc);
-                    {   // refill this slot with the op's item RING places ahead, if there is one
-                        const int rq = ro.slot0 + r_it * ro.stride;
-                        if (r_it < ro.my_iter && rq < ro.total_q) {
-                            c_issue<BITS, ZP, SCF16>(ring[k], d, rq, r_st, lane, lane16);
-                            r_st += wpq;
-                            if (r_st >= nst) { r_st = h; ++r_it; }
-                        }
-                    }
+                    issue_next(ring[k]);               // refill this slot with the item RING places ahead, if there is one
                     c_st += wpq;
                     if (c_st >= nst) {
                         finish(true, cacc);
                         cacc = 0.f;
-                        gq = ro.slot0 + c_it * ro.stride;
                         c_st = h;
-                        if (c_it >= ro.my_iter || gq >= ro.total_q) { done = true; break; }
                     }
+                    if (--left == 0) break;
                 }
             }
         }
@@ -418,7 +488,7 @@ int chain_buf_u4(int K) {
     const int nu = K / 32, nst = (nu + 63) / 64;
     return 4 * (nst * 64 + 1) + (2 * nst * 32 * 4 + 15) / 16;      // [4][tstride] tables + [2][GP] floats
 }
-size_t chain_lds_bytes(int buf_u4) { return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4; }
+size_t chain_lds_bytes(int buf_u4, int nops) { return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4 + sizeof(ChainOp) * (size_t)nops; }
 
 hipError_t launch_decode_chain(const ChainArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st) {
     if (a.nops < 1 || grid < 1) return hipErrorInvalidValue;

@@ -897,6 +897,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             c->bytes += w->w_bytes + w->sc_bytes;
         }
         o.nmat = (int)r.w.size();
+        for (int m = 0; m < 4; ++m) o.q_end[m] = (m < o.nmat - 1) ? o.m[m].q_end : 0x7fffffff;
         o.K = s0.K; o.nu = s0.K / 32; o.nst = (o.nu + 63) / 64; o.tstride = o.nst * 64 + 1;
         o.G = s0.K / 64; o.GP = o.nst * 32; o.nsg = s0.K / s0.gs;
         o.gs_shift = 0;
@@ -918,8 +919,10 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         if (o.K > maxK) maxK = o.K;
     }
     c->buf_u4 = chain_buf_u4(maxK);
-    c->lds_bytes = chain_lds_bytes(c->buf_u4);
-    if (c->lds_bytes > 160 * 1024) return bail(fail(TMAC_HIP_E_NOMATCH, "K = %d needs %zu bytes of LDS", maxK, c->lds_bytes));
+    c->lds_bytes = chain_lds_bytes(c->buf_u4, (int)c->ops.size());
+    if (c->lds_bytes > 160 * 1024)
+        return bail(fail(TMAC_HIP_E_NOMATCH, "%zu calls with K up to %d need %zu bytes of LDS (LUT buffers + call descriptors): record shorter chains",
+                         c->ops.size(), maxK, c->lds_bytes));
     if (hipMalloc((void**)&c->d_ops, sizeof(ChainOp) * c->ops.size()) != hipSuccess ||
         hipMemcpy(c->d_ops, c->ops.data(), sizeof(ChainOp) * c->ops.size(), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(TMAC_HIP_E_RUNTIME, "descriptor upload failed"));
@@ -936,6 +939,8 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
     memset(&a, 0, sizeof(a));
     a.ops = c->d_ops; a.nops = (int)c->ops.size(); a.ctl = c->ctl; a.out_f16 = c->out_f16;
     a.spin_limit = g_chain_spin_limit; a.buf_u4 = c->buf_u4; a.stamps = c->stamps;
+    a.poll_sleep = getenv("TMAC_CHAIN_POLL_SLEEP") ? atoi(getenv("TMAC_CHAIN_POLL_SLEEP")) : 1;
+    a.issue_first = getenv("TMAC_CHAIN_ISSUE_FIRST") ? atoi(getenv("TMAC_CHAIN_ISSUE_FIRST")) : 0;
     hipError_t e = launch_decode_chain(a, c->bits, c->zp != 0, c->sc_f16 != 0, c->grid, c->lds_bytes, (hipStream_t)stream);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no decode-chain kernel for this configuration");
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "decode chain launch: %s", hipGetErrorString(e));

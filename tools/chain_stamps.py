@@ -13,7 +13,7 @@ print(f"{nops} calls, {nwg} workgroups, launch span {st[:, :, 6].max() - t0:.1f}
 pub = st[:, :, 5]                      # last publish of wave 0 of each workgroup
 complete = pub.max(axis=1)             # (approximately: other waves may publish slightly later)
 lo, hi = 8, nops - 8
-print("kind      period | entry->in  polls | in->lut | lut->pub | pub spread (max-min, p95-p50) | in-done minus last pub (min/mean/max) | in spread")
+print("kind      period | entry->in  polls | in->issued->built->barrier | lut->pub | pub spread (max-min, p95-p50) | in-done minus last pub (min/mean/max) | in spread")
 for k, name in enumerate(names):
     idx = np.arange(lo + (k - lo) % 4, hi, 4)
     per = np.mean(complete[idx] - complete[idx - 1])
@@ -21,7 +21,7 @@ for k, name in enumerate(names):
     prev = pub[idx - 1]
     lastp = prev.max(axis=1)
     d = s[:, :, 1] - lastp[:, None]
-    print(f"{name:8s} {per:7.2f} | {np.mean(s[:, :, 1] - s[:, :, 0]):7.2f} {np.mean(raw[idx, :, 7]):6.2f} | {np.mean(s[:, :, 2] - s[:, :, 1]):6.2f} | "
+    print(f"{name:8s} {per:7.2f} | {np.mean(s[:, :, 1] - s[:, :, 0]):7.2f} {np.mean(raw[idx, :, 7]):6.2f} | {np.mean(s[:, :, 3] - s[:, :, 1]):5.2f} {np.mean(s[:, :, 4] - s[:, :, 3]):5.2f} {np.mean(s[:, :, 2] - s[:, :, 4]):5.2f} | "
           f"{np.mean(s[:, :, 5] - s[:, :, 2]):6.2f} | "
           f"{np.mean(prev.max(axis=1) - prev.min(axis=1)):5.2f} {np.mean(np.percentile(prev, 95, axis=1) - np.median(prev, axis=1)):5.2f} | "
           f"{np.mean(d.min(axis=1)):5.2f} {np.mean(d):5.2f} {np.mean(d.max(axis=1)):5.2f} | {np.mean(s[:, :, 1].max(axis=1) - s[:, :, 1].min(axis=1)):5.2f}")

@@ -141,7 +141,7 @@ int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weights, int nma
  * Scope: 2- or 4-bit QUAD-layout weights, per-group scales (group size >= 128) with act groups of 64, fp16 activations;
  * chained outputs fp16; one scale dtype and zero-point setting per chain.  Anything else: -1 from tmac_hip_chain_end and
  * the caller keeps launching the calls one by one.  Results are bit-identical to tmac_hip_qgemm_fused_dev with
- * 768-thread workgroups and the same number of waves per row quad (tmac_hip_debug_quad_config(768, wpq)).
+ * the same threads per workgroup and waves per row quad (tmac_hip_debug_quad_config(tmac_hip_chain_threads(), wpq)).
  * A chain must not be launched concurrently with itself; the GPU must be able to hold one workgroup per CU (true unless
  * other work occupies CUs for the whole duration: every wait inside the kernel is bounded and reports through
  * tmac_hip_chain_status instead of hanging). */
@@ -156,6 +156,7 @@ int32_t tmac_hip_chain_status(tmac_hip_chain* chain, uint32_t* error_word);
  * (any pointer may be NULL) */
 int32_t tmac_hip_chain_info(const tmac_hip_chain* chain, int op, int32_t* nops, int32_t* wpq, int32_t* grid, size_t* bytes);
 int32_t tmac_hip_chain_free(tmac_hip_chain* chain);
+int32_t tmac_hip_chain_threads(void);   /* threads per workgroup of k_decode_chain (the launch configuration its results are bit-identical with) */
 /* profiling / A-B knobs: s_memrealtime stamps (100 MHz) [calls][workgroups][8] of wave 0 (0 call entry, 1 activations complete, 2 LUT
  * built, 3 weights of the call landed, 5 last row quad published, 6 all loads landed, 7 number of polls) into a device buffer (NULL = off); waves per row quad forced for chains built from now on (0 = per-call
  * choice) and the poll limit of a hand-off (0 = keep) */

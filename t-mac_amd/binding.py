@@ -97,6 +97,7 @@ def load_library() -> C.CDLL:
         "tmac_hip_chain_info": ([vp, C.c_int, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)], i32),
         "tmac_hip_chain_free": ([vp], i32),
         "tmac_hip_chain_set_stamps": ([vp, vp], i32),
+        "tmac_hip_chain_threads": ([], i32),
         "tmac_hip_debug_chain_config": ([C.c_int, C.c_uint], i32),
         "tmac_hip_debug_quad_config": ([C.c_int, C.c_int], i32),
         "tmac_hip_selftest": ([vp, vp, C.c_int], i32),

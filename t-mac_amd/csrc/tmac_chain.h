@@ -6,7 +6,10 @@
 
 namespace tmac {
 
-constexpr int CHAIN_FT = 768;            // threads per workgroup (12 waves, one workgroup per CU)
+#ifndef TMAC_CHAIN_FT
+#define TMAC_CHAIN_FT 768
+#endif
+constexpr int CHAIN_FT = TMAC_CHAIN_FT;   // threads per workgroup (12 waves = 3 per SIMD, one workgroup per CU; 1024 measured 6 % slower)
 constexpr int CHAIN_NWV = CHAIN_FT / 64;
 
 struct ChainMat {
@@ -44,6 +47,7 @@ struct ChainArgs {
     int buf_u4;                    // uint4 per LDS LUT buffer (two buffers, by op parity)
     int poll_sleep;                // s_sleep between two polls of a hand-off (A/B knob)
     int issue_first;               // A/B knob: issue an op's weights before polling for its activations
+    int poll_mode;                 // A/B knob: 0 dwordx4 sc1 | 1 dwordx4 sc0 sc1 | 2 dwordx4 nt | 3 dwordx4 plain
     unsigned long long* stamps;    // optional [nops][grid][8] of wave 0, s_memrealtime (100 MHz): 0 op entry, 1 activations complete, 2 LUT built
                                    // (barrier passed), 3 current ring landed, 5 last quad published, 6 everything in flight landed, 7 polls
 };

@@ -299,7 +299,16 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     ++polls;
                     bool ok;
                     if (nr == 1) {
-                        c_poll1(g0, v);
+                        if (a.poll_mode == 0) c_poll1(g0, v);
+                        else if (a.poll_mode == 1)
+                            asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                                         : "=&v"(v[0]), "=&v"(v[1]) : "v"(g0) : "memory");
+                        else if (a.poll_mode == 2)
+                            asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx4 %1, %2, off offset:16 nt\n\ts_waitcnt vmcnt(0)"
+                                         : "=&v"(v[0]), "=&v"(v[1]) : "v"(g0) : "memory");
+                        else
+                            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
+                                         : "=&v"(v[0]), "=&v"(v[1]) : "v"(g0) : "memory");
                         ok = !n0 || ((v[0].x == gen) & (v[0].z == gen) & (v[1].x == gen) & (v[1].z == gen));
                     } else if (nr == 2) {
                         c_poll2(g0, g1, v);

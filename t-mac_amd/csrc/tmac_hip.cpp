@@ -810,8 +810,8 @@ extern "C" int32_t tmac_hip_chain_begin(void) {
 static int chain_pick_wpq(int total_q, int nst, int grid) {
     int best = 1;
     long best_cost = 1L << 60;
-    for (int wpq = 1; wpq <= 3; ++wpq) {          // the combinations k_gemv_quad is instantiated for with 768 threads
-        if (wpq > 1 && wpq > nst) continue;
+    for (int wpq = 1; wpq <= 4; ++wpq) {          // the combinations k_gemv_quad is instantiated for with this many threads
+        if (CHAIN_NWV % wpq || (wpq > 1 && wpq > nst)) continue;
         const long ipi = CHAIN_NWV / wpq;
         const long iters = (total_q + (long)grid * ipi - 1) / ((long)grid * ipi);
         const long steps = (nst + wpq - 1) / wpq;
@@ -940,7 +940,8 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
     a.ops = c->d_ops; a.nops = (int)c->ops.size(); a.ctl = c->ctl; a.out_f16 = c->out_f16;
     a.spin_limit = g_chain_spin_limit; a.buf_u4 = c->buf_u4; a.stamps = c->stamps;
     a.poll_sleep = getenv("TMAC_CHAIN_POLL_SLEEP") ? atoi(getenv("TMAC_CHAIN_POLL_SLEEP")) : 1;
-    a.issue_first = getenv("TMAC_CHAIN_ISSUE_FIRST") ? atoi(getenv("TMAC_CHAIN_ISSUE_FIRST")) : 0;
+    a.issue_first = getenv("TMAC_CHAIN_ISSUE_FIRST") ? atoi(getenv("TMAC_CHAIN_ISSUE_FIRST")) : 1;
+    a.poll_mode = getenv("TMAC_CHAIN_POLL_MODE") ? atoi(getenv("TMAC_CHAIN_POLL_MODE")) : 0;
     hipError_t e = launch_decode_chain(a, c->bits, c->zp != 0, c->sc_f16 != 0, c->grid, c->lds_bytes, (hipStream_t)stream);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no decode-chain kernel for this configuration");
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "decode chain launch: %s", hipGetErrorString(e));
@@ -980,6 +981,8 @@ extern "C" int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* c, unsigned long lo
     c->stamps = dev_buffer;
     return TMAC_HIP_OK;
 }
+
+extern "C" int32_t tmac_hip_chain_threads(void) { return CHAIN_FT; }
 
 extern "C" int32_t tmac_hip_debug_chain_config(int force_wpq, unsigned spin_limit) {
     if (force_wpq < 0 || (force_wpq && CHAIN_NWV % force_wpq)) return fail(TMAC_HIP_E_ARG, "waves per quad must divide %d", CHAIN_NWV);

@@ -148,6 +148,7 @@ class DecodeChain:
         n, g, b = C.c_int32(0), C.c_int32(0), C.c_size_t(0)
         check(B.lib().tmac_hip_chain_info(self._h, 0, C.byref(n), None, C.byref(g), C.byref(b)))
         self.nops, self.grid, self.weight_bytes = n.value, g.value, b.value
+        self.threads = int(B.lib().tmac_hip_chain_threads())     # threads per workgroup of k_decode_chain (for A/B against k_gemv_quad)
 
     def launch(self, stream=None) -> None:
         check(B.lib().tmac_hip_chain_launch(self._h, _stream(stream)))

@@ -87,8 +87,8 @@ class Model:
         for i, (K, rows, src) in enumerate(self.ops):
             x = self.x_ext[i] if src is None else got[src[0]][src[1]]
             assert x.numel() == K
-            # (a) the same call on its own, 768 threads, the chain's waves per quad
-            L.tmac_hip_debug_quad_config(768, chain.wpq(i))
+            # (a) the same call on its own, the chain's threads per workgroup and waves per quad
+            L.tmac_hip_debug_quad_config(chain.threads, chain.wpq(i))
             ref = [torch.empty_like(o) for o in got[i]]
             try:
                 self.wr.fused(self.ws[i], x, ref, 1, act_dtype=tm.F16)

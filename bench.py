@@ -1,24 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py — W2A8 LUT-GEMV throughput of the T-MAC hot path on MI355X (BASELINE.json metric).
+"""bench.py — throughput of T-MAC's LUT mpGEMM hot path on MI355X (BASELINE.json metric and configs).
 
-Workload (config.workload = "llama-2-7b-w2a8-decode-all-layers", BASELINE.json configs[1]):
-one "step" = one decoded token's worth of the hot path = for each of 32 layers
+Default workload (config.workload = "llama-2-7b-w2a8-decode-all-layers", BASELINE.json configs[1]): one "step" = one
+decoded token's worth of the hot path = for each of 32 layers
     preprocessor(x0)  -> q,k,v   3 x qgemm_lut (4096 x 4096)
     preprocessor(x1)  -> o       1 x qgemm_lut (4096 x 4096)
     preprocessor(x2)  -> gate,up 2 x qgemm_lut (11008 x 4096)
     preprocessor(x3)  -> down    1 x qgemm_lut (4096 x 11008)
-with W2 weights (group 128, zero points, act group 64; python/t_mac/model_utils.py:27-32,
-tools/run_pipeline.py:405-419), fp16 activations/scales/outputs, fp32 accumulation, every layer's
-weights distinct (1.62 GB of 2-bit planes, > the 256 MB Infinity Cache).  The launches are chained by
-real data (x1 = q, x2 = o, x3 = gate, next x0 = down) on one stream, as a decoder would issue them.
-Synthetic data: uniform random weights, |N(0,1)|-shaped scales sized so activations stay O(1).
+with W2 weights (group 128, zero points, act group 64; python/t_mac/model_utils.py:27-32, tools/run_pipeline.py:405-419),
+fp16 activations/scales/outputs, fp32 accumulation, every layer's weights distinct (1.62 GB of 2-bit planes, > the 256 MB
+Infinity Cache).  The calls are chained by real data (x1 = q, x2 = o, x3 = gate, next x0 = down), as a decoder issues them.
+Synthetic data: uniform random weights, |N(0,1)|-shaped scales and zero points sized so that the chained activations stay O(1).
 
-value = algorithmic bytes of the 224 GEMVs per step (SURVEY.md 8d formula) / step time, GB/s.
+--workload selects the other BASELINE configurations (same JSON schema, each with its own roofline):
+    llama2-7b-w4          configs[2]: the same shapes with 4-bit GPTQ-style weights (zero points), N = 1
+    bitnet-3b             configs[3]: BitNet-b1.58-3B shapes (3200/8640), ternary in 2 bits, one scale, act group = K, N = 1
+    llama2-7b-w2-prefill  configs[4]: the W2 shapes at N = 256 (one-hot MFMA GEMM; roofline bound "mfma")
 
---gpus N > 1 (launched through torch.distributed.run, one rank per GPU, RCCL): weight ROWS are sharded
-over the ranks (tile-aligned), the integer path needs no reduction, and the only exchange step is an
-all-gather of each produced activation vector (fp16, 8-22 KB) before the next LUT build; total work is
-fixed, so "scaling" is "strong".
+--path: chain = the step's fused calls recorded once and executed by ONE persistent launch (k_decode_chain; default where
+the configuration is covered); fused = one launch per fused call, replayed as a hipGraph; split = preprocessor + one
+launch per matrix.  value = algorithmic bytes of the step's GEMVs (SURVEY.md 8d formula) / step time, GB/s (decode), or
+tokens/s (prefill).
+
+--gpus N > 1 (launched through torch.distributed.run, one rank per GPU, RCCL): weight ROWS are sharded over the ranks
+(tile-aligned), the integer path needs no reduction, and the only exchange step is an all-gather of each produced activation
+block before the next LUT build; total work is fixed, so "scaling" is "strong".
 """
 from __future__ import annotations
 
@@ -33,54 +39,71 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
-LAYERS = 32
-# (name, Mw, K, count per layer, input slot)
-MATS = [("qkv", 4096, 4096, 3, 0), ("o", 4096, 4096, 1, 1), ("gate_up", 11008, 4096, 2, 2), ("down", 4096, 11008, 1, 3)]
-BITS, GS, AGS, BM, KF = 2, 128, 64, 128, 16
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_I8_PEAK_TOPS = 3944.0   # MI355X_MICROARCH.md: v_mfma_i32_16x16x64_i8 microbenchmark ceiling (the instruction k_gemm_onehot issues)
+KF = 16
+
+LLAMA = [("qkv", 4096, 4096, 3, 0), ("o", 4096, 4096, 1, 1), ("gate_up", 11008, 4096, 2, 2), ("down", 4096, 11008, 1, 3)]
+BITNET = [("qkv", 3200, 3200, 3, 0), ("o", 3200, 3200, 1, 1), ("gate_up", 8640, 3200, 2, 2), ("down", 3200, 8640, 1, 3)]
+# (name, Mw, K, count per layer, input slot); python/t_mac/model_utils.py:27-54
+WORKLOADS = {
+    "llama2-7b-w2": dict(tag="llama-2-7b-w2a8-decode-all-layers", mats=LLAMA, layers=32, bits=2, bm=128, gs=128, ags=64, zp=True, mg=-1, N=1,
+                         metric="W2A8 GEMV GB/s (llama-2-7B all-layer decode, N=1)", weights="W2 g128 zero-point, act_group 64"),
+    "llama2-7b-w4": dict(tag="llama-2-7b-w4a16-decode-all-layers", mats=LLAMA, layers=32, bits=4, bm=256, gs=128, ags=64, zp=True, mg=-1, N=1,
+                         metric="W4 (GPTQ-style) GEMV GB/s (llama-2-7B all-layer decode, N=1)", weights="W4 g128 zero-point, act_group 64"),
+    "bitnet-3b": dict(tag="bitnet-b1.58-3b-decode-all-layers", mats=BITNET, layers=26, bits=2, bm=128, gs=0, ags=0, zp=False, mg=1, N=1,
+                      metric="W1.58A8 GEMV GB/s (BitNet-b1.58-3B all-layer decode, N=1)", weights="ternary in 2 bits, one scale, act_group = K (int32 path)"),
+    "llama2-7b-w2-prefill": dict(tag="llama-2-7b-w2a8-prefill-256", mats=LLAMA, layers=32, bits=2, bm=128, gs=128, ags=64, zp=True, mg=-1, N=256,
+                                 metric="W2A8 prefill tokens/s (llama-2-7B all-layer mpGEMM, N=256)", weights="W2 g128 zero-point, act_group 64"),
+}
 
 
-def algorithmic_bytes(Mw, K, bits=BITS, gs=GS, ags=AGS, zp=True, N=1):
+def algorithmic_bytes(Mw, K, bits, gs, ags, zp, mg, N=1):
     """weight planes + fp16 scales(/zeros) + int8 QLUT + fp16 LUT scales/biases + fp16 out"""
-    return Mw * K * bits // 8 + Mw * (K // gs) * (2 if zp else 1) * 2 + N * (K // 4) * 16 + N * (K // ags) * 4 + N * Mw * 2
+    sc = mg * 4 if mg >= 1 else Mw * (K // gs) * (2 if zp else 1) * 2
+    g = 1 if mg >= 1 else K // ags
+    return Mw * K * bits // 8 + sc + N * (K // 4) * 16 + N * g * 4 + N * Mw * 2
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--layers", type=int, default=LAYERS, help=argparse.SUPPRESS)   # debugging only
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="llama2-7b-w2")
+    ap.add_argument("--layers", type=int, default=None, help=argparse.SUPPRESS)   # debugging only
     ap.add_argument("--variant", type=int, default=0, help="GEMV kernel variant (0 auto, 1 mqsad, 2 sdwa)")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the headline GEMV with events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--path", choices=["chain", "fused", "split"], default="chain",
-                    help="chain: the token's 128 fused calls recorded once and executed by ONE persistent launch "
-                         "(k_decode_chain: in-kernel hand-off of the activation vectors, weights of the next call streaming "
-                         "in behind the current one); fused: LUT build inside the GEMV kernel, q/k/v and gate/up batched "
-                         "(4 launches/layer, hipGraph replay); split: preprocessor + one GEMV launch per matrix (11 launches/layer)")
+    ap.add_argument("--path", choices=["auto", "chain", "fused", "split"], default="auto",
+                    help="auto: chain where k_decode_chain covers the configuration (N = 1, per-group scales, one GPU), else fused")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the check of one layer's outputs (the launches being timed, at full size) against the oracle")
-    ap.add_argument("--stamps", action="store_true", help="chain path: report per-call times from in-kernel s_memtime stamps")
-    ap.add_argument("--autotune", action="store_true",
-                    help="measure the kernel's launch configurations on this rank's shard shapes before the run instead of "
-                         "trusting the built-in heuristic (tmac_hip_autotune_fused; outside the timed region)")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
-    ap.add_argument("--eager-collectives", action="store_true",
-                    help="multi-GPU: launch eagerly instead of capturing the RCCL all-gathers into the hipGraph "
-                         "(~47 us of host time per launch + collective, 6 ms per token)")
+    ap.add_argument("--stamps", action="store_true", help="chain path: report per-call times from in-kernel stamps (costs ~6 %%)")
+    ap.add_argument("--floors", action="store_true", help="fused path: also time launches that only read the same bytes")
+    ap.add_argument("--autotune", action="store_true", help="fused path: measure the launch configurations first (tmac_hip_autotune_fused)")
+    ap.add_argument("--no-graph", action="store_true", help="fused/split: launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--eager-collectives", action="store_true", help="multi-GPU: do not capture the RCCL all-gathers into the hipGraph")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # debugging: take the multi-GPU code path with 1 rank
-    return ap.parse_args()
+    a = ap.parse_args()
+    wl = WORKLOADS[a.workload]
+    if a.steps is None:
+        a.steps = 20 if wl["N"] == 1 else 5
+    if a.warmup is None:
+        a.warmup = 5 if wl["N"] == 1 else 2
+    if a.layers is None:
+        a.layers = wl["layers"]
+    return a
 
 
 def cpu_baseline(seconds=6.0):
-    """The reference kernel (oracle/_ref, built from /root/reference by oracle/Makefile) — or, if that
-    prebuilt file is absent, our scalar port — timed on this box's host cores over a bounded sample: the
-    three W2 shapes of one llama-2-7B layer (one matrix each).  Tiles are split over threads with an OpenMP
-    static schedule exactly as llama.cpp splits them (tmac_gemm_wrapper.h:197-199); best of >= 5 after a
-    warm-up (deploy/benchmark.cc:36-45 method).  Test-infrastructure code used as a reported baseline."""
+    """The reference kernel (oracle/_ref, built from /root/reference by oracle/Makefile) — or, if that prebuilt file is
+    absent, our scalar port — timed on this box's host cores over a bounded sample: the three W2 shapes of one llama-2-7B
+    layer (one matrix each).  Tiles are split over threads with an OpenMP static schedule exactly as llama.cpp splits them
+    (tmac_gemm_wrapper.h:197-199); best of >= 5 after a warm-up (deploy/benchmark.cc:36-45 method).  Test-infrastructure
+    code used as a reported baseline."""
     import ctypes as C
     from oracle import oracle as orc
+    BITS, BM, GS, AGS = 2, 128, 128, 64
     cores = os.cpu_count() or 1
     rng = np.random.default_rng(0)
     shapes = [(4096, 4096), (11008, 4096), (4096, 11008)]
@@ -94,7 +117,7 @@ def cpu_baseline(seconds=6.0):
         S = np.abs(rng.standard_normal((M // BM, K // GS, BM // BITS * 2))).astype(np.float32)
         Bv = rng.standard_normal((1, K)).astype(np.float32)
         work.append((Mw, K, A, S, Bv))
-    total_bytes = sum(algorithmic_bytes(Mw, K) for Mw, K in shapes)
+    total_bytes = sum(algorithmic_bytes(Mw, K, BITS, GS, AGS, True, -1) for Mw, K in shapes)
 
     def run_once(nthreads):
         t0 = time.perf_counter()
@@ -134,6 +157,9 @@ def cpu_baseline(seconds=6.0):
 
 def main():
     args = parse()
+    wl = WORKLOADS[args.workload]
+    MATS, BITS, BM, GS, ZP, MG, N = wl["mats"], wl["bits"], wl["bm"], wl["gs"], wl["zp"], wl["mg"], wl["N"]
+    decode = N == 1
     # The contract is ONE JSON line on stdout.  Libraries underneath write banners to file descriptor 1 (RCCL prints its
     # version block there under torchrun), so everything else that reaches fd 1 is sent to stderr and the original stdout
     # is kept for the result line alone.
@@ -150,74 +176,86 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dist_on = world > 1 or args.force_dist
-    if dist_on and args.path == "chain":
-        args.path = "fused"            # the persistent chain is a single-GPU launch; row shards exchange through RCCL between launches
+    chain_ok = decode and MG < 1 and not dist_on and args.variant == 0
+    if args.path == "auto":
+        args.path = "chain" if chain_ok else "fused"
+    if args.path == "chain" and not chain_ok:
+        raise SystemExit("bench.py: --path chain covers N = 1, per-group scales, one GPU")
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     import tmac_amd
-    from tmac_amd import KCfg, F16
+    from tmac_amd import KCfg, F16, F32
     L = tmac_amd.lib()
     tmac_amd.binding.check(L.tmac_hip_init(local_rank))
     tmac_amd.binding.check(L.tmac_hip_set_variant(args.variant))
     dev = torch.device("cuda", local_rank)
     gen = torch.Generator(device=dev); gen.manual_seed(1234)   # same weights on every rank, sliced by rank below
-    wr = tmac_amd.TMACGeMMWrapper(act_group_size=AGS)
-    wr.set_workspace(11008, 1)
+    ags_of = (lambda K: K) if MG >= 1 else (lambda K: wl["ags"])
+    maxK = max(m[2] for m in MATS)
+    wr = tmac_amd.TMACGeMMWrapper(act_group_size=ags_of(maxK))
+    wr.set_workspace(maxK, N)
 
     # ---- synthetic, row-sharded weights, registered (re-tiled on the GPU) once --------------------
-    rpt = BM // BITS                                  # 64 output rows per reference tile
-    layers = []
-    host_l0 = {}
+    rpt = BM // BITS                                  # output rows per reference tile
+    layers, host_l0, shard_rows = [], {}, {}
     bytes_per_step = 0
-    shard_rows = {}
+    ops_per_step = 0.0
     for name, Mw, K, cnt, slot in MATS:
         ntiles = Mw // rpt
         tiles_per_rank = (ntiles + world - 1) // world          # ragged split -> padded with extra synthetic rows
         shard_rows[name] = tiles_per_rank * rpt
-        bytes_per_step += cnt * algorithmic_bytes(Mw, K)
+        bytes_per_step += cnt * algorithmic_bytes(Mw, K, BITS, GS, ags_of(K), ZP, MG, N)
+        ops_per_step += cnt * 2.0 * (Mw * BITS) * (K / 4 * 8) * N        # int8 MFMA work the one-hot GEMM issues (8-entry half tables)
     bytes_per_step *= args.layers
+    ops_per_step *= args.layers
+    lvl = (2 ** BITS - 1) / 2.0 - 2 ** (BITS - 1)                # mean weight level minus the offset 2^(b-1)
+    wvar = (4 ** BITS - 1) / 12.0                                 # variance of a uniform b-bit level
+    keep_host = not args.no_verify and world == 1 and MG < 1
     for li in range(args.layers):
         mats = {}
         for name, Mw, K, cnt, slot in MATS:
             Mloc = shard_rows[name]
-            cfg = KCfg.make(Mloc, K, BITS, BM, KF, GS, AGS, True)
-            c = 1.0 / np.sqrt(2.25 * K)           # E[((w - 1.5) s - n)^2] = (1.25 + 1) c^2 for w uniform in 0..3: unit gain per GEMV
+            cfg = KCfg.make(Mloc, K, BITS, BM, KF, GS if GS else 128, ags_of(K), ZP, MG, N)
             ws = []
             for _ in range(cnt):
                 A = torch.randint(0, 256, (Mloc * BITS // BM, K // 4, BM // 2), dtype=torch.uint8, device=dev, generator=gen)
-                S = (torch.randn((Mloc * BITS // BM, K // GS, rpt // 8, 2, 8), device=dev, generator=gen) * c)
-                S[:, :, :, 0, :].abs_()
-                # zero = (mean weight level - 2^(b-1)) * scale + noise: the real weight (w - 2^(b-1)) * scale - zero has mean 0, so
-                # a common component of the activations is not amplified from layer to layer (it grew 16x per GEMV and the
-                # chained vectors overflowed fp16 after a few layers)
-                S[:, :, :, 1, :] += S[:, :, :, 0, :] * ((2 ** BITS - 1) / 2.0 - 2 ** (BITS - 1))
-                S = S.half().contiguous()
-                ws.append(tmac_amd.Weights(A, S, Mloc, K, BITS, cfg, scales_dtype=F16, dev_dtype=F16, on_device=True))
-                if li == 0 and not args.no_verify:
-                    host_l0.setdefault(name, []).append((A.cpu().numpy(), S.float().cpu().numpy().reshape(Mloc * BITS // BM, K // GS, -1)))
+                if MG >= 1:
+                    # one scale: the common-mode gain of a GEMV is 0.5 * scale * K; 2 / K keeps the chained vectors finite
+                    S = torch.full((MG,), 2.0 / K, device=dev, dtype=torch.float32)
+                    ws.append(tmac_amd.Weights(A, S, Mloc, K, BITS, cfg, scales_dtype=F32, dev_dtype=F32, on_device=True))
+                else:
+                    # real weight = (w - 2^(b-1)) scale - zero.  zero = (mean level - 2^(b-1)) scale + noise makes it zero-mean,
+                    # so a common component of the activations is not amplified from call to call (with independent zeros
+                    # it grew 16x per GEMV and the chained vectors overflowed fp16 after a few layers); c: unit gain
+                    c = 1.0 / np.sqrt((wvar + 1.0) * K)
+                    S = torch.randn((Mloc * BITS // BM, K // GS, rpt // 8, 2 if ZP else 1, 8), device=dev, generator=gen) * c
+                    S[:, :, :, 0, :].abs_()
+                    if ZP:
+                        S[:, :, :, 1, :] += S[:, :, :, 0, :] * lvl
+                    S = S.half().contiguous()
+                    ws.append(tmac_amd.Weights(A, S, Mloc, K, BITS, cfg, scales_dtype=F16, dev_dtype=F16, on_device=True))
+                    if li == 0 and keep_host:
+                        host_l0.setdefault(name, []).append((A.cpu().numpy(), S.float().cpu().numpy().reshape(Mloc * BITS // BM, K // GS, -1)))
                 del A, S
             mats[name] = ws
         layers.append(mats)
     torch.cuda.synchronize()
 
-    # activations: x[slot] full vectors (fp16); per-matrix local outputs
-    xdim = {0: 4096, 1: 4096, 2: 4096, 3: 11008}
-    x = {s: torch.randn(xdim[s], device=dev, generator=gen).half() for s in xdim}
-    outs = {name: [torch.empty(shard_rows[name], dtype=torch.float16, device=dev) for _ in range(cnt)]
+    # activations: x[slot] full blocks [N][K] (fp16); per-matrix local outputs [N][rows of this rank]
+    xdim = {slot: K for name, Mw, K, cnt, slot in MATS}
+    shp = (lambda k: (k,)) if decode else (lambda k: (N, k))
+    x = {s: torch.randn(shp(xdim[s]), device=dev, generator=gen).half() for s in xdim}
+    outs = {name: [torch.empty(shp(shard_rows[name]), dtype=torch.float16, device=dev) for _ in range(cnt)]
             for name, Mw, K, cnt, slot in MATS}
-    gathered = {name: torch.empty(shard_rows[name] * world, dtype=torch.float16, device=dev) for name, *_ in MATS}
+    gathered = {name: torch.empty((world,) + shp(shard_rows[name]), dtype=torch.float16, device=dev) for name, *_ in MATS}
     nxt = {"qkv": 1, "o": 2, "gate_up": 3, "down": 0}
-    logical = {"qkv": 4096, "o": 4096, "gate_up": 11008, "down": 4096}
-    ev_pairs = []
-    use_ev = not args.no_kernel_events
+    logical = {name: Mw for name, Mw, K, cnt, slot in MATS}
 
-    # launch-configuration tuning on this rank's shard shapes (one measurement per distinct matrix set; the table is keyed
-    # by shape, so layer 0 stands for all layers).  Outside the timed region, like the reference's offline autotvm tuning.
     tuned = {}
-    if args.path == "fused" and args.autotune and args.variant == 0:
+    if args.path == "fused" and args.autotune and args.variant == 0 and decode:
         for name, Mw, K, cnt, slot in MATS:
             r = wr.autotune(layers[0][name], F16, F16)
             tuned[name] = [r["ft"], r["wpq"], round(r["us"], 2), round(r["heuristic_us"], 2)]
@@ -225,102 +263,79 @@ def main():
 
     fused_calls = args.path in ("chain", "fused")
 
-    def step(record):
+    def calls(mats, xin, out_of, exchange=True):
+        """the hot-path calls of one layer; xin / out_of: dicts of input blocks per slot / output lists per matrix group"""
+        for name, Mw, K, cnt, slot in MATS:
+            if fused_calls:
+                wr.fused(mats[name], xin[slot], out_of[name], N, act_dtype=F16, out_dtype=F16)
+            else:
+                wr.llama_cpp_init(xin[slot], Mw, K, N, BITS, act_group_size=ags_of(K), act_dtype=F16)
+                for i in range(cnt):
+                    wr.llama_cpp_compute(mats[name][i], out_of[name][i], N, out_dtype=F16)
+            # exchange step: the first output of the group becomes the next activation block
+            if dist_on and exchange:
+                dist.all_gather_into_tensor(gathered[name], out_of[name][0])
+                g = gathered[name]
+                xin[nxt[name]] = (g.reshape(-1)[:logical[name]] if decode
+                                  else g.permute(1, 0, 2).reshape(N, -1)[:, :logical[name]].contiguous())
+            else:
+                xin[nxt[name]] = out_of[name][0]
+
+    def step():
         for li in range(args.layers):
-            mats = layers[li]
-            for name, Mw, K, cnt, slot in MATS:
-                if fused_calls:
-                    wr.fused(mats[name], x[slot], outs[name], 1, act_dtype=F16, out_dtype=F16)
-                else:
-                    wr.llama_cpp_init(x[slot], Mw, K, 1, BITS, act_dtype=F16)
-                    for i in range(cnt):
-                        wr.llama_cpp_compute(mats[name][i], outs[name][i], 1, out_dtype=F16)
-                # exchange step: the first output of the group becomes the next activation vector
-                if dist_on:
-                    dist.all_gather_into_tensor(gathered[name], outs[name][0])
-                    x[nxt[name]] = gathered[name][:logical[name]]
-                else:
-                    x[nxt[name]] = outs[name][0]
+            calls(layers[li], x, outs)
 
     def barrier():
         if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # One step (128 launches + the all-gathers) is captured into a hipGraph and replayed.  With RCCL collectives inside,
-    # capture was exercised with one rank only on the development box (1.27 ms per step against 6.0 ms eager): if
-    # capture raises, the run falls back to eager launches; if the first replay does not finish, a watchdog ends the
-    # process instead of hanging the node.
-    use_graph = (not args.no_graph) and not (dist_on and args.eager_collectives) and args.path != "chain"
-    graph = None
-    chain = None
+    # ---- launch mechanism ---------------------------------------------------------------------------------------------
+    # (prefill launches are 50+ us each: replaying them from a graph buys nothing, and the fused entry point's per-stream LUT
+    # workspace must not be allocated inside a capture)
+    use_graph = (not args.no_graph) and not (dist_on and args.eager_collectives) and args.path != "chain" and decode
+    graph, chain, stamp_buf = None, None, None
     if args.path == "chain":
         # record the token's calls once (they are not launched while recording); one launch per step from here on
-        step(False)                                  # leaves x[0] = the down projection's output, as in a decode loop
+        step()                                       # leaves x[0] = the down projection's output, as in a decode loop
         torch.cuda.synchronize()
         with wr.record_chain() as rec:
-            step(False)
+            step()
         chain = rec.chain
         if args.stamps:
             stamp_buf = torch.zeros(chain.nops * chain.grid * 8, dtype=torch.int64, device=dev)
             chain.set_stamps(stamp_buf)
     if use_graph:
+        # One step (the launches + the all-gathers) is captured into a hipGraph and replayed.  With RCCL collectives inside,
+        # capture was exercised with one rank only on the development box: if capture raises, the run falls back to eager
+        # launches; if the first replay does not finish, a watchdog ends the process instead of hanging the node.
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                step(False)
+                step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             if dist_on:
                 # ProcessGroupNCCL's watchdog thread polls the events of earlier collectives; under the default (global)
-                # capture mode such a query from another thread invalidates the capture and kills the process (seen on the
-                # development box).  Let it reap what has completed, then capture in thread-local mode, where only this
-                # thread's calls are policed.
+                # capture mode such a query from another thread invalidates the capture and kills the process.  Let it reap
+                # what has completed, then capture in thread-local mode, where only this thread's calls are policed.
                 time.sleep(1.0)
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                    step(False)
+                    step()
             else:
                 with torch.cuda.graph(graph):
-                    step(False)
+                    step()
         except Exception as e:   # capture not supported with this RCCL / torch build: measured eagerly instead
             if not dist_on:
                 raise
             sys.stderr.write(f"bench.py: graph capture with collectives failed ({e!r}); launching eagerly\n")
-            graph = None
-            use_graph = False
+            graph, use_graph = None, False
             try:
                 torch.cuda.synchronize()
             except Exception:
                 pass
-
-    def first_step():
-        # every rank runs exactly one step here whether its capture succeeded or not, so that the ranks stay aligned on
-        # the number of collectives issued; a failed capture can leave a sticky HIP error behind, hence one retry
-        if graph is not None:
-            graph.replay()
-        else:
-            try:
-                step(False)
-            except tmac_amd.binding.TMACHipError:
-                torch.cuda.synchronize()
-                step(False)
-        torch.cuda.synchronize()
-
-    if dist_on:
-        import threading
-        done = threading.Event()
-
-        def watchdog():
-            if not done.wait(240.0):
-                sys.stderr.write("bench.py: the first step with RCCL all-gathers did not complete; "
-                                 "rerun with --eager-collectives\n")
-                sys.stderr.flush()
-                os._exit(3)
-        threading.Thread(target=watchdog, daemon=True).start()
-        first_step()
-        done.set()
 
     def run_step():
         if chain is not None:
@@ -328,7 +343,25 @@ def main():
         elif graph is not None:
             graph.replay()
         else:
-            step(False)
+            step()
+
+    if dist_on:
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(240.0):
+                sys.stderr.write("bench.py: the first step with RCCL all-gathers did not complete; rerun with --eager-collectives\n")
+                sys.stderr.flush()
+                os._exit(3)
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            run_step()
+        except tmac_amd.binding.TMACHipError:
+            torch.cuda.synchronize()
+            run_step()
+        torch.cuda.synchronize()
+        done.set()
 
     for _ in range(args.warmup):
         run_step()
@@ -349,28 +382,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
+    finite = bool(torch.isfinite(outs["down"][0].float()).all().item())     # the chained activations stayed finite
 
-    # ---- roofline of the dominant kernel: the GEMV on the headline shape (4096 x 11008 W2) ----------
-    # hipEvent pair (on the launch stream) around back-to-back launches of that kernel over all layers'
-    # distinct weights (32 x 11.3 MB > MALL), so the figure includes the inter-kernel boundary.
-    roof = None
+    # ---- roofline of the dominant kernel ------------------------------------------------------------------------------
     traffic, traffic_src = None, None
-    try:    # HBM bytes per launch of the dominant kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)
+    kkey = {"chain": "k_decode_chain", "fused": "k_gemv_quad_headline", "split": "k_gemv_quad_headline"}[args.path] if decode else "k_gemm_onehot"
+    try:    # HBM bytes per launch of that kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            tj = json.load(f)
-        ent = tj.get("k_decode_chain" if args.path == "chain" else "k_gemv_quad_headline")
-        if ent and (args.path != "chain" or ent.get("layers") == args.layers):
+            ent = json.load(f).get(args.workload, {}).get(kkey)
+        if ent and ent.get("layers", args.layers) == args.layers:
             traffic, traffic_src = ent["bytes_per_launch"], ent.get("source")
     except Exception:
         pass
-    if args.path == "chain":
+    roof = None
+    if not decode:
+        ach = ops_per_step / world / (ev_ms_per_step * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "k_gemm_onehot (one-hot int8 MFMA GEMM; LUT build kernels included in the time)",
+                "achieved": round(ach, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8 MFMA work issued: 2 x bit-plane rows x 8-entry half tables x N)",
+                "frac": round(ach / MFMA_I8_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "ops_per_step": ops_per_step, "timing": "hipEvent pair on the launch stream around the %d timed steps" % args.steps}
+    elif args.path == "chain":
         ach = bytes_per_step / (ev_ms_per_step * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_decode_chain: one persistent launch per decoded token (all %d GEMVs, LUT builds and "
-                                          "in-kernel hand-offs of the llama-2-7B W2 g128 zp layer stack)" % (7 * args.layers),
+        roof = {"bound": "hbm", "kernel": "k_decode_chain: one persistent launch per decoded token (all %d GEMVs, LUT builds and in-kernel "
+                                          "hand-offs of the layer stack)" % (7 * args.layers),
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": bytes_per_step, "avg_launch_us": round(ev_ms_per_step * 1e3, 2),
-                "launches_timed": args.steps,
+                "algorithmic_bytes_per_launch": bytes_per_step, "avg_launch_us": round(ev_ms_per_step * 1e3, 2), "launches_timed": args.steps,
                 "timing": "hipEvent pair on the launch stream around the %d timed launches" % args.steps}
         if args.stamps:
             raw = stamp_buf.cpu().numpy().reshape(chain.nops, chain.grid, 8)
@@ -380,37 +417,37 @@ def main():
             except Exception:
                 pass
             st = raw[:, :, :7].astype(np.float64) * 0.01                     # s_memrealtime: 100 MHz -> us (wave 0 of every workgroup)
-            names = [m[0] for m in MATS]
             ends = st[:, :, 5].max(axis=1)                                    # a call is complete when its last row quad is published
             dur = ends - np.concatenate([[st[0, :, 0].min()], ends[:-1]])
             per = {}
-            for k, name in enumerate(names):
+            for k, (name, Mw, K, cnt, slot) in enumerate(MATS):
                 sel = st[k::4]
                 per[name] = {"us": round(float(np.mean(dur[k::4])), 3),
                              "wait_input_us": round(float(np.mean(sel[:, :, 1] - sel[:, :, 0])), 3),
                              "lut_build_us": round(float(np.mean(sel[:, :, 2] - sel[:, :, 1])), 3),
                              "lookups_us": round(float(np.mean(sel[:, :, 5] - sel[:, :, 2])), 3),
                              "polls": round(float(np.mean(raw[k::4, :, 7])), 2)}
-            hb = algorithmic_bytes(4096, 11008)
+            name, Mw, K, cnt, slot = MATS[3]
+            hb = algorithmic_bytes(Mw, K, BITS, GS, ags_of(K), ZP, MG)
             roof["per_call_from_stamps"] = per
-            roof["headline_gemv"] = {"shape": "4096x11008 W2 g128 zp (the down projection inside the launch)", "us": per["down"]["us"],
-                                     "GBps": round(hb / (per["down"]["us"] * 1e-6) / 1e9, 1) if per["down"]["us"] > 0 else None,
-                                     "frac": round(hb / (per["down"]["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if per["down"]["us"] > 0 else None}
-    elif use_ev:
-        xin = torch.randn(11008, device=dev, generator=gen).half()
-        wr.llama_cpp_init(xin, 4096, 11008, 1, BITS, act_dtype=F16)
-        reps, skip = 10, 3            # the first replays run while the clocks settle after the timed region
-        durs = []
+            roof["headline_gemv"] = {"shape": f"{Mw}x{K} (the down projection inside the launch)", "us": per["down"]["us"],
+                                     "GBps": round(hb / (per["down"]["us"] * 1e-6) / 1e9, 1), "frac": round(hb / (per["down"]["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+    else:
+        # per-launch paths: back-to-back launches of the GEMV on the headline shape (the down projection of every layer:
+        # distinct weights > MALL), replayed from a hipGraph like the timed region, inside a hipEvent pair
+        name, Mw, K, cnt, slot = MATS[3]
+        xin = torch.randn(K, device=dev, generator=gen).half()
+        wr.llama_cpp_init(xin, Mw, K, 1, BITS, act_group_size=ags_of(K), act_dtype=F16)
+        reps, skip, durs = 10, 3, []
 
         def headline_launches():
             for li in range(args.layers):
-                if args.path == "fused":
-                    wr.fused(layers[li]["down"], xin, outs["down"], 1, act_dtype=F16, out_dtype=F16)
+                if fused_calls:
+                    wr.fused(layers[li][name], xin, outs[name], 1, act_dtype=F16, out_dtype=F16)
                 else:
-                    wr.llama_cpp_compute(layers[li]["down"][0], outs["down"][0], 1, out_dtype=F16)
-
+                    wr.llama_cpp_compute(layers[li][name][0], outs[name][0], 1, out_dtype=F16)
         rgraph = None
-        if use_graph:   # same launch mechanism as the timed region: the 32 launches replayed from a hipGraph
+        if use_graph:
             headline_launches()
             torch.cuda.synchronize()
             rgraph = torch.cuda.CUDAGraph()
@@ -419,31 +456,27 @@ def main():
         for r in range(reps + skip):
             e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            if rgraph is not None:
-                rgraph.replay()
-            else:
-                headline_launches()
+            rgraph.replay() if rgraph is not None else headline_launches()
             e1.record()
             torch.cuda.synchronize()
             if r >= skip:
                 durs.append(e0.elapsed_time(e1) * 1e-3 / args.layers)
         durs = np.array(durs)
-        hb = algorithmic_bytes(shard_rows["down"], 11008)
+        hb = algorithmic_bytes(shard_rows[name], K, BITS, GS, ags_of(K), ZP, MG)
         ach = hb / float(np.mean(durs)) / 1e9
-        # floor of this launch structure, measured the same way: a kernel that only READS the same number of bytes
-        # (distinct buffers per launch, > MALL in total) and an empty kernel, as dependent nodes of a replayed graph
         floor = None
-        if use_graph:
+        if use_graph and args.floors:
+            # floor of this launch structure, measured the same way: launches that only READ the same number of bytes
+            # (distinct buffers, > MALL in total) and near-empty launches, as dependent nodes of a replayed graph
             nb = (hb + 4095) // 4096 * 4096
             bufs = [torch.empty(nb, dtype=torch.uint8, device=dev).fill_(0x5a) for _ in range(args.layers)]
             sink = torch.zeros(4096, dtype=torch.uint8, device=dev)
-            cs = torch.cuda.current_stream().cuda_stream
 
             def floor_time(nbytes):
-                def launches():
-                    for b in bufs:
-                        tmac_amd.binding.check(L.tmac_hip_debug_stream_read(b.data_ptr(), nbytes, sink.data_ptr(), cs))
-                launches(); torch.cuda.synchronize()
+                cs = torch.cuda.current_stream().cuda_stream
+                for b in bufs:
+                    tmac_amd.binding.check(L.tmac_hip_debug_stream_read(b.data_ptr(), nbytes, sink.data_ptr(), cs))
+                torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     cs2 = torch.cuda.current_stream().cuda_stream
@@ -456,104 +489,87 @@ def main():
                     if r >= 3:
                         ts.append(f0.elapsed_time(f1) * 1e-3 / len(bufs))
                 return float(np.mean(ts))
-            floor = {"pure_read_same_bytes_us": round(floor_time(hb // 16 * 16) * 1e6, 3),
-                     "near_empty_launch_us": round(floor_time(4096) * 1e6, 3)}
+            floor = {"pure_read_same_bytes_us": round(floor_time(hb // 16 * 16) * 1e6, 3), "near_empty_launch_us": round(floor_time(4096) * 1e6, 3)}
             del bufs
-            # and of the whole step: the same 4 launches per layer, each only reading its matrices' bytes (distinct buffers)
-            sizes = [cnt * algorithmic_bytes(shard_rows[name], K) // 16 * 16 for name, Mw, K, cnt, slot in MATS]
-            sbufs = [[torch.empty(sz, dtype=torch.uint8, device=dev).fill_(0x5a) for sz in sizes] for _ in range(args.layers)]
-
-            def step_reads(stream):
-                for lb_ in sbufs:
-                    for b_, sz in zip(lb_, sizes):
-                        tmac_amd.binding.check(L.tmac_hip_debug_stream_read(b_.data_ptr(), sz, sink.data_ptr(), stream))
-            step_reads(cs); torch.cuda.synchronize()
-            sg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(sg):
-                step_reads(torch.cuda.current_stream().cuda_stream)
-            ts = []
-            for r in range(8):
-                f0 = torch.cuda.Event(enable_timing=True); f1 = torch.cuda.Event(enable_timing=True)
-                f0.record(); sg.replay(); f1.record(); torch.cuda.synchronize()
-                if r >= 3:
-                    ts.append(f0.elapsed_time(f1))
-            floor["pure_read_step_ms"] = round(float(np.mean(ts)), 4)
-            del sbufs, sg
-        roof = {"bound": "hbm", "kernel": ("k_gemv_quad, LUT build fused" if args.path == "fused" else "k_gemv_quad, LUT prebuilt") + ", headline shape 4096x11008 W2 g128 zp", "achieved": round(ach, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        roof = {"bound": "hbm", "kernel": ("k_gemv_quad, LUT build fused" if fused_calls else "k_gemv_quad, LUT prebuilt") + f", headline shape {Mw}x{K}",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": hb, "avg_launch_us": round(float(np.mean(durs)) * 1e6, 3),
-                "min_launch_us": round(float(np.min(durs)) * 1e6, 3), "launches_timed": reps * args.layers,
-                "launch_floor": floor,
-                "timing": "hipEvent pair on the launch stream around %d back-to-back launches (distinct weights, %s), mean of 10" % (args.layers, "hipGraph replay" if use_graph else "eager")}
+                "min_launch_us": round(float(np.min(durs)) * 1e6, 3), "launches_timed": reps * args.layers, "launch_floor": floor,
+                "timing": "hipEvent pair on the launch stream around %d back-to-back launches (distinct weights, %s), mean of 10"
+                          % (args.layers, "hipGraph replay" if use_graph else "eager")}
 
     # ---- verification (outside the timed region): the launches being timed, at full size, against the oracle ----------
     verified = None
-    if not args.no_verify and world == 1 and host_l0:
+    if host_l0:
         from oracle import oracle as orc
-        vx = torch.randn(4096, device=dev, generator=gen).half()
-        vouts = {name: [torch.zeros(Mw, dtype=torch.float16, device=dev) for _ in range(cnt)] for name, Mw, K, cnt, slot in MATS}
-        vin = {"qkv": vx, "o": vouts["qkv"][0], "gate_up": vouts["o"][0], "down": vouts["gate_up"][0]}
-
-        def vcalls():
-            for name, Mw, K, cnt, slot in MATS:
-                if fused_calls:
-                    wr.fused(layers[0][name], vin[name], vouts[name], 1, act_dtype=F16, out_dtype=F16)
-                else:
-                    wr.llama_cpp_init(vin[name], Mw, K, 1, BITS, act_dtype=F16)
-                    for i in range(cnt):
-                        wr.llama_cpp_compute(layers[0][name][i], vouts[name][i], 1, out_dtype=F16)
+        vshape = (lambda k: (k,)) if decode else (lambda k: (N, k))
+        vx0 = torch.randn(vshape(MATS[0][2]), device=dev, generator=gen).half()
+        vx = {MATS[0][4]: vx0}
+        vouts = {name: [torch.zeros(vshape(Mw), dtype=torch.float16, device=dev) for _ in range(cnt)] for name, Mw, K, cnt, slot in MATS}
+        ok = True
         if args.path == "chain":
             with wr.record_chain() as vrec:
-                vcalls()
+                calls(layers[0], vx, vouts, exchange=False)
             vrec.chain.launch()
             torch.cuda.synchronize()
             ok = vrec.chain.status() == 0
             vrec.chain.free()
         else:
-            vcalls()
+            calls(layers[0], vx, vouts, exchange=False)
             torch.cuda.synchronize()
-            ok = True
         worst = 0.0
+        rows = [0] if decode else [0, N - 1]          # prefill: two of the N activation rows (the oracle takes seconds per row)
         for name, Mw, K, cnt, slot in MATS:
-            q, ls, lb = orc.preprocessor(vin[name].float().cpu().numpy()[None, :], AGS)
+            src = vx0 if slot == MATS[0][4] else vouts[[n_ for n_ in nxt if nxt[n_] == slot][0]][0]     # what this call consumed
+            xin_h = src.float().cpu().numpy().reshape(-1, K)[rows]
+            q, ls, lb = orc.preprocessor(xin_h, ags_of(K))
             for i in range(cnt):
                 A, S = host_l0[name][i]
-                ref = orc.qgemm_float(A, q, S, ls, lb, Mw, K, 1, BITS, BM, KF, GS, AGS, True)[0]
-                got = vouts[name][i].float().cpu().numpy()
+                ref = orc.qgemm_float(A, q, S, ls, lb, Mw, K, len(rows), BITS, BM, KF, GS, ags_of(K), ZP)
+                got = vouts[name][i].float().cpu().numpy().reshape(-1, Mw)[rows]
                 worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)))
         verified = {"ok": bool(ok and worst <= 1e-3), "max_rel_err": float("%.3g" % worst), "tolerance": 1e-3,
-                    "what": "layer 0's seven GEMVs (q/k/v, o, gate/up, down at full size, chained) through the timed path vs oracle/ (fp16 outputs)"}
+                    "what": "layer 0's seven mpGEMMs (q/k/v, o, gate/up, down at full size, chained) through the timed path vs oracle/ "
+                            "(fp16 outputs%s)" % ("" if decode else "; activation rows 0 and N-1")}
         if not verified["ok"]:
             sys.stderr.write("bench.py: VERIFICATION FAILED: %r\n" % (verified,))
 
     if rank == 0:
+        sec = ms_per_step * 1e-3
         res = {
-            "metric": "W2A8 GEMV GB/s (llama-2-7B all-layer decode, N=1)",
-            "value": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9, 2),
-            "unit": "GB/s",
+            "metric": wl["metric"],
+            "value": round(bytes_per_step / sec / 1e9, 2) if decode else round(N / sec, 1),
+            "unit": "GB/s" if decode else "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int8",
             "data": "synthetic",
-            "tokens_per_s": round(1e3 / ms_per_step, 1),
-            "frac_of_hbm_peak": round(bytes_per_step / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4),
-            "config": {"workload": "llama-2-7b-w2a8-decode-all-layers", "layers": args.layers,
-                       "gemv_per_step": 7 * args.layers, "launches_per_step": 1 if args.path == "chain" else (4 if args.path == "fused" else 11) * args.layers, "path": args.path,
+            "tokens_per_s": round(N / sec, 1),
+            "algorithmic_GBps": round(bytes_per_step / sec / 1e9, 2),
+            "frac_of_hbm_peak": round(bytes_per_step / sec / 1e9 / (HBM_PEAK_GBS * world), 4),
+            "config": {"workload": wl["tag"], "layers": args.layers, "N": N,
+                       "gemm_per_step": 7 * args.layers,
+                       "launches_per_step": 1 if args.path == "chain" else (4 if fused_calls else 11) * args.layers + (0 if decode else 4 * args.layers), "path": args.path,
                        "autotune": tuned,
-                       "algorithmic_bytes_per_step": bytes_per_step, "weights": "W2 g128 zero-point, act_group 64",
+                       "algorithmic_bytes_per_step": bytes_per_step, "weights": wl["weights"],
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
-                       "kernel_variant": args.variant, "launch": "one persistent launch per step" if args.path == "chain" else ("hipGraph replay" if use_graph else "eager")},
+                       "kernel_variant": args.variant,
+                       "launch": "one persistent launch per step" if args.path == "chain" else ("hipGraph replay" if use_graph else "eager")},
             "roofline": roof,
             "verified": verified,
+            "activations_finite": finite,
             "event_ms_per_step": round(ev_ms_per_step, 4),
             "cpu_baseline": None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "llama2-7b-w2":
             try:
                 res["cpu_baseline"] = cpu_baseline()
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"error": repr(e)}
+        elif args.workload != "llama2-7b-w2":
+            res["cpu_baseline"] = {"note": "the reference's prebuilt CPU kernels are timed with the default workload (llama2-7b-w2) only"}
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(res) + "\n").encode())
     if dist_on:

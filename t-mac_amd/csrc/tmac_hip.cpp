@@ -637,15 +637,19 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
     {
         std::lock_guard<std::mutex> lk(g_mu);
         tmac_hip_workspace*& slot = g_fused_ws[st];
+        int needK = s0.K, needN = N;
         if (slot && (slot->maxK < s0.K || slot->maxN < N)) {
-            // the old buffers may still be read by launches in flight on this stream
+            // grow to the maximum seen in BOTH dimensions (mixed shapes -- K = 4096 / 11008, growing N -- would otherwise
+            // free and reallocate on every other call); the old buffers may still be read by launches in flight
+            needK = slot->maxK > s0.K ? slot->maxK : s0.K;
+            needN = slot->maxN > N ? slot->maxN : N;
             hipError_t e = hipStreamSynchronize(st);
             if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "stream sync: %s", hipGetErrorString(e));
             tmac_hip_workspace_free(slot);
             slot = nullptr;
         }
         if (!slot) {
-            int32_t rc = tmac_hip_workspace_create(&slot, s0.K, N);
+            int32_t rc = tmac_hip_workspace_create(&slot, needK, needN);
             if (rc) { slot = nullptr; return rc; }
         }
         ws = slot;
@@ -1318,7 +1322,10 @@ extern "C" int32_t tmac_hip_cache_clear(void) {
     g_tiles.clear();
     for (HostRun* r : g_runs) { tmac_hip_free_weights(r->w); delete r; }
     g_runs.clear();
-    for (auto& kv : g_fused_ws) tmac_hip_workspace_free(kv.second);
+    for (auto& kv : g_fused_ws) {
+        (void)hipStreamSynchronize(kv.first);      // launches in flight may still read the LUT workspace
+        tmac_hip_workspace_free(kv.second);
+    }
     g_fused_ws.clear();
     return TMAC_HIP_OK;
 }

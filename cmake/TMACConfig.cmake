@@ -11,12 +11,12 @@
 # Optional input: -DTMAC_KCFG=<path to the kcfg.ini the model was converted with> (else $TMAC_KCFG_FILE at run time).
 get_filename_component(_tmac_root "${CMAKE_CURRENT_LIST_DIR}/.." ABSOLUTE)
 set(TMAC_INCLUDE_DIRS "${_tmac_root}/include")
-set(TMAC_LIB_DIR "${_tmac_root}/t-mac_amd/lib")
+set(TMAC_LIB_DIR "${_tmac_root}/tmac_amd/lib")
 
 find_library(tmac_hip_LIBRARY tmac_hip HINTS "${TMAC_LIB_DIR}" NO_DEFAULT_PATH)
 if(NOT tmac_hip_LIBRARY)
   set(TMAC_FOUND FALSE)
-  set(TMAC_NOT_FOUND_MESSAGE "libtmac_hip.so not found in ${TMAC_LIB_DIR}: run `make -C ${_tmac_root}/t-mac_amd/csrc` (hipcc, gfx950)")
+  set(TMAC_NOT_FOUND_MESSAGE "libtmac_hip.so not found in ${TMAC_LIB_DIR}: run `make -C ${_tmac_root}/tmac_amd/csrc` (hipcc, gfx950)")
   return()
 endif()
 

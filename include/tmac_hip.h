@@ -29,6 +29,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libtmac_hip.so is built with -fvisibility=hidden: exactly what this header declares is exported */
+#pragma GCC visibility push(default)
 
 #define TMAC_HIP_OK 0
 #define TMAC_HIP_E_NOMATCH (-1)   /* no kernel for this shape/config (reference: dispatcher returns -1) */
@@ -185,7 +187,7 @@ int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const tmac_hip_wo
 int32_t tmac_hip_qgemm_fused_partial_sums(const tmac_hip_weights* w, const void* B_dev, tmac_dtype_t act_dtype,
                                           int32_t* PS_host, float* C_host, float* lut_host, int N, void* stream);
 /* Runs v_perm_b32 / v_mqsad_pk_u16_u8 / lookup4 on n quadruples of host words (in[4n] -> out[4n]); the
- * test-suite compares the result with the host models of t-mac_amd/csrc/tmac_core.h. */
+ * test-suite compares the result with the host models of tmac_amd/csrc/tmac_core.h. */
 int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host, int n);
 /* one wave of v_mfma_i32_16x16x64_i8: in[64][8] (A regs 0-3, B regs 4-7 per lane) -> out[64][4] (D regs) */
 int32_t tmac_hip_selftest_mfma(const uint32_t* in_host, int32_t* out_host);
@@ -275,6 +277,7 @@ TMAC_DECL_P(6400, 8640, 1, 2) TMAC_DECL_P(17280, 3200, 1, 2) TMAC_DECL_P(6400, 3
 #undef TMAC_DECL_Q
 #undef TMAC_DECL_P
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,7 @@
 """ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE — see oracle/tmac_oracle.c header).
 
 Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
-this module.  Nothing under ``t-mac_amd/`` does.
+this module.  Nothing under ``tmac_amd/`` does.
 
 Two libraries live here:
 

@@ -2,7 +2,7 @@
  * tmac_oracle.c — CPU restatement of T-MAC's LUT mpGEMM hot path (x86 / fp32 flavour).
  *
  * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
- * and bench.py's cpu_baseline leg may load it.  The product path (t-mac_amd/) never
+ * and bench.py's cpu_baseline leg may load it.  The product path (tmac_amd/) never
  * links, imports or calls anything in oracle/.
  *
  * Parity status: PINNED.  Every function below is checked bit-for-bit against the

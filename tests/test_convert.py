@@ -1,4 +1,4 @@
-"""Converter-side formats (t-mac_amd/convert.py) against the reference's own Python (imports without TVM) and against
+"""Converter-side formats (tmac_amd/convert.py) against the reference's own Python (imports without TVM) and against
 the kcfg parser of the C library.  CPU only."""
 import os
 import sys

@@ -1,4 +1,4 @@
-"""CPU emulation of the tiled GEMV kernel's integer path (t-mac_amd/csrc/emu.cpp) vs the oracle and the
+"""CPU emulation of the tiled GEMV kernel's integer path (tmac_amd/csrc/emu.cpp) vs the oracle and the
 golden vectors.  The emulation compiles the same tmac_layout.h / tmac_core.h the HIP kernels use, so this
 pins the device layout, the nibble recoding and the perm/mqsad arithmetic without a GPU."""
 import ctypes as C
@@ -17,8 +17,8 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 @pytest.fixture(scope="module")
 def emu():
-    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "t-mac_amd", "csrc"), "emu"], check=True)
-    return C.CDLL(os.path.join(ROOT, "t-mac_amd", "lib", "libtmac_emu.so"))
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tmac_amd", "csrc"), "emu"], check=True)
+    return C.CDLL(os.path.join(ROOT, "tmac_amd", "lib", "libtmac_emu.so"))
 
 
 def run_emu(emu, A, q, Mw, K, bits, bm, kf, ags, mode):

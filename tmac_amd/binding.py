@@ -1,6 +1,6 @@
 """ctypes binding of libtmac_hip.so (C-ABI: include/tmac_hip.h).
 
-The library is built IN-TREE (``t-mac_amd/lib/libtmac_hip.so``, ``make -C t-mac_amd/csrc``) so that
+The library is built IN-TREE (``tmac_amd/lib/libtmac_hip.so``, ``make -C tmac_amd/csrc``) so that
 it travels with the repo snapshot to the GPU box.  There is deliberately no fallback: if the
 library is missing, or no HIP device is visible when a compute entry point is called, an exception
 is raised.

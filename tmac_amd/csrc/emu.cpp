@@ -1,6 +1,6 @@
 // emu.cpp — CPU emulation of the tiled GEMV kernel's INTEGER path (test infrastructure).
 //
-// Built by g++ into t-mac_amd/lib/libtmac_emu.so and used only by tests/test_emulation.py
+// Built by g++ into tmac_amd/lib/libtmac_emu.so and used only by tests/test_emulation.py
 // (-m "not gpu"): it runs the very same layout math (tmac_layout.h) and per-thread lookup /
 // accumulate code (tmac_core.h) the HIP kernels compile, with v_perm_b32 / v_mqsad_pk_u16_u8
 // replaced by their bit-exact host models, thread by thread, and returns the integer partial

@@ -26,7 +26,7 @@
 #pragma once
 #include <stdint.h>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define TMAC_HD __host__ __device__ __forceinline__
 #else
 #define TMAC_HD inline

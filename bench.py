@@ -83,6 +83,9 @@ def parse():
     ap.add_argument("--autotune", action="store_true", help="fused path: measure the launch configurations first (tmac_hip_autotune_fused)")
     ap.add_argument("--no-graph", action="store_true", help="fused/split: launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--eager-collectives", action="store_true", help="multi-GPU: do not capture the RCCL all-gathers into the hipGraph")
+    ap.add_argument("--comm", choices=["torch", "lib"], default="torch",
+                    help="multi-GPU exchange step: torch.distributed (ProcessGroupNCCL = RCCL; default, the path exercised so far) or the "
+                         "library's own communicator (tmac_hip_comm_*: RCCL through the C-ABI, bootstrapped over torch.distributed)")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # debugging: take the multi-GPU code path with 1 rank
     a = ap.parse_args()
     wl = WORKLOADS[a.workload]
@@ -262,6 +265,14 @@ def main():
         torch.cuda.synchronize()
 
     fused_calls = args.path in ("chain", "fused")
+    lib_comm = None
+    if dist_on and args.comm == "lib":
+        # rank 0 creates the RCCL id, torch.distributed carries the 128 bytes to the other ranks (bootstrap only)
+        idt = torch.zeros(tmac_amd.Comm.ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(tmac_amd.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        lib_comm = tmac_amd.Comm(bytes(idt.cpu().numpy().tobytes()), rank, world)
 
     def calls(mats, xin, out_of, exchange=True):
         """the hot-path calls of one layer; xin / out_of: dicts of input blocks per slot / output lists per matrix group"""
@@ -274,7 +285,10 @@ def main():
                     wr.llama_cpp_compute(mats[name][i], out_of[name][i], N, out_dtype=F16)
             # exchange step: the first output of the group becomes the next activation block
             if dist_on and exchange:
-                dist.all_gather_into_tensor(gathered[name], out_of[name][0])
+                if lib_comm is not None:
+                    lib_comm.allgather(out_of[name][0], gathered[name], out_of[name][0].numel() * 2)
+                else:
+                    dist.all_gather_into_tensor(gathered[name], out_of[name][0])
                 g = gathered[name]
                 xin[nxt[name]] = (g.reshape(-1)[:logical[name]] if decode
                                   else g.permute(1, 0, 2).reshape(N, -1)[:, :logical[name]].contiguous())

@@ -165,6 +165,25 @@ int32_t tmac_hip_chain_threads(void);   /* threads per workgroup of k_decode_cha
 int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* chain, unsigned long long* dev_buffer);
 int32_t tmac_hip_debug_chain_config(int force_waves_per_quad, unsigned spin_limit);
 
+/* ---- multi-GPU exchange step ------------------------------------------------------------------
+ * One process per GPU; weight ROWS are sharded over the ranks (tile-aligned; register a rank's tiles with
+ * tmac_hip_register_weights: tiles are contiguous in the reference layout).  An M-tile needs only its own A / Scales
+ * slice plus the WHOLE LUT (include/t-mac/tmac_gemm_wrapper.h:197-199), so the only exchange is an all-gather of what the
+ * next LUT build needs whole: the activation block the shards produced (N x rows x 2 bytes), or int8 QLUT slices built from
+ * a K slice (tmac_hip_workspace_ptrs gives the device pointers).  K is never split: integer sums stay bit-identical to
+ * one GPU.  RCCL over xGMI, resolved with dlopen at the first call (single-GPU users need no RCCL).
+ *   rank 0:     tmac_hip_comm_unique_id(id)  -> hand the TMAC_HIP_COMM_ID_BYTES to every rank (MPI, a file, a socket)
+ *   every rank: hipSetDevice / tmac_hip_init(its GPU); tmac_hip_comm_init(&comm, id, rank, world)
+ *   per step:   tmac_hip_comm_allgather(comm, my_part_dev, whole_dev, bytes_per_rank, stream)   (whole = world x bytes_per_rank)
+ * Errors: tmac_hip_comm_last_error(). */
+#define TMAC_HIP_COMM_ID_BYTES 128
+typedef struct tmac_hip_comm tmac_hip_comm;
+int32_t tmac_hip_comm_unique_id(void* id_out);
+int32_t tmac_hip_comm_init(tmac_hip_comm** out, const void* id, int rank, int world);
+int32_t tmac_hip_comm_allgather(tmac_hip_comm* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+int32_t tmac_hip_comm_destroy(tmac_hip_comm* comm);
+const char* tmac_hip_comm_last_error(void);
+
 /* Raw device pointers of the workspace, for collectives (RCCL all-gather of the LUT over xGMI):
  *   qlut_dev  : kernel-layout half tables, nbytes_qlut per activation row
  *   lut_scales/lut_biases : fp32 [N][K/act_group_size] */

@@ -10,7 +10,7 @@ The package directory is ``tmac_amd/``; ``t-mac_amd`` at the repo root is a syml
 """
 from .binding import (TMACHipError, KCfg, lib, lib_path, F32, F16, load_library, build_library)  # noqa: F401
 from .weights import preprocess_weights  # noqa: F401
-from .wrapper import TMACGeMMWrapper, Weights, Workspace, DecodeChain  # noqa: F401
+from .wrapper import TMACGeMMWrapper, Weights, Workspace, DecodeChain, Comm  # noqa: F401
 from . import convert, weights, sharding, binding  # noqa: F401
 
 __version__ = "0.1.0"

@@ -90,6 +90,11 @@ def load_library() -> C.CDLL:
         "tmac_hip_tune_save": ([C.c_char_p], i32),
         "tmac_hip_tune_load": ([C.c_char_p], i32),
         "tmac_hip_tune_clear": ([], i32),
+        "tmac_hip_comm_unique_id": ([vp], i32),
+        "tmac_hip_comm_init": ([C.POINTER(vp), vp, C.c_int, C.c_int], i32),
+        "tmac_hip_comm_allgather": ([vp, vp, vp, sz, vp], i32),
+        "tmac_hip_comm_destroy": ([vp], i32),
+        "tmac_hip_comm_last_error": ([], C.c_char_p),
         "tmac_hip_chain_begin": ([], i32),
         "tmac_hip_chain_end": ([C.POINTER(vp)], i32),
         "tmac_hip_chain_launch": ([vp, vp], i32),

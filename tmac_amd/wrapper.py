@@ -138,6 +138,45 @@ class Workspace:
             pass
 
 
+class Comm:
+    """The exchange step of the row-sharded multi-GPU path through the C-ABI (tmac_hip_comm_*: RCCL over xGMI, one process
+    per GPU).  ``Comm.unique_id()`` on rank 0, hand the 128 bytes to every rank, ``Comm(id, rank, world)`` on each."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * Comm.ID_BYTES)()
+        rc = B.lib().tmac_hip_comm_unique_id(buf)
+        if rc:
+            raise B.TMACHipError(rc, B.lib().tmac_hip_comm_last_error().decode())
+        return bytes(buf)
+
+    def __init__(self, uid: bytes, rank: int, world: int):
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        buf = (C.c_char * Comm.ID_BYTES).from_buffer_copy(uid)
+        rc = B.lib().tmac_hip_comm_init(C.byref(self._h), buf, rank, world)
+        if rc:
+            raise B.TMACHipError(rc, B.lib().tmac_hip_comm_last_error().decode())
+
+    def allgather(self, send, recv, nbytes_per_rank: int, stream=None) -> None:
+        rc = B.lib().tmac_hip_comm_allgather(self._h, _ptr(send), _ptr(recv), nbytes_per_rank, _stream(stream))
+        if rc:
+            raise B.TMACHipError(rc, B.lib().tmac_hip_comm_last_error().decode())
+
+    def destroy(self):
+        if self._h:
+            B.lib().tmac_hip_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class DecodeChain:
     """A recorded sequence of ``TMACGeMMWrapper.fused`` calls (N = 1) executed by ONE persistent kernel launch
     (tmac_hip_chain_*, include/tmac_hip.h).  Built by ``TMACGeMMWrapper.record_chain``."""

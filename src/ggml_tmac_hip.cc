@@ -1,0 +1,135 @@
+// ggml_tmac_hip.cc — device-resident ggml op-hook glue on top of libtmac_hip.so's C-ABI (include/ggml-tmac-hip.h).
+// Plain C++ (no HIP headers): it binds tmac_hip.h exactly as a llama.cpp fork would.  The only device memory it owns is a
+// staging pair (activations in, outputs out); weights live in tmac_hip_weights handles.
+#include "../include/ggml-tmac-hip.h"
+
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "../include/tmac_hip.h"
+
+namespace {
+
+// the HIP runtime calls the glue needs (device + pinned buffers, copies, a stream), resolved from the runtime that
+// libtmac_hip.so already brought into the process: the fork's build needs no hipcc and no HIP headers
+struct Hip {
+    int (*Malloc)(void**, size_t) = nullptr;
+    int (*Free)(void*) = nullptr;
+    int (*HostMalloc)(void**, size_t, unsigned) = nullptr;
+    int (*HostFree)(void*) = nullptr;
+    int (*MemcpyAsync)(void*, const void*, size_t, int, void*) = nullptr;
+    int (*StreamCreateWithFlags)(void**, unsigned) = nullptr;
+    int (*StreamSynchronize)(void*) = nullptr;
+} hip;
+bool g_ready = false;
+void* g_stream = nullptr;
+void *g_dx = nullptr, *g_dy = nullptr, *g_px = nullptr, *g_py = nullptr;
+size_t g_nx = 0, g_ny = 0;
+std::mutex g_mu;
+thread_local char g_err[256] = "";
+
+struct Handle {
+    tmac_hip_weights* w;
+    int M, K, bits;
+};
+
+int fail(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return -3; }
+
+bool load_hip() {
+    void* h = dlopen("libamdhip64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libamdhip64.so.7", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("libamdhip64.so.6", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return false;
+#define SYM(f, n) (*(void**)(&hip.f) = dlsym(h, n))
+    SYM(Malloc, "hipMalloc"); SYM(Free, "hipFree"); SYM(HostMalloc, "hipHostMalloc"); SYM(HostFree, "hipHostFree");
+    SYM(MemcpyAsync, "hipMemcpyAsync"); SYM(StreamCreateWithFlags, "hipStreamCreateWithFlags"); SYM(StreamSynchronize, "hipStreamSynchronize");
+#undef SYM
+    return hip.Malloc && hip.Free && hip.HostMalloc && hip.HostFree && hip.MemcpyAsync && hip.StreamCreateWithFlags && hip.StreamSynchronize;
+}
+
+int grow(void** dev, void** pin, size_t* have, size_t need) {
+    if (*have >= need) return 0;
+    if (g_stream) hip.StreamSynchronize(g_stream);
+    if (*dev) hip.Free(*dev);
+    if (*pin) hip.HostFree(*pin);
+    *dev = *pin = nullptr; *have = 0;
+    if (hip.Malloc(dev, need) != 0 || hip.HostMalloc(pin, need, 0) != 0) return fail("staging allocation failed");
+    *have = need;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" const char* ggml_tmac_hip_last_error(void) { return g_err[0] ? g_err : tmac_hip_last_error(); }
+
+extern "C" int ggml_tmac_hip_init(const char* kcfg_file, int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_err[0] = 0;
+    int rc = tmac_hip_init(device);
+    if (rc) return rc;
+    if ((rc = tmac_hip_load_kcfg(kcfg_file))) return rc;
+    if (!g_ready) {
+        if (!load_hip()) return fail("HIP runtime not found");
+        if (hip.StreamCreateWithFlags(&g_stream, 1 /* hipStreamNonBlocking */) != 0) return fail("stream creation failed");
+        g_ready = true;
+    }
+    return 0;
+}
+
+extern "C" int ggml_tmac_hip_can_mul_mat(const struct tmac_ggml_tensor* w, int bits) {
+    if (!w) return 0;
+    tmac_kcfg c;
+    return tmac_hip_get_kcfg((int)w->ne[1], (int)w->ne[0], 1, bits, &c) == 0;
+}
+
+extern "C" int ggml_tmac_hip_upload(struct tmac_ggml_tensor* w, int bits) {
+    if (!w || !w->data) return fail("null tensor");
+    g_err[0] = 0;
+    const int M = (int)w->ne[1], K = (int)w->ne[0];
+    tmac_kcfg c;
+    int rc = tmac_hip_get_kcfg(M, K, 1, bits, &c);
+    if (rc) return rc;
+    // blob = [M * K * bits / 8 bytes of weight tiles][scales_size fp32] (python/t_mac/model_utils.py:243-271)
+    const char* blob = (const char*)w->data;
+    const void* scales = blob + (size_t)M * K * bits / 8;
+    tmac_hip_weights* h = nullptr;
+    rc = tmac_hip_register_weights(&h, blob, scales, M, K, bits, &c, TMAC_F32, TMAC_F32, nullptr);
+    if (rc) return rc;
+    w->extra = new Handle{h, M, K, bits};
+    return 0;
+}
+
+extern "C" int ggml_tmac_hip_mul_mat(const struct tmac_ggml_tensor* w, const struct tmac_ggml_tensor* x, struct tmac_ggml_tensor* dst) {
+    if (!g_ready) return fail("ggml_tmac_hip_init has not been called");
+    if (!w || !w->extra || !x || !x->data || !dst || !dst->data) return fail("null tensor");
+    g_err[0] = 0;
+    std::lock_guard<std::mutex> lk(g_mu);
+    const Handle* h = (const Handle*)w->extra;
+    const int N = (int)x->ne[1];
+    if (x->ne[0] != h->K || dst->ne[0] != h->M || dst->ne[1] != N) return fail("shape mismatch");
+    const size_t bx = sizeof(float) * (size_t)N * h->K, by = sizeof(float) * (size_t)N * h->M;
+    int rc;
+    if ((rc = grow(&g_dx, &g_px, &g_nx, bx)) || (rc = grow(&g_dy, &g_py, &g_ny, by))) return rc;
+    memcpy(g_px, x->data, bx);
+    if (hip.MemcpyAsync(g_dx, g_px, bx, 1 /* H2D */, g_stream) != 0) return fail("H2D copy failed");
+    const tmac_hip_weights* wl[1] = {h->w};
+    void* cl[1] = {g_dy};
+    if ((rc = tmac_hip_qgemm_fused_dev(wl, 1, g_dx, TMAC_F32, cl, TMAC_F32, N, g_stream))) return rc;   // LUT build + mpGEMM, one launch at N = 1
+    if (hip.MemcpyAsync(g_py, g_dy, by, 2 /* D2H */, g_stream) != 0) return fail("D2H copy failed");
+    if (hip.StreamSynchronize(g_stream) != 0) return fail("stream synchronisation failed");
+    memcpy(dst->data, g_py, by);
+    return 0;
+}
+
+extern "C" void ggml_tmac_hip_free(struct tmac_ggml_tensor* w) {
+    if (!w || !w->extra) return;
+    Handle* h = (Handle*)w->extra;
+    if (g_stream) hip.StreamSynchronize(g_stream);
+    tmac_hip_free_weights(h->w);
+    delete h;
+    w->extra = nullptr;
+}

@@ -14,6 +14,7 @@
 #include <fstream>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -1241,46 +1242,103 @@ struct TileKey {
 struct HostRun {
     tmac_hip_weights* w = nullptr;   // the run registered as one matrix
     int ntile = 0, Mw_tile = 0;
-    std::vector<float> C;            // [ntile * Mw_tile] outputs for LUT generation `gen`
+    float* C = nullptr;              // pinned host memory: [n][ntile * Mw_tile] outputs for LUT generation `gen`
+    size_t C_elems = 0;
     unsigned long long gen = 0;
+    unsigned long long used = 0;     // LRU stamp
+    size_t dev_bytes = 0;
 };
 struct TileInfo {
     tmac_hip_weights* w = nullptr;   // the tile alone (first pass; released when a run takes over)
     const void* S = nullptr;         // its scale pointer
     HostRun* run = nullptr;
     int idx = 0;                     // tile index inside the run
+    uint64_t sample = 0;             // hash of sampled weight + scale bytes at registration: a reused pointer with other
+                                     // contents (model reload, in-place edit) is detected instead of served stale
+    size_t a_bytes = 0, s_bytes = 0;
 };
 static std::map<TileKey, TileInfo> g_tiles;
 static std::vector<HostRun*> g_runs;
 static tmac_hip_workspace* g_ws = nullptr;
 static void* g_hostC = nullptr;  // device staging for C / B
 static size_t g_hostC_bytes = 0;
+static void* g_pin = nullptr;    // pinned host staging (activations in, LUT out)
+static size_t g_pin_bytes = 0;
+static hipStream_t g_hstream = nullptr;   // the host-pointer layer's own stream: async copies + launches, one sync per entry point
+static std::shared_mutex g_host_mu;       // tile calls served from a computed run take it shared; everything else exclusive
+static unsigned long long g_use_clock = 0;
+static size_t g_cache_dev_bytes = 0, g_cache_cap_bytes = 0;
 // host copy of the LUT (qlut | lut_scales | lut_biases) that g_ws currently holds, and its generation
 static std::vector<unsigned char> g_lut_host;
 static int g_lut_k = 0, g_lut_n = 0, g_lut_ags = 0;
 static unsigned long long g_lut_gen = 0;
+static const void *g_lut_q = nullptr, *g_lut_ls = nullptr, *g_lut_lb = nullptr;   // the caller's buffers the host copy was taken from
 static int g_host_runs = 1;      // A/B knob (tmac_hip_debug_host_runs)
 
+static uint64_t fnv64(const void* p, size_t n, uint64_t h = 1469598103934665603ull) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+// 4 x 32 bytes of the weight tile and 2 x 32 bytes of its scales
+static uint64_t tile_sample(const void* A, size_t a_bytes, const void* S, size_t s_bytes) {
+    uint64_t h = 1469598103934665603ull;
+    const size_t n = a_bytes < 32 ? a_bytes : 32;
+    for (int i = 0; i < 4; ++i) h = fnv64((const char*)A + (a_bytes - n) * i / 3, n, h);
+    if (S && s_bytes) {
+        const size_t m = s_bytes < 32 ? s_bytes : 32;
+        h = fnv64(S, m, h);
+        h = fnv64((const char*)S + s_bytes - m, m, h);
+    }
+    return h;
+}
+
+static int32_t host_stream() {
+    if (g_hstream) return TMAC_HIP_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&g_hstream, hipStreamNonBlocking));
+    if (const char* e = getenv("TMAC_HIP_HOST_CACHE_MB")) g_cache_cap_bytes = (size_t)atoll(e) << 20;
+    if (!g_cache_cap_bytes) g_cache_cap_bytes = (size_t)64 << 30;      // weights cached on the device for host-pointer callers: 64 GB by default
+    return TMAC_HIP_OK;
+}
 static int32_t host_ws(int K, int N) {
     if (g_ws && g_ws->maxK >= K && g_ws->maxN >= N) return TMAC_HIP_OK;
-    if (g_ws) tmac_hip_workspace_free(g_ws);
+    if (g_ws) { if (g_hstream) (void)hipStreamSynchronize(g_hstream); tmac_hip_workspace_free(g_ws); }
     g_ws = nullptr;
     g_lut_k = 0;                 // a new workspace holds no LUT
     return tmac_hip_workspace_create(&g_ws, K, N);
 }
 static int32_t host_stage(size_t bytes) {
     if (g_hostC_bytes >= bytes) return TMAC_HIP_OK;
+    if (g_hstream) (void)hipStreamSynchronize(g_hstream);
     if (g_hostC) (void)hipFree(g_hostC);
     g_hostC = nullptr; g_hostC_bytes = 0;
     HIP_TRY(hipMalloc(&g_hostC, bytes));
     g_hostC_bytes = bytes;
     return TMAC_HIP_OK;
 }
+static int32_t host_pin(size_t bytes) {
+    if (g_pin_bytes >= bytes) return TMAC_HIP_OK;
+    if (g_hstream) (void)hipStreamSynchronize(g_hstream);
+    if (g_pin) (void)hipHostFree(g_pin);
+    g_pin = nullptr; g_pin_bytes = 0;
+    HIP_TRY(hipHostMalloc(&g_pin, bytes, hipHostMallocDefault));
+    g_pin_bytes = bytes;
+    return TMAC_HIP_OK;
+}
 
+// Is the LUT the caller passes the one the workspace holds?  Same buffers as at the last full comparison and a matching
+// sample: yes (llama.cpp builds the LUT once per matmul and passes it to every tile call).  Otherwise compare in full.
+static bool lut_sample_ok(const void* q, size_t nq) {
+    const size_t n = nq < 64 ? nq : 64;
+    return memcmp(g_lut_host.data(), q, n) == 0 && memcmp(g_lut_host.data() + (nq - n) / 2, (const char*)q + (nq - n) / 2, n) == 0 &&
+           memcmp(g_lut_host.data() + nq - n, (const char*)q + nq - n, n) == 0;
+}
 static bool lut_is_current(const void* q, const void* ls, const void* lb, int k, int n, int ags) {
     if (g_lut_k != k || g_lut_n != n || g_lut_ags != ags) return false;
     const size_t nq = (size_t)n * (k / 4) * 16, ns = sizeof(float) * (size_t)n * (k / ags);
     if (g_lut_host.size() != nq + 2 * ns) return false;
+    if (q == g_lut_q && ls == g_lut_ls && lb == g_lut_lb)
+        return lut_sample_ok(q, nq) && memcmp(g_lut_host.data() + nq, ls, ns) == 0 && memcmp(g_lut_host.data() + nq + ns, lb, ns) == 0;
     return memcmp(g_lut_host.data(), q, nq) == 0 && memcmp(g_lut_host.data() + nq, ls, ns) == 0 &&
            memcmp(g_lut_host.data() + nq + ns, lb, ns) == 0;
 }
@@ -1291,6 +1349,7 @@ static void lut_remember(const void* q, const void* ls, const void* lb, int k, i
     memcpy(g_lut_host.data() + nq, ls, ns);
     memcpy(g_lut_host.data() + nq + ns, lb, ns);
     g_lut_k = k; g_lut_n = n; g_lut_ags = ags;
+    g_lut_q = q; g_lut_ls = ls; g_lut_lb = lb;
     ++g_lut_gen;
 }
 
@@ -1316,12 +1375,38 @@ static bool find_cfg(int k, int n, int b, int bm_filter, int m_filter, tmac_kcfg
     return false;
 }
 
+static void free_run(HostRun* r) {
+    if (r->w) tmac_hip_free_weights(r->w);
+    if (r->C) (void)hipHostFree(r->C);
+    g_cache_dev_bytes -= r->dev_bytes < g_cache_dev_bytes ? r->dev_bytes : g_cache_dev_bytes;
+    delete r;
+}
+// drop one run (or one lone tile) and every tile entry that points into it
+static void evict_run(HostRun* r) {
+    for (auto it = g_tiles.begin(); it != g_tiles.end();) it = (it->second.run == r) ? g_tiles.erase(it) : std::next(it);
+    for (size_t i = 0; i < g_runs.size(); ++i) if (g_runs[i] == r) { g_runs.erase(g_runs.begin() + i); break; }
+    free_run(r);
+}
+// least recently used runs go first when the device-side cache of host-pointer weights outgrows its cap
+static void evict_to_cap(const HostRun* keep) {
+    while (g_cache_dev_bytes > g_cache_cap_bytes && !g_runs.empty()) {
+        HostRun* lru = nullptr;
+        for (HostRun* r : g_runs) if (r != keep && (!lru || r->used < lru->used)) lru = r;
+        if (!lru) break;
+        if (g_hstream) (void)hipStreamSynchronize(g_hstream);
+        evict_run(lru);
+    }
+}
+
 extern "C" int32_t tmac_hip_cache_clear(void) {
+    std::unique_lock<std::shared_mutex> hl(g_host_mu);
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_hstream) (void)hipStreamSynchronize(g_hstream);
     for (auto& kv : g_tiles) if (kv.second.w) tmac_hip_free_weights(kv.second.w);
     g_tiles.clear();
-    for (HostRun* r : g_runs) { tmac_hip_free_weights(r->w); delete r; }
+    for (HostRun* r : g_runs) free_run(r);
     g_runs.clear();
+    g_cache_dev_bytes = 0;
     for (auto& kv : g_fused_ws) {
         (void)hipStreamSynchronize(kv.first);      // launches in flight may still read the LUT workspace
         tmac_hip_workspace_free(kv.second);
@@ -1339,6 +1424,7 @@ extern "C" int32_t tmac_hip_debug_host_runs(int on) {
 
 extern "C" int32_t preprocessor_int8(int m, int k, int n, int b, void* B, void* LUT_Scales, void* LUT_Biases, void* QLUT) {
     if (!B || !LUT_Scales || !LUT_Biases || !QLUT) return fail(TMAC_HIP_E_ARG, "null argument");
+    std::unique_lock<std::shared_mutex> hl(g_host_mu);
     std::lock_guard<std::mutex> lk(g_mu);
     tmac_kcfg cfg;
     // `m` is only a dispatch key in the reference too (qgemm.py:518-519)
@@ -1346,13 +1432,26 @@ extern "C" int32_t preprocessor_int8(int m, int k, int n, int b, void* B, void* 
         return fail(TMAC_HIP_E_NOMATCH, "preprocessor_int8: no kcfg for m=%d k=%d n=%d b=%d", m, k, n, b);
     int32_t rc = ensure_device();
     if (rc) return rc;
+    if ((rc = host_stream())) return rc;
     if ((rc = host_ws(k, n))) return rc;
-    if ((rc = host_stage(sizeof(float) * (size_t)n * k))) return rc;
     const int ags = cfg.act_group_size;
+    const size_t nb = sizeof(float) * (size_t)n * k, nq = (size_t)n * (k / 4) * 16, ns = sizeof(float) * (size_t)n * (k / ags);
+    if ((rc = host_stage(nb))) return rc;
+    if ((rc = host_pin(nb + nq + 2 * ns))) return rc;
     g_lut_k = 0;     // the workspace is about to change
-    HIP_TRY(hipMemcpy(g_hostC, B, sizeof(float) * (size_t)n * k, hipMemcpyHostToDevice));
-    if ((rc = tmac_hip_preprocessor_dev(g_ws, g_hostC, TMAC_F32, k, n, ags, nullptr))) return rc;
-    if ((rc = tmac_hip_workspace_read(g_ws, (int8_t*)QLUT, (float*)LUT_Scales, (float*)LUT_Biases, k, n, ags, nullptr))) return rc;
+    // pinned staging, everything asynchronous on the layer's own stream, ONE synchronisation:
+    // activations up, LUT build, LUT (the caller owns it: tmac_gemm_wrapper.h:170-195) back down
+    char* pin = (char*)g_pin;
+    memcpy(pin, B, nb);
+    HIP_TRY(hipMemcpyAsync(g_hostC, pin, nb, hipMemcpyHostToDevice, g_hstream));
+    if ((rc = tmac_hip_preprocessor_dev(g_ws, g_hostC, TMAC_F32, k, n, ags, g_hstream))) return rc;
+    HIP_TRY(hipMemcpyAsync(pin + nb, g_ws->qlut_ref, nq, hipMemcpyDeviceToHost, g_hstream));
+    HIP_TRY(hipMemcpyAsync(pin + nb + nq, g_ws->lut_scales, ns, hipMemcpyDeviceToHost, g_hstream));
+    HIP_TRY(hipMemcpyAsync(pin + nb + nq + ns, g_ws->lut_biases, ns, hipMemcpyDeviceToHost, g_hstream));
+    HIP_TRY(hipStreamSynchronize(g_hstream));
+    memcpy(QLUT, pin + nb, nq);
+    memcpy(LUT_Scales, pin + nb + nq, ns);
+    memcpy(LUT_Biases, pin + nb + nq + ns, ns);
     // the LUT the caller now holds is the one in the workspace: the qgemm calls that follow need not upload it again
     lut_remember(QLUT, LUT_Scales, LUT_Biases, k, n, ags);
     return TMAC_HIP_OK;
@@ -1381,74 +1480,123 @@ static HostRun* build_run(const TileKey& key, const tmac_kcfg& cfg, int Mw_tile,
         return nullptr;     // e.g. out of device memory: the tiles keep serving themselves
     HostRun* r = new HostRun();
     r->w = w; r->ntile = n; r->Mw_tile = Mw_tile;
+    r->dev_bytes = w->w_bytes + w->sc_bytes;
+    g_cache_dev_bytes += r->dev_bytes;
     g_runs.push_back(r);
     TileKey kk = first->first;
     for (int i = 0; i < n; ++i) {
         TileInfo& ti = g_tiles[kk];
-        tmac_hip_free_weights(ti.w);
+        if (ti.w) { g_cache_dev_bytes -= ti.w->w_bytes + ti.w->sc_bytes; tmac_hip_free_weights(ti.w); }
         ti.w = nullptr; ti.run = r; ti.idx = i;
         kk.A = (const char*)kk.A + a_bytes;
     }
     return r;
 }
 
+// copy one tile's rows out of a run's host result
+static void serve_from_run(const HostRun* r, const TileInfo& ti, int n, int Mw_tile, void* C) {
+    const size_t Mw_run = (size_t)r->ntile * Mw_tile;
+    for (int i = 0; i < n; ++i)   // C tile is [n][Mw_tile] (kernels.cc:1068: C + n * bm/bits)
+        memcpy((float*)C + (size_t)i * Mw_tile, r->C + (size_t)i * Mw_run + (size_t)ti.idx * Mw_tile, sizeof(float) * Mw_tile);
+}
+
 extern "C" int32_t qgemm_lut_int8(int m, int k, int n, int b, void* A, void* LUT, void* Scales, void* LUT_Scales,
                                   void* LUT_Biases, void* C) {
     if (!A || !LUT || !Scales || !LUT_Scales || !LUT_Biases || !C) return fail(TMAC_HIP_E_ARG, "null argument");
+    const int Mw_tile = m / b;
+    const TileKey key{A, m, k, b};
+    {
+        // Fast path, shared lock: the tile belongs to a run whose output for THIS LUT is already on the host.  This is what
+        // llama.cpp's worker threads hit concurrently, one tile each (tmac_gemm_wrapper.h:197-199): they copy their rows out
+        // side by side instead of queueing on one mutex.
+        std::shared_lock<std::shared_mutex> sl(g_host_mu);
+        auto it = g_tiles.find(key);
+        if (it != g_tiles.end() && it->second.run && it->second.S == Scales) {
+            const TileInfo& ti = it->second;
+            const HostRun* r = ti.run;
+            if (r->gen == g_lut_gen && r->C && r->C_elems == (size_t)n * r->ntile * Mw_tile && LUT == g_lut_q && LUT_Scales == g_lut_ls &&
+                LUT_Biases == g_lut_lb && g_lut_k == k && g_lut_n == n && lut_sample_ok(LUT, (size_t)n * (k / 4) * 16) &&
+                tile_sample(A, ti.a_bytes, Scales, ti.s_bytes) == ti.sample) {
+                serve_from_run(r, ti, n, Mw_tile, C);
+                return TMAC_HIP_OK;
+            }
+        }
+    }
+    std::unique_lock<std::shared_mutex> hl(g_host_mu);
     std::lock_guard<std::mutex> lk(g_mu);
     tmac_kcfg cfg;
     if (!find_cfg(k, n, b, m, 0, &cfg)) return fail(TMAC_HIP_E_NOMATCH, "qgemm_lut_int8: no kcfg with bm=%d k=%d n=%d b=%d", m, k, n, b);
     int32_t rc = ensure_device();
     if (rc) return rc;
-    const int Mw_tile = m / b;
-    TileKey key{A, m, k, b};
+    if ((rc = host_stream())) return rc;
+    tmac_kcfg tc = cfg;
+    if (tc.m_groups >= 1) tc.m_groups = 1;  // a tile sees one unified scale
+    Shape tshape;
+    if ((rc = make_shape(tshape, Mw_tile, k, b, &tc))) return rc;
+    const size_t a_bytes = ref_weight_bytes(tshape), s_bytes = ref_scale_elems(tshape) * sizeof(float);
+    const uint64_t sample = tile_sample(A, a_bytes, Scales, s_bytes);
     auto it = g_tiles.find(key);
+    if (it != g_tiles.end() && (it->second.S != Scales || it->second.sample != sample)) {
+        // the pointer is known but its contents (or its scales) are not what was registered: a model was reloaded at the
+        // same addresses, or edited in place.  Drop what was cached for it and register afresh.
+        if (g_hstream) (void)hipStreamSynchronize(g_hstream);
+        if (it->second.run) evict_run(it->second.run);
+        else {
+            if (it->second.w) { g_cache_dev_bytes -= it->second.w->w_bytes + it->second.w->sc_bytes; tmac_hip_free_weights(it->second.w); }
+            g_tiles.erase(it);
+        }
+        it = g_tiles.end();
+    }
     const bool known = it != g_tiles.end();
     if (!known) {
-        tmac_kcfg tc = cfg;
-        if (tc.m_groups >= 1) tc.m_groups = 1;  // a tile sees one unified scale
         TileInfo ti;
         if ((rc = register_impl(&ti.w, A, Scales, false, Mw_tile, k, b, &tc, TMAC_F32, TMAC_F32, nullptr))) return rc;
-        ti.S = Scales;
+        ti.S = Scales; ti.sample = sample; ti.a_bytes = a_bytes; ti.s_bytes = s_bytes;
+        g_cache_dev_bytes += ti.w->w_bytes + ti.w->sc_bytes;
         it = g_tiles.insert(std::make_pair(key, ti)).first;
-    } else if (it->second.S != Scales) {
-        return fail(TMAC_HIP_E_ARG, "qgemm_lut_int8: tile %p was registered with other scales (tiles are cached by pointer; "
-                                    "tmac_hip_cache_clear() after changing weights)", A);
     }
     if ((rc = host_ws(k, n))) return rc;
     if (!lut_is_current(LUT, LUT_Scales, LUT_Biases, k, n, cfg.act_group_size)) {
         g_lut_k = 0;
         if ((rc = tmac_hip_workspace_write(g_ws, (const int8_t*)LUT, (const float*)LUT_Scales, (const float*)LUT_Biases, k, n,
-                                           cfg.act_group_size, nullptr)))
+                                           cfg.act_group_size, g_hstream)))
             return rc;
         lut_remember(LUT, LUT_Scales, LUT_Biases, k, n, cfg.act_group_size);
     }
     TileInfo& ti = it->second;
     // a tile that comes back (second GEMV on its matrix) with registered neighbours: group the run
-    if (g_host_runs && known && !ti.run && ti.w) {
-        const Shape& ts = ti.w->s;
-        const size_t s_bytes = ts.m_groups >= 1 ? 0 : ref_scale_elems(ts) * sizeof(float);
-        build_run(key, cfg, Mw_tile, ref_weight_bytes(ts), s_bytes);
-    }
+    if (g_host_runs && known && !ti.run && ti.w) build_run(key, cfg, Mw_tile, a_bytes, s_bytes);
     if (ti.run) {
         HostRun* r = ti.run;
-        const size_t Mw_run = (size_t)r->ntile * Mw_tile;
-        if (r->gen != g_lut_gen || r->C.size() != (size_t)n * Mw_run) {
-            r->C.resize((size_t)n * Mw_run);
-            const size_t bytes = sizeof(float) * r->C.size();
+        r->used = ++g_use_clock;
+        const size_t Mw_run = (size_t)r->ntile * Mw_tile, elems = (size_t)n * Mw_run;
+        if (r->gen != g_lut_gen || r->C_elems != elems) {
+            if (r->C_elems != elems) {
+                if (r->C) (void)hipHostFree(r->C);
+                r->C = nullptr; r->C_elems = 0;
+                HIP_TRY(hipHostMalloc((void**)&r->C, sizeof(float) * elems, hipHostMallocDefault));
+                r->C_elems = elems;
+            }
+            const size_t bytes = sizeof(float) * elems;
             if ((rc = host_stage(bytes))) return rc;
-            if ((rc = qgemm_impl(r->w, g_ws, g_hostC, TMAC_F32, n, nullptr, nullptr))) return rc;
-            HIP_TRY(hipMemcpy(r->C.data(), g_hostC, bytes, hipMemcpyDeviceToHost));
+            // the whole run in one launch, its output straight into the run's pinned host buffer, one synchronisation
+            if ((rc = qgemm_impl(r->w, g_ws, g_hostC, TMAC_F32, n, nullptr, g_hstream))) return rc;
+            HIP_TRY(hipMemcpyAsync(r->C, g_hostC, bytes, hipMemcpyDeviceToHost, g_hstream));
+            HIP_TRY(hipStreamSynchronize(g_hstream));
             r->gen = g_lut_gen;
         }
-        for (int i = 0; i < n; ++i)   // C tile is [n][Mw_tile] (kernels.cc:1068: C + n * bm/bits)
-            memcpy((float*)C + (size_t)i * Mw_tile, r->C.data() + (size_t)i * Mw_run + (size_t)ti.idx * Mw_tile, sizeof(float) * Mw_tile);
+        serve_from_run(r, ti, n, Mw_tile, C);
+        evict_to_cap(r);
         return TMAC_HIP_OK;
     }
     tmac_hip_weights* w = ti.w;
-    if ((rc = host_stage(sizeof(float) * (size_t)n * Mw_tile))) return rc;
-    if ((rc = qgemm_impl(w, g_ws, g_hostC, TMAC_F32, n, nullptr, nullptr))) return rc;
-    HIP_TRY(hipMemcpy(C, g_hostC, sizeof(float) * (size_t)n * Mw_tile, hipMemcpyDeviceToHost));
+    const size_t cb = sizeof(float) * (size_t)n * Mw_tile;
+    if ((rc = host_stage(cb))) return rc;
+    if ((rc = host_pin(cb))) return rc;
+    if ((rc = qgemm_impl(w, g_ws, g_hostC, TMAC_F32, n, nullptr, g_hstream))) return rc;
+    HIP_TRY(hipMemcpyAsync(g_pin, g_hostC, cb, hipMemcpyDeviceToHost, g_hstream));
+    HIP_TRY(hipStreamSynchronize(g_hstream));
+    memcpy(C, g_pin, cb);
     return TMAC_HIP_OK;
 }
 

@@ -51,6 +51,24 @@ int main(int argc, char** argv) {
         worst = std::fmax(worst, err / mx);
         printf("pass %d: %.1f us per GEMV (preprocessor + %d tile calls from %d threads), max rel err %.3g\n", pass, last_us, ntile, nth, err / mx);
     }
+    {   // steady-state cost of the route from one caller thread (no thread start-up in the timing): 50 GEMVs, new activations each
+        float* xf = (float*)xb.data();
+        auto t0 = std::chrono::steady_clock::now();
+        for (int rep = 0; rep < 50; ++rep) {
+            xf[rep % K] += 0.25f;
+            wr.llama_cpp_init(xb.data(), qlut.data(), ls.data(), lb.data(), Mw, K, 1, bits);
+            for (int i = 0; i < ntile; ++i)
+                wr.llama_cpp_compute(A.data() + (size_t)i * a_tile, (float*)S.data() + (size_t)i * s_tile, qlut.data(), ls.data(), lb.data(),
+                                     C.data() + (size_t)i * rows, rows, K, 1, bits);
+        }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 50;
+        printf("TIMING %.1f us per GEMV from one thread (preprocessor call + %d tile calls, host pointers, PCIe both ways)\n", us, ntile);
+        for (int rep = 0; rep < 50; ++rep) xf[rep % K] -= 0.25f;
+        wr.llama_cpp_init(xb.data(), qlut.data(), ls.data(), lb.data(), Mw, K, 1, bits);
+        for (int i = 0; i < ntile; ++i)
+            wr.llama_cpp_compute(A.data() + (size_t)i * a_tile, (float*)S.data() + (size_t)i * s_tile, qlut.data(), ls.data(), lb.data(),
+                                 C.data() + (size_t)i * rows, rows, K, 1, bits);
+    }
     // a model "reloaded" at the same addresses: other weight bytes behind the same pointers must not be served from the cache
     for (size_t i = 0; i < A.size(); i += 97) A[i] = (char)(A[i] ^ 0x5a);
     std::vector<float> C2(Mw, -1.0f);

@@ -127,6 +127,8 @@ int main(int argc, char** argv) {
 // ---- instruction-rate probes (v_perm_b32, v_mqsad_pk_u16_u8, sdwa byte add) --------------------------
 template <int WHICH>
 __global__ void k_rate(uint32_t* out, int iters) {
+    __shared__ unsigned char lut[2048];
+    if (WHICH == 5) { for (int i = threadIdx.x; i < 2048; i += blockDim.x) lut[i] = (unsigned char)(i * 37 + 11); __syncthreads(); }
     uint32_t a = threadIdx.x * 2654435761u, b = a ^ 0x9e3779b9u, c = a + 7, d = b + 11;
     unsigned long long q0 = a, q1 = b, q2 = c, q3 = d;
     for (int i = 0; i < iters; ++i) {
@@ -140,8 +142,13 @@ __global__ void k_rate(uint32_t* out, int iters) {
                 q2 = __builtin_amdgcn_mqsad_pk_u16_u8(q3, 0xffu, q2); q3 = __builtin_amdgcn_mqsad_pk_u16_u8(q0, 0xffu, q3);
             } else if (WHICH == 2) {  // 4 independent v_add_u32 (baseline)
                 a += b; b += c; c += d; d += a;
-            } else {                  // byte-select adds (sdwa)
+            } else if (WHICH == 3) {  // byte-select adds (sdwa)
                 a += (b >> 8) & 0xff; b += (c >> 16) & 0xff; c += d >> 24; d += a & 0xff;
+            } else if (WHICH == 4) {  // 4 independent ds_bpermute_b32 chains: one dword from a data-dependent lane per instruction
+                a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a & 0xfcu), (int)b); b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(b & 0xfcu), (int)c);
+                c = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c & 0xfcu), (int)d); d = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(d & 0xfcu), (int)a);
+            } else {                  // 4 independent LDS byte gathers (ds_read_u8 at a data-dependent address in a 2 KB table)
+                a = lut[a & 2047]; b = lut[(b + a) & 2047]; c = lut[(c + b) & 2047]; d = lut[(d + c) & 2047];
             }
         }
     }
@@ -169,5 +176,9 @@ int rate_main() {
     rate<0>("v_perm_b32", out);
     rate<1>("v_mqsad_pk_u16_u8", out);
     rate<3>("v_add_u32_sdwa (byte)", out);
+    rate<4>("ds_bpermute_b32", out);
+    rate<5>("ds_read_u8 (LDS gather)", out);
+    printf("lookups per wave-instruction: v_perm_b32 on a half table 4 (x64 lanes) at 11 VALU per 8 lookups incl. index and sign handling; "
+           "ds_bpermute_b32 1 (a dword from one lane); ds_read_u8 1\n");
     return 0;
 }

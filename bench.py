@@ -40,7 +40,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
-MFMA_I8_PEAK_TOPS = 3944.0   # MI355X_MICROARCH.md: v_mfma_i32_16x16x64_i8 microbenchmark ceiling (the instruction k_gemm_onehot issues)
+MFMA_I8_PEAK_TOPS = 4404.0   # MI355X_MICROARCH.md: v_mfma_i32_32x32x32_i8 microbenchmark ceiling (the instruction k_gemm_planes issues; 16x16x64: 3944)
 KF = 16
 
 LLAMA = [("qkv", 4096, 4096, 3, 0), ("o", 4096, 4096, 1, 1), ("gate_up", 11008, 4096, 2, 2), ("down", 4096, 11008, 1, 3)]
@@ -211,7 +211,7 @@ def main():
         tiles_per_rank = (ntiles + world - 1) // world          # ragged split -> padded with extra synthetic rows
         shard_rows[name] = tiles_per_rank * rpt
         bytes_per_step += cnt * algorithmic_bytes(Mw, K, BITS, GS, ags_of(K), ZP, MG, N)
-        ops_per_step += cnt * 2.0 * (Mw * BITS) * (K / 4 * 8) * N        # int8 MFMA work the one-hot GEMM issues (8-entry half tables)
+        ops_per_step += cnt * 2.0 * Mw * (K / 4 * 8) * N        # int8 MFMA work k_gemm_planes issues: one operand row per OUTPUT row (planes combined), 8-entry half tables
     bytes_per_step *= args.layers
     ops_per_step *= args.layers
     lvl = (2 ** BITS - 1) / 2.0 - 2 ** (BITS - 1)                # mean weight level minus the offset 2^(b-1)
@@ -305,9 +305,9 @@ def main():
         torch.cuda.synchronize()
 
     # ---- launch mechanism ---------------------------------------------------------------------------------------------
-    # (prefill launches are 50+ us each: replaying them from a graph buys nothing, and the fused entry point's per-stream LUT
-    # workspace must not be allocated inside a capture)
-    use_graph = (not args.no_graph) and not (dist_on and args.eager_collectives) and args.path != "chain" and decode
+    # (the fused entry point's per-stream LUT workspace for N > 1 must not be allocated inside a capture: the warm-up step and
+    # the capture below run on the same side stream, so the workspace exists and has its final size when capture starts)
+    use_graph = (not args.no_graph) and not (dist_on and args.eager_collectives) and args.path != "chain"
     graph, chain, stamp_buf = None, None, None
     if args.path == "chain":
         # record the token's calls once (they are not launched while recording); one launch per step from here on
@@ -336,10 +336,10 @@ def main():
                 # capture mode such a query from another thread invalidates the capture and kills the process.  Let it reap
                 # what has completed, then capture in thread-local mode, where only this thread's calls are policed.
                 time.sleep(1.0)
-                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                     step()
             else:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, stream=side):
                     step()
         except Exception as e:   # capture not supported with this RCCL / torch build: measured eagerly instead
             if not dist_on:
@@ -400,7 +400,7 @@ def main():
 
     # ---- roofline of the dominant kernel ------------------------------------------------------------------------------
     traffic, traffic_src = None, None
-    kkey = {"chain": "k_decode_chain", "fused": "k_gemv_quad_headline", "split": "k_gemv_quad_headline"}[args.path] if decode else "k_gemm_onehot"
+    kkey = {"chain": "k_decode_chain", "fused": "k_gemv_quad_headline", "split": "k_gemv_quad_headline"}[args.path] if decode else "k_gemm_planes"
     try:    # HBM bytes per launch of that kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ent = json.load(f).get(args.workload, {}).get(kkey)
@@ -411,8 +411,8 @@ def main():
     roof = None
     if not decode:
         ach = ops_per_step / world / (ev_ms_per_step * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "k_gemm_onehot (one-hot int8 MFMA GEMM; LUT build kernels included in the time)",
-                "achieved": round(ach, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8 MFMA work issued: 2 x bit-plane rows x 8-entry half tables x N)",
+        roof = {"bound": "mfma", "kernel": "k_gemm_planes (plane-combined one-hot int8 MFMA GEMM; LUT build kernels included in the time)",
+                "achieved": round(ach, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8 MFMA work issued: 2 x output rows x (K/4 tables x 8 half-table entries) x N)",
                 "frac": round(ach / MFMA_I8_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "ops_per_step": ops_per_step, "timing": "hipEvent pair on the launch stream around the %d timed steps" % args.steps}
     elif args.path == "chain":

@@ -244,6 +244,18 @@ int32_t tmac_hip_debug_stream_read(const void* dev_src, size_t bytes, void* dev_
 int32_t tmac_hip_debug_quad_config(int force_threads, int force_waves_per_quad);
 int32_t tmac_hip_debug_stamps(unsigned long long* dev_buffer);
 int32_t tmac_hip_debug_pairs_min_n(int n);
+/* N > 1 kernel selection and parity taps.  0 (default): k_gemm_planes (bit-planes combined inside the matrix-core operand,
+ * tmac_gemm2.hip) wherever it covers the configuration (2- and 4-bit weights, per-group scales, act_group_size 64);
+ * 1: always k_gemm_onehot (one matrix-core row per bit-plane row; also the only one for unified-scale weights).
+ * tmac_hip_debug_gemm_comb_sums: int32 [N][Mw][K/64], the integers sum_p 2^p PS_p (PS_p as tmac_hip_qgemm_partial_sums
+ * returns them per bit-plane) that k_gemm_planes feeds into the fp32 chain; the workspace must hold the LUT of a
+ * tmac_hip_preprocessor_dev call with N >= 2 rows.  tmac_hip_debug_gemm_image_read: the LUT image that kernel streams,
+ * in plain layouts: signed half tables int8 [N][K/4][8] (entry j of table t; entry 15 - j is its negation,
+ * lut_ctor.cc:152-155), lut_scales, lut_biases and the sum of each act group's 128 half-table entries, fp32 [N][K/64]. */
+int32_t tmac_hip_debug_gemm_kernel(int which);
+int32_t tmac_hip_debug_gemm_comb_sums(const tmac_hip_weights* w, const tmac_hip_workspace* ws, int32_t* comb_host, int N, void* stream);
+int32_t tmac_hip_debug_gemm_image_read(const tmac_hip_workspace* ws, int8_t* half_tables_host, float* lut_scales_host,
+                                       float* lut_biases_host, float* entry_sums_host, int N, void* stream);
 /* host-pointer entry points: 1 (default) = tiles with contiguous weight / scale pointers are grouped into runs once they
  * have been seen, and a run's output is computed in one launch per LUT and handed out tile by tile; 0 = every tile call is
  * served on its own */

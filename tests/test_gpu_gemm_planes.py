@@ -1,0 +1,135 @@
+"""k_gemm_planes (tmac_gemm2.hip): qgemm_lut for N > 1 with the bit-planes combined inside the matrix-core operand.
+
+Bars: (a) the LUT image it streams (k_lut_image) bit-identical to the oracle's QLUT / lut_scales / lut_biases
+(lut_ctor.cc restated in oracle/tmac_oracle.c); (b) the integers it feeds into the fp32 chain, comb = sum_p 2^p PS_p,
+bit-identical to the oracle's per-plane partial sums (tbl.cc:445-462) combined as integers; (c) outputs within 1e-3 of
+max|C| of the oracle (fp32 chain regrouped: K split over 8 waves, zero-point term once per weight group) -- measured
+~1e-6; (d) the same outputs as k_gemm_onehot (the per-plane kernel, whose integer path is tapped plane by plane in
+test_gpu_parity.py).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tm():
+    import torch
+    import tmac_amd
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    assert tmac_amd.lib().tmac_hip_device_count() > 0
+    return tmac_amd
+
+
+def rel_err(c, ref):
+    return float(np.abs(c.astype(np.float64) - ref.astype(np.float64)).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def mrow(o, p, bits):
+    return (o // 8) * 8 * bits + p * 8 + (o % 8)
+
+
+def run(tm, case, Mw, K, bits, bm, gs, zp, N, scale_f16=False, act_f16=False, out_f16=False, kernel=0, want_comb=True):
+    import torch
+    L = tm.lib()
+    tm.binding.check(L.tmac_hip_set_gemm_min_n(1))
+    tm.binding.check(L.tmac_hip_debug_gemm_kernel(kernel))
+    try:
+        A = orc.preprocess_weights(case["w"], bits, bm, 16)
+        S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm)
+        cfg = tm.KCfg.make(Mw, K, bits, bm, 16, gs, 64, zp, -1, N)
+        wr = tm.TMACGeMMWrapper(act_group_size=64)
+        wr.set_workspace(K, N)
+        w = wr.register_weights(A, S, Mw, K, bits, cfg, scales_dtype=tm.F32, dev_dtype=tm.F16 if scale_f16 else tm.F32)
+        Bt = torch.from_numpy(case["B"]).cuda()
+        if act_f16:
+            Bt = Bt.half()
+        Ct = torch.full((N, Mw), float("nan"), dtype=torch.float16 if out_f16 else torch.float32, device="cuda")
+        wr.llama_cpp_init(Bt, Mw, K, N, bits)
+        wr.llama_cpp_compute(w, Ct, N)
+        torch.cuda.synchronize()
+        out = dict(C=Ct.float().cpu().numpy(), A=A, S=S)
+        if kernel == 0:
+            out["img"] = wr.workspace.read_gemm_image(K, N)
+            if want_comb:
+                out["comb"] = wr.comb_sums(w, N)
+        w.free()
+        return out
+    finally:
+        L.tmac_hip_debug_gemm_kernel(0)
+        L.tmac_hip_set_gemm_min_n(32)
+
+
+CASES = [
+    # Mw,   K,    bits, bm,  gs,  zp,    N
+    (128, 1024, 2, 128, 128, True, 64),
+    (128, 1024, 2, 128, 128, True, 2),       # two activation rows in a 64-row tile
+    (320, 3200, 2, 320, 128, True, 33),      # 25 weight groups over 8 waves: ragged K ranges; rows / tokens ragged
+    (512, 2048, 4, 256, 128, True, 16),
+    (256, 1024, 4, 256, 64, False, 130),     # group size 64 (one act group per weight group), three token blocks
+    (704, 1024, 2, 128, 128, False, 8),      # 11 row blocks: the last XCD round is partly empty
+    (64, 512, 2, 128, 256, True, 70),        # group size 256: 2 weight groups, six of the eight waves idle
+    (1088, 11008, 2, 128, 128, True, 40),    # K = 11008: 86 weight groups
+    (192, 4096, 4, 256, 128, True, 256),
+]
+
+
+@pytest.mark.parametrize("Mw,K,bits,bm,gs,zp,N", CASES)
+def test_gemm_planes(tm, Mw, K, bits, bm, gs, zp, N):
+    case = orc.make_case(9000 + N + K, Mw, K, N=N, bits=bits, gs=gs, ags=64, zero_point=zp)
+    r = run(tm, case, Mw, K, bits, bm, gs, zp, N)
+    q, ls, lb = orc.preprocessor(case["B"], 64)
+    # (a) the LUT image: entries 0..7 of every table, scales, biases bit for bit; the entry sums are what they say
+    h, gls, glb, hs = r["img"]
+    assert np.array_equal(h, q[:, :, :8])
+    assert np.array_equal(gls.view(np.uint32), ls.view(np.uint32)) and np.array_equal(glb.view(np.uint32), lb.view(np.uint32))
+    assert np.array_equal(hs, q[:, :, :8].astype(np.int32).reshape(N, K // 64, 128).sum(-1).astype(np.float32))
+    # (b) comb = sum_p 2^p PS_p
+    PS = np.stack([orc.partial_sums(r["A"], q[n], Mw, K, bits, bm, 16, 64) for n in range(N)])       # [N][M][G]
+    rows = np.arange(Mw)
+    comb = sum((PS[:, mrow(rows, p, bits), :].astype(np.int64) << p) for p in range(bits))
+    assert np.array_equal(r["comb"].astype(np.int64), comb)
+    # (c) outputs
+    Cc = orc.qgemm_float(r["A"], q, r["S"], ls, lb, Mw, K, N, bits, bm, 16, gs, 64, zp)
+    assert rel_err(r["C"], Cc) <= 1e-5
+    # (d) the per-plane kernel on the same inputs
+    r1 = run(tm, case, Mw, K, bits, bm, gs, zp, N, kernel=1)
+    assert rel_err(r["C"], r1["C"]) <= 1e-5
+
+
+@pytest.mark.parametrize("scale_f16,act_f16,out_f16", [(True, True, True), (True, False, False), (False, True, True)])
+def test_gemm_planes_dtypes(tm, scale_f16, act_f16, out_f16):
+    Mw, K, bits, bm, gs, N = 256, 2048, 2, 128, 128, 96
+    case = orc.make_case(77, Mw, K, N=N, bits=bits, gs=gs, ags=64, fp16_values=True)
+    r = run(tm, case, Mw, K, bits, bm, gs, True, N, scale_f16=scale_f16, act_f16=act_f16, out_f16=out_f16, want_comb=False)
+    q, ls, lb = orc.preprocessor(case["B"], 64)
+    Cc = orc.qgemm_float(r["A"], q, r["S"], ls, lb, Mw, K, N, bits, bm, 16, gs, 64, True)
+    assert rel_err(r["C"], Cc) <= (1e-3 if out_f16 else 1e-5)
+
+
+def test_gemm_planes_edge_activations(tm):
+    """all-zero act groups (scale 0), huge and tiny magnitudes, exact .5 ties: the LUT image equals the oracle's bit for
+    bit and the outputs stay finite where the oracle's are"""
+    Mw, K, bits, bm, gs, N = 128, 1024, 2, 128, 128, 12
+    case = orc.make_case(5, Mw, K, N=N, bits=bits, gs=gs, ags=64)
+    B = case["B"]
+    B[0, :64] = 0.0
+    B[1, :] = 0.0
+    B[2, 128:192] *= 1e20
+    B[3, 192:256] *= 1e-20
+    B[4, 256:320] = np.tile(np.array([0.5, 1.5, 2.5, 127.0], np.float32), 16)
+    r = run(tm, case, Mw, K, bits, bm, gs, True, N)
+    q, ls, lb = orc.preprocessor(case["B"], 64)
+    h, gls, glb, hs = r["img"]
+    assert np.array_equal(h, q[:, :, :8])
+    assert np.array_equal(gls.view(np.uint32), ls.view(np.uint32)) and np.array_equal(glb.view(np.uint32), lb.view(np.uint32))
+    Cc = orc.qgemm_float(r["A"], q, r["S"], ls, lb, Mw, K, N, bits, bm, 16, gs, 64, True)
+    finite = np.isfinite(Cc)
+    assert np.array_equal(np.isfinite(r["C"]), finite)
+    for n in range(N):
+        m = finite[n]
+        if m.any():
+            assert rel_err(r["C"][n][m], Cc[n][m]) <= 1e-5

@@ -1,0 +1,426 @@
+// tmac_gemm2.hip — k_gemm_planes: qgemm_lut for N > 1 activation rows (prefill), bit-planes combined inside the
+// matrix-core operand; k_lut_image: the LUT build that feeds it.
+//
+// The reference loops its GEMV micro-kernel over the activation rows (python/t_mac/ops/qgemm.py:183-190,228-231); per
+// (activation row n, output row o, act group kk) it needs the integer
+//     comb[n][o][kk] = sum_p 2^p * PS_p,   PS_p = sum_t QLUT[n][t][nibble_p(o, t)]      (tbl.cc:445-462, planes p)
+// and then the fp32 chain  C += ((comb / 2) * lut_scale + lut_bias / 2) * scale + zero * lut_bias   (tbl.cc:464-526).
+// k_gemm_onehot (tmac_gemm.hip) forms PS_p per bit-plane row as a product with a signed one-hot matrix.  Here the
+// planes are merged BEFORE the matrix core: the A operand byte of (o, table t, half-table entry e) is
+//     S[o][(t, e)] = sum_p 2^p * (+-1 if the recoded nibble of plane p selects entry e)        in {-3..3} (W2)
+// so one MFMA row is an OUTPUT row (not a bit-plane row): half the MFMA work for W2, a quarter for W4, and one fp32
+// chain per output instead of one conversion per plane.  comb is bit-identical to the per-plane sums combined as
+// integers (integer arithmetic, no rounding); a debug tap exposes it for the parity tests.
+//
+// Operand construction: in the QUAD layout byte beta of dword 2P (W2) holds the plane-0 and plane-1 nibbles of table 2P
+// for row 4q + beta: that byte is a JOINT index into a 256-entry table of 8-byte operand rows, kept in LDS in 32 copies
+// (copy = lane & 31, entry stride 256 B) so that a wave's ds_read_b64 gather never has a bank conflict.  W4 has two joint
+// bytes per table (planes 0/1 and 2/3): the entries carry a +3 bias per byte so that  row01 + (row23 << 2)  needs no
+// byte-wise carry handling; the bias (15 per operand byte) leaves with the sum of the table entries, which the LUT build
+// provides per (n, kk) and the epilogue folds into the int -> float conversion constant.
+//
+// v_mfma_i32_32x32x32_i8: one instruction = 32 output rows x 32 activation rows x 4 tables.  Wave tile 64 x 64 (2 x 2
+// MFMA tiles); a workgroup = 4 waves = one 64 x 64 output tile, the waves split K by weight groups and reduce through
+// LDS at the end (at N = 256 a llama-2-7B projection has only 256 such tiles; a 4 x larger workgroup tile would leave
+// three quarters of the chip idle).  Each wave is on its own: it streams its half-table chunks global -> LDS
+// (global_load_lds, no registers), its weights global -> registers, one act group ahead, with no workgroup barrier in
+// the main loop.  Roofline: int8 MFMA; ops = 2 * Mw * (K / 4 * 8) * N.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "tmac_quad_core.h"
+#include "tmac_kernels.h"
+
+namespace tmac {
+
+typedef int p4i_t __attribute__((ext_vector_type(4)));
+typedef int p16i_t __attribute__((ext_vector_type(16)));
+typedef float p2f_t __attribute__((ext_vector_type(2)));
+typedef float p4f_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// LUT build for the GEMM: the pair-wise build of k_preprocess_pairs (same arithmetic, lut_ctor.cc:120-215 bit for bit)
+// with 8 activation rows x 8 pairs per 64 lanes, written in the layout the GEMM streams:
+//   bimg [unit u][pair P][n] uint4   signed half tables of tables 2P, 2P+1 of unit u (32 activations) for row n
+//   colv [3][kk][n] float            lut_scales | lut_biases | sum of the act group's 128 half-table entries
+// n runs over Npad rows (rows >= N repeat row N-1: finite values, never stored).
+// ---------------------------------------------------------------------------------------------
+template <bool F16>
+__global__ __launch_bounds__(256) void k_lut_image(const void* __restrict__ B, uint4* __restrict__ bimg, float* __restrict__ colv,
+                                                   int K, int N, int Npad) {
+    const int G = K / 64, kk = blockIdx.y;
+    const int n = blockIdx.x * 32 + (threadIdx.x >> 3), p = threadIdx.x & 7;
+    const int nn = min(n, N - 1);
+    float x[8];
+    if (F16) {
+        const uint4 v = reinterpret_cast<const uint4*>(reinterpret_cast<const __half*>(B) + (size_t)nn * K + kk * 64)[p];
+        const uint32_t r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __half2 hh = *reinterpret_cast<const __half2*>(&r[i]);
+            x[2 * i] = __low2float(hh); x[2 * i + 1] = __high2float(hh);
+        }
+    } else {
+        const float4* src = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(B) + (size_t)nn * K + kk * 64) + 2 * p;
+        const float4 a0 = src[0], a1 = src[1];
+        x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
+    }
+    const float s0 = __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3])));
+    const float s1 = __fadd_rn(__fadd_rn(fabsf(x[4]), fabsf(x[5])), __fadd_rn(fabsf(x[6]), fabsf(x[7])));
+    const float mx = q_half_allmax(fmaxf(s0, s1));
+    const float scales = div127(mx);
+    const float t_scales = (scales != 0.0f) ? rcp_exact(scales) : 0.0f;
+    uint32_t lo0, hi0, lo1, hi1;
+    float La, Lb;
+    q_table8<true>(x[0], x[1], x[2], x[3], t_scales, lo0, hi0, La);
+    q_table8<true>(x[4], x[5], x[6], x[7], t_scales, lo1, hi1, Lb);
+    const int u = 2 * kk + (p >> 2);
+    bimg[(size_t)(u * 4 + (p & 3)) * Npad + n] = make_uint4(lo0, hi0, lo1, hi1);
+    // sum of the 16 signed entries of this lane's two half tables, then over the 8 lanes of the act group
+    int h = 0;
+    const uint32_t d[4] = {lo0, hi0, lo1, hi1};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        h += (int)(int8_t)(d[i] & 0xff) + (int)(int8_t)((d[i] >> 8) & 0xff) + (int)(int8_t)((d[i] >> 16) & 0xff) + ((int)d[i] >> 24);
+    h += (int)qdpp_u<0xB1>((uint32_t)h);
+    h += (int)qdpp_u<0x4E>((uint32_t)h);
+    h += (int)qdpp_u<0x104>((uint32_t)h);
+    float va = -La, vb = -Lb;               // lut_biases, lut_ctor.cc:25-31 (summation order as in k_preprocess_pairs)
+    va = __fadd_rn(va, qdpp_f<0x4E>(va));
+    vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));
+    va = __fadd_rn(va, qdpp_f<0xB1>(va));
+    vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));
+    const float v = __fadd_rn(va, vb);
+    const float c1 = qdpp_f<0x104>(v);
+    if (p == 0) {
+        colv[((size_t)0 * G + kk) * Npad + n] = scales;
+        colv[((size_t)1 * G + kk) * Npad + n] = __fadd_rn(__fadd_rn(0.0f, v), c1);
+        colv[((size_t)2 * G + kk) * Npad + n] = (float)h;
+    }
+}
+
+hipError_t launch_lut_image(const void* B, int act_f16, void* bimg, float* colv, int K, int N, int Npad, hipStream_t st) {
+    if (K % 64 != 0 || N < 1 || Npad < N || Npad % 64 != 0) return hipErrorInvalidValue;
+    dim3 g(Npad / 32, K / 64), b(256);
+    if (act_f16) hipLaunchKernelGGL((k_lut_image<true>), g, b, 0, st, B, (uint4*)bimg, colv, K, N, Npad);
+    else hipLaunchKernelGGL((k_lut_image<false>), g, b, 0, st, B, (uint4*)bimg, colv, K, N, Npad);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+constexpr int P_NWV = 8;                           // waves per workgroup = K ranges
+constexpr int P_PAT_BYTES = 256 * 32 * 8;          // joint-index operand rows, 32 copies
+constexpr int P_BB_OFF = P_PAT_BYTES;              // half-table chunk of one act group: [wave][unit 2][pair 4][n 64] uint4
+constexpr int P_BB_WAVE = 8192;
+constexpr int P_SC_OFF = P_BB_OFF + P_NWV * P_BB_WAVE; // weight scales / zeros of the wave's 64 rows: [wave][buffer][sc 64 | zr 64] float
+constexpr int P_SC_WAVE = 2 * 512;
+constexpr int P_LDS_BYTES = P_SC_OFF + P_NWV * P_SC_WAVE;
+
+typedef __attribute__((address_space(3))) void* p_lds_ptr;
+
+// Everything the main loop loads goes through buffer instructions: per-lane byte offsets are computed once, the part that
+// changes from act group to act group is a scalar offset (no vector address arithmetic in the loop).
+template <int BITS, bool ZP, bool DUMP>
+__global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
+    constexpr int NJ = BITS;                   // uint4 per unit and row quad in the QUAD layout
+    constexpr int WPU = BITS / 2;              // uint4 of a unit's weights one lane needs per tile row (W2: both steps in one)
+    const Shape& s = a.s;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int kb = lane >> 5, j = lane & 31;
+
+    // blockIdx -> (row block, token block): consecutive workgroup ids go round the 8 XCDs, so XCD x takes row blocks
+    // x, x + 8, ... with all their token blocks one after the other (they share the weight rows in that XCD's L2)
+    const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
+    int bx = xcd + 8 * (qid / a.gy);
+    const int by = qid % a.gy;
+    if (bx >= a.gx) return;
+    int mi = 0;
+    while (mi + 1 < a.nmat && bx >= a.m[mi].wg_end) ++mi;
+    if (mi > 0) bx -= a.m[mi - 1].wg_end;
+    const GemmMat M = a.m[mi];
+    const int Mw = M.Mw, G = s.K / 64, nu = s.K / 32, nst = (nu + 63) >> 6, nq = (Mw + 3) >> 2;
+    const int row0 = bx * 64, n0 = by * 64;
+    const int apg_sh = a.apg_shift, apg_m = (1 << apg_sh) - 1, nsg = G >> apg_sh;      // act groups per weight group: 1 << apg_sh
+    const int g_lo = (w * nsg) / P_NWV, g_hi = ((w + 1) * nsg) / P_NWV;
+    const int k_lo = g_lo << apg_sh, k_end = g_hi << apg_sh;
+
+    // ---- per-lane constants and the first loads (they do not need the operand rows built below) ------------------------
+    // v_perm selector that builds an operand-row address from a weight dword: byte 0 = copy offset, byte 1 = byte beta of the dword
+    const uint32_t psel = 0x0c0c0000u | ((4u + (lane & 3)) << 8);
+    const uint32_t copyoff = (uint32_t)j * 8u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.W), (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.bimg), (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.colv), (short)0, 0x7fffffff, 0x00020000);
+    int wvoff[2];                              // byte offset of (row quad of this lane in tile row rt, uint4 kb [W2] / 2 kb [W4]) in the weights
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int quad = min((row0 >> 2) + rt * 8 + (j >> 2), nq - 1);
+        wvoff[rt] = ((quad * nst * NJ + (BITS == 2 ? kb : 2 * kb)) * 64) * 16;
+    }
+    const int bvoff = (n0 + lane) * 16, cvoff = (n0 + j) * 4;
+    const uint32_t bb_wave = P_BB_OFF + w * P_BB_WAVE, sc_wave = P_SC_OFF + w * P_SC_WAVE;
+
+    uint4 wv[2][2][WPU];                       // weights of the act group: [unit][tile row][..]
+    float st_sc = 0.f, st_zr = 0.f;            // scale / zero of row (row0 + lane) for the NEXT weight group, staged
+    p2f_t sc[2][8];                            // [tile row][pair of accumulator rows]
+    float lbs[2] = {0.f, 0.f};                 // lut_biases summed over the act groups of the current weight group, per n tile
+
+    auto dma_chunk = [&](int kk) {             // the act group's half tables, 64 activation rows: global -> LDS, no registers
+#pragma unroll
+        for (int ul = 0; ul < 2; ++ul)
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + (ul * 4 + pr) * 1024), 16, bvoff,
+                                                     ((2 * kk + ul) * 4 + pr) * a.Npad * 16, 0, 0);
+    };
+    auto load_weights = [&](int kk) {
+#pragma unroll
+        for (int ul = 0; ul < 2; ++ul) {
+            const int u = 2 * kk + ul, so = ((u >> 6) * NJ * 64 + (u & 63)) * 16;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int q = 0; q < WPU; ++q) {
+                    const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt], so + q * 1024, 0);
+                    wv[ul][rt][q] = make_uint4(v[0], v[1], v[2], v[3]);
+                }
+        }
+    };
+    auto pat_row = [&](uint32_t d) -> uint2 {
+        return *reinterpret_cast<const uint2*>(plds + __builtin_amdgcn_perm(d, copyoff, psel));
+    };
+    auto load_staged = [&](int g) {            // scale / zero of row (row0 + lane), weight group g -> registers
+        const int quad = min((row0 >> 2) + (lane >> 2), nq - 1);
+        const size_t si = quad_scale_index(s, quad, g, lane & 3, 0);
+        st_sc = q_ld_scale(M.SC, a.sc_f16, si);
+        if (ZP) st_zr = q_ld_scale(M.SC, a.sc_f16, si + 1);
+    };
+    auto write_staged = [&](int buf) {
+        float* p = reinterpret_cast<float*>(plds + sc_wave + buf * 512);
+        p[lane] = st_sc;
+        if (ZP) p[64 + lane] = st_zr;
+    };
+    // accumulator rows of this lane in tile row rt: 8 q4 + 4 kb + (0..3), q4 = 0..3
+    auto read_rows = [&](int buf, int which, int rt, p2f_t (&dst)[8]) {
+        const unsigned char* p = plds + sc_wave + buf * 512 + which * 256;
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const p4f_t v = *reinterpret_cast<const p4f_t*>(p + (32 * rt + 8 * q4 + 4 * kb) * 4);
+            dst[2 * q4] = (p2f_t){v.x, v.y}; dst[2 * q4 + 1] = (p2f_t){v.z, v.w};
+        }
+    };
+
+    const bool work = k_lo < k_end;
+    if (work) {
+        dma_chunk(k_lo);
+        load_weights(k_lo);
+        load_staged(g_lo);
+    }
+
+    // ---- joint-index operand rows: entry b = (i1 << 4) | i0, byte e = s(i0) [e == i0 & 7] + 2 s(i1) [e == i1 & 7] (+ 3 for W4)
+    {
+        const int b = tid & 255, i0 = b & 15, i1 = b >> 4;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int v = (BITS == 4) ? 3 : 0;
+            if (e == (i0 & 7)) v += (i0 & 8) ? -1 : 1;
+            if (e == (i1 & 7)) v += (i1 & 8) ? -2 : 2;
+            const uint32_t by8 = (uint32_t)(v & 0xff) << (8 * (e & 3));
+            if (e < 4) lo |= by8; else hi |= by8;
+        }
+        uint4* pt = reinterpret_cast<uint4*>(plds) + b * 16 + (tid >> 8) * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pt[c] = make_uint4(lo, hi, lo, hi);
+    }
+    __syncthreads();
+
+    p2f_t facc[2][2][8];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) facc[rt][nt][r] = (p2f_t){0.f, 0.f};
+
+    if (work) {
+        write_staged(0);
+        read_rows(0, 0, 0, sc[0]);
+        read_rows(0, 0, 1, sc[1]);
+        if (g_lo + 1 < g_hi) load_staged(g_lo + 1);
+    }
+    const p16i_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int kk = k_lo; kk < k_end; ++kk) {
+        const int g = kk >> apg_sh;
+        const bool glast = (kk & apg_m) == apg_m;          // last act group of its weight group
+        const bool more = glast && g + 1 < g_hi;
+        const int cbuf = (g - g_lo) & 1, nbuf = cbuf ^ 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk of kk is in LDS, its weights and the staged scales in registers
+        if (more) {
+            write_staged(nbuf);
+            if (g + 2 < g_hi) load_staged(g + 2);
+        }
+        // B operands of the whole act group (both n tiles, four 32-deep steps), then the chunk buffer is free for kk + 1
+        p4i_t bv[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (((ks >> 1) * 4 + 2 * kb + (ks & 1)) * 64 + nt * 32 + j) * 16);
+                bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+            }
+        // column values of the act group: v = psf * (ls / 2) + hlbx,  hlbx = lb / 2  [- 15 * (entry sum) * (ls / 2) for the +15 operand bias of W4]
+        float hls[2], hlbx[2], lb[2];
+        int bias[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float ls = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, cvoff + nt * 128, kk * a.Npad * 4, 0));
+            lb[nt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, cvoff + nt * 128, (G + kk) * a.Npad * 4, 0));
+            hls[nt] = __fmul_rn(0.5f, ls);
+            hlbx[nt] = __fmul_rn(0.5f, lb[nt]);
+            bias[nt] = 0;
+            if (BITS == 4) {
+                const float hs15 = __fmul_rn(15.0f, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, cvoff + nt * 128, (2 * G + kk) * a.Npad * 4, 0)));
+                hlbx[nt] = __fmaf_rn(-hs15, hls[nt], hlbx[nt]);
+                bias[nt] = (int)hs15;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (kk + 1 < k_end) dma_chunk(kk + 1);
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+            // A operands of tile row rt: the joint plane index of (row, table) selects the operand row
+            p4i_t av[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if constexpr (BITS == 2) {
+                    const uint4 q = wv[ks >> 1][rt][0];
+                    const uint2 t0 = pat_row((ks & 1) ? q.z : q.x), t1 = pat_row((ks & 1) ? q.w : q.y);
+                    av[ks] = (p4i_t){(int)t0.x, (int)t0.y, (int)t1.x, (int)t1.y};
+                } else {
+                    const uint4 q = wv[ks >> 1][rt][ks & 1];
+                    const uint2 a0 = pat_row(q.x), a1 = pat_row(q.y), b0 = pat_row(q.z), b1 = pat_row(q.w);
+                    av[ks] = (p4i_t){(int)(a0.x + (a1.x << 2)), (int)(a0.y + (a1.y << 2)), (int)(b0.x + (b1.x << 2)), (int)(b0.y + (b1.y << 2))};
+                }
+            }
+            if (rt == 1 && kk + 1 < k_end) load_weights(kk + 1);      // the registers are free: next act group's weights
+            p16i_t cc[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                cc[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0], bv[nt][0], zero16, 0, 0, 0);
+#pragma unroll
+                for (int ks = 1; ks < 4; ++ks) cc[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[ks], bv[nt][ks], cc[nt], 0, 0, 0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                // C += ((comb / 2) ls + lb / 2) scale [+ zero lb, once per weight group below], cf. k_gemv_quad / k_gemm_onehot (W4)
+                const p2f_t h2 = {hls[nt], hls[nt]}, b2 = {hlbx[nt], hlbx[nt]};
+#pragma unroll
+                for (int r2 = 0; r2 < 8; ++r2) {
+                    const p2f_t ps = {(float)cc[nt][2 * r2], (float)cc[nt][2 * r2 + 1]};
+                    const p2f_t v = __builtin_elementwise_fma(ps, h2, b2);
+                    facc[rt][nt][r2] = __builtin_elementwise_fma(v, sc[rt][r2], facc[rt][nt][r2]);
+                }
+                if (DUMP) {
+                    const int nn = n0 + nt * 32 + j;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int orow = row0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * kb;
+                        if (nn < a.N && orow < Mw) a.dump[((size_t)nn * Mw + orow) * G + kk] = cc[nt][r] - bias[nt];
+                    }
+                }
+            }
+            if (ZP && glast) {                 // zero points: zero * (sum of lut_biases over the weight group), tbl.cc:497-505 regrouped
+                p2f_t zr[8];
+                read_rows(cbuf, 1, rt, zr);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float l = __fadd_rn(lbs[nt], lb[nt]);
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; ++r2) facc[rt][nt][r2] = __builtin_elementwise_fma(zr[r2], (p2f_t){l, l}, facc[rt][nt][r2]);
+                }
+            }
+            if (more) read_rows(nbuf, 0, rt, sc[rt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) lbs[nt] = glast ? 0.f : __fadd_rn(lbs[nt], lb[nt]);
+    }
+
+    // ---- reduce the K ranges through LDS (operand rows and chunk buffers are free now) and store ------------------
+    __syncthreads();
+    {
+        unsigned char* red = plds + w * 16384;                // [n 64][o 64] fp32, 16-byte slots XOR-swizzled by n & 15
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int nl = nt * 32 + j, slot = (8 * rt + 2 * q4 + kb) ^ (nl & 15);
+                    *reinterpret_cast<p4f_t*>(red + nl * 256 + slot * 16) =
+                        (p4f_t){facc[rt][nt][2 * q4][0], facc[rt][nt][2 * q4][1], facc[rt][nt][2 * q4 + 1][0], facc[rt][nt][2 * q4 + 1][1]};
+                }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 64 * P_NWV * i, nl = idx >> 4, sl = idx & 15;
+        const unsigned char* p = plds + nl * 256 + ((sl ^ (nl & 15)) * 16);
+        p4f_t v = *reinterpret_cast<const p4f_t*>(p);
+#pragma unroll
+        for (int ww = 1; ww < P_NWV; ++ww) v += *reinterpret_cast<const p4f_t*>(p + ww * 16384);
+        const int n = n0 + nl, o = row0 + sl * 4;
+        if (n < a.N && o < Mw) {
+            if (a.out_f16) {
+                const __half2 h0 = __floats2half2_rn(v.x, v.y), h1 = __floats2half2_rn(v.z, v.w);
+                *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(M.C) + (size_t)n * Mw + o) =
+                    make_uint2(*reinterpret_cast<const uint32_t*>(&h0), *reinterpret_cast<const uint32_t*>(&h1));
+            } else {
+                *reinterpret_cast<p4f_t*>(reinterpret_cast<float*>(M.C) + (size_t)n * Mw + o) = v;
+            }
+        }
+    }
+}
+
+bool gemm_planes_supported(const Shape& s) {
+    if (s.lay != 2 || (s.bits != 2 && s.bits != 4) || s.K % 64 != 0 || s.Mw % 4 != 0) return false;
+    if (s.m_groups >= 1) return false;                                   // unified scale: k_gemm_onehot
+    const int apg = s.gs / 64;
+    return s.ags == 64 && s.gs >= 64 && s.gs % 64 == 0 && s.K % s.gs == 0 && (apg & (apg - 1)) == 0;
+}
+
+hipError_t launch_gemm_planes(const Gemm2Args& a_in, hipStream_t st) {
+    if (!gemm_planes_supported(a_in.s) || a_in.nmat < 1 || a_in.nmat > 4 || (a_in.dump && a_in.nmat != 1)) return hipErrorInvalidValue;
+    if (a_in.N < 1 || a_in.Npad % 64 != 0 || a_in.Npad < ((a_in.N + 63) & ~63)) return hipErrorInvalidValue;
+    Gemm2Args a = a_in;
+    int gx = 0;
+    for (int i = 0; i < a.nmat; ++i) {
+        if (a.m[i].Mw % 4 != 0) return hipErrorInvalidValue;
+        gx += (a.m[i].Mw + 63) / 64;
+        a.m[i].wg_end = gx;
+    }
+    a.apg_shift = 0;
+    while ((64 << a.apg_shift) < a.s.gs) ++a.apg_shift;
+    a.gx = gx;
+    a.gy = (a.N + 63) / 64;
+    dim3 g(((gx + 7) & ~7) * a.gy), b(64 * P_NWV);
+#define PL3(B, Z, D) do { \
+        static bool attr_set = false; \
+        if (!attr_set) { \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_planes<B, Z, D>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES); \
+            if (e != hipSuccess) return e; \
+            attr_set = true; \
+        } \
+        hipLaunchKernelGGL((k_gemm_planes<B, Z, D>), g, b, P_LDS_BYTES, st, a); } while (0)
+#define PL2(B, Z) do { if (a.dump) PL3(B, Z, true); else PL3(B, Z, false); } while (0)
+    if (a.s.bits == 2) { if (a.s.zero_point) PL2(2, true); else PL2(2, false); }
+    else { if (a.s.zero_point) PL2(4, true); else PL2(4, false); }
+#undef PL2
+#undef PL3
+    return hipGetLastError();
+}
+
+}  // namespace tmac

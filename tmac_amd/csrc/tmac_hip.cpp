@@ -73,11 +73,17 @@ struct tmac_hip_workspace {
     size_t dump_elems = 0;
     int K = 0, N = 0, ags = 0;   // what the LUT currently holds
     size_t qdev_u4_per_row = 0;
+    // the LUT as k_gemm_planes streams it (tmac_gemm2.hip): built next to the layouts above when N > 1 and ags = 64
+    void* gimg = nullptr;        // uint4 [maxK/32][4][gNpad]
+    float* gcol = nullptr;       // fp32 [3][K/64][gNpad]   (rows of the CURRENT K: the stride follows ws->K)
+    int gNpad = 0;
+    bool gimg_valid = false;
 };
 
 static std::mutex g_mu;
 static int g_device = -1;
 static int g_variant = V_AUTO;
+static int g_gemm_kernel = 0;   // N > 1 kernel: 0 = k_gemm_planes where it covers the configuration, 1 = k_gemm_onehot (A/B: tmac_hip_debug_gemm_kernel)
 static int g_pairs_min_n = 2;   // tmac_hip_preprocessor_dev: rows from which the pair-wise LUT build is used (A/B: tmac_hip_debug_pairs_min_n)
 static int g_fa_mode = 0;   // fast aggregation for weights registered from now on (tmac_hip_set_fast_aggregation)
 static int g_force_ft = 0, g_force_wpq = 0;   // A/B knobs of the quad kernel (0 = heuristic)
@@ -437,6 +443,11 @@ extern "C" int32_t tmac_hip_workspace_create(tmac_hip_workspace** out, int maxK,
     if (e == hipSuccess) e = hipMemset(ws->qlut_lds, 0x80, nl);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->lut_scales, ns);
     if (e == hipSuccess) e = hipMalloc((void**)&ws->lut_biases, ns);
+    if (maxN > 1) {
+        ws->gNpad = (maxN + 63) & ~63;
+        if (e == hipSuccess) e = hipMalloc(&ws->gimg, (size_t)2 * maxK * ws->gNpad);
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->gcol, sizeof(float) * 3 * (size_t)(maxK / 64) * ws->gNpad);
+    }
     if (e != hipSuccess) {   // nothing of a half-built workspace is left behind
         tmac_hip_workspace_free(ws);
         return fail(TMAC_HIP_E_RUNTIME, "workspace allocation (K=%d, N=%d): %s", maxK, maxN, hipGetErrorString(e));
@@ -452,6 +463,8 @@ extern "C" int32_t tmac_hip_workspace_free(tmac_hip_workspace* ws) {
     if (ws->qlut_lds) (void)hipFree(ws->qlut_lds);
     if (ws->lut_scales) (void)hipFree(ws->lut_scales);
     if (ws->lut_biases) (void)hipFree(ws->lut_biases);
+    if (ws->gimg) (void)hipFree(ws->gimg);
+    if (ws->gcol) (void)hipFree(ws->gcol);
     if (ws->dump) (void)hipFree(ws->dump);
     delete ws;
     return TMAC_HIP_OK;
@@ -482,6 +495,12 @@ extern "C" int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void*
         : launch_preprocess(B_dev, (Dtype)act_dtype, ws->qlut_ref, ws->qlut_dev, ws->qlut_lds, ws->lut_scales, ws->lut_biases,
                             K, N, act_group_size, ws->qdev_u4_per_row, (hipStream_t)stream);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
+    ws->gimg_valid = false;
+    if (act_group_size == 64 && N >= 2 && ws->gimg && g_gemm_kernel != 1) {   // what k_gemm_planes streams (tmac_hip_qgemm_dev may pick it)
+        e = launch_lut_image(B_dev, act_dtype == TMAC_F16, ws->gimg, ws->gcol, K, N, ws->gNpad, (hipStream_t)stream);
+        if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT image launch: %s", hipGetErrorString(e));
+        ws->gimg_valid = true;
+    }
     return TMAC_HIP_OK;
 }
 
@@ -544,6 +563,25 @@ static int32_t gemm_multi(const tmac_hip_weights* const* wl, int nmat, const tma
     return TMAC_HIP_OK;
 }
 
+static bool planes_ok(const tmac_hip_weights* w) {
+    return g_gemm_kernel != 1 && w->s.lay == 2 && w->lo_ok && w->s.ts == 8 && !w->fa && gemm_planes_supported(w->s);
+}
+
+// k_gemm_planes over up to 4 matrices that share K and the quantisation config; the workspace holds the LUT image
+static int32_t planes_multi(const tmac_hip_weights* const* wl, int nmat, const tmac_hip_workspace* ws, void* const* C_list,
+                            tmac_dtype_t out_dtype, int N, int32_t* comb_dump, hipStream_t st) {
+    Gemm2Args ga;
+    memset(&ga, 0, sizeof(ga));
+    const tmac_hip_weights* w0 = wl[0];
+    ga.s = w0->s; ga.nmat = nmat;
+    for (int i = 0; i < nmat; ++i) { ga.m[i].W = wl[i]->W; ga.m[i].SC = wl[i]->SC; ga.m[i].C = C_list[i]; ga.m[i].Mw = wl[i]->s.Mw; }
+    ga.sc_f16 = w0->sc_dtype == F16; ga.out_f16 = out_dtype == TMAC_F16;
+    ga.bimg = (const uint4*)ws->gimg; ga.colv = ws->gcol; ga.Npad = ws->gNpad; ga.N = N; ga.dump = comb_dump;
+    hipError_t e = launch_gemm_planes(ga, st);
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "plane-combined gemm launch: %s", hipGetErrorString(e));
+    return TMAC_HIP_OK;
+}
+
 static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* ws, void* C_dev, tmac_dtype_t out_dtype,
                           int N, int32_t* dump, hipStream_t st) {
     if (!w || !ws || !C_dev) return fail(TMAC_HIP_E_ARG, "null argument");
@@ -558,6 +596,10 @@ static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* w
     }
     if (w->fa && v != V_REF_LAYOUT && v != V_LO_MQSAD && v != V_LO_SDWA)
         return fail(TMAC_HIP_E_NOMATCH, "fast-aggregation weights run on the two-kernel path only");
+    if (v == V_FUSED && !dump && ws->gimg_valid && planes_ok(w) && gemm_pays(w->s, w->s.Mw, N)) {
+        void* cl[1] = {C_dev};
+        return planes_multi(&w, 1, ws, cl, out_dtype, N, nullptr, st);
+    }
     if (v == V_FUSED && gemm_pays(w->s, w->s.Mw, N) && gemm_onehot_supported(w->s)) {
         void* cl[1] = {C_dev};
         return gemm_multi(&w, 1, ws, cl, out_dtype, N, dump, st);
@@ -623,6 +665,68 @@ extern "C" int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const 
     return rc;
 }
 
+extern "C" int32_t tmac_hip_debug_gemm_kernel(int which) {
+    if (which < 0 || which > 1) return fail(TMAC_HIP_E_ARG, "gemm kernel selector must be 0 (auto) or 1 (k_gemm_onehot)");
+    g_gemm_kernel = which;
+    return TMAC_HIP_OK;
+}
+
+// Parity tap of k_gemm_planes: the combined integer sums comb[n][o][kk] = sum_p 2^p PS_p it feeds into the fp32 chain.
+extern "C" int32_t tmac_hip_debug_gemm_comb_sums(const tmac_hip_weights* w, const tmac_hip_workspace* ws_c, int32_t* comb_host,
+                                                 int N, void* stream) {
+    if (!w || !ws_c || !comb_host) return fail(TMAC_HIP_E_ARG, "null argument");
+    auto* ws = const_cast<tmac_hip_workspace*>(ws_c);
+    hipStream_t st = (hipStream_t)stream;
+    if (!ws->gimg_valid || ws->K != w->s.K || N <= 0 || N > ws->N) return fail(TMAC_HIP_E_ARG, "the workspace holds no LUT image for K=%d, N=%d", w->s.K, N);
+    if (!planes_ok(w)) return fail(TMAC_HIP_E_NOMATCH, "k_gemm_planes does not cover this configuration");
+    const size_t elems = (size_t)N * w->s.Mw * (w->s.K / 64);
+    if (ws->dump_elems < elems) {
+        if (ws->dump) (void)hipFree(ws->dump);
+        ws->dump = nullptr; ws->dump_elems = 0;
+        HIP_TRY(hipMalloc((void**)&ws->dump, elems * sizeof(int32_t)));
+        ws->dump_elems = elems;
+    }
+    HIP_TRY(hipMemsetAsync(ws->dump, 0x7f, elems * sizeof(int32_t), st));
+    void* Ctmp = nullptr;
+    HIP_TRY(hipMalloc(&Ctmp, sizeof(float) * (size_t)N * w->s.Mw));
+    void* cl[1] = {Ctmp};
+    int32_t rc = planes_multi(&w, 1, ws, cl, TMAC_F32, N, ws->dump, st);
+    if (rc == TMAC_HIP_OK) {
+        hipError_t e = hipMemcpyAsync(comb_host, ws->dump, elems * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) rc = fail(TMAC_HIP_E_RUNTIME, "comb-sum readback: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(Ctmp);
+    return rc;
+}
+
+// The LUT image of the workspace in plain layouts: half tables int8 [N][K/4][8], then lut_scales, lut_biases and the
+// per-act-group entry sums, fp32 [N][K/64] each.
+extern "C" int32_t tmac_hip_debug_gemm_image_read(const tmac_hip_workspace* ws, int8_t* half_tables_host, float* lut_scales_host,
+                                                  float* lut_biases_host, float* entry_sums_host, int N, void* stream) {
+    if (!ws || !half_tables_host || !lut_scales_host || !lut_biases_host || !entry_sums_host) return fail(TMAC_HIP_E_ARG, "null argument");
+    if (!ws->gimg_valid || N <= 0 || N > ws->N) return fail(TMAC_HIP_E_ARG, "the workspace holds no LUT image for N=%d", N);
+    hipStream_t st = (hipStream_t)stream;
+    const int K = ws->K, G = K / 64, Np = ws->gNpad;
+    std::vector<uint8_t> img((size_t)2 * K * Np);
+    std::vector<float> col((size_t)3 * G * Np);
+    HIP_TRY(hipMemcpyAsync(img.data(), ws->gimg, img.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(col.data(), ws->gcol, col.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int n = 0; n < N; ++n) {
+        for (int t2 = 0; t2 < K / 8; ++t2) {           // pair t2 = tables 2 t2, 2 t2 + 1: unit t2 / 4, pair t2 % 4
+            const uint8_t* src = img.data() + (((size_t)(t2 >> 2) * 4 + (t2 & 3)) * Np + n) * 16;
+            memcpy(half_tables_host + ((size_t)n * (K / 4) + 2 * t2) * 8, src, 16);
+        }
+        for (int kk = 0; kk < G; ++kk) {
+            lut_scales_host[(size_t)n * G + kk] = col[((size_t)0 * G + kk) * Np + n];
+            lut_biases_host[(size_t)n * G + kk] = col[((size_t)1 * G + kk) * Np + n];
+            entry_sums_host[(size_t)n * G + kk] = col[((size_t)2 * G + kk) * Np + n];
+        }
+    }
+    return TMAC_HIP_OK;
+}
+
 static unsigned long long* g_stamps = nullptr;   // debug: phase stamps of the next fused launches
 static int32_t* g_stamp_dump = nullptr;
 
@@ -656,6 +760,20 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
         ws = slot;
     }
     int32_t rc;
+    bool planes = g_variant != V_REF_LAYOUT && ws->gimg != nullptr;
+    for (int i = 0; i < nmat && planes; ++i) {
+        const Shape &x = wl[i]->s, &y = s0;
+        planes = planes_ok(wl[i]) && x.bits == y.bits && x.gs == y.gs && x.zero_point == y.zero_point && wl[i]->sc_dtype == wl[0]->sc_dtype;
+    }
+    if (planes) {
+        // the plane-combined GEMM reads its own LUT image only: one build, one launch for all matrices
+        rc = check_lut_shape(ws, s0.K, N, s0.ags);
+        if (rc) return rc;
+        ws->K = 0; ws->N = 0; ws->gimg_valid = false;      // the other layouts of this workspace are not built
+        hipError_t e = launch_lut_image(B_dev, act_dtype == TMAC_F16, ws->gimg, ws->gcol, s0.K, N, ws->gNpad, st);
+        if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT image launch: %s", hipGetErrorString(e));
+        return planes_multi(wl, nmat, ws, C_list, out_dtype, N, nullptr, st);
+    }
     if ((s0.ags == 64 || (s0.ags == s0.K && s0.K <= 12288)) && g_variant != V_REF_LAYOUT) {
         // only the one-hot GEMM reads this workspace: build the half-table image alone, two tables per lane
         rc = check_lut_shape(ws, s0.K, N, s0.ags);

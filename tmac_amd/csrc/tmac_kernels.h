@@ -68,6 +68,20 @@ struct GemmArgs {
     int N;
 };
 
+// plane-combined one-hot GEMM (tmac_gemm2.hip): the LUT comes as the image k_lut_image writes
+struct Gemm2Args {
+    Shape s;                  // K, bits, gs, ags = 64, zero_point (Mw unused)
+    GemmMat m[4];
+    int nmat;
+    int sc_f16, out_f16;
+    const uint4* bimg;        // uint4 [K/32 units][4 pairs][Npad]: signed half tables of tables 2P, 2P+1 of the unit, per activation row
+    const float* colv;        // fp32 [3][K/64][Npad]: lut_scales | lut_biases | sum of the act group's half-table entries
+    int Npad, N;
+    int32_t* dump;            // optional tap [N][Mw][K/64]: sum_p 2^p PS_p (nmat == 1)
+    int gx, gy;               // filled by the launcher: row blocks (64 rows, all matrices) and token blocks (64 rows of activations)
+    int apg_shift;            // filled by the launcher: log2(act groups per weight group)
+};
+
 struct GemvArgs {
     Shape s;
     const void* W;        // device layout weights (uint4)        | reference blob for V_REF_LAYOUT
@@ -102,6 +116,9 @@ hipError_t launch_preprocess_pairs_row(const void* B, int act_f16, void* qlut_ld
 hipError_t launch_stream_read(const void* src, size_t bytes, void* sink, hipStream_t st);   // measurement aid, see tmac_kernels.hip
 bool gemm_onehot_supported(const Shape& s);
 hipError_t launch_gemm_onehot(const GemmArgs& a, hipStream_t st);
+bool gemm_planes_supported(const Shape& s);
+hipError_t launch_lut_image(const void* B, int act_f16, void* bimg, float* colv, int K, int N, int Npad, hipStream_t st);
+hipError_t launch_gemm_planes(const Gemm2Args& a, hipStream_t st);
 // fused kernel (tmac_fused.hip)
 bool gemv_fused_supported(const Shape& s);
 size_t qlut_lds_u4(int K);   // uint4 per activation row of the LDS-image LUT

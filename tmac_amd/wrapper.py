@@ -118,6 +118,17 @@ class Workspace:
                                               act_group_size, _stream(stream)))
         return q, ls, lb
 
+    def read_gemm_image(self, K: int, N: int, stream=None):
+        """The LUT image k_gemm_planes streams, in plain layouts: half tables int8 [N][K/4][8], lut_scales, lut_biases,
+        entry sums fp32 [N][K/64]."""
+        h = np.zeros((N, K // 4, 8), np.int8)
+        ls = np.zeros((N, K // 64), np.float32)
+        lb = np.zeros((N, K // 64), np.float32)
+        hs = np.zeros((N, K // 64), np.float32)
+        check(B.lib().tmac_hip_debug_gemm_image_read(self._h, h.ctypes.data, ls.ctypes.data, lb.ctypes.data, hs.ctypes.data, N,
+                                                     _stream(stream)))
+        return h, ls, lb, hs
+
     def write(self, qlut: np.ndarray, lut_scales: np.ndarray, lut_biases: np.ndarray, act_group_size: int, stream=None):
         q = np.ascontiguousarray(qlut, np.int8)
         ls = np.ascontiguousarray(lut_scales, np.float32)
@@ -368,6 +379,12 @@ class TMACGeMMWrapper:
                                                         c.ctypes.data, lut.ctypes.data, N, _stream(stream)))
         self.last_fused_lut = lut   # [N][0] = LUT scales, [N][1] = LUT biases built inside the kernel
         return ps, c
+
+    def comb_sums(self, weights: Weights, N: int, stream=None) -> np.ndarray:
+        """Parity tap of the plane-combined GEMM (k_gemm_planes): int32 [N][Mw][K/64], sum_p 2^p PS_p."""
+        out = np.zeros((N, weights.Mw, weights.K // 64), np.int32)
+        check(B.lib().tmac_hip_debug_gemm_comb_sums(weights.handle, self.workspace.handle, out.ctypes.data, N, _stream(stream)))
+        return out
 
     def partial_sums(self, weights: Weights, N: int = 1, stream=None) -> np.ndarray:
         """Parity tap: int32 [N][M][K/ags] (or [N][M] for the unified-scale path), M-space row order."""

@@ -147,8 +147,24 @@ __global__ void k_rate(uint32_t* out, int iters) {
             } else if (WHICH == 4) {  // 4 independent ds_bpermute_b32 chains: one dword from a data-dependent lane per instruction
                 a = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(a & 0xfcu), (int)b); b = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(b & 0xfcu), (int)c);
                 c = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c & 0xfcu), (int)d); d = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(d & 0xfcu), (int)a);
-            } else {                  // 4 independent LDS byte gathers (ds_read_u8 at a data-dependent address in a 2 KB table)
+            } else if (WHICH == 5) {  // 4 independent LDS byte gathers (ds_read_u8 at a data-dependent address in a 2 KB table)
                 a = lut[a & 2047]; b = lut[(b + a) & 2047]; c = lut[(c + b) & 2047]; d = lut[(d + c) & 2047];
+            } else if (WHICH == 6) {  // v_pk_fma_f32, 4 independent chains on 64-bit register pairs
+                asm volatile("v_pk_fma_f32 %0, %0, %4, %0\n\tv_pk_fma_f32 %1, %1, %4, %1\n\tv_pk_fma_f32 %2, %2, %4, %2\n\tv_pk_fma_f32 %3, %3, %4, %3"
+                             : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(q0));
+            } else if (WHICH == 7) {  // v_cvt_f32_i32
+                asm volatile("v_cvt_f32_i32 %0, %0\n\tv_cvt_f32_i32 %1, %1\n\tv_cvt_f32_i32 %2, %2\n\tv_cvt_f32_i32 %3, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+            } else if (WHICH == 8) {  // v_fma_f32
+                asm volatile("v_fma_f32 %0, %0, %1, %0\n\tv_fma_f32 %1, %1, %2, %1\n\tv_fma_f32 %2, %2, %3, %2\n\tv_fma_f32 %3, %3, %0, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+            } else if (WHICH == 9) {  // v_pk_add_f32
+                asm volatile("v_pk_add_f32 %0, %0, %4\n\tv_pk_add_f32 %1, %1, %4\n\tv_pk_add_f32 %2, %2, %4\n\tv_pk_add_f32 %3, %3, %4"
+                             : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3) : "v"(q0));
+            } else if (WHICH == 10) { // v_mov_b64
+                asm volatile("v_mov_b64 %0, %1\n\tv_mov_b64 %1, %2\n\tv_mov_b64 %2, %3\n\tv_mov_b64 %3, %0" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));
+            } else if (WHICH == 11) { // v_mov_b32
+                asm volatile("v_mov_b32 %0, %1\n\tv_mov_b32 %1, %2\n\tv_mov_b32 %2, %3\n\tv_mov_b32 %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+            } else {                  // v_add_u32 through asm (the compiler cannot merge the chain)
+                asm volatile("v_add_u32 %0, %0, %1\n\tv_add_u32 %1, %1, %2\n\tv_add_u32 %2, %2, %3\n\tv_add_u32 %3, %3, %0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
             }
         }
     }
@@ -178,6 +194,13 @@ int rate_main() {
     rate<3>("v_add_u32_sdwa (byte)", out);
     rate<4>("ds_bpermute_b32", out);
     rate<5>("ds_read_u8 (LDS gather)", out);
+    rate<12>("v_add_u32 (asm)", out);
+    rate<11>("v_mov_b32", out);
+    rate<10>("v_mov_b64", out);
+    rate<7>("v_cvt_f32_i32", out);
+    rate<8>("v_fma_f32", out);
+    rate<6>("v_pk_fma_f32", out);
+    rate<9>("v_pk_add_f32", out);
     printf("lookups per wave-instruction: v_perm_b32 on a half table 4 (x64 lanes) at 11 VALU per 8 lookups incl. index and sign handling; "
            "ds_bpermute_b32 1 (a dword from one lane); ds_read_u8 1\n");
     return 0;

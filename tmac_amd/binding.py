@@ -82,6 +82,7 @@ def load_library() -> C.CDLL:
         "tmac_hip_workspace_write": ([vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp], i32),
         "tmac_hip_qgemm_partial_sums": ([vp, vp, vp, C.c_int, vp], i32),
         "tmac_hip_debug_gemm_kernel": ([C.c_int], i32),
+        "tmac_hip_debug_gemm_stamps": ([vp], i32),
         "tmac_hip_debug_gemm_comb_sums": ([vp, vp, vp, C.c_int, vp], i32),
         "tmac_hip_debug_gemm_image_read": ([vp, vp, vp, vp, vp, C.c_int, vp], i32),
         "tmac_hip_set_variant": ([C.c_int], i32),

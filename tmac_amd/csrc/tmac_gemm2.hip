@@ -122,7 +122,7 @@ typedef __attribute__((address_space(3))) void* p_lds_ptr;
 
 // Everything the main loop loads goes through buffer instructions: per-lane byte offsets are computed once, the part that
 // changes from act group to act group is a scalar offset (no vector address arithmetic in the loop).
-template <int BITS, bool ZP, bool DUMP>
+template <int BITS, bool ZP, bool DUMP, bool SCF16>
 __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
     constexpr int NJ = BITS;                   // uint4 per unit and row quad in the QUAD layout
@@ -164,44 +164,58 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
     const uint32_t bb_wave = P_BB_OFF + w * P_BB_WAVE, sc_wave = P_SC_OFF + w * P_SC_WAVE;
 
     uint4 wv[2][2][WPU];                       // weights of the act group: [unit][tile row][..]
-    float st_sc = 0.f, st_zr = 0.f;            // scale / zero of row (row0 + lane) for the NEXT weight group, staged
-    p2f_t sc[2][8];                            // [tile row][pair of accumulator rows]
+    uint32_t st_sc[2] = {0u, 0u}, st_zr[2] = {0u, 0u};   // raw scale / zero of row (row0 + lane) of the next two weight groups (by parity), staged
     float lbs[2] = {0.f, 0.f};                 // lut_biases summed over the act groups of the current weight group, per n tile
 
-    auto dma_chunk = [&](int kk) {             // the act group's half tables, 64 activation rows: global -> LDS, no registers
+    // the act group's half tables, 64 activation rows: global -> LDS, no registers.  Issued in four parts (unit ul, pairs 2 h, 2 h + 1)
+    // spread over the step: a vector-memory instruction holds its wave until the address path takes it, and all eight waves
+    // feed the same path
+    auto dma_part = [&](int kk, int part) {
+        const int ul = part >> 1;
 #pragma unroll
-        for (int ul = 0; ul < 2; ++ul)
-#pragma unroll
-            for (int pr = 0; pr < 4; ++pr)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + (ul * 4 + pr) * 1024), 16, bvoff,
+        for (int pr = 2 * (part & 1); pr < 2 * (part & 1) + 2; ++pr)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + (ul * 4 + pr) * 1024), 16, bvoff,
                                                      ((2 * kk + ul) * 4 + pr) * a.Npad * 16, 0, 0);
     };
-    auto load_weights = [&](int kk) {
+    auto dma_chunk = [&](int kk) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) dma_part(kk, part);
+    };
+    auto load_weights = [&](int kk, int rt) {  // tile row rt of the act group's two units
 #pragma unroll
         for (int ul = 0; ul < 2; ++ul) {
             const int u = 2 * kk + ul, so = ((u >> 6) * NJ * 64 + (u & 63)) * 16;
 #pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int q = 0; q < WPU; ++q) {
-                    const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt], so + q * 1024, 0);
-                    wv[ul][rt][q] = make_uint4(v[0], v[1], v[2], v[3]);
-                }
+            for (int q = 0; q < WPU; ++q) {
+                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt], so + q * 1024, 0);
+                wv[ul][rt][q] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
         }
     };
     auto pat_row = [&](uint32_t d) -> uint2 {
         return *reinterpret_cast<const uint2*>(plds + __builtin_amdgcn_perm(d, copyoff, psel));
     };
-    auto load_staged = [&](int g) {            // scale / zero of row (row0 + lane), weight group g -> registers
+    auto load_staged = [&](int g) {            // scale / zero of row (row0 + lane), weight group g -> registers, raw (converted when written to LDS)
         const int quad = min((row0 >> 2) + (lane >> 2), nq - 1);
         const size_t si = quad_scale_index(s, quad, g, lane & 3, 0);
-        st_sc = q_ld_scale(M.SC, a.sc_f16, si);
-        if (ZP) st_zr = q_ld_scale(M.SC, a.sc_f16, si + 1);
+        const int sl = (g - g_lo) & 1;
+        if constexpr (SCF16) {
+            st_sc[sl] = reinterpret_cast<const unsigned short*>(M.SC)[si];
+            if (ZP) st_zr[sl] = reinterpret_cast<const unsigned short*>(M.SC)[si + 1];
+        } else {
+            st_sc[sl] = reinterpret_cast<const uint32_t*>(M.SC)[si];
+            if (ZP) st_zr[sl] = reinterpret_cast<const uint32_t*>(M.SC)[si + 1];
+        }
     };
-    auto write_staged = [&](int buf) {
-        float* p = reinterpret_cast<float*>(plds + sc_wave + buf * 512);
-        p[lane] = st_sc;
-        if (ZP) p[64 + lane] = st_zr;
+    auto st_val = [&](uint32_t raw) -> float {
+        if constexpr (SCF16) return __half2float(__ushort_as_half((unsigned short)raw));
+        else return __uint_as_float(raw);
+    };
+    auto write_staged = [&](int g) {           // LDS buffer and staged set of group g: (g - g_lo) & 1
+        const int sl = (g - g_lo) & 1;
+        float* p = reinterpret_cast<float*>(plds + sc_wave + sl * 512);
+        p[lane] = st_val(st_sc[sl]);
+        if (ZP) p[64 + lane] = st_val(st_zr[sl]);
     };
     // accumulator rows of this lane in tile row rt: 8 q4 + 4 kb + (0..3), q4 = 0..3
     auto read_rows = [&](int buf, int which, int rt, p2f_t (&dst)[8]) {
@@ -213,11 +227,26 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
         }
     };
 
+    // profiling: s_memrealtime (100 MHz) at fixed points of every act-group step of workgroup 0
+    unsigned long long* stp = (a.stamps && blockIdx.x == 0) ? a.stamps + (size_t)w * 64 * 8 : nullptr;
+#define PSTAMP(step, i) do { if (stp && (step) < 64 && lane == 0) stp[(step) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    PSTAMP(0, 5);
+    float cn[2][3];                            // column values (lut_scales, lut_biases, entry sums) of the NEXT act group, per n tile
+    auto load_cols = [&](int kk) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int c = 0; c < (BITS == 4 ? 3 : 2); ++c)
+                cn[nt][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, cvoff + nt * 128, (c * G + kk) * a.Npad * 4, 0));
+    };
     const bool work = k_lo < k_end;
-    if (work) {
+    if (work) {                                // everything the first step needs is in flight while the operand rows are built
         dma_chunk(k_lo);
-        load_weights(k_lo);
+        load_weights(k_lo, 0);
+        load_weights(k_lo, 1);
+        load_cols(k_lo);
         load_staged(g_lo);
+        if (g_lo + 1 < g_hi) load_staged(g_lo + 1);
     }
 
     // ---- joint-index operand rows: entry b = (i1 << 4) | i0, byte e = s(i0) [e == i0 & 7] + 2 s(i1) [e == i1 & 7] (+ 3 for W4)
@@ -234,7 +263,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
         }
         uint4* pt = reinterpret_cast<uint4*>(plds) + b * 16 + (tid >> 8) * 8;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) pt[c] = make_uint4(lo, hi, lo, hi);
+        for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo, hi);     // 8 consecutive entries (lanes) -> 8 different 16-byte slots of the 256-byte rows
     }
     __syncthreads();
 
@@ -246,25 +275,45 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) facc[rt][nt][r] = (p2f_t){0.f, 0.f};
 
+    PSTAMP(0, 6);
     if (work) {
-        write_staged(0);
-        read_rows(0, 0, 0, sc[0]);
-        read_rows(0, 0, 1, sc[1]);
-        if (g_lo + 1 < g_hi) load_staged(g_lo + 1);
+        write_staged(g_lo);
+        if (g_lo + 2 < g_hi) load_staged(g_lo + 2);
     }
     const p16i_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // One act group (64 activations = four 32-deep MFMA steps) per iteration.  The order below interleaves the four units a
+    // step keeps busy -- the vector-memory path (chunk DMA, weight loads), LDS (operand reads), the matrix core and the VALU
+    // (fp32 scale chain) -- inside ONE wave: the operands of tile row 1 are fetched while the MFMAs of tile row 0 run, the
+    // epilogue of tile row 0 runs under the MFMAs of tile row 1.  sched_barrier keeps the compiler from regrouping the phases.
+    auto build_av = [&](int rt, p4i_t (&av)[4]) {       // A operands of tile row rt: the joint plane index of (row, table) selects the operand row
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (BITS == 2) {
+                const uint4 q = wv[ks >> 1][rt][0];
+                const uint2 t0 = pat_row((ks & 1) ? q.z : q.x), t1 = pat_row((ks & 1) ? q.w : q.y);
+                av[ks] = (p4i_t){(int)t0.x, (int)t0.y, (int)t1.x, (int)t1.y};
+            } else {
+                const uint4 q = wv[ks >> 1][rt][ks & 1];
+                const uint2 a0 = pat_row(q.x), a1 = pat_row(q.y), b0 = pat_row(q.z), b1 = pat_row(q.w);
+                av[ks] = (p4i_t){(int)(a0.x + (a1.x << 2)), (int)(a0.y + (a1.y << 2)), (int)(b0.x + (b1.x << 2)), (int)(b0.y + (b1.y << 2))};
+            }
+        }
+    };
     for (int kk = k_lo; kk < k_end; ++kk) {
         const int g = kk >> apg_sh;
         const bool glast = (kk & apg_m) == apg_m;          // last act group of its weight group
         const bool more = glast && g + 1 < g_hi;
-        const int cbuf = (g - g_lo) & 1, nbuf = cbuf ^ 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk of kk is in LDS, its weights and the staged scales in registers
+        const bool next = kk + 1 < k_end;
+        const int cbuf = (g - g_lo) & 1;
+        PSTAMP(kk - k_lo, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk of kk is in LDS, its weights, column values and the staged scales in registers
         if (more) {
-            write_staged(nbuf);
-            if (g + 2 < g_hi) load_staged(g + 2);
+            write_staged(g + 1);
+            if (g + 3 < g_hi) load_staged(g + 3);
         }
-        // B operands of the whole act group (both n tiles, four 32-deep steps), then the chunk buffer is free for kk + 1
-        p4i_t bv[2][4];
+        // B operands of the whole act group (both n tiles, four 32-deep steps); A operands and row scales of tile row 0
+        p4i_t bv[2][4], av0[4], av1[4];
+        p2f_t sc0[8];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -272,85 +321,104 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
                 const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (((ks >> 1) * 4 + 2 * kb + (ks & 1)) * 64 + nt * 32 + j) * 16);
                 bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
             }
-        // column values of the act group: v = psf * (ls / 2) + hlbx,  hlbx = lb / 2  [- 15 * (entry sum) * (ls / 2) for the +15 operand bias of W4]
-        float hls[2], hlbx[2], lb[2];
+        build_av(0, av0);
+        read_rows(cbuf, 0, 0, sc0);
+        // column values of the act group (loaded one step ahead): v = comb * H + hlbx with H = ls / 2,
+        // hlbx = lb / 2  [- 15 * (entry sum) * (ls / 2) for the +15 operand bias of W4]
+        float H[2], hlbx[2], lb[2];
         int bias[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const float ls = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, cvoff + nt * 128, kk * a.Npad * 4, 0));
-            lb[nt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, cvoff + nt * 128, (G + kk) * a.Npad * 4, 0));
-            hls[nt] = __fmul_rn(0.5f, ls);
+            const float hls = __fmul_rn(0.5f, cn[nt][0]);
+            lb[nt] = cn[nt][1];
+            H[nt] = hls;
             hlbx[nt] = __fmul_rn(0.5f, lb[nt]);
             bias[nt] = 0;
             if (BITS == 4) {
-                const float hs15 = __fmul_rn(15.0f, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, cvoff + nt * 128, (2 * G + kk) * a.Npad * 4, 0)));
-                hlbx[nt] = __fmaf_rn(-hs15, hls[nt], hlbx[nt]);
+                const float hs15 = __fmul_rn(15.0f, cn[nt][2]);
+                hlbx[nt] = __fmaf_rn(-hs15, hls, hlbx[nt]);
                 bias[nt] = (int)hs15;
             }
         }
+        if (next) { load_cols(kk + 1); load_weights(kk + 1, 0); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (kk + 1 < k_end) dma_chunk(kk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        auto chain = [&](const p4i_t (&av)[4], int nt, p16i_t& c) {      // one 32 x 32 tile of the act group: four dependent MFMAs
+            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0], bv[nt][0], zero16, 0, 0, 0);
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-            // A operands of tile row rt: the joint plane index of (row, table) selects the operand row
-            p4i_t av[4];
+            for (int ks = 1; ks < 4; ++ks) c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[ks], bv[nt][ks], c, 0, 0, 0);
+        };
+        // C += ((comb / 2) ls + lb / 2) scale [+ zero lb, once per weight group], cf. k_gemv_quad / k_gemm_onehot (W4)
+        auto epilogue = [&](int rt, int nt, const p16i_t& c, const p2f_t (&sc)[8]) {
+            // three passes of independent instructions over the lane's 16 values (in place: int32 -> fp32 -> scaled), not
+            // 8 dependent three-instruction chains through one temporary
+            const p2f_t h2 = {H[nt], H[nt]}, b2 = {hlbx[nt], hlbx[nt]};
+            p2f_t x[8];
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if constexpr (BITS == 2) {
-                    const uint4 q = wv[ks >> 1][rt][0];
-                    const uint2 t0 = pat_row((ks & 1) ? q.z : q.x), t1 = pat_row((ks & 1) ? q.w : q.y);
-                    av[ks] = (p4i_t){(int)t0.x, (int)t0.y, (int)t1.x, (int)t1.y};
-                } else {
-                    const uint4 q = wv[ks >> 1][rt][ks & 1];
-                    const uint2 a0 = pat_row(q.x), a1 = pat_row(q.y), b0 = pat_row(q.z), b1 = pat_row(q.w);
-                    av[ks] = (p4i_t){(int)(a0.x + (a1.x << 2)), (int)(a0.y + (a1.y << 2)), (int)(b0.x + (b1.x << 2)), (int)(b0.y + (b1.y << 2))};
+            for (int r2 = 0; r2 < 8; ++r2) x[r2] = (p2f_t){(float)c[2 * r2], (float)c[2 * r2 + 1]};
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) x[r2] = __builtin_elementwise_fma(x[r2], h2, b2);
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) facc[rt][nt][r2] = __builtin_elementwise_fma(x[r2], sc[r2], facc[rt][nt][r2]);
+            if (DUMP) {
+                const int nn = n0 + nt * 32 + j;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int orow = row0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * kb;
+                    if (nn < a.N && orow < Mw) a.dump[((size_t)nn * Mw + orow) * G + kk] = c[r] - bias[nt];
                 }
             }
-            if (rt == 1 && kk + 1 < k_end) load_weights(kk + 1);      // the registers are free: next act group's weights
-            p16i_t cc[2];
+        };
+        auto zero_points = [&](int rt) {       // zero * (sum of lut_biases over the weight group), tbl.cc:497-505 regrouped
+            p2f_t zr[8];
+            read_rows(cbuf, 1, rt, zr);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                cc[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0], bv[nt][0], zero16, 0, 0, 0);
+                const float l = __fadd_rn(lbs[nt], lb[nt]);
 #pragma unroll
-                for (int ks = 1; ks < 4; ++ks) cc[nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[ks], bv[nt][ks], cc[nt], 0, 0, 0);
+                for (int r2 = 0; r2 < 8; ++r2) facc[rt][nt][r2] = __builtin_elementwise_fma(zr[r2], (p2f_t){l, l}, facc[rt][nt][r2]);
             }
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                // C += ((comb / 2) ls + lb / 2) scale [+ zero lb, once per weight group below], cf. k_gemv_quad / k_gemm_onehot (W4)
-                const p2f_t h2 = {hls[nt], hls[nt]}, b2 = {hlbx[nt], hlbx[nt]};
-#pragma unroll
-                for (int r2 = 0; r2 < 8; ++r2) {
-                    const p2f_t ps = {(float)cc[nt][2 * r2], (float)cc[nt][2 * r2 + 1]};
-                    const p2f_t v = __builtin_elementwise_fma(ps, h2, b2);
-                    facc[rt][nt][r2] = __builtin_elementwise_fma(v, sc[rt][r2], facc[rt][nt][r2]);
-                }
-                if (DUMP) {
-                    const int nn = n0 + nt * 32 + j;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int orow = row0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * kb;
-                        if (nn < a.N && orow < Mw) a.dump[((size_t)nn * Mw + orow) * G + kk] = cc[nt][r] - bias[nt];
-                    }
-                }
-            }
-            if (ZP && glast) {                 // zero points: zero * (sum of lut_biases over the weight group), tbl.cc:497-505 regrouped
-                p2f_t zr[8];
-                read_rows(cbuf, 1, rt, zr);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const float l = __fadd_rn(lbs[nt], lb[nt]);
-#pragma unroll
-                    for (int r2 = 0; r2 < 8; ++r2) facc[rt][nt][r2] = __builtin_elementwise_fma(zr[r2], (p2f_t){l, l}, facc[rt][nt][r2]);
-                }
-            }
-            if (more) read_rows(nbuf, 0, rt, sc[rt]);
-        }
+        };
+
+        // tile pipeline: the MFMAs of tile t + 1 run under the fp32 chain of tile t (two accumulator sets)
+        constexpr bool SC2 = BITS == 2;        // W2: tile row 1's scales in registers of their own, fetched early (W4 has none to spare)
+        p16i_t ca, cb;
+        p2f_t sc1s[SC2 ? 8 : 1];
+        p2f_t (&sc1)[8] = *reinterpret_cast<p2f_t (*)[8]>(SC2 ? &sc1s[0] : &sc0[0]);
+        chain(av0, 0, ca);
+        if (next) dma_part(kk + 1, 0);                     // (the chunk buffer has been read: lgkmcnt(0) above)
+        chain(av0, 1, cb);
+        if (next) dma_part(kk + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        build_av(1, av1);
+        if (SC2) read_rows(cbuf, 0, 1, sc1);
+        if (next) load_weights(kk + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(0, 0, ca, sc0);
+        __builtin_amdgcn_sched_barrier(0);
+        chain(av1, 0, ca);
+        if (next) dma_part(kk + 1, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(0, 1, cb, sc0);
+        if (!SC2) read_rows(cbuf, 0, 1, sc1);
+        __builtin_amdgcn_sched_barrier(0);
+        chain(av1, 1, cb);
+        if (next) dma_part(kk + 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ZP && glast) zero_points(0);
+        epilogue(1, 0, ca, sc1);
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(1, 1, cb, sc1);
+        if (ZP && glast) zero_points(1);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) lbs[nt] = glast ? 0.f : __fadd_rn(lbs[nt], lb[nt]);
     }
 
     // ---- reduce the K ranges through LDS (operand rows and chunk buffers are free now) and store ------------------
+    PSTAMP(1, 5);
     __syncthreads();
+    PSTAMP(1, 6);
     {
         unsigned char* red = plds + w * 16384;                // [n 64][o 64] fp32, 16-byte slots XOR-swizzled by n & 15
 #pragma unroll
@@ -383,6 +451,8 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
             }
         }
     }
+    PSTAMP(2, 5);
+#undef PSTAMP
 }
 
 bool gemm_planes_supported(const Shape& s) {
@@ -407,19 +477,21 @@ hipError_t launch_gemm_planes(const Gemm2Args& a_in, hipStream_t st) {
     a.gx = gx;
     a.gy = (a.N + 63) / 64;
     dim3 g(((gx + 7) & ~7) * a.gy), b(64 * P_NWV);
-#define PL3(B, Z, D) do { \
+#define PL4(B, Z, D, H) do { \
         static bool attr_set = false; \
         if (!attr_set) { \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_planes<B, Z, D>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES); \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_planes<B, Z, D, H>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES); \
             if (e != hipSuccess) return e; \
             attr_set = true; \
         } \
-        hipLaunchKernelGGL((k_gemm_planes<B, Z, D>), g, b, P_LDS_BYTES, st, a); } while (0)
+        hipLaunchKernelGGL((k_gemm_planes<B, Z, D, H>), g, b, P_LDS_BYTES, st, a); } while (0)
+#define PL3(B, Z, D) do { if (a.sc_f16) PL4(B, Z, D, true); else PL4(B, Z, D, false); } while (0)
 #define PL2(B, Z) do { if (a.dump) PL3(B, Z, true); else PL3(B, Z, false); } while (0)
     if (a.s.bits == 2) { if (a.s.zero_point) PL2(2, true); else PL2(2, false); }
     else { if (a.s.zero_point) PL2(4, true); else PL2(4, false); }
 #undef PL2
 #undef PL3
+#undef PL4
     return hipGetLastError();
 }
 

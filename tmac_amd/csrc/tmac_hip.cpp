@@ -563,6 +563,8 @@ static int32_t gemm_multi(const tmac_hip_weights* const* wl, int nmat, const tma
     return TMAC_HIP_OK;
 }
 
+static unsigned long long* g_gemm_stamps = nullptr;   // profiling: device buffer for k_gemm_planes' step stamps (tmac_hip_debug_gemm_stamps)
+
 static bool planes_ok(const tmac_hip_weights* w) {
     return g_gemm_kernel != 1 && w->s.lay == 2 && w->lo_ok && w->s.ts == 8 && !w->fa && gemm_planes_supported(w->s);
 }
@@ -577,6 +579,7 @@ static int32_t planes_multi(const tmac_hip_weights* const* wl, int nmat, const t
     for (int i = 0; i < nmat; ++i) { ga.m[i].W = wl[i]->W; ga.m[i].SC = wl[i]->SC; ga.m[i].C = C_list[i]; ga.m[i].Mw = wl[i]->s.Mw; }
     ga.sc_f16 = w0->sc_dtype == F16; ga.out_f16 = out_dtype == TMAC_F16;
     ga.bimg = (const uint4*)ws->gimg; ga.colv = ws->gcol; ga.Npad = ws->gNpad; ga.N = N; ga.dump = comb_dump;
+    ga.stamps = g_gemm_stamps;
     hipError_t e = launch_gemm_planes(ga, st);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "plane-combined gemm launch: %s", hipGetErrorString(e));
     return TMAC_HIP_OK;
@@ -663,6 +666,11 @@ extern "C" int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const 
     }
     (void)hipFree(Ctmp);
     return rc;
+}
+
+extern "C" int32_t tmac_hip_debug_gemm_stamps(unsigned long long* dev_buffer) {
+    g_gemm_stamps = dev_buffer;
+    return TMAC_HIP_OK;
 }
 
 extern "C" int32_t tmac_hip_debug_gemm_kernel(int which) {

@@ -80,6 +80,7 @@ struct Gemm2Args {
     int32_t* dump;            // optional tap [N][Mw][K/64]: sum_p 2^p PS_p (nmat == 1)
     int gx, gy;               // filled by the launcher: row blocks (64 rows, all matrices) and token blocks (64 rows of activations)
     int apg_shift;            // filled by the launcher: log2(act groups per weight group)
+    unsigned long long* stamps; // optional s_memrealtime stamps of workgroup 0: [wave 8][step 64][8] (profiling; tools/gemm2_stamps.py)
 };
 
 struct GemvArgs {

@@ -1,0 +1,35 @@
+"""Step stamps of k_gemm_planes (workgroup 0): where an act-group step of each wave spends its time.
+usage: gemm2_stamps.py [Mw K N]   (W2 g128 zero points, fp16 scales / activations / outputs)"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tmac_amd
+from tmac_amd import KCfg, F16
+L = tmac_amd.lib()
+dev = torch.device("cuda")
+Mw, K, N = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (4096, 4096, 256)
+BITS, BM = 2, 128
+wr = tmac_amd.TMACGeMMWrapper(act_group_size=64)
+A = torch.randint(0, 256, (Mw * BITS // BM, K // 4, BM // 2), dtype=torch.uint8, device=dev)
+S = (torch.randn((Mw * BITS // BM, K // 128, BM // BITS // 8, 2, 8), device=dev) * 0.01).half().contiguous()
+w = tmac_amd.Weights(A, S, Mw, K, BITS, KCfg.make(Mw, K, BITS, BM), scales_dtype=F16, dev_dtype=F16, on_device=True)
+x = torch.randn(N, K, device=dev).half()
+out = torch.empty(N, Mw, dtype=torch.float16, device=dev)
+for _ in range(3):
+    wr.fused([w], x, [out], N)
+torch.cuda.synchronize()
+buf = torch.zeros(8 * 64 * 8, dtype=torch.int64, device=dev)
+tmac_amd.binding.check(L.tmac_hip_debug_gemm_stamps(buf.data_ptr()))
+wr.fused([w], x, [out], N)
+torch.cuda.synchronize()
+L.tmac_hip_debug_gemm_stamps(None)
+st = buf.cpu().numpy().reshape(8, 64, 8).astype(np.int64)
+t0 = st[:, 0, 5].min()
+us = lambda v: (v - t0) / 100.0
+print(f"{Mw} x {K}, N = {N}: workgroup 0, times in us from the first wave's start (s_memrealtime, 10 ns)")
+for wv in range(8):
+    s = st[wv]
+    nsteps = int((s[:, 0] > 0).sum())
+    print(f"wave {wv}: start {us(s[0,5]):6.2f}  operand rows built {us(s[0,6]):6.2f}  loop end {us(s[1,5]):6.2f}  reduce barrier {us(s[1,6]):6.2f}  stored {us(s[2,5]):6.2f}   steps {nsteps}")
+    tops = [us(s[k, 0]) for k in range(nsteps)] + [us(s[1, 5])]
+    print("    step durations: " + " ".join(f"{tops[k + 1] - tops[k]:5.2f}" for k in range(nsteps)))

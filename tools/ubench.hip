@@ -92,7 +92,65 @@ static int graph_main() {
 }
 
 int rate_main();
+// ---- L2 -> LDS streaming probe: what one CU gets from an L2-resident image with a bounded number of bytes in flight -----
+// Every wave repeats: issue NB 1 KB global_load_lds (buffer form, scalar offsets), wait for all of them.  All workgroups
+// read the SAME image (as the prefill GEMM's workgroups of one XCD do), at a wave-specific rotating offset.
+template <int NB, bool TOLDS>
+__global__ __launch_bounds__(512) void k_dma(const uint32_t* img, uint32_t img_bytes, int iters, uint32_t* out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dl[];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(img), (short)0, 0x7fffffff, 0x00020000);
+    uint32_t off = (uint32_t)((w * 131 + blockIdx.x * 17) % 1024) * 1024u, acc = 0;
+    u32x4 r[NB];
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const uint32_t so = (off + b * 65536u) % img_bytes;
+            if (TOLDS) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(uintptr_t)(w * NB * 1024 + b * 1024), 16, lane * 16, so, 0, 0);
+            else r[b] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, so, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!TOLDS)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc += r[b].x;
+        off = (off + 8192u) % img_bytes;
+    }
+    if (TOLDS) acc = *reinterpret_cast<const uint32_t*>(dl + threadIdx.x * 4);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+}
+
+template <int NB, bool TOLDS>
+static void dma_run(const uint32_t* img, uint32_t bytes, int waves, uint32_t* out) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int iters = 200;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dma<NB, TOLDS>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * NB * 1024));
+    hipLaunchKernelGGL((k_dma<NB, TOLDS>), dim3(256), dim3(64 * waves), 8 * NB * 1024, 0, img, bytes, 10, out);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k_dma<NB, TOLDS>), dim3(256), dim3(64 * waves), 8 * NB * 1024, 0, img, bytes, iters, out);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us_it = ms * 1e3 / iters, kb = (double)waves * NB;
+    printf("%-9s image %5.1f MB, %d waves/CU x %2d KB in flight: %6.2f us per round, %6.1f GB/s per CU, %5.2f TB/s chip\n", TOLDS ? "-> LDS" : "-> VGPR",
+           bytes / 1048576.0, waves, NB, us_it, kb * 1024 / us_it * 1e-3, kb * 1024 * 256 / us_it * 1e-6);
+}
+
+int dma_main() {
+    uint32_t* img; CK(hipMalloc((void**)&img, 64u << 20)); CK(hipMemset(img, 1, 64u << 20));
+    uint32_t* out; CK(hipMalloc((void**)&out, 256 * 512 * 4));
+    for (uint32_t mb : {2u, 8u, 64u}) {
+        dma_run<8, true>(img, mb << 20, 8, out);
+        dma_run<8, true>(img, mb << 20, 4, out);
+        dma_run<8, true>(img, mb << 20, 1, out);
+        dma_run<4, true>(img, mb << 20, 8, out);
+        dma_run<16, true>(img, mb << 20, 8, out);
+        dma_run<8, false>(img, mb << 20, 8, out);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'd') return dma_main();
     if (argc > 1 && argv[1][0] == 'g') return graph_main();
     if (argc > 1) return rate_main();
     const size_t big = 12734128 / 16384 * 16384 + 16384, small = 4743424 / 16384 * 16384 + 16384;

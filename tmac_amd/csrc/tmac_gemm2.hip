@@ -280,7 +280,14 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
         write_staged(g_lo);
         if (g_lo + 2 < g_hi) load_staged(g_lo + 2);
     }
-    const p16i_t zero16 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // accumulators start from the bits of 3.0f, the middle of the binade [2, 4): as a float the int32 result is 3 + comb * 2^-22
+    // exactly for |comb| < 2^21 (it is < 2^19 here), so int -> float is one packed subtraction per pair.  The 16 registers are
+    // made opaque to the compiler, which otherwise rebuilds the constant vector with 15 moves in front of every chain.
+    // W4 has no registers to spare for that: its chains start from zero and the conversion is 16 v_cvt_f32_i32 per tile.
+    constexpr bool MAGIC = BITS == 2;
+    constexpr int CI = MAGIC ? 0x40400000 : 0;
+    p16i_t cinit = {CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI};
+    if (MAGIC) asm volatile("" : "+v"(cinit));
     // One act group (64 activations = four 32-deep MFMA steps) per iteration.  The order below interleaves the four units a
     // step keeps busy -- the vector-memory path (chunk DMA, weight loads), LDS (operand reads), the matrix core and the VALU
     // (fp32 scale chain) -- inside ONE wave: the operands of tile row 1 are fetched while the MFMAs of tile row 0 run, the
@@ -306,6 +313,9 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
         const bool next = kk + 1 < k_end;
         const int cbuf = (g - g_lo) & 1;
         PSTAMP(kk - k_lo, 0);
+        // the older wave of a SIMD wins every issue conflict (its four K ranges finish ~15 % earlier and then wait at the
+        // reduction): alternate the priority between the two waves of a SIMD step by step
+        if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk of kk is in LDS, its weights, column values and the staged scales in registers
         if (more) {
             write_staged(g + 1);
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
             }
         build_av(0, av0);
         read_rows(cbuf, 0, 0, sc0);
-        // column values of the act group (loaded one step ahead): v = comb * H + hlbx with H = ls / 2,
+        // column values of the act group (loaded one step ahead): v = x * H + hlbx with x = comb * 2^-22, H = (ls / 2) * 2^22,
         // hlbx = lb / 2  [- 15 * (entry sum) * (ls / 2) for the +15 operand bias of W4]
         float H[2], hlbx[2], lb[2];
         int bias[2];
@@ -331,7 +341,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
         for (int nt = 0; nt < 2; ++nt) {
             const float hls = __fmul_rn(0.5f, cn[nt][0]);
             lb[nt] = cn[nt][1];
-            H[nt] = hls;
+            H[nt] = MAGIC ? __fmul_rn(hls, 4194304.0f) : hls;
             hlbx[nt] = __fmul_rn(0.5f, lb[nt]);
             bias[nt] = 0;
             if (BITS == 4) {
@@ -345,7 +355,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
         __builtin_amdgcn_sched_barrier(0);
 
         auto chain = [&](const p4i_t (&av)[4], int nt, p16i_t& c) {      // one 32 x 32 tile of the act group: four dependent MFMAs
-            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0], bv[nt][0], zero16, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0], bv[nt][0], cinit, 0, 0, 0);
 #pragma unroll
             for (int ks = 1; ks < 4; ++ks) c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[ks], bv[nt][ks], c, 0, 0, 0);
         };
@@ -356,7 +366,9 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
             const p2f_t h2 = {H[nt], H[nt]}, b2 = {hlbx[nt], hlbx[nt]};
             p2f_t x[8];
 #pragma unroll
-            for (int r2 = 0; r2 < 8; ++r2) x[r2] = (p2f_t){(float)c[2 * r2], (float)c[2 * r2 + 1]};
+            for (int r2 = 0; r2 < 8; ++r2)
+                x[r2] = MAGIC ? (p2f_t){__int_as_float(c[2 * r2]), __int_as_float(c[2 * r2 + 1])} - (p2f_t){3.0f, 3.0f}
+                              : (p2f_t){(float)c[2 * r2], (float)c[2 * r2 + 1]};
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2) x[r2] = __builtin_elementwise_fma(x[r2], h2, b2);
 #pragma unroll
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int orow = row0 + 32 * rt + (r & 3) + 8 * (r >> 2) + 4 * kb;
-                    if (nn < a.N && orow < Mw) a.dump[((size_t)nn * Mw + orow) * G + kk] = c[r] - bias[nt];
+                    if (nn < a.N && orow < Mw) a.dump[((size_t)nn * Mw + orow) * G + kk] = c[r] - CI - bias[nt];
                 }
             }
         };
@@ -415,6 +427,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
         for (int nt = 0; nt < 2; ++nt) lbs[nt] = glast ? 0.f : __fadd_rn(lbs[nt], lb[nt]);
     }
 
+    __builtin_amdgcn_s_setprio(0);
     // ---- reduce the K ranges through LDS (operand rows and chunk buffers are free now) and store ------------------
     PSTAMP(1, 5);
     __syncthreads();

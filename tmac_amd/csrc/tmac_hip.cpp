@@ -232,12 +232,17 @@ extern "C" int32_t tmac_hip_set_gemm_min_n(int n) {
     return TMAC_HIP_OK;
 }
 // GEMM or row loop for N activation rows on matrices with total_Mw output rows?  An explicitly set threshold is taken
-// literally; the default (32) also asks for a grid that fills the chip: with fewer than 128 workgroups of 128 bit-plane
-// rows the row loop is faster up to 64 rows (profiles/r01_small_n.txt: 4096 x 11008 at N = 32: 88 us against 152 us).
+// literally.  The default: from 12 rows where k_gemm_planes covers the configuration (its 64-row tile costs 15-37 us on the
+// llama-2-7B shapes whatever N <= 64 is, the row loop 1.4-3 us per row: profiles/r02_gemm_planes_shapes.txt, r01_small_n.txt);
+// from 32 rows with k_gemm_onehot, which also asks for a grid that fills the chip (with fewer than 128 workgroups of 128
+// bit-plane rows the row loop is faster up to 64 rows: 4096 x 11008 at N = 32: 88 us against 152 us).
+constexpr int PLANES_MIN_N = 12;
+static bool planes_covers(const Shape& s) { return g_gemm_kernel != 1 && s.lay == 2 && s.ts == 8 && gemm_planes_supported(s); }
 static bool gemm_pays(const Shape& s, long total_Mw, int N) {
-    if (g_gemm_min_n <= 0 || N < g_gemm_min_n) return false;
-    if (g_gemm_min_n != 32) return true;
-    return N >= 64 || (total_Mw * s.bits + 127) / 128 >= 128;
+    if (g_gemm_min_n <= 0) return false;
+    if (g_gemm_min_n != 32) return N >= g_gemm_min_n;
+    if (planes_covers(s)) return N >= PLANES_MIN_N;
+    return N >= 32 && (N >= 64 || (total_Mw * s.bits + 127) / 128 >= 128);
 }
 
 extern "C" int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host, int n) {
@@ -496,7 +501,8 @@ extern "C" int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void*
                             K, N, act_group_size, ws->qdev_u4_per_row, (hipStream_t)stream);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
     ws->gimg_valid = false;
-    if (act_group_size == 64 && N >= 2 && ws->gimg && g_gemm_kernel != 1) {   // what k_gemm_planes streams (tmac_hip_qgemm_dev may pick it)
+    const int gmin = g_gemm_min_n <= 0 ? 0x7fffffff : (g_gemm_min_n != 32 ? (g_gemm_min_n > 2 ? g_gemm_min_n : 2) : PLANES_MIN_N);
+    if (act_group_size == 64 && N >= gmin && ws->gimg && g_gemm_kernel != 1) {   // what k_gemm_planes streams (tmac_hip_qgemm_dev may pick it)
         e = launch_lut_image(B_dev, act_dtype == TMAC_F16, ws->gimg, ws->gcol, K, N, ws->gNpad, (hipStream_t)stream);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT image launch: %s", hipGetErrorString(e));
         ws->gimg_valid = true;

@@ -1,6 +1,6 @@
 """Per-shape timing of the N > 1 kernels on the llama-2-7B shapes: LUT image build and k_gemm_planes through the fused
 entry point (one call = k_lut_image + k_gemm_planes) and the GEMM alone, replayed from a hipGraph.
-usage: bench_gemm2.py [N] [bits]"""
+usage: bench_gemm2.py [N] [bits] [kernel: 0 = k_gemm_planes (default), 1 = k_gemm_onehot]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,6 +11,9 @@ dev = torch.device("cuda")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 BITS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 BM = 128 if BITS == 2 else 256
+KERNEL = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+tmac_amd.binding.check(L.tmac_hip_debug_gemm_kernel(KERNEL))
+L.tmac_hip_set_gemm_min_n(1)
 wr = tmac_amd.TMACGeMMWrapper(act_group_size=64)
 
 
@@ -32,7 +35,7 @@ def timeit(fn, reps=20):
     return best
 
 
-print("N =", N, " bits =", BITS)
+print("N =", N, " bits =", BITS, " kernel =", "k_gemm_onehot" if KERNEL else "k_gemm_planes")
 for name, Mw, K, nshare in [("o", 4096, 4096, 1), ("qkv", 4096, 4096, 3), ("gate_up", 11008, 4096, 2), ("down", 4096, 11008, 1)]:
     ws, outs = [], []
     for _ in range(nshare):
@@ -43,11 +46,9 @@ for name, Mw, K, nshare in [("o", 4096, 4096, 1), ("qkv", 4096, 4096, 3), ("gate
     x = torch.randn(N, K, device=dev).half()
     t = timeit(lambda: wr.fused(ws, x, outs, N))
     if nshare == 1:   # the GEMM alone: LUT built once by the split entry point, then only tmac_hip_qgemm_dev in the graph
-        L.tmac_hip_set_gemm_min_n(1)
         wr.set_workspace(K, N)
         wr.llama_cpp_init(x, Mw, K, N, BITS)
         tg = timeit(lambda: wr.llama_cpp_compute(ws[0], outs[0], N))
-        L.tmac_hip_set_gemm_min_n(32)
         print(f"{name:8s} gemm alone {tg:8.1f} us")
     ops = 2.0 * Mw * nshare * (K / 4 * 8) * N
     print(f"{name:8s} {nshare} x {Mw} x {K}: LUT image + gemm {t:8.1f} us  ({ops / t * 1e-6:7.1f} int8 TOP/s issued, {ops / t * 1e-6 / 4404 * 100:5.1f} % of the 32x32x32 i8 ceiling)")

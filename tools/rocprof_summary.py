@@ -23,7 +23,7 @@ for tag in ("trace_chain", "trace_fused", "trace_prefill"):
             if "tmac::" in r["Name"] and "retile" not in r["Name"]:
                 print(f"  {short(r['Name']):110s} calls {int(r['Calls']):6d}  avg {float(r['AverageNs']) / 1e3:10.2f}  min {float(r['MinNs']) / 1e3:10.2f}  max {float(r['MaxNs']) / 1e3:10.2f}  total {float(r['TotalDurationNs']) / 1e6:9.2f} ms")
 
-for tag in sorted(t for t in os.listdir(root) if t.startswith(("fetch_", "sq1_", "sq2_")) and os.path.isdir(os.path.join(root, t))):
+for tag in sorted(t for t in os.listdir(root) if t.startswith(("fetch_", "sq1_", "sq2_", "lds_", "sq_")) and os.path.isdir(os.path.join(root, t))):
     acc = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(root, tag, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):

@@ -133,3 +133,43 @@ def test_gemm_planes_edge_activations(tm):
         m = finite[n]
         if m.any():
             assert rel_err(r["C"][n][m], Cc[n][m]) <= 1e-5
+
+
+@pytest.mark.parametrize("Mw,K,N", [(320, 3200, 40), (160, 640, 33), (3200, 8640, 70), (3200, 3200, 256), (64, 12288, 13)])
+def test_gemm_planes_unified_scale(tm, Mw, K, N):
+    """the BitNet flavour (m_groups = 1, one act group per row) through k_gemm_planes_us: the LUT image of the row-wise build
+    bit-identical to the oracle's, the combined integer totals bit-identical to the oracle's per-plane totals, and the
+    outputs BIT-IDENTICAL to the oracle's scale-final expression (qgemm.py:170-174) -- integer accumulation has no order"""
+    import torch
+    bits, bm = 2, 320 if Mw % 160 == 0 else 128
+    if Mw % (bm // bits) != 0:
+        bm = 128
+    case = orc.make_case(400 + N + K, Mw, K, N=N, bits=bits, ags=K, zero_point=False, m_groups=1)
+    L = tm.lib()
+    tm.binding.check(L.tmac_hip_set_gemm_min_n(1))
+    try:
+        A = orc.preprocess_weights(case["w"], bits, bm, 16)
+        S = case["sc"]
+        cfg = tm.KCfg.make(Mw, K, bits, bm, 16, 128, K, False, 1, N)
+        wr = tm.TMACGeMMWrapper(act_group_size=K)
+        wr.set_workspace(K, N)
+        w = wr.register_weights(A, S, Mw, K, bits, cfg, scales_dtype=tm.F32, dev_dtype=tm.F32)
+        Bt = torch.from_numpy(case["B"]).cuda()
+        Ct = torch.full((N, Mw), float("nan"), dtype=torch.float32, device="cuda")
+        wr.llama_cpp_init(Bt, Mw, K, N, bits)
+        wr.llama_cpp_compute(w, Ct, N)
+        torch.cuda.synchronize()
+        h, gls, glb, _ = wr.workspace.read_gemm_image(K, N, act_group_size=K)
+        comb = wr.comb_sums(w, N)
+        C = Ct.cpu().numpy()
+        w.free()
+    finally:
+        L.tmac_hip_set_gemm_min_n(32)
+    q, ls, lb = orc.preprocessor(case["B"], K)
+    assert np.array_equal(h, q[:, :, :8])
+    assert np.array_equal(gls.view(np.uint32), ls.view(np.uint32)) and np.array_equal(glb.view(np.uint32), lb.view(np.uint32))
+    Cc, cb = orc.qgemm_scale_final(A, q, S, ls[:, 0], lb[:, 0], Mw, K, N, bits, bm, 16, 1)      # cb: int32 [N][M] per-plane totals
+    rows = np.arange(Mw)
+    want = sum((cb[:, mrow(rows, p, bits)].astype(np.int64) << p) for p in range(bits))
+    assert np.array_equal(comb[:, :, 0].astype(np.int64), want)
+    assert np.array_equal(C.view(np.uint32), Cc.view(np.uint32))

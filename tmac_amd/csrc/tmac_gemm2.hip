@@ -468,9 +468,172 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
 #undef PSTAMP
 }
 
+// ---------------------------------------------------------------------------------------------
+// The unified-scale flavour (BitNet: m_groups >= 1, one act group per activation row; tbl_g4_int8_int32_update +
+// qgemm.py:170-174) on the same operands: nothing is scaled per act group, so the int32 tiles accumulate over the wave's whole
+// K range, the eight ranges are added as integers (exact, any order) and the scale-final expression
+//   C = ((comb / 2) * lut_scale[n] + lut_bias[n] / 2) * scale[o / (Mw / m_groups)]
+// runs once per output -- bit for bit what the GEMV kernel and the oracle compute from the per-plane totals (comb / 2 =
+// sum_p alpha_p * total_p is exact in fp32: |comb| < 2^24).  2-bit weights (the signed operand rows need no bias term).
+// The LUT image comes from k_preprocess_pairs_row (tmac_quad.hip), colv holds lut_scales | lut_biases with one act group.
+template <bool DUMP>
+__global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes_us(Gemm2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
+    constexpr int NJ = 2;
+    const Shape& s = a.s;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int kb = lane >> 5, j = lane & 31;
+    const int xcd = blockIdx.x & 7, qid = blockIdx.x >> 3;
+    int bx = xcd + 8 * (qid / a.gy);
+    const int by = qid % a.gy;
+    if (bx >= a.gx) return;
+    int mi = 0;
+    while (mi + 1 < a.nmat && bx >= a.m[mi].wg_end) ++mi;
+    if (mi > 0) bx -= a.m[mi - 1].wg_end;
+    const GemmMat M = a.m[mi];
+    const int Mw = M.Mw, nk = s.K / 64, nu = s.K / 32, nst = (nu + 63) >> 6, nq = (Mw + 3) >> 2;
+    const int row0 = bx * 64, n0 = by * 64;
+    const int k_lo = (w * nk) / P_NWV, k_end = ((w + 1) * nk) / P_NWV;        // 64-activation steps of this wave
+
+    const uint32_t psel = 0x0c0c0000u | ((4u + (lane & 3)) << 8);
+    const uint32_t copyoff = (uint32_t)j * 8u;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.W), (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.bimg), (short)0, 0x7fffffff, 0x00020000);
+    int wvoff[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+        const int quad = min((row0 >> 2) + rt * 8 + (j >> 2), nq - 1);
+        wvoff[rt] = ((quad * nst * NJ + kb) * 64) * 16;
+    }
+    const int bvoff = (n0 + lane) * 16;
+    const uint32_t bb_wave = P_BB_OFF + w * P_BB_WAVE;
+    uint4 wv[2][2];
+    auto dma_chunk = [&](int kk) {
+#pragma unroll
+        for (int ul = 0; ul < 2; ++ul)
+#pragma unroll
+            for (int pr = 0; pr < 4; ++pr)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + (ul * 4 + pr) * 1024), 16, bvoff,
+                                                         ((2 * kk + ul) * 4 + pr) * a.Npad * 16, 0, 0);
+    };
+    auto load_weights = [&](int kk, int rt) {
+#pragma unroll
+        for (int ul = 0; ul < 2; ++ul) {
+            const int u = 2 * kk + ul, so = ((u >> 6) * NJ * 64 + (u & 63)) * 16;
+            const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt], so, 0);
+            wv[ul][rt] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    auto pat_row = [&](uint32_t d) -> uint2 { return *reinterpret_cast<const uint2*>(plds + __builtin_amdgcn_perm(d, copyoff, psel)); };
+    const bool work = k_lo < k_end;
+    if (work) { dma_chunk(k_lo); load_weights(k_lo, 0); load_weights(k_lo, 1); }
+    {
+        const int b = tid & 255, i0 = b & 15, i1 = b >> 4;
+        uint32_t lo = 0, hi = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int v = 0;
+            if (e == (i0 & 7)) v += (i0 & 8) ? -1 : 1;
+            if (e == (i1 & 7)) v += (i1 & 8) ? -2 : 2;
+            const uint32_t by8 = (uint32_t)(v & 0xff) << (8 * (e & 3));
+            if (e < 4) lo |= by8; else hi |= by8;
+        }
+        uint4* pt = reinterpret_cast<uint4*>(plds) + b * 16 + (tid >> 8) * 8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo, hi);
+    }
+    __syncthreads();
+
+    p16i_t acc[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0;
+    for (int kk = k_lo; kk < k_end; ++kk) {
+        const bool next = kk + 1 < k_end;
+        if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        p4i_t bv[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (((ks >> 1) * 4 + 2 * kb + (ks & 1)) * 64 + nt * 32 + j) * 16);
+                bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+            }
+        p4i_t av[2][4];
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const uint4 q = wv[ks >> 1][rt];
+                const uint2 t0 = pat_row((ks & 1) ? q.z : q.x), t1 = pat_row((ks & 1) ? q.w : q.y);
+                av[rt][ks] = (p4i_t){(int)t0.x, (int)t0.y, (int)t1.x, (int)t1.y};
+            }
+        if (next) { load_weights(kk + 1, 0); load_weights(kk + 1, 1); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (next) dma_chunk(kk + 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[rt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[rt][ks], bv[nt][ks], acc[rt][nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __syncthreads();
+    {
+        unsigned char* red = plds + w * 16384;                // [n 64][o 64] int32, 16-byte slots XOR-swizzled by n & 15
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int nl = nt * 32 + j, slot = (8 * rt + 2 * q4 + kb) ^ (nl & 15);
+                    *reinterpret_cast<p4i_t*>(red + nl * 256 + slot * 16) =
+                        (p4i_t){acc[rt][nt][4 * q4], acc[rt][nt][4 * q4 + 1], acc[rt][nt][4 * q4 + 2], acc[rt][nt][4 * q4 + 3]};
+                }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 64 * P_NWV * i, nl = idx >> 4, sl = idx & 15;
+        const unsigned char* p = plds + nl * 256 + ((sl ^ (nl & 15)) * 16);
+        p4i_t v = *reinterpret_cast<const p4i_t*>(p);
+#pragma unroll
+        for (int ww = 1; ww < P_NWV; ++ww) v += *reinterpret_cast<const p4i_t*>(p + ww * 16384);
+        const int n = n0 + nl, o = row0 + sl * 4;
+        if (n < a.N && o < Mw) {
+            const float ls = a.colv[n], hlb = __fmul_rn(a.colv[a.Npad + n], 0.5f);
+            float r[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (DUMP) a.dump[(size_t)n * Mw + o + e] = v[e];
+                const float t = __fmul_rn((float)v[e], 0.5f);
+                const float x = __fadd_rn(__fmul_rn(t, ls), hlb);
+                r[e] = __fmul_rn(x, q_ld_scale(M.SC, a.sc_f16, (o + e) / (Mw / s.m_groups)));
+            }
+            if (a.out_f16) {
+                const __half2 h0 = __floats2half2_rn(r[0], r[1]), h1 = __floats2half2_rn(r[2], r[3]);
+                *reinterpret_cast<uint2*>(reinterpret_cast<__half*>(M.C) + (size_t)n * Mw + o) =
+                    make_uint2(*reinterpret_cast<const uint32_t*>(&h0), *reinterpret_cast<const uint32_t*>(&h1));
+            } else {
+                *reinterpret_cast<p4f_t*>(reinterpret_cast<float*>(M.C) + (size_t)n * Mw + o) = (p4f_t){r[0], r[1], r[2], r[3]};
+            }
+        }
+    }
+}
+
+bool gemm_planes_us_supported(const Shape& s) {
+    return s.lay == 2 && s.bits == 2 && s.K % 64 == 0 && s.Mw % 4 == 0 && s.m_groups >= 1 && s.ags == s.K && s.Mw % s.m_groups == 0;
+}
+
 bool gemm_planes_supported(const Shape& s) {
     if (s.lay != 2 || (s.bits != 2 && s.bits != 4) || s.K % 64 != 0 || s.Mw % 4 != 0) return false;
-    if (s.m_groups >= 1) return false;                                   // unified scale: k_gemm_onehot
+    if (s.m_groups >= 1) return gemm_planes_us_supported(s);             // unified scale: k_gemm_planes_us
     const int apg = s.gs / 64;
     return s.ags == 64 && s.gs >= 64 && s.gs % 64 == 0 && s.K % s.gs == 0 && (apg & (apg - 1)) == 0;
 }
@@ -490,6 +653,19 @@ hipError_t launch_gemm_planes(const Gemm2Args& a_in, hipStream_t st) {
     a.gx = gx;
     a.gy = (a.N + 63) / 64;
     dim3 g(((gx + 7) & ~7) * a.gy), b(64 * P_NWV);
+    if (a.s.m_groups >= 1) {
+        static bool attr_us[2] = {false, false};
+        const int d = a.dump ? 1 : 0;
+        const void* fn = d ? reinterpret_cast<const void*>(&k_gemm_planes_us<true>) : reinterpret_cast<const void*>(&k_gemm_planes_us<false>);
+        if (!attr_us[d]) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+            if (e != hipSuccess) return e;
+            attr_us[d] = true;
+        }
+        if (d) hipLaunchKernelGGL((k_gemm_planes_us<true>), g, b, P_LDS_BYTES, st, a);
+        else hipLaunchKernelGGL((k_gemm_planes_us<false>), g, b, P_LDS_BYTES, st, a);
+        return hipGetLastError();
+    }
 #define PL4(B, Z, D, H) do { \
         static bool attr_set = false; \
         if (!attr_set) { \

@@ -489,6 +489,9 @@ extern "C" int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void*
     if (rc) return rc;
     if (!B_dev) return fail(TMAC_HIP_E_ARG, "null activations");
     ws->K = K; ws->N = N; ws->ags = act_group_size; ws->qdev_u4_per_row = qdev_u4_for_K(K);
+    const int gmin = g_gemm_min_n <= 0 ? 0x7fffffff : (g_gemm_min_n != 32 ? (g_gemm_min_n > 2 ? g_gemm_min_n : 2) : PLANES_MIN_N);
+    // one act group per row: the row-wise pair build also writes the LUT image of the plane-combined GEMM when that may be chosen
+    const bool row_img = act_group_size == K && K <= 12288 && N >= g_pairs_min_n && N >= gmin && ws->gimg && g_gemm_kernel != 1;
     // several activation rows with 64-activation groups: the pair-wise build (two tables per lane, all three layouts);
     // otherwise one workgroup per act group (any act_group_size, and cheaper than it looks for a single row)
     hipError_t e = (act_group_size == 64 && N >= g_pairs_min_n)
@@ -496,12 +499,12 @@ extern "C" int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void*
                                   ws->qlut_dev, ws->qdev_u4_per_row, (hipStream_t)stream)
         : (act_group_size == K && K <= 12288 && N >= g_pairs_min_n)
         ? launch_preprocess_pairs_row(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, K, N, ws->qlut_ref,
-                                      ws->qlut_dev, ws->qdev_u4_per_row, (hipStream_t)stream)
+                                      ws->qlut_dev, ws->qdev_u4_per_row, row_img ? ws->gimg : nullptr, row_img ? ws->gcol : nullptr, ws->gNpad,
+                                      (hipStream_t)stream)
         : launch_preprocess(B_dev, (Dtype)act_dtype, ws->qlut_ref, ws->qlut_dev, ws->qlut_lds, ws->lut_scales, ws->lut_biases,
                             K, N, act_group_size, ws->qdev_u4_per_row, (hipStream_t)stream);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
-    ws->gimg_valid = false;
-    const int gmin = g_gemm_min_n <= 0 ? 0x7fffffff : (g_gemm_min_n != 32 ? (g_gemm_min_n > 2 ? g_gemm_min_n : 2) : PLANES_MIN_N);
+    ws->gimg_valid = row_img;
     if (act_group_size == 64 && N >= gmin && ws->gimg && g_gemm_kernel != 1) {   // what k_gemm_planes streams (tmac_hip_qgemm_dev may pick it)
         e = launch_lut_image(B_dev, act_dtype == TMAC_F16, ws->gimg, ws->gcol, K, N, ws->gNpad, (hipStream_t)stream);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT image launch: %s", hipGetErrorString(e));
@@ -693,7 +696,7 @@ extern "C" int32_t tmac_hip_debug_gemm_comb_sums(const tmac_hip_weights* w, cons
     hipStream_t st = (hipStream_t)stream;
     if (!ws->gimg_valid || ws->K != w->s.K || N <= 0 || N > ws->N) return fail(TMAC_HIP_E_ARG, "the workspace holds no LUT image for K=%d, N=%d", w->s.K, N);
     if (!planes_ok(w)) return fail(TMAC_HIP_E_NOMATCH, "k_gemm_planes does not cover this configuration");
-    const size_t elems = (size_t)N * w->s.Mw * (w->s.K / 64);
+    const size_t elems = (size_t)N * w->s.Mw * (w->s.m_groups >= 1 ? 1 : w->s.K / 64);
     if (ws->dump_elems < elems) {
         if (ws->dump) (void)hipFree(ws->dump);
         ws->dump = nullptr; ws->dump_elems = 0;
@@ -721,7 +724,7 @@ extern "C" int32_t tmac_hip_debug_gemm_image_read(const tmac_hip_workspace* ws, 
     if (!ws || !half_tables_host || !lut_scales_host || !lut_biases_host || !entry_sums_host) return fail(TMAC_HIP_E_ARG, "null argument");
     if (!ws->gimg_valid || N <= 0 || N > ws->N) return fail(TMAC_HIP_E_ARG, "the workspace holds no LUT image for N=%d", N);
     hipStream_t st = (hipStream_t)stream;
-    const int K = ws->K, G = K / 64, Np = ws->gNpad;
+    const int K = ws->K, G = ws->ags == K ? 1 : K / 64, Np = ws->gNpad;     // (one act group per row: no entry sums, zeros returned)
     std::vector<uint8_t> img((size_t)2 * K * Np);
     std::vector<float> col((size_t)3 * G * Np);
     HIP_TRY(hipMemcpyAsync(img.data(), ws->gimg, img.size(), hipMemcpyDeviceToHost, st));
@@ -735,7 +738,7 @@ extern "C" int32_t tmac_hip_debug_gemm_image_read(const tmac_hip_workspace* ws, 
         for (int kk = 0; kk < G; ++kk) {
             lut_scales_host[(size_t)n * G + kk] = col[((size_t)0 * G + kk) * Np + n];
             lut_biases_host[(size_t)n * G + kk] = col[((size_t)1 * G + kk) * Np + n];
-            entry_sums_host[(size_t)n * G + kk] = col[((size_t)2 * G + kk) * Np + n];
+            entry_sums_host[(size_t)n * G + kk] = ws->ags == K ? 0.0f : col[((size_t)2 * G + kk) * Np + n];
         }
     }
     return TMAC_HIP_OK;
@@ -777,14 +780,19 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
     bool planes = g_variant != V_REF_LAYOUT && ws->gimg != nullptr;
     for (int i = 0; i < nmat && planes; ++i) {
         const Shape &x = wl[i]->s, &y = s0;
-        planes = planes_ok(wl[i]) && x.bits == y.bits && x.gs == y.gs && x.zero_point == y.zero_point && wl[i]->sc_dtype == wl[0]->sc_dtype;
+        planes = planes_ok(wl[i]) && x.bits == y.bits && x.gs == y.gs && x.zero_point == y.zero_point && x.ags == y.ags &&
+                 x.m_groups == y.m_groups && wl[i]->sc_dtype == wl[0]->sc_dtype;
     }
+    if (planes && s0.m_groups >= 1 && s0.K > 12288) planes = false;   // (the row-wise LUT build's limit)
     if (planes) {
         // the plane-combined GEMM reads its own LUT image only: one build, one launch for all matrices
         rc = check_lut_shape(ws, s0.K, N, s0.ags);
         if (rc) return rc;
         ws->K = 0; ws->N = 0; ws->gimg_valid = false;      // the other layouts of this workspace are not built
-        hipError_t e = launch_lut_image(B_dev, act_dtype == TMAC_F16, ws->gimg, ws->gcol, s0.K, N, ws->gNpad, st);
+        hipError_t e = s0.m_groups >= 1
+            ? launch_preprocess_pairs_row(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, s0.K, N, nullptr, nullptr, 0,
+                                          ws->gimg, ws->gcol, ws->gNpad, st)
+            : launch_lut_image(B_dev, act_dtype == TMAC_F16, ws->gimg, ws->gcol, s0.K, N, ws->gNpad, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT image launch: %s", hipGetErrorString(e));
         return planes_multi(wl, nmat, ws, C_list, out_dtype, N, nullptr, st);
     }
@@ -795,7 +803,8 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
         ws->K = s0.K; ws->N = N; ws->ags = s0.ags; ws->qdev_u4_per_row = qdev_u4_for_K(s0.K);
         hipError_t e = s0.ags == 64
             ? launch_preprocess_pairs(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, s0.K, N, nullptr, nullptr, 0, st)
-            : launch_preprocess_pairs_row(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, s0.K, N, nullptr, nullptr, 0, st);
+            : launch_preprocess_pairs_row(B_dev, act_dtype == TMAC_F16, ws->qlut_lds, ws->lut_scales, ws->lut_biases, s0.K, N, nullptr, nullptr, 0,
+                                          nullptr, nullptr, 0, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
     } else {
         rc = tmac_hip_preprocessor_dev(ws, B_dev, act_dtype, s0.K, N, s0.ags, st);

@@ -112,8 +112,9 @@ hipError_t launch_qlut_ref_to_dev(const int8_t* qlut_ref, void* qlut_dev, void* 
 hipError_t launch_preprocess_pairs(const void* B, int act_f16, void* qlut_lds, float* lut_scales, float* lut_biases, int K, int N,
                                    int8_t* qlut_ref, void* qlut_dev, size_t qdev_u4_per_row, hipStream_t st);
 // the same for act_group_size = K (one act group per activation row; K <= 12288)
+// bimg / colv (both or neither; Npad = row stride of the image): also the LUT image k_gemm_planes_us streams (tmac_gemm2.hip)
 hipError_t launch_preprocess_pairs_row(const void* B, int act_f16, void* qlut_lds, float* lut_scales, float* lut_biases, int K, int N,
-                                       int8_t* qlut_ref, void* qlut_dev, size_t qdev_u4_per_row, hipStream_t st);
+                                       int8_t* qlut_ref, void* qlut_dev, size_t qdev_u4_per_row, void* bimg, float* colv, int Npad, hipStream_t st);
 hipError_t launch_stream_read(const void* src, size_t bytes, void* sink, hipStream_t st);   // measurement aid, see tmac_kernels.hip
 bool gemm_onehot_supported(const Shape& s);
 hipError_t launch_gemm_onehot(const GemmArgs& a, hipStream_t st);

@@ -695,7 +695,8 @@ template <bool F16, bool ALL, int PT>
 __global__ __launch_bounds__(PT) void k_preprocess_pairs_row(const void* __restrict__ B, uint4* __restrict__ qlut_lds,
                                                                float* __restrict__ lut_scales, float* __restrict__ lut_biases,
                                                                int K, int tstride, uint4* __restrict__ qlut_ref,
-                                                               uint2* __restrict__ qlut_dev, size_t qdev_u4_per_row) {
+                                                               uint2* __restrict__ qlut_dev, size_t qdev_u4_per_row,
+                                                               uint4* __restrict__ bimg, float* __restrict__ colv, int Npad) {
     extern __shared__ float prs[];          // [PT/64] wave maxima | [K/32] chunk sums
     constexpr int NWV = PT / 64;
     const int P = K / 8, n = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
@@ -748,6 +749,7 @@ __global__ __launch_bounds__(PT) void k_preprocess_pairs_row(const void* __restr
         for (int c = 0; c < nc; ++c) biases = __fadd_rn(biases, l_cs[c]);
         lut_scales[n] = gscale;
         lut_biases[n] = biases;
+        if (colv) { colv[n] = gscale; colv[Npad + n] = biases; }      // the layout k_gemm_planes_us reads (tmac_gemm2.hip)
     }
 #pragma unroll
     for (int r = 0; r < NPR; ++r) {
@@ -758,6 +760,8 @@ __global__ __launch_bounds__(PT) void k_preprocess_pairs_row(const void* __restr
             q_table8<false>(x[r][0], x[r][1], x[r][2], x[r][3], gtinv, lo0, hi0, La);
             q_table8<false>(x[r][4], x[r][5], x[r][6], x[r][7], gtinv, lo1, hi1, Lb);
             qlut_lds[((size_t)n * 4 + (p & 3)) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
+            if (bimg)   // signed half tables, [unit][pair][n]: what the plane-combined GEMM streams
+                bimg[(size_t)p * Npad + n] = make_uint4(lo0 ^ 0x80808080u, hi0 ^ 0x80808080u, lo1 ^ 0x80808080u, hi1 ^ 0x80808080u);
             if (ALL) {
                 const int seg = p >> 3, j8 = p & 7;
                 *reinterpret_cast<uint4*>(qlut_dev + ((size_t)n * qdev_u4_per_row + qlut_dev_u4_index(seg, j8)) * 2) = make_uint4(lo0, hi0, lo1, hi1);
@@ -773,14 +777,14 @@ __global__ __launch_bounds__(PT) void k_preprocess_pairs_row(const void* __restr
 }
 
 hipError_t launch_preprocess_pairs_row(const void* B, int act_f16, void* qlut_lds, float* lut_scales, float* lut_biases, int K, int N,
-                                       int8_t* qlut_ref, void* qlut_dev, size_t qdev_u4_per_row, hipStream_t st) {
+                                       int8_t* qlut_ref, void* qlut_dev, size_t qdev_u4_per_row, void* bimg, float* colv, int Npad, hipStream_t st) {
     constexpr int PT = 512;
     if (K % 64 != 0 || N < 1 || K > 24 * PT || ((qlut_ref == nullptr) != (qlut_dev == nullptr))) return hipErrorInvalidValue;
     const int tstride = (((K / 32) + 15) & ~15) + 1;
     const size_t shmem = sizeof(float) * (PT / 64 + K / 32);
     dim3 g(N), b(PT);
 #define PLR(F, A) hipLaunchKernelGGL((k_preprocess_pairs_row<F, A, PT>), g, b, shmem, st, B, (uint4*)qlut_lds, lut_scales, lut_biases, K, tstride, \
-                                     (uint4*)qlut_ref, (uint2*)qlut_dev, qdev_u4_per_row)
+                                     (uint4*)qlut_ref, (uint2*)qlut_dev, qdev_u4_per_row, (uint4*)bimg, colv, Npad)
     if (qlut_ref) { if (act_f16) PLR(true, true); else PLR(false, true); }
     else { if (act_f16) PLR(true, false); else PLR(false, false); }
 #undef PLR

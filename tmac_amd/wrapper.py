@@ -118,13 +118,14 @@ class Workspace:
                                               act_group_size, _stream(stream)))
         return q, ls, lb
 
-    def read_gemm_image(self, K: int, N: int, stream=None):
+    def read_gemm_image(self, K: int, N: int, act_group_size: int = 64, stream=None):
         """The LUT image k_gemm_planes streams, in plain layouts: half tables int8 [N][K/4][8], lut_scales, lut_biases,
-        entry sums fp32 [N][K/64]."""
+        entry sums fp32 [N][K/act_group_size] (act_group_size 64, or K for the unified-scale flavour)."""
+        G = K // act_group_size
         h = np.zeros((N, K // 4, 8), np.int8)
-        ls = np.zeros((N, K // 64), np.float32)
-        lb = np.zeros((N, K // 64), np.float32)
-        hs = np.zeros((N, K // 64), np.float32)
+        ls = np.zeros((N, G), np.float32)
+        lb = np.zeros((N, G), np.float32)
+        hs = np.zeros((N, G), np.float32)
         check(B.lib().tmac_hip_debug_gemm_image_read(self._h, h.ctypes.data, ls.ctypes.data, lb.ctypes.data, hs.ctypes.data, N,
                                                      _stream(stream)))
         return h, ls, lb, hs
@@ -382,7 +383,8 @@ class TMACGeMMWrapper:
 
     def comb_sums(self, weights: Weights, N: int, stream=None) -> np.ndarray:
         """Parity tap of the plane-combined GEMM (k_gemm_planes): int32 [N][Mw][K/64], sum_p 2^p PS_p."""
-        out = np.zeros((N, weights.Mw, weights.K // 64), np.int32)
+        G = 1 if weights.cfg.m_groups >= 1 else weights.K // 64
+        out = np.zeros((N, weights.Mw, G), np.int32)
         check(B.lib().tmac_hip_debug_gemm_comb_sums(weights.handle, self.workspace.handle, out.ctypes.data, N, _stream(stream)))
         return out
 

@@ -38,6 +38,14 @@ static int32_t fail(int32_t code, const char* fmt, ...) {
     return code;
 }
 
+// device scratch of the test taps and self-tests: freed on every return path
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
@@ -92,7 +100,19 @@ static unsigned long long g_kcfg_gen = 0;   // bumped whenever g_kcfg changes (m
 
 static size_t qdev_u4_for_K(int K) { return (size_t)((K / (4 * TS) + KL - 1) / KL) * 8 * KL; }
 
+// tmac_hip_init selects the device for the calling thread only (hipSetDevice is per thread); entry points reached from other
+// threads -- llama.cpp calls qgemm_lut_int8 from every worker -- bind to the same device on their first call.
+static inline void bind_thread_device() {
+    static thread_local int bound = -2;
+    const int d = g_device;
+    if (d >= 0 && bound != d) {
+        (void)hipSetDevice(d);
+        bound = d;
+    }
+}
+
 static int32_t ensure_device() {
+    bind_thread_device();
     if (g_device >= 0) return TMAC_HIP_OK;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -249,15 +269,13 @@ extern "C" int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host
     if (!in_host || !out_host || n <= 0) return fail(TMAC_HIP_E_ARG, "bad selftest arguments");
     int32_t rc = ensure_device();
     if (rc) return rc;
-    uint32_t *din = nullptr, *dout = nullptr;
+    DevBuf din, dout;
     const size_t bytes = sizeof(uint32_t) * 4 * (size_t)n;
-    HIP_TRY(hipMalloc((void**)&din, bytes));
-    HIP_TRY(hipMalloc((void**)&dout, bytes));
-    HIP_TRY(hipMemcpy(din, in_host, bytes, hipMemcpyHostToDevice));
-    hipError_t e = launch_selftest(din, dout, n, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(out_host, dout, bytes, hipMemcpyDeviceToHost);
-    (void)hipFree(din);
-    (void)hipFree(dout);
+    HIP_TRY(din.alloc(bytes));
+    HIP_TRY(dout.alloc(bytes));
+    HIP_TRY(hipMemcpy(din.p, in_host, bytes, hipMemcpyHostToDevice));
+    hipError_t e = launch_selftest(din.as<uint32_t>(), dout.as<uint32_t>(), n, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_host, dout.p, bytes, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "selftest: %s", hipGetErrorString(e));
     return TMAC_HIP_OK;
 }
@@ -265,13 +283,12 @@ extern "C" int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host
 extern "C" int32_t tmac_hip_selftest_permlane(const uint32_t* in_host, uint32_t* out_host) {
     int32_t rc = ensure_device();
     if (rc) return rc;
-    uint32_t *din = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc((void**)&din, 128 * 4));
-    HIP_TRY(hipMalloc((void**)&dout, 256 * 4));
-    HIP_TRY(hipMemcpy(din, in_host, 128 * 4, hipMemcpyHostToDevice));
-    hipError_t e = launch_selftest_permlane(din, dout, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(out_host, dout, 256 * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(din); (void)hipFree(dout);
+    DevBuf din, dout;
+    HIP_TRY(din.alloc(128 * 4));
+    HIP_TRY(dout.alloc(256 * 4));
+    HIP_TRY(hipMemcpy(din.p, in_host, 128 * 4, hipMemcpyHostToDevice));
+    hipError_t e = launch_selftest_permlane(din.as<uint32_t>(), dout.as<uint32_t>(), nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_host, dout.p, 256 * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "selftest_permlane: %s", hipGetErrorString(e));
     return TMAC_HIP_OK;
 }
@@ -280,13 +297,12 @@ extern "C" int32_t tmac_hip_selftest_mfma(const uint32_t* in_host, int32_t* out_
     if (!in_host || !out_host) return fail(TMAC_HIP_E_ARG, "bad selftest arguments");
     int32_t rc = ensure_device();
     if (rc) return rc;
-    uint32_t* din = nullptr; int32_t* dout = nullptr;
-    HIP_TRY(hipMalloc((void**)&din, 64 * 8 * 4));
-    HIP_TRY(hipMalloc((void**)&dout, 64 * 4 * 4));
-    HIP_TRY(hipMemcpy(din, in_host, 64 * 8 * 4, hipMemcpyHostToDevice));
-    hipError_t e = launch_selftest_mfma(din, dout, nullptr);
-    if (e == hipSuccess) e = hipMemcpy(out_host, dout, 64 * 4 * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(din); (void)hipFree(dout);
+    DevBuf din, dout;
+    HIP_TRY(din.alloc(64 * 8 * 4));
+    HIP_TRY(dout.alloc(64 * 4 * 4));
+    HIP_TRY(hipMemcpy(din.p, in_host, 64 * 8 * 4, hipMemcpyHostToDevice));
+    hipError_t e = launch_selftest_mfma(din.as<uint32_t>(), dout.as<int32_t>(), nullptr);
+    if (e == hipSuccess) e = hipMemcpy(out_host, dout.p, 64 * 4 * 4, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "selftest_mfma: %s", hipGetErrorString(e));
     return TMAC_HIP_OK;
 }
@@ -485,6 +501,7 @@ static int32_t check_lut_shape(tmac_hip_workspace* ws, int K, int N, int ags) {
 
 extern "C" int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void* B_dev, tmac_dtype_t act_dtype, int K,
                                              int N, int act_group_size, void* stream) {
+    bind_thread_device();
     int32_t rc = check_lut_shape(ws, K, N, act_group_size);
     if (rc) return rc;
     if (!B_dev) return fail(TMAC_HIP_E_ARG, "null activations");
@@ -596,6 +613,7 @@ static int32_t planes_multi(const tmac_hip_weights* const* wl, int nmat, const t
 
 static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* ws, void* C_dev, tmac_dtype_t out_dtype,
                           int N, int32_t* dump, hipStream_t st) {
+    bind_thread_device();
     if (!w || !ws || !C_dev) return fail(TMAC_HIP_E_ARG, "null argument");
     if (ws->K != w->s.K || ws->ags != w->s.ags)
         return fail(TMAC_HIP_E_ARG, "workspace LUT (K=%d, ags=%d) does not match the weights (K=%d, ags=%d)", ws->K, ws->ags, w->s.K, w->s.ags);
@@ -665,15 +683,16 @@ extern "C" int32_t tmac_hip_qgemm_partial_sums(const tmac_hip_weights* w, const 
         ws->dump_elems = elems;
     }
     HIP_TRY(hipMemsetAsync(ws->dump, 0x7f, elems * sizeof(int32_t), st));
-    void* Ctmp = nullptr;
-    HIP_TRY(hipMalloc(&Ctmp, sizeof(float) * (size_t)N * w->s.Mw));
-    int32_t rc = qgemm_impl(w, ws, Ctmp, TMAC_F32, N, ws->dump, st);
+    DevBuf Ctmp;
+    HIP_TRY(Ctmp.alloc(sizeof(float) * (size_t)N * w->s.Mw));
+    int32_t rc = qgemm_impl(w, ws, Ctmp.p, TMAC_F32, N, ws->dump, st);
     if (rc == TMAC_HIP_OK) {
         hipError_t e = hipMemcpyAsync(PS_host, ws->dump, elems * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(TMAC_HIP_E_RUNTIME, "partial-sum readback: %s", hipGetErrorString(e));
+    } else {
+        (void)hipStreamSynchronize(st);      // nothing of this call may still use the scratch that is freed on return
     }
-    (void)hipFree(Ctmp);
     return rc;
 }
 
@@ -704,16 +723,17 @@ extern "C" int32_t tmac_hip_debug_gemm_comb_sums(const tmac_hip_weights* w, cons
         ws->dump_elems = elems;
     }
     HIP_TRY(hipMemsetAsync(ws->dump, 0x7f, elems * sizeof(int32_t), st));
-    void* Ctmp = nullptr;
-    HIP_TRY(hipMalloc(&Ctmp, sizeof(float) * (size_t)N * w->s.Mw));
-    void* cl[1] = {Ctmp};
+    DevBuf Ctmp;
+    HIP_TRY(Ctmp.alloc(sizeof(float) * (size_t)N * w->s.Mw));
+    void* cl[1] = {Ctmp.p};
     int32_t rc = planes_multi(&w, 1, ws, cl, TMAC_F32, N, ws->dump, st);
     if (rc == TMAC_HIP_OK) {
         hipError_t e = hipMemcpyAsync(comb_host, ws->dump, elems * sizeof(int32_t), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(TMAC_HIP_E_RUNTIME, "comb-sum readback: %s", hipGetErrorString(e));
+    } else {
+        (void)hipStreamSynchronize(st);
     }
-    (void)hipFree(Ctmp);
     return rc;
 }
 
@@ -750,7 +770,7 @@ static int32_t* g_stamp_dump = nullptr;
 // Prefill through the fused entry point: one LUT build (k_preprocess) into a workspace owned by the library, one
 // one-hot MFMA GEMM per matrix.  The workspace is per stream (launches on one stream are ordered; two streams must not
 // share LUT buffers) and grows on demand; tmac_hip_cache_clear() releases them.
-static std::map<hipStream_t, tmac_hip_workspace*> g_fused_ws;
+static std::map<std::pair<int, hipStream_t>, tmac_hip_workspace*> g_fused_ws;   // per (device, stream): the null stream exists on every device
 
 static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
                              void* const* C_list, tmac_dtype_t out_dtype, int N, hipStream_t st) {
@@ -758,7 +778,7 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
     tmac_hip_workspace* ws = nullptr;
     {
         std::lock_guard<std::mutex> lk(g_mu);
-        tmac_hip_workspace*& slot = g_fused_ws[st];
+        tmac_hip_workspace*& slot = g_fused_ws[std::make_pair(g_device, st)];
         int needK = s0.K, needN = N;
         if (slot && (slot->maxK < s0.K || slot->maxN < N)) {
             // grow to the maximum seen in BOTH dimensions (mixed shapes -- K = 4096 / 11008, growing N -- would otherwise
@@ -1080,6 +1100,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
 }
 
 extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
+    bind_thread_device();
     if (!c) return fail(TMAC_HIP_E_ARG, "null chain");
     ChainArgs a;
     memset(&a, 0, sizeof(a));
@@ -1139,6 +1160,7 @@ extern "C" int32_t tmac_hip_debug_chain_config(int force_wpq, unsigned spin_limi
 
 static int32_t fused_impl(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
                           void* const* C_list, tmac_dtype_t out_dtype, int N, int32_t* dump, float* lut_tap, hipStream_t st) {
+    bind_thread_device();
     if (!wl || !C_list || !B_dev || nmat < 1 || nmat > 4 || N < 1) return fail(TMAC_HIP_E_ARG, "bad fused arguments (1..4 matrices)");
     if (g_chain_rec && !dump && !lut_tap) return chain_record(wl, nmat, B_dev, act_dtype, C_list, out_dtype, N);
     if (g_gemm_min_n > 0 && N >= g_gemm_min_n && !dump && !lut_tap) {
@@ -1340,25 +1362,23 @@ extern "C" int32_t tmac_hip_qgemm_fused_partial_sums(const tmac_hip_weights* w, 
     hipStream_t st = (hipStream_t)stream;
     const size_t G = (w->s.m_groups >= 1 && w->s.ags == w->s.K) ? 1 : (size_t)w->s.ngroups();
     const size_t elems = (size_t)N * w->s.M() * G;
-    int32_t* dump = nullptr;
-    void* Ctmp = nullptr;
-    float* ltap = nullptr;
+    DevBuf dump, Ctmp, ltap;
     const size_t lt = (size_t)N * 2 * w->s.ngroups();
-    HIP_TRY(hipMalloc((void**)&ltap, lt * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&dump, elems * sizeof(int32_t)));
-    HIP_TRY(hipMalloc(&Ctmp, sizeof(float) * (size_t)N * w->s.Mw));
-    HIP_TRY(hipMemsetAsync(dump, 0x7f, elems * sizeof(int32_t), st));
-    int32_t rc = fused_impl(&w, 1, B_dev, act_dtype, &Ctmp, TMAC_F32, N, dump, ltap, st);
+    HIP_TRY(ltap.alloc(lt * sizeof(float)));
+    HIP_TRY(dump.alloc(elems * sizeof(int32_t)));
+    HIP_TRY(Ctmp.alloc(sizeof(float) * (size_t)N * w->s.Mw));
+    HIP_TRY(hipMemsetAsync(dump.p, 0x7f, elems * sizeof(int32_t), st));
+    void* cl[1] = {Ctmp.p};
+    int32_t rc = fused_impl(&w, 1, B_dev, act_dtype, cl, TMAC_F32, N, dump.as<int32_t>(), ltap.as<float>(), st);
     if (rc == TMAC_HIP_OK) {
-        hipError_t e = hipMemcpyAsync(PS_host, dump, elems * sizeof(int32_t), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && C_host) e = hipMemcpyAsync(C_host, Ctmp, sizeof(float) * (size_t)N * w->s.Mw, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess && lut_host) e = hipMemcpyAsync(lut_host, ltap, lt * sizeof(float), hipMemcpyDeviceToHost, st);
+        hipError_t e = hipMemcpyAsync(PS_host, dump.p, elems * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && C_host) e = hipMemcpyAsync(C_host, Ctmp.p, sizeof(float) * (size_t)N * w->s.Mw, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && lut_host) e = hipMemcpyAsync(lut_host, ltap.p, lt * sizeof(float), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) rc = fail(TMAC_HIP_E_RUNTIME, "fused tap readback: %s", hipGetErrorString(e));
+    } else {
+        (void)hipStreamSynchronize(st);
     }
-    (void)hipFree(ltap);
-    (void)hipFree(dump);
-    (void)hipFree(Ctmp);
     return rc;
 }
 
@@ -1549,7 +1569,7 @@ extern "C" int32_t tmac_hip_cache_clear(void) {
     g_runs.clear();
     g_cache_dev_bytes = 0;
     for (auto& kv : g_fused_ws) {
-        (void)hipStreamSynchronize(kv.first);      // launches in flight may still read the LUT workspace
+        (void)hipStreamSynchronize(kv.first.second);      // launches in flight may still read the LUT workspace
         tmac_hip_workspace_free(kv.second);
     }
     g_fused_ws.clear();
@@ -1564,6 +1584,7 @@ extern "C" int32_t tmac_hip_debug_host_runs(int on) {
 }
 
 extern "C" int32_t preprocessor_int8(int m, int k, int n, int b, void* B, void* LUT_Scales, void* LUT_Biases, void* QLUT) {
+    bind_thread_device();
     if (!B || !LUT_Scales || !LUT_Biases || !QLUT) return fail(TMAC_HIP_E_ARG, "null argument");
     std::unique_lock<std::shared_mutex> hl(g_host_mu);
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1643,6 +1664,7 @@ static void serve_from_run(const HostRun* r, const TileInfo& ti, int n, int Mw_t
 
 extern "C" int32_t qgemm_lut_int8(int m, int k, int n, int b, void* A, void* LUT, void* Scales, void* LUT_Scales,
                                   void* LUT_Biases, void* C) {
+    bind_thread_device();
     if (!A || !LUT || !Scales || !LUT_Scales || !LUT_Biases || !C) return fail(TMAC_HIP_E_ARG, "null argument");
     const int Mw_tile = m / b;
     const TileKey key{A, m, k, b};

@@ -53,16 +53,20 @@ int main(int argc, char** argv) {
     }
     {   // steady-state cost of the route from one caller thread (no thread start-up in the timing): 50 GEMVs, new activations each
         float* xf = (float*)xb.data();
+        double init_us = 0;
         auto t0 = std::chrono::steady_clock::now();
         for (int rep = 0; rep < 50; ++rep) {
             xf[rep % K] += 0.25f;
+            auto ti0 = std::chrono::steady_clock::now();
             wr.llama_cpp_init(xb.data(), qlut.data(), ls.data(), lb.data(), Mw, K, 1, bits);
+            init_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ti0).count();
             for (int i = 0; i < ntile; ++i)
                 wr.llama_cpp_compute(A.data() + (size_t)i * a_tile, (float*)S.data() + (size_t)i * s_tile, qlut.data(), ls.data(), lb.data(),
                                      C.data() + (size_t)i * rows, rows, K, 1, bits);
         }
         const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 50;
-        printf("TIMING %.1f us per GEMV from one thread (preprocessor call + %d tile calls, host pointers, PCIe both ways)\n", us, ntile);
+        printf("TIMING %.1f us per GEMV from one thread (preprocessor call + %d tile calls, host pointers, PCIe both ways); preprocessor call %.1f us, tile calls %.1f us\n",
+               us, ntile, init_us / 50, us - init_us / 50);
         for (int rep = 0; rep < 50; ++rep) xf[rep % K] -= 0.25f;
         wr.llama_cpp_init(xb.data(), qlut.data(), ls.data(), lb.data(), Mw, K, 1, bits);
         for (int i = 0; i < ntile; ++i)

@@ -17,6 +17,7 @@
 #include <shared_mutex>
 #include <sstream>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "../../include/tmac_hip.h"
@@ -1400,9 +1401,30 @@ struct TileKey {
 // reference layout stores a matrix tile after tile) form a RUN; once a run has been seen whole, the first tile call
 // that arrives with a new LUT computes the run's entire output in one launch and the following tile calls are served
 // from that result as long as the LUT bytes they pass are the ones it was computed from (compared in full).
+// verbatim sample of a tile's weight and scale bytes (4 x 16 + 2 x 16 bytes): what the per-call staleness check of a grouped
+// tile compares (a memcmp of 96 bytes instead of a 192-byte hash per tile call)
+struct TileBytes { unsigned char b[96]; };
+static void tile_bytes(const void* A, size_t a_bytes, const void* S, size_t s_bytes, TileBytes& out) {
+    const size_t n = a_bytes < 16 ? a_bytes : 16, m = s_bytes < 16 ? s_bytes : 16;
+    memset(out.b, 0, sizeof(out.b));
+    for (int i = 0; i < 4; ++i) memcpy(out.b + 16 * i, (const char*)A + (a_bytes - n) * i / 3, n);
+    if (S && s_bytes) { memcpy(out.b + 64, S, m); memcpy(out.b + 80, (const char*)S + s_bytes - m, m); }
+}
+static bool tile_bytes_match(const void* A, size_t a_bytes, const void* S, size_t s_bytes, const TileBytes& ref) {
+    const size_t n = a_bytes < 16 ? a_bytes : 16, m = s_bytes < 16 ? s_bytes : 16;
+    for (int i = 0; i < 4; ++i) if (memcmp(ref.b + 16 * i, (const char*)A + (a_bytes - n) * i / 3, n) != 0) return false;
+    if (S && s_bytes) return memcmp(ref.b + 64, S, m) == 0 && memcmp(ref.b + 80, (const char*)S + s_bytes - m, m) == 0;
+    return true;
+}
+
 struct HostRun {
     tmac_hip_weights* w = nullptr;   // the run registered as one matrix
     int ntile = 0, Mw_tile = 0;
+    // direct addressing of the run's tiles (they are contiguous in the caller's memory): tile i = (A0 + i * a_bytes, S0 + i * s_bytes)
+    const char* A0 = nullptr; const char* S0 = nullptr;
+    size_t a_bytes = 0, s_bytes = 0;
+    int m = 0, k = 0, b = 0;
+    std::vector<TileBytes> bytes;    // per tile: the sample the fast path compares
     float* C = nullptr;              // pinned host memory: [n][ntile * Mw_tile] outputs for LUT generation `gen`
     size_t C_elems = 0;
     unsigned long long gen = 0;
@@ -1420,6 +1442,7 @@ struct TileInfo {
 };
 static std::map<TileKey, TileInfo> g_tiles;
 static std::vector<HostRun*> g_runs;
+static unsigned long long g_run_epoch = 1;   // bumped (under the exclusive lock) whenever a run is created or freed: per-thread run memos check it
 static tmac_hip_workspace* g_ws = nullptr;
 static void* g_hostC = nullptr;  // device staging for C / B
 static size_t g_hostC_bytes = 0;
@@ -1461,6 +1484,31 @@ static int32_t host_stream() {
     if (!g_cache_cap_bytes) g_cache_cap_bytes = (size_t)64 << 30;      // weights cached on the device for host-pointer callers: 64 GB by default
     return TMAC_HIP_OK;
 }
+// Completion of the host-pointer calls: a flag in pinned host memory that the last launch of the call sets and this thread spins
+// on (a hipStreamSynchronize costs ~8 us more per call); bounded, with the stream synchronisation as the fallback.
+static uint32_t* g_hflag = nullptr;
+static uint32_t g_hflag_gen = 0;
+static int g_host_zero_copy = -1;      // $TMAC_HIP_HOST_ZERO_COPY (default 1): 0 restores copy commands + hipStreamSynchronize
+static bool host_zero_copy() {
+    if (g_host_zero_copy < 0) { const char* e = getenv("TMAC_HIP_HOST_ZERO_COPY"); g_host_zero_copy = e ? atoi(e) != 0 : 1; }
+    return g_host_zero_copy != 0;
+}
+static int32_t host_flag_init() {
+    if (g_hflag) return TMAC_HIP_OK;
+    HIP_TRY(hipHostMalloc((void**)&g_hflag, 64, hipHostMallocDefault));
+    *g_hflag = 0;
+    return TMAC_HIP_OK;
+}
+static int32_t host_flag_wait(uint32_t val) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(g_hflag, __ATOMIC_ACQUIRE) == val) return TMAC_HIP_OK;
+        if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+    HIP_TRY(hipStreamSynchronize(g_hstream));      // slow launch (first use, contention) or an error: the stream tells
+    return TMAC_HIP_OK;
+}
+
 static int32_t host_ws(int K, int N) {
     if (g_ws && g_ws->maxK >= K && g_ws->maxN >= N) return TMAC_HIP_OK;
     if (g_ws) { if (g_hstream) (void)hipStreamSynchronize(g_hstream); tmac_hip_workspace_free(g_ws); }
@@ -1537,6 +1585,7 @@ static bool find_cfg(int k, int n, int b, int bm_filter, int m_filter, tmac_kcfg
 }
 
 static void free_run(HostRun* r) {
+    ++g_run_epoch;
     if (r->w) tmac_hip_free_weights(r->w);
     if (r->C) (void)hipHostFree(r->C);
     g_cache_dev_bytes -= r->dev_bytes < g_cache_dev_bytes ? r->dev_bytes : g_cache_dev_bytes;
@@ -1605,12 +1654,23 @@ extern "C" int32_t preprocessor_int8(int m, int k, int n, int b, void* B, void* 
     // activations up, LUT build, LUT (the caller owns it: tmac_gemm_wrapper.h:170-195) back down
     char* pin = (char*)g_pin;
     memcpy(pin, B, nb);
-    HIP_TRY(hipMemcpyAsync(g_hostC, pin, nb, hipMemcpyHostToDevice, g_hstream));
-    if ((rc = tmac_hip_preprocessor_dev(g_ws, g_hostC, TMAC_F32, k, n, ags, g_hstream))) return rc;
-    HIP_TRY(hipMemcpyAsync(pin + nb, g_ws->qlut_ref, nq, hipMemcpyDeviceToHost, g_hstream));
-    HIP_TRY(hipMemcpyAsync(pin + nb + nq, g_ws->lut_scales, ns, hipMemcpyDeviceToHost, g_hstream));
-    HIP_TRY(hipMemcpyAsync(pin + nb + nq + ns, g_ws->lut_biases, ns, hipMemcpyDeviceToHost, g_hstream));
-    HIP_TRY(hipStreamSynchronize(g_hstream));
+    if (host_zero_copy() && nq <= (1u << 20) && nq % 16 == 0 && ns % 16 == 0) {
+        // small LUT (decode): the build reads the activations from the pinned buffer itself, one single-workgroup launch writes
+        // the LUT back into it and raises the flag
+        if ((rc = host_flag_init())) return rc;
+        if ((rc = tmac_hip_preprocessor_dev(g_ws, pin, TMAC_F32, k, n, ags, g_hstream))) return rc;
+        const uint32_t val = ++g_hflag_gen;
+        hipError_t e = launch_host_copy3_flag(g_ws->qlut_ref, nq, g_ws->lut_scales, g_ws->lut_biases, ns, pin + nb, g_hflag, val, g_hstream);
+        if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT copy-back launch: %s", hipGetErrorString(e));
+        if ((rc = host_flag_wait(val))) return rc;
+    } else {
+        HIP_TRY(hipMemcpyAsync(g_hostC, pin, nb, hipMemcpyHostToDevice, g_hstream));
+        if ((rc = tmac_hip_preprocessor_dev(g_ws, g_hostC, TMAC_F32, k, n, ags, g_hstream))) return rc;
+        HIP_TRY(hipMemcpyAsync(pin + nb, g_ws->qlut_ref, nq, hipMemcpyDeviceToHost, g_hstream));
+        HIP_TRY(hipMemcpyAsync(pin + nb + nq, g_ws->lut_scales, ns, hipMemcpyDeviceToHost, g_hstream));
+        HIP_TRY(hipMemcpyAsync(pin + nb + nq + ns, g_ws->lut_biases, ns, hipMemcpyDeviceToHost, g_hstream));
+        HIP_TRY(hipStreamSynchronize(g_hstream));
+    }
     memcpy(QLUT, pin + nb, nq);
     memcpy(LUT_Scales, pin + nb + nq, ns);
     memcpy(LUT_Biases, pin + nb + nq + ns, ns);
@@ -1643,8 +1703,13 @@ static HostRun* build_run(const TileKey& key, const tmac_kcfg& cfg, int Mw_tile,
     HostRun* r = new HostRun();
     r->w = w; r->ntile = n; r->Mw_tile = Mw_tile;
     r->dev_bytes = w->w_bytes + w->sc_bytes;
+    r->A0 = (const char*)first->first.A; r->S0 = (const char*)first->second.S; r->a_bytes = a_bytes; r->s_bytes = s_bytes;
+    r->m = key.bm; r->k = key.K; r->b = key.bits;
+    r->bytes.resize(n);
+    for (int i = 0; i < n; ++i) tile_bytes(r->A0 + (size_t)i * a_bytes, a_bytes, r->S0 + (size_t)i * s_bytes, s_bytes, r->bytes[i]);
     g_cache_dev_bytes += r->dev_bytes;
     g_runs.push_back(r);
+    ++g_run_epoch;
     TileKey kk = first->first;
     for (int i = 0; i < n; ++i) {
         TileInfo& ti = g_tiles[kk];
@@ -1673,6 +1738,26 @@ extern "C" int32_t qgemm_lut_int8(int m, int k, int n, int b, void* A, void* LUT
         // llama.cpp's worker threads hit concurrently, one tile each (tmac_gemm_wrapper.h:197-199): they copy their rows out
         // side by side instead of queueing on one mutex.
         std::shared_lock<std::shared_mutex> sl(g_host_mu);
+        // the run this thread served last (valid while no run has been created or freed since): its tiles are addressed
+        // directly, no table lookup
+        static thread_local const HostRun* memo_run = nullptr;
+        static thread_local unsigned long long memo_epoch = 0;
+        if (memo_run && memo_epoch == g_run_epoch) {
+            const HostRun* r = memo_run;
+            const ptrdiff_t da = (const char*)A - r->A0;
+            if (r->m == m && r->k == k && r->b == b && da >= 0 && (size_t)da < r->a_bytes * (size_t)r->ntile && (size_t)da % r->a_bytes == 0) {
+                const int idx = (int)((size_t)da / r->a_bytes);
+                if ((const char*)Scales == r->S0 + (size_t)idx * r->s_bytes && r->gen == g_lut_gen && r->C &&
+                    r->C_elems == (size_t)n * r->ntile * Mw_tile && LUT == g_lut_q && LUT_Scales == g_lut_ls && LUT_Biases == g_lut_lb &&
+                    g_lut_k == k && g_lut_n == n && lut_sample_ok(LUT, (size_t)n * (k / 4) * 16) &&
+                    tile_bytes_match(A, r->a_bytes, Scales, r->s_bytes, r->bytes[idx])) {
+                    const size_t Mw_run = (size_t)r->ntile * Mw_tile;
+                    for (int i = 0; i < n; ++i)
+                        memcpy((float*)C + (size_t)i * Mw_tile, r->C + (size_t)i * Mw_run + (size_t)idx * Mw_tile, sizeof(float) * Mw_tile);
+                    return TMAC_HIP_OK;
+                }
+            }
+        }
         auto it = g_tiles.find(key);
         if (it != g_tiles.end() && it->second.run && it->second.S == Scales) {
             const TileInfo& ti = it->second;
@@ -1681,6 +1766,7 @@ extern "C" int32_t qgemm_lut_int8(int m, int k, int n, int b, void* A, void* LUT
                 LUT_Biases == g_lut_lb && g_lut_k == k && g_lut_n == n && lut_sample_ok(LUT, (size_t)n * (k / 4) * 16) &&
                 tile_sample(A, ti.a_bytes, Scales, ti.s_bytes) == ti.sample) {
                 serve_from_run(r, ti, n, Mw_tile, C);
+                memo_run = r; memo_epoch = g_run_epoch;
                 return TMAC_HIP_OK;
             }
         }
@@ -1743,9 +1829,19 @@ extern "C" int32_t qgemm_lut_int8(int m, int k, int n, int b, void* A, void* LUT
             const size_t bytes = sizeof(float) * elems;
             if ((rc = host_stage(bytes))) return rc;
             // the whole run in one launch, its output straight into the run's pinned host buffer, one synchronisation
-            if ((rc = qgemm_impl(r->w, g_ws, g_hostC, TMAC_F32, n, nullptr, g_hstream))) return rc;
-            HIP_TRY(hipMemcpyAsync(r->C, g_hostC, bytes, hipMemcpyDeviceToHost, g_hstream));
-            HIP_TRY(hipStreamSynchronize(g_hstream));
+            if (host_zero_copy() && bytes <= (1u << 20)) {
+                // the kernel stores the run's output into the pinned host buffer itself; a one-thread launch raises the flag
+                if ((rc = host_flag_init())) return rc;
+                if ((rc = qgemm_impl(r->w, g_ws, r->C, TMAC_F32, n, nullptr, g_hstream))) return rc;
+                const uint32_t val = ++g_hflag_gen;
+                hipError_t e = launch_host_flag(g_hflag, val, g_hstream);
+                if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "flag launch: %s", hipGetErrorString(e));
+                if ((rc = host_flag_wait(val))) return rc;
+            } else {
+                if ((rc = qgemm_impl(r->w, g_ws, g_hostC, TMAC_F32, n, nullptr, g_hstream))) return rc;
+                HIP_TRY(hipMemcpyAsync(r->C, g_hostC, bytes, hipMemcpyDeviceToHost, g_hstream));
+                HIP_TRY(hipStreamSynchronize(g_hstream));
+            }
             r->gen = g_lut_gen;
         }
         serve_from_run(r, ti, n, Mw_tile, C);

@@ -115,7 +115,11 @@ hipError_t launch_preprocess_pairs(const void* B, int act_f16, void* qlut_lds, f
 // bimg / colv (both or neither; Npad = row stride of the image): also the LUT image k_gemm_planes_us streams (tmac_gemm2.hip)
 hipError_t launch_preprocess_pairs_row(const void* B, int act_f16, void* qlut_lds, float* lut_scales, float* lut_biases, int K, int N,
                                        int8_t* qlut_ref, void* qlut_dev, size_t qdev_u4_per_row, void* bimg, float* colv, int Npad, hipStream_t st);
-hipError_t launch_stream_read(const void* src, size_t bytes, void* sink, hipStream_t st);   // measurement aid, see tmac_kernels.hip
+hipError_t launch_stream_read(const void* src, size_t bytes, void* sink, hipStream_t st);
+// host-pointer route (tmac_kernels.hip): results into pinned host memory by the GPU's own stores, then a flag the host spins on
+hipError_t launch_host_copy3_flag(const void* q, size_t nq, const void* ls, const void* lb, size_t ns, void* dst_pinned, uint32_t* flag,
+                                  uint32_t val, hipStream_t st);
+hipError_t launch_host_flag(uint32_t* flag, uint32_t val, hipStream_t st);   // measurement aid, see tmac_kernels.hip
 bool gemm_onehot_supported(const Shape& s);
 hipError_t launch_gemm_onehot(const GemmArgs& a, hipStream_t st);
 bool gemm_planes_supported(const Shape& s);

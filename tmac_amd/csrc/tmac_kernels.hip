@@ -545,6 +545,34 @@ __global__ __launch_bounds__(256) void k_stream_read(const u32x4* __restrict__ s
     if (r == 0x12345678u) sink[blockIdx.x & 1023] = r;   // practically never: keeps the loads alive without store traffic
 }
 
+// Host-pointer route: what a call hands back goes straight into the caller-visible pinned host buffer, followed by a flag the
+// host spins on -- one small launch instead of copy commands plus a stream synchronisation.  One workgroup: the flag must
+// follow every store of the launch.  copy3: three device regions (QLUT, LUT scales, LUT biases) -> one pinned host buffer.
+__global__ __launch_bounds__(1024) void k_host_copy3_flag(const uint4* __restrict__ q, size_t nq16, const uint4* __restrict__ ls,
+                                                         const uint4* __restrict__ lb, size_t ns16, uint4* __restrict__ dst,
+                                                         uint32_t* flag, uint32_t val) {
+    for (size_t i = threadIdx.x; i < nq16; i += 1024) dst[i] = q[i];
+    for (size_t i = threadIdx.x; i < ns16; i += 1024) { dst[nq16 + i] = ls[i]; dst[nq16 + ns16 + i] = lb[i]; }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_host_flag(uint32_t* flag, uint32_t val) {
+    __threadfence_system();
+    __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_host_copy3_flag(const void* q, size_t nq, const void* ls, const void* lb, size_t ns, void* dst_pinned, uint32_t* flag,
+                                  uint32_t val, hipStream_t st) {
+    if (nq % 16 || ns % 16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_host_copy3_flag, dim3(1), dim3(1024), 0, st, (const uint4*)q, nq / 16, (const uint4*)ls, (const uint4*)lb, ns / 16,
+                       (uint4*)dst_pinned, flag, val);
+    return hipGetLastError();
+}
+hipError_t launch_host_flag(uint32_t* flag, uint32_t val, hipStream_t st) {
+    hipLaunchKernelGGL(k_host_flag, dim3(1), dim3(1), 0, st, flag, val);
+    return hipGetLastError();
+}
+
 hipError_t launch_stream_read(const void* src, size_t bytes, void* sink, hipStream_t st) {
     const size_t n16 = bytes / 16;
     hipLaunchKernelGGL(k_stream_read, dim3((unsigned)((n16 + 511) / 512)), dim3(256), 0, st, (const u32x4*)src, n16, (uint32_t*)sink);

@@ -20,11 +20,12 @@
 // provides per (n, kk) and the epilogue folds into the int -> float conversion constant.
 //
 // v_mfma_i32_32x32x32_i8: one instruction = 32 output rows x 32 activation rows x 4 tables.  Wave tile 64 x 64 (2 x 2
-// MFMA tiles); a workgroup = 4 waves = one 64 x 64 output tile, the waves split K by weight groups and reduce through
-// LDS at the end (at N = 256 a llama-2-7B projection has only 256 such tiles; a 4 x larger workgroup tile would leave
-// three quarters of the chip idle).  Each wave is on its own: it streams its half-table chunks global -> LDS
-// (global_load_lds, no registers), its weights global -> registers, one act group ahead, with no workgroup barrier in
-// the main loop.  Roofline: int8 MFMA; ops = 2 * Mw * (K / 4 * 8) * N.
+// MFMA tiles); a workgroup = 8 waves = ONE 64 x 64 output tile, the waves split K by weight groups and reduce through
+// LDS at the end (at N = 256 a llama-2-7B projection has only 256 such tiles: one per CU; a larger workgroup tile would
+// idle most of the chip).  Each wave is on its own between the kernel's two barriers: it streams its half-table chunks
+// global -> LDS (buffer_load ... lds, no registers), its weights, column values and weight scales global -> registers one
+// act group ahead, through buffer instructions whose only varying part is a scalar offset.
+// Roofline: int8 MFMA; ops = 2 * Mw * (K / 4 * 8) * N.  Measured: instruction-issue bound.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -641,6 +642,10 @@ bool gemm_planes_supported(const Shape& s) {
 hipError_t launch_gemm_planes(const Gemm2Args& a_in, hipStream_t st) {
     if (!gemm_planes_supported(a_in.s) || a_in.nmat < 1 || a_in.nmat > 4 || (a_in.dump && a_in.nmat != 1)) return hipErrorInvalidValue;
     if (a_in.N < 1 || a_in.Npad % 64 != 0 || a_in.Npad < ((a_in.N + 63) & ~63)) return hipErrorInvalidValue;
+    // buffer instructions address with 32-bit byte offsets: the LUT image and every weight matrix must stay below 2 GB
+    if ((size_t)2 * a_in.s.K * a_in.Npad >= ((size_t)1 << 31)) return hipErrorInvalidValue;
+    for (int i = 0; i < a_in.nmat; ++i)
+        if ((size_t)((a_in.m[i].Mw + 3) / 4) * ((a_in.s.K / 32 + 63) / 64) * a_in.s.bits * 1024 >= ((size_t)1 << 31)) return hipErrorInvalidValue;
     Gemm2Args a = a_in;
     int gx = 0;
     for (int i = 0; i < a.nmat; ++i) {

@@ -593,8 +593,10 @@ static int32_t gemm_multi(const tmac_hip_weights* const* wl, int nmat, const tma
 static unsigned long long* g_gemm_stamps = nullptr;   // profiling: device buffer for k_gemm_planes' step stamps (tmac_hip_debug_gemm_stamps)
 
 static bool planes_ok(const tmac_hip_weights* w) {
-    return g_gemm_kernel != 1 && w->s.lay == 2 && w->lo_ok && w->s.ts == 8 && !w->fa && gemm_planes_supported(w->s);
+    return g_gemm_kernel != 1 && w->s.lay == 2 && w->lo_ok && w->s.ts == 8 && !w->fa && gemm_planes_supported(w->s) &&
+           w->w_bytes < ((size_t)1 << 31);
 }
+static bool planes_image_fits(const tmac_hip_workspace* ws, int K) { return ws->gimg && (size_t)2 * K * ws->gNpad < ((size_t)1 << 31); }
 
 // k_gemm_planes over up to 4 matrices that share K and the quantisation config; the workspace holds the LUT image
 static int32_t planes_multi(const tmac_hip_weights* const* wl, int nmat, const tmac_hip_workspace* ws, void* const* C_list,
@@ -608,6 +610,7 @@ static int32_t planes_multi(const tmac_hip_weights* const* wl, int nmat, const t
     ga.bimg = (const uint4*)ws->gimg; ga.colv = ws->gcol; ga.Npad = ws->gNpad; ga.N = N; ga.dump = comb_dump;
     ga.stamps = g_gemm_stamps;
     hipError_t e = launch_gemm_planes(ga, st);
+    if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "plane-combined gemm: configuration or sizes not covered (LUT image and matrices must stay below 2 GB)");
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "plane-combined gemm launch: %s", hipGetErrorString(e));
     return TMAC_HIP_OK;
 }
@@ -627,7 +630,7 @@ static int32_t qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspace* w
     }
     if (w->fa && v != V_REF_LAYOUT && v != V_LO_MQSAD && v != V_LO_SDWA)
         return fail(TMAC_HIP_E_NOMATCH, "fast-aggregation weights run on the two-kernel path only");
-    if (v == V_FUSED && !dump && ws->gimg_valid && planes_ok(w) && gemm_pays(w->s, w->s.Mw, N)) {
+    if (v == V_FUSED && !dump && ws->gimg_valid && planes_ok(w) && planes_image_fits(ws, w->s.K) && gemm_pays(w->s, w->s.Mw, N)) {
         void* cl[1] = {C_dev};
         return planes_multi(&w, 1, ws, cl, out_dtype, N, nullptr, st);
     }
@@ -798,7 +801,7 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
         ws = slot;
     }
     int32_t rc;
-    bool planes = g_variant != V_REF_LAYOUT && ws->gimg != nullptr;
+    bool planes = g_variant != V_REF_LAYOUT && planes_image_fits(ws, s0.K);
     for (int i = 0; i < nmat && planes; ++i) {
         const Shape &x = wl[i]->s, &y = s0;
         planes = planes_ok(wl[i]) && x.bits == y.bits && x.gs == y.gs && x.zero_point == y.zero_point && x.ags == y.ags &&

@@ -45,7 +45,8 @@ struct ChainArgs {
     int out_f16;
     unsigned spin_limit;           // polls of one hand-off before a wave gives up and sets ctl[2]
     int buf_u4;                    // uint4 per LDS LUT buffer (two buffers, by op parity)
-    int poll_sleep;                // s_sleep between two polls of a hand-off (A/B knob)
+    int poll_sleep;                // s_sleep 1 (64 cycles) count between two polls of a hand-off (A/B knob)
+    int poll_delay;                // s_sleep 1 count before the first poll of a hand-off (A/B knob)
     int issue_first;               // A/B knob: issue an op's weights before polling for its activations
     int poll_mode;                 // A/B knob: 0 dwordx4 sc1 | 1 dwordx4 sc0 sc1 | 2 dwordx4 nt | 3 dwordx4 plain
     unsigned long long* stamps;    // optional [nops][grid][8] of wave 0, s_memrealtime (100 MHz): 0 op entry, 1 activations complete, 2 LUT built

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             if (gran) {
                 const uint4 *g0 = in4 + 2 * (size_t)p0, *g1 = in4 + 2 * (size_t)p1, *g2 = in4 + 2 * (size_t)p2;
                 unsigned spins = 0;
+                for (int z = 0; z < a.poll_delay; ++z) __builtin_amdgcn_s_sleep(1);      // A/B knob: wait before the first poll
                 for (;;) {
                     ++polls;
                     bool ok;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                             aborted = true;
                         }
                     }
-                    if (a.poll_sleep) __builtin_amdgcn_s_sleep(1);
+                    for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
                 for (int r = 0; r < NRMAX; ++r) { xw[r][0] = v[2 * r].y; xw[r][1] = v[2 * r].w; xw[r][2] = v[2 * r + 1].y; xw[r][3] = v[2 * r + 1].w; }

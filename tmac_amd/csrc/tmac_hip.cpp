@@ -1110,7 +1110,12 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
     memset(&a, 0, sizeof(a));
     a.ops = c->d_ops; a.nops = (int)c->ops.size(); a.ctl = c->ctl; a.out_f16 = c->out_f16;
     a.spin_limit = g_chain_spin_limit; a.buf_u4 = c->buf_u4; a.stamps = c->stamps;
-    a.poll_sleep = getenv("TMAC_CHAIN_POLL_SLEEP") ? atoi(getenv("TMAC_CHAIN_POLL_SLEEP")) : 1;
+    // a workgroup reaches the polls of an op right after publishing its own share of the previous one: the first poll cannot
+    // succeed before the slowest producer's stores have crossed the fabric (~1 us), and every failed poll is 16 KB per workgroup
+    // of fabric traffic that the stores compete with.  Waiting ~0.75 us before the first poll and ~0.5 us between polls:
+    // 0.757 -> 0.735 ms per llama-2-7B token (profiles/r02_chain_prefetch_ab.txt, E)
+    a.poll_sleep = getenv("TMAC_CHAIN_POLL_SLEEP") ? atoi(getenv("TMAC_CHAIN_POLL_SLEEP")) : 16;
+    a.poll_delay = getenv("TMAC_CHAIN_POLL_DELAY") ? atoi(getenv("TMAC_CHAIN_POLL_DELAY")) : 24;
     a.issue_first = getenv("TMAC_CHAIN_ISSUE_FIRST") ? atoi(getenv("TMAC_CHAIN_ISSUE_FIRST")) : 1;
     a.poll_mode = getenv("TMAC_CHAIN_POLL_MODE") ? atoi(getenv("TMAC_CHAIN_POLL_MODE")) : 0;
     hipError_t e = launch_decode_chain(a, c->bits, c->zp != 0, c->sc_f16 != 0, c->grid, c->lds_bytes, (hipStream_t)stream);

@@ -219,7 +219,7 @@ def main():
     ops_per_step *= args.layers
     lvl = (2 ** BITS - 1) / 2.0 - 2 ** (BITS - 1)                # mean weight level minus the offset 2^(b-1)
     wvar = (4 ** BITS - 1) / 12.0                                 # variance of a uniform b-bit level
-    keep_host = not args.no_verify and world == 1 and MG < 1
+    keep_host = not args.no_verify and world == 1
     for li in range(args.layers):
         mats = {}
         for name, Mw, K, cnt, slot in MATS:
@@ -232,6 +232,8 @@ def main():
                     # one scale: the common-mode gain of a GEMV is 0.5 * scale * K; 2 / K keeps the chained vectors finite
                     S = torch.full((MG,), 2.0 / K, device=dev, dtype=torch.float32)
                     ws.append(tmac_amd.Weights(A, S, Mloc, K, BITS, cfg, scales_dtype=F32, dev_dtype=F32, on_device=True))
+                    if li == 0 and keep_host:
+                        host_l0.setdefault(name, []).append((A.cpu().numpy(), S.cpu().numpy()))
                 else:
                     # real weight = (w - 2^(b-1)) scale - zero.  zero = (mean level - 2^(b-1)) scale + noise makes it zero-mean,
                     # so a common component of the activations is not amplified from call to call (with independent zeros
@@ -543,7 +545,10 @@ def main():
             q, ls, lb = orc.preprocessor(xin_h, ags_of(K))
             for i in range(cnt):
                 A, S = host_l0[name][i]
-                ref = orc.qgemm_float(A, q, S, ls, lb, Mw, K, len(rows), BITS, BM, KF, GS, ags_of(K), ZP)
+                if MG >= 1:
+                    ref, _ = orc.qgemm_scale_final(A, q, S, ls[:, 0], lb[:, 0], Mw, K, len(rows), BITS, BM, KF, MG)
+                else:
+                    ref = orc.qgemm_float(A, q, S, ls, lb, Mw, K, len(rows), BITS, BM, KF, GS, ags_of(K), ZP)
                 got = vouts[name][i].float().cpu().numpy().reshape(-1, Mw)[rows]
                 worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)))
         verified = {"ok": bool(ok and worst <= 1e-3), "max_rel_err": float("%.3g" % worst), "tolerance": 1e-3,

@@ -1,9 +1,7 @@
 # SQ / LDS counters of k_gemm_planes on the llama-2-7B prefill shapes (tools/bench_gemm2.py), one --pmc pass per counter group
 cd /tmp; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_gemm2; rm -rf $O; mkdir -p $O
-for d in 0; do
-  TMAC_GEMM2_DBG=$d timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_ADDR_CONFLICT --output-format csv -d $O/lds_$d -- python $R/tools/bench_gemm2.py > $O/lds_$d.log 2>&1
-  TMAC_GEMM2_DBG=$d timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/sq_$d -- python $R/tools/bench_gemm2.py > $O/sq_$d.log 2>&1
-done
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_ADDR_CONFLICT --output-format csv -d $O/lds -- python $R/tools/bench_gemm2.py > $O/lds.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/sq -- python $R/tools/bench_gemm2.py > $O/sq.log 2>&1
 cd $R
 python - <<'PY' > $O/summary.txt 2>&1
 import csv, glob, os, sys

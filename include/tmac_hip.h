@@ -71,6 +71,16 @@ int32_t tmac_hip_device_count(void);
 /* kcfg.ini handling: same file format and section names as the reference
  * (deploy/compile.py:153-165; lookup tmac_gemm_wrapper.h:230-255).  `path` NULL -> $TMAC_KCFG_FILE. */
 int32_t tmac_hip_load_kcfg(const char* path);
+/* replace != 0: the file becomes the whole table (the reference's runtime holds exactly one kcfg.ini); 0 merges as
+ * tmac_hip_load_kcfg does.  tmac_hip_clear_kcfg empties the table.  The per-tile host-pointer entry points return -1 when
+ * several loaded sections match their (bm, k, n, b) key and disagree on the quantisation layout. */
+int32_t tmac_hip_load_kcfg_ex(const char* path, int replace);
+int32_t tmac_hip_clear_kcfg(void);
+/* Puts every piece of process-global state back to that of a freshly loaded library: kcfg table, tuning table, all
+ * tmac_hip_set_* / tmac_hip_debug_* knobs, the host-pointer layer's caches, LUT workspace and staging buffers, the fused
+ * entry point's per-stream workspaces.  Registered weights, workspaces and chains the caller holds stay valid.
+ * Synchronises the library's own streams.  (tests/conftest.py calls it before every GPU test.) */
+int32_t tmac_hip_reset_state(void);
 /* M here is the number of WEIGHT rows (as in TMACGeMMWrapper::get_kcfg); fills zero_point /
  * act_group_size / m_groups from scales_size / lut_scales_size as the reference's shapes imply. */
 int32_t tmac_hip_get_kcfg(int M, int K, int N, int bits, tmac_kcfg* out);
@@ -263,6 +273,9 @@ int32_t tmac_hip_debug_gemm_image_read(const tmac_hip_workspace* ws, int8_t* hal
  * have been seen, and a run's output is computed in one launch per LUT and handed out tile by tile; 0 = every tile call is
  * served on its own */
 int32_t tmac_hip_debug_host_runs(int on);
+/* test knob: 0 skips the synchronisation that orders tmac_hip_workspace_create's null-stream fills before the workspace's
+ * first user on another stream -- the round-2 defect (all-zero LUT image), kept reproducible for tests/test_gpu_hostptr.py */
+int32_t tmac_hip_debug_ws_fill_sync(int on);
 /* Launch-configuration tuner of the fused decode kernel (the role autotvm's grid search over
  * (bm, kfactor, bn) plays for the reference's CPU kernels, python/t_mac/ops/base.py:84-127, qgemm.py:98-116).
  * tmac_hip_autotune_fused times every (threads per workgroup, waves per row quad) configuration of k_gemv_quad on the

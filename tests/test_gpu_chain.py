@@ -24,8 +24,13 @@ def tm():
     import tmac_amd
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     assert tmac_amd.lib().tmac_hip_device_count() > 0
-    tmac_amd.binding.check(tmac_amd.lib().tmac_hip_debug_chain_config(0, 1 << 17))   # a broken hand-off fails in ~0.2 s, not 2 s
     return tmac_amd
+
+
+@pytest.fixture(autouse=True)
+def _short_spin(tm):
+    # after conftest's per-test reset: a broken hand-off fails in ~0.2 s, not 2 s
+    tm.binding.check(tm.lib().tmac_hip_debug_chain_config(0, 1 << 17))
 
 
 def rel_err(c, ref):

@@ -65,6 +65,11 @@ def load_library() -> C.CDLL:
         "tmac_hip_version": ([], C.c_char_p),
         "tmac_hip_device_count": ([], i32),
         "tmac_hip_load_kcfg": ([C.c_char_p], i32),
+        "tmac_hip_load_kcfg_ex": ([C.c_char_p, C.c_int], i32),
+        "tmac_hip_clear_kcfg": ([], i32),
+        "tmac_hip_reset_state": ([], i32),
+        "tmac_hip_debug_ws_fill_sync": ([C.c_int], i32),
+        "tmac_hip_debug_host_runs": ([C.c_int], i32),
         "tmac_hip_get_kcfg": ([C.c_int] * 4 + [C.POINTER(KCfg)], i32),
         "tmac_hip_set_kcfg": ([C.c_int] * 4 + [C.POINTER(KCfg)], i32),
         "tmac_hip_register_weights": ([C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(KCfg), C.c_int, C.c_int, vp], i32),

@@ -99,6 +99,7 @@ static int g_force_ft = 0, g_force_wpq = 0;   // A/B knobs of the quad kernel (0
 static std::map<std::string, tmac_kcfg> g_kcfg;
 static unsigned long long g_kcfg_gen = 0;   // bumped whenever g_kcfg changes (memoised lookups check it)
 
+static int g_ws_fill_sync = 1;   // test knob (tmac_hip_debug_ws_fill_sync): 0 re-opens the round-2 race between the workspace fills and its first user
 static size_t qdev_u4_for_K(int K) { return (size_t)((K / (4 * TS) + KL - 1) / KL) * 8 * KL; }
 
 // tmac_hip_init selects the device for the calling thread only (hipSetDevice is per thread); entry points reached from other
@@ -148,7 +149,16 @@ static void derive_kcfg(tmac_kcfg& c, int M_bits, int K, int N, int bits) {
     }
 }
 
-extern "C" int32_t tmac_hip_load_kcfg(const char* path) {
+extern "C" int32_t tmac_hip_load_kcfg(const char* path) { return tmac_hip_load_kcfg_ex(path, 0); }
+
+extern "C" int32_t tmac_hip_clear_kcfg(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_kcfg.clear();
+    ++g_kcfg_gen;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_load_kcfg_ex(const char* path, int replace) {
     std::string p = path ? path : "";
     if (p.empty()) {
         const char* e = getenv("TMAC_KCFG_FILE");  // tmac_gemm_wrapper.h:40-56
@@ -176,6 +186,7 @@ extern "C" int32_t tmac_hip_load_kcfg(const char* path) {
         k.erase(k.find_last_not_of(" \t") + 1);
         raw[sec][k] = atoll(v.c_str());
     }
+    if (replace) { g_kcfg.clear(); ++g_kcfg_gen; }     // the file becomes the whole table (the reference holds exactly one kcfg.ini)
     for (auto& kv : raw) {
         int t, m, k, n, b;
         if (sscanf(kv.first.c_str(), "qgemm_lut_t%d_int8_m%d_k%d_n%d_b%d", &t, &m, &k, &n, &b) != 5) continue;
@@ -470,6 +481,10 @@ extern "C" int32_t tmac_hip_workspace_create(tmac_hip_workspace** out, int maxK,
         if (e == hipSuccess) e = hipMalloc(&ws->gimg, (size_t)2 * maxK * ws->gNpad);
         if (e == hipSuccess) e = hipMalloc((void**)&ws->gcol, sizeof(float) * 3 * (size_t)(maxK / 64) * ws->gNpad);
     }
+    // The fills above are null-stream work and the workspace's users launch on streams of their own (the host-pointer layer
+    // and the ggml glue on NON-BLOCKING streams, which the null stream does not order): a fill that lands after the first
+    // LUT build leaves all-zero half tables behind (round 2: qgemm_lut_int8 returned the bias terms only).  Complete them here.
+    if (e == hipSuccess && g_ws_fill_sync) e = hipStreamSynchronize(nullptr);
     if (e != hipSuccess) {   // nothing of a half-built workspace is left behind
         tmac_hip_workspace_free(ws);
         return fail(TMAC_HIP_E_RUNTIME, "workspace allocation (K=%d, N=%d): %s", maxK, maxN, hipGetErrorString(e));
@@ -1099,6 +1114,8 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
     const unsigned ctl0[4] = {1u, 0u, 0u, 0u};
     if (hipMalloc((void**)&c->ctl, sizeof(ctl0)) != hipSuccess || hipMemcpy(c->ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(TMAC_HIP_E_RUNTIME, "control word allocation failed"));
+    // the granule fills above ran on the null stream; the chain is launched on the caller's (possibly non-blocking) stream
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return bail(fail(TMAC_HIP_E_RUNTIME, "hand-off buffer initialisation failed"));
     *out = c;
     return TMAC_HIP_OK;
 }
@@ -1572,24 +1589,35 @@ static void lut_remember(const void* q, const void* ls, const void* lb, int k, i
 
 // first kcfg entry whose (k, n, b) match and, when bm_filter > 0, whose bm matches; looked up once per distinct key (the
 // per-tile entry points come here on every call) -- the memo is dropped when the table changes
-static bool find_cfg(int k, int n, int b, int bm_filter, int m_filter, tmac_kcfg* out) {
-    static std::map<std::array<int, 5>, tmac_kcfg> memo;
+static bool same_numerics(const tmac_kcfg& a, const tmac_kcfg& b) {
+    return a.bm == b.bm && a.kfactor == b.kfactor && a.group_size == b.group_size && a.act_group_size == b.act_group_size &&
+           a.zero_point == b.zero_point && (a.m_groups >= 1) == (b.m_groups >= 1);
+}
+// 1 = found, 0 = no section matches, -1 = several sections match and disagree on what the bytes mean
+static int find_cfg(int k, int n, int b, int bm_filter, int m_filter, tmac_kcfg* out, bool act_only = false) {
+    static std::map<std::array<int, 6>, std::pair<int, tmac_kcfg>> memo;
     static unsigned long long memo_for = ~0ull;
     if (memo_for != g_kcfg_gen) { memo.clear(); memo_for = g_kcfg_gen; }
-    const std::array<int, 5> mk = {k, n, b, bm_filter, m_filter};
+    const std::array<int, 6> mk = {k, n, b, bm_filter, m_filter, act_only ? 1 : 0};
     auto mi = memo.find(mk);
-    if (mi != memo.end()) { *out = mi->second; return true; }
+    if (mi != memo.end()) { *out = mi->second.second; return mi->second.first; }
+    int found = 0;
+    tmac_kcfg first;
+    memset(&first, 0, sizeof(first));
     for (auto& kv : g_kcfg) {
         int t, m, kk, nn, bb;
         if (sscanf(kv.first.c_str(), "qgemm_lut_t%d_int8_m%d_k%d_n%d_b%d", &t, &m, &kk, &nn, &bb) != 5) continue;
         if (kk != k || nn != n || bb != b) continue;
         if (bm_filter > 0 && kv.second.bm != bm_filter) continue;
         if (m_filter > 0 && m != m_filter) continue;
-        *out = kv.second;
-        memo[mk] = kv.second;
-        return true;
+        if (!found) { first = kv.second; found = 1; }
+        // the reference compiles ONE kernel per (bm, k, n, b) name (deploy/compile.py:52-71): sections that share the key and
+        // disagree on the quantisation layout cannot both be served through the per-tile entry point
+        else if (act_only ? first.act_group_size != kv.second.act_group_size : !same_numerics(first, kv.second)) { found = -1; break; }
     }
-    return false;
+    memo[mk] = std::make_pair(found, first);
+    *out = first;
+    return found;
 }
 
 static void free_run(HostRun* r) {
@@ -1647,8 +1675,11 @@ extern "C" int32_t preprocessor_int8(int m, int k, int n, int b, void* B, void* 
     std::lock_guard<std::mutex> lk(g_mu);
     tmac_kcfg cfg;
     // `m` is only a dispatch key in the reference too (qgemm.py:518-519)
-    if (!find_cfg(k, n, b, 0, m, &cfg) && !find_cfg(k, n, b, 0, 0, &cfg))
-        return fail(TMAC_HIP_E_NOMATCH, "preprocessor_int8: no kcfg for m=%d k=%d n=%d b=%d", m, k, n, b);
+    int fc = find_cfg(k, n, b, 0, m, &cfg, true);      // the LUT build depends on the act group size alone
+    if (fc == 0) fc = find_cfg(k, n, b, 0, 0, &cfg, true);
+    if (fc <= 0)
+        return fail(TMAC_HIP_E_NOMATCH, fc ? "preprocessor_int8: the loaded kcfg sections for m=%d k=%d n=%d b=%d disagree on the act group size"
+                                           : "preprocessor_int8: no kcfg for m=%d k=%d n=%d b=%d", m, k, n, b);
     int32_t rc = ensure_device();
     if (rc) return rc;
     if ((rc = host_stream())) return rc;
@@ -1782,7 +1813,10 @@ extern "C" int32_t qgemm_lut_int8(int m, int k, int n, int b, void* A, void* LUT
     std::unique_lock<std::shared_mutex> hl(g_host_mu);
     std::lock_guard<std::mutex> lk(g_mu);
     tmac_kcfg cfg;
-    if (!find_cfg(k, n, b, m, 0, &cfg)) return fail(TMAC_HIP_E_NOMATCH, "qgemm_lut_int8: no kcfg with bm=%d k=%d n=%d b=%d", m, k, n, b);
+    const int fc = find_cfg(k, n, b, m, 0, &cfg);
+    if (fc <= 0)
+        return fail(TMAC_HIP_E_NOMATCH, fc ? "qgemm_lut_int8: the loaded kcfg sections with bm=%d k=%d n=%d b=%d disagree on the quantisation layout (load ONE kcfg.ini: tmac_hip_load_kcfg_ex(path, 1))"
+                                           : "qgemm_lut_int8: no kcfg with bm=%d k=%d n=%d b=%d", m, k, n, b);
     int32_t rc = ensure_device();
     if (rc) return rc;
     if ((rc = host_stream())) return rc;
@@ -1884,3 +1918,35 @@ TMAC_DEF_Q(256, 4096, 1, 2) TMAC_DEF_Q(512, 4096, 1, 2) TMAC_DEF_Q(128, 14336, 1
 TMAC_DEF_P(28672, 4096, 1, 2) TMAC_DEF_P(8192, 14336, 1, 2) TMAC_DEF_P(2048, 4096, 1, 2)
 TMAC_DEF_Q(128, 8640, 1, 2) TMAC_DEF_Q(128, 3200, 1, 2) TMAC_DEF_Q(320, 3200, 1, 2)
 TMAC_DEF_P(6400, 8640, 1, 2) TMAC_DEF_P(17280, 3200, 1, 2) TMAC_DEF_P(6400, 3200, 1, 2)
+
+// ---------------------------------------------------------------------------------------------
+// process-global state: one call puts all of it back to the state of a freshly loaded library
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t tmac_hip_debug_ws_fill_sync(int on) {
+    g_ws_fill_sync = on ? 1 : 0;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_reset_state(void) {
+    int32_t rc = tmac_hip_cache_clear();      // host-pointer tiles / runs, the fused entry point's per-stream workspaces
+    {
+        std::unique_lock<std::shared_mutex> hl(g_host_mu);
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_hstream) (void)hipStreamSynchronize(g_hstream);
+        if (g_ws) { tmac_hip_workspace_free(g_ws); g_ws = nullptr; }
+        if (g_hostC) { (void)hipFree(g_hostC); g_hostC = nullptr; g_hostC_bytes = 0; }
+        if (g_pin) { (void)hipHostFree(g_pin); g_pin = nullptr; g_pin_bytes = 0; }
+        g_lut_host.clear();
+        g_lut_k = g_lut_n = g_lut_ags = 0;
+        g_lut_q = g_lut_ls = g_lut_lb = nullptr;
+        ++g_lut_gen;
+        g_kcfg.clear();
+        ++g_kcfg_gen;
+        g_variant = V_AUTO; g_gemm_min_n = 32; g_gemm_kernel = 0; g_pairs_min_n = 2; g_fa_mode = 0;
+        g_force_ft = g_force_wpq = 0; g_host_runs = 1; g_ws_fill_sync = 1;
+        g_chain_wpq = 0; g_chain_spin_limit = 1u << 21;
+        g_stamps = nullptr; g_gemm_stamps = nullptr;
+    }
+    (void)tmac_hip_tune_clear();
+    return rc;
+}

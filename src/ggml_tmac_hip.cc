@@ -104,10 +104,10 @@ extern "C" int ggml_tmac_hip_upload(struct tmac_ggml_tensor* w, int bits) {
 }
 
 extern "C" int ggml_tmac_hip_mul_mat(const struct tmac_ggml_tensor* w, const struct tmac_ggml_tensor* x, struct tmac_ggml_tensor* dst) {
+    std::lock_guard<std::mutex> lk(g_mu);      // before ANY shared state (g_ready, g_err, the staging buffers) is touched
     if (!g_ready) return fail("ggml_tmac_hip_init has not been called");
     if (!w || !w->extra || !x || !x->data || !dst || !dst->data) return fail("null tensor");
     g_err[0] = 0;
-    std::lock_guard<std::mutex> lk(g_mu);
     const Handle* h = (const Handle*)w->extra;
     const int N = (int)x->ne[1];
     if (x->ne[0] != h->K || dst->ne[0] != h->M || dst->ne[1] != N) return fail("shape mismatch");

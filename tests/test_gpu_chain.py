@@ -14,7 +14,7 @@ from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 
-BITS_BM = {2: 128, 4: 256}
+BITS_BM = {1: 64, 2: 128, 3: 192, 4: 256}      # (1-bit: 64 rows per tile so that the 64-row matrices below stay tileable)
 KF, GS, AGS = 16, 128, 64
 
 
@@ -38,11 +38,14 @@ def rel_err(c, ref):
 
 
 class Model:
-    """ops: list of (K, [Mw, ...], src) with src = None (external activations) or (op index, matrix index)"""
+    """ops: list of (K, [Mw, ...], src) with src = None (external activations) or (op index, matrix index).
+    mg = -1: per-group scales (+ zero points), act groups of 64 (tbl.cc:323-532); mg >= 1: unified scale(s), one act group
+    per row, int32 totals + scale-final (BitNet: tbl.cc:536-630, qgemm.py:170-174)."""
 
-    def __init__(self, tm, ops, bits=2, zp=True, dev_f16=True, seed=0, out_f16=True):
+    def __init__(self, tm, ops, bits=2, zp=True, dev_f16=True, seed=0, out_f16=True, mg=-1, ternary=False):
         import torch
-        self.tm, self.ops, self.bits, self.zp = tm, ops, bits, zp
+        self.tm, self.ops, self.bits, self.zp, self.mg = tm, ops, bits, zp and mg < 1, mg
+        zp = self.zp
         bm = BITS_BM[bits]
         self.wr = tm.TMACGeMMWrapper(act_group_size=AGS)
         rng = np.random.default_rng(seed)
@@ -50,17 +53,29 @@ class Model:
         for i, (K, rows, src) in enumerate(ops):
             hs, ws, os_ = [], [], []
             for m, Mw in enumerate(rows):
-                case = orc.make_case(1000 * seed + 10 * i + m, Mw, K, bits=bits, gs=GS, ags=AGS, zero_point=zp, fp16_values=True)
-                c = 1.0 / np.sqrt(2.5 * K)           # keeps the chained activations O(1)
-                case["sc"] = (case["sc"] * c).astype(np.float16).astype(np.float32)
-                if zp:                               # zero-mean real weights: a common component of x is not amplified op after op
-                    lvl = (2 ** bits - 1) / 2.0 - 2 ** (bits - 1)
-                    case["zr"] = (case["zr"] * c + lvl * case["sc"]).astype(np.float16).astype(np.float32)
-                else:                                # without zero points the mean level is -1/2 scale: damp the chain instead
-                    case["sc"] = (case["sc"] * (4.0 / np.sqrt(K))).astype(np.float16).astype(np.float32)
+                ags = K if mg >= 1 else AGS
+                case = orc.make_case(1000 * seed + 10 * i + m, Mw, K, bits=bits, gs=GS, ags=ags, zero_point=zp, m_groups=mg, fp16_values=True)
+                if mg >= 1 and bits == 2 and ternary:
+                    # BitNet's own data: ternary weights {-1, 0, 1} stored as levels {1, 2, 3} of the 2-bit format: zero-mean,
+                    # variance 2/3 -- a chain of any depth keeps O(1) activations with scales around 1 / sqrt(2 K / 3)
+                    case["w"] = np.random.default_rng(5000 + 1000 * seed + 10 * i + m).integers(1, 4, size=(Mw, K), dtype=np.uint8)
                 A = orc.preprocess_weights(case["w"], bits, bm, KF)
-                S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm)
-                cfg = tm.KCfg.make(Mw, K, bits, bm, KF, GS, AGS, zp)
+                if mg >= 1 and bits == 2 and ternary:
+                    S = ((0.8 + 0.4 * np.minimum(case["sc"], 1.0)) / np.sqrt(2.0 * K / 3.0)).astype(np.float16).astype(np.float32)
+                elif mg >= 1:
+                    # no zero points: the weights' mean level is -1/2 scale, the common component of x grows 0.5 scale K per op;
+                    # 0.6 / sqrt(K) keeps a chain a few ops deep inside fp16
+                    S = ((0.5 + case["sc"]) * (0.6 / np.sqrt(K))).astype(np.float16).astype(np.float32)
+                else:
+                    c = 1.0 / np.sqrt(2.5 * K)           # keeps the chained activations O(1)
+                    case["sc"] = (case["sc"] * c).astype(np.float16).astype(np.float32)
+                    if zp:                               # zero-mean real weights: a common component of x is not amplified op after op
+                        lvl = (2 ** bits - 1) / 2.0 - 2 ** (bits - 1)
+                        case["zr"] = (case["zr"] * c + lvl * case["sc"]).astype(np.float16).astype(np.float32)
+                    else:                                # without zero points the mean level is -1/2 scale: damp the chain instead
+                        case["sc"] = (case["sc"] * (4.0 / np.sqrt(K))).astype(np.float16).astype(np.float32)
+                    S = orc.preprocess_scales(case["sc"], case["zr"] if zp else None, bits, bm)
+                cfg = tm.KCfg.make(Mw, K, bits, bm, KF, GS, ags, zp, mg)
                 ws.append(self.wr.register_weights(A, S, Mw, K, bits, cfg, scales_dtype=tm.F32, dev_dtype=tm.F16 if dev_f16 else tm.F32))
                 hs.append((A, S))
                 os_.append(torch.zeros(Mw, dtype=torch.float16 if out_f16 else torch.float32, device="cuda"))
@@ -81,6 +96,24 @@ class Model:
             self.issue()
         return rec.chain
 
+    def oracle_outputs(self, i, x):
+        """the oracle's fp32 outputs of op i on the activation vector x (numpy fp32 [K])"""
+        K, rows, _ = self.ops[i]
+        xb = x[None, :]
+        out = []
+        if self.mg >= 1:
+            q, ls, lb = orc.preprocessor(xb, K)
+            for m, Mw in enumerate(rows):
+                A, S = self.host[i][m]
+                Cc, _ = orc.qgemm_scale_final(A, q, S, ls[:, 0], lb[:, 0], Mw, K, 1, self.bits, BITS_BM[self.bits], KF, self.mg)
+                out.append(Cc[0])
+        else:
+            q, ls, lb = orc.preprocessor(xb, AGS)
+            for m, Mw in enumerate(rows):
+                A, S = self.host[i][m]
+                out.append(orc.qgemm_float(A, q, S, ls, lb, Mw, K, 1, self.bits, BITS_BM[self.bits], KF, GS, AGS, self.zp)[0])
+        return out
+
     def check(self, chain, oracle_ops=None):
         """after chain.launch(): compare every op with its stand-alone launch and with the oracle"""
         import torch
@@ -92,6 +125,7 @@ class Model:
         for i, (K, rows, src) in enumerate(self.ops):
             x = self.x_ext[i] if src is None else got[src[0]][src[1]]
             assert x.numel() == K
+            assert bool(torch.isfinite(x.float()).all()) and float(x.float().abs().max()) > 0, f"op {i}: degenerate activations"
             # (a) the same call on its own, the chain's threads per workgroup and waves per quad
             L.tmac_hip_debug_quad_config(chain.threads, chain.wpq(i))
             ref = [torch.empty_like(o) for o in got[i]]
@@ -106,12 +140,14 @@ class Model:
                                       b.view(np.uint16 if b.dtype == np.float16 else np.uint32)), f"op {i} matrix {m}: chain != stand-alone launch"
             # (b) the oracle on the activation vector the chain produced
             if oracle_ops is None or i in oracle_ops:
-                xb = x.float().cpu().numpy()[None, :]
-                q, ls, lb = orc.preprocessor(xb, AGS)
-                for m, Mw in enumerate(rows):
-                    A, S = self.host[i][m]
-                    Cc = orc.qgemm_float(A, q, S, ls, lb, Mw, K, 1, self.bits, BITS_BM[self.bits], KF, GS, AGS, self.zp)
-                    assert rel_err(got[i][m].float().cpu().numpy(), Cc[0]) <= 1e-3, f"op {i} matrix {m} vs oracle"
+                want = self.oracle_outputs(i, x.float().cpu().numpy())
+                for m in range(len(rows)):
+                    g = got[i][m].cpu().numpy()
+                    if self.mg >= 1 and g.dtype == np.float16:
+                        # the int32 totals are exact and scale-final is three individually rounded fp32 operations: the fp16
+                        # outputs are the oracle's fp32 values rounded once -- bit for bit
+                        assert np.array_equal(g.view(np.uint16), want[m].astype(np.float16).view(np.uint16)), f"op {i} matrix {m} vs oracle (bits)"
+                    assert rel_err(g.astype(np.float32), want[m]) <= 1e-3, f"op {i} matrix {m} vs oracle"
 
     def free(self):
         for ws in self.ws:
@@ -144,6 +180,62 @@ def test_small_chain(tm, bits, zp, dev_f16):
                 o.fill_(float(rep))
         chain.launch()
         m.check(chain, oracle_ops=None if rep == 0 else [])
+    chain.free()
+    m.free()
+
+
+@pytest.mark.parametrize("bits,zp", [(1, True), (3, True), (3, False), (1, False)])
+def test_small_chain_one_and_three_bit_weights(tm, bits, zp):
+    """W1 / W3 (the 1-/3-bit tiles of python/t_mac/ops/qgemm.py:98-116) through the persistent chain"""
+    m = Model(tm, SMALL, bits=bits, zp=zp, dev_f16=True, seed=20 + bits + zp)
+    chain = m.record()
+    for rep in range(2):
+        chain.launch()
+        m.check(chain, oracle_ops=None if rep == 0 else [])
+    chain.free()
+    m.free()
+
+
+# unified scale (BitNet): K = 640 .. 8640 (one to five 64-unit steps, K = 8640 with the ragged last step and two build rounds
+# per thread), few and many quads, a fused triple, an older output consumed, an external vector mid-chain
+UNIFIED = [
+    (3200, [3200, 640, 640], None),
+    (3200, [3200], (0, 0)),
+    (3200, [8640, 8640], (1, 0)),
+    (8640, [3200], (2, 0)),
+    (640, [1024], (0, 1)),
+    (1024, [64], (4, 0)),
+    (3200, [256], None),
+]
+
+
+@pytest.mark.parametrize("bits,mg,dev_f16", [(2, 1, False), (2, 1, True), (1, 1, False), (4, 1, True), (3, 1, False), (2, 4, False)])
+def test_unified_scale_chain(tm, bits, mg, dev_f16):
+    """the int32 / scale-final path (a5: tbl.cc:536-630, qgemm.py:170-174,192-206) inside the persistent chain: every op
+    bit-identical to its stand-alone launch, fp16 outputs bit-identical to the oracle's fp32 results rounded once"""
+    m = Model(tm, UNIFIED, bits=bits, zp=False, dev_f16=dev_f16, seed=40 + bits + mg, mg=mg)
+    chain = m.record()
+    assert chain.nops == len(UNIFIED)
+    for rep in range(3):
+        for os_ in m.outs:
+            for o in os_:
+                o.fill_(float(rep))
+        chain.launch()
+        m.check(chain, oracle_ops=None if rep == 0 else [])
+    chain.free()
+    m.free()
+
+
+def test_bitnet_layer_full_size(tm):
+    """BitNet-b1.58-3B's decode calls at full size (python/t_mac/model_utils.py:50-54: 3200 x 3200 q/k/v/o, 8640 x 3200
+    gate/up, 3200 x 8640 down; ternary weights in 2 bits, one scale per matrix), one layer and a half chained as bench.py
+    --workload bitnet-3b chains them"""
+    ops = [(3200, [3200, 3200, 3200], None), (3200, [3200], (0, 0)), (3200, [8640, 8640], (1, 0)), (8640, [3200], (2, 0)),
+           (3200, [3200, 3200, 3200], (3, 0)), (3200, [3200], (4, 0))]
+    m = Model(tm, ops, bits=2, zp=False, dev_f16=False, seed=77, mg=1, ternary=True)
+    chain = m.record()
+    chain.launch()
+    m.check(chain)
     chain.free()
     m.free()
 
@@ -193,6 +285,94 @@ def test_chain_rejections(tm):
     assert rec.chain.status() == 0
     rec.chain.free()
     w.free()
+
+
+def test_chain_hazards_are_refused(tm):
+    """Workgroups of the chain are not synchronised with each other: data flow is taken from byte RANGES, and whatever no
+    hand-off orders is refused with -1 instead of computed wrongly (overlapping buffers, write-after-read,
+    write-after-write between independent calls)."""
+    import torch
+    wr = tm.TMACGeMMWrapper(act_group_size=AGS)
+
+    def mat(Mw, K, seed):
+        case = orc.make_case(seed, Mw, K, bits=2, fp16_values=True)
+        c = 1.0 / np.sqrt(2.5 * K)                   # unit gain, zero-mean real weights (as Model): the chained values stay O(1)
+        case["sc"] = (case["sc"] * c).astype(np.float16).astype(np.float32)
+        case["zr"] = (case["zr"] * c - 0.5 * case["sc"]).astype(np.float16).astype(np.float32)
+        A = orc.preprocess_weights(case["w"], 2, 128, KF)
+        S = orc.preprocess_scales(case["sc"], case["zr"], 2, 128)
+        return wr.register_weights(A, S, Mw, K, 2, tm.KCfg.make(Mw, K, 2, 128, KF, GS, AGS, True))
+
+    a, b = mat(512, 512, 1), mat(512, 512, 2)
+    few, tail = mat(128, 512, 3), mat(512, 128, 4)      # 128 rows = 32 quads: most workgroups own no row of `few`
+    big = torch.zeros(4096, dtype=torch.float16, device="cuda")
+    x = torch.randn(512, device="cuda").half()
+    y = torch.randn(512, device="cuda").half()
+    o1, o2 = big[0:512], big[1024:1536]
+
+    def refused(calls):
+        with pytest.raises(tm.TMACHipError) as e:
+            with wr.record_chain():
+                calls()
+        assert e.value.code == -1, e.value
+        return str(e.value)
+
+    def partial_overlap():          # (1) activations that overlap an earlier output without being it
+        wr.fused([a], x, [big[0:512]], 1)
+        wr.fused([b], big[256:768], [o2], 1)
+
+    def war_unordered():            # (2) the second call overwrites what the first reads from memory and depends on nothing
+        wr.fused([a], x, [o1], 1)
+        wr.fused([b], y, [x], 1)
+
+    def war_thin_reader():          # (3) ... a hand-off path exists, but the reader does not give every workgroup rows
+        wr.fused([few], x, [big[2048:2176]], 1)
+        wr.fused([tail], big[2048:2176], [x], 1)
+
+    def waw_unordered():            # (4) two independent calls write overlapping outputs
+        wr.fused([a], x, [o1], 1)
+        wr.fused([b], y, [big[256:768]], 1)
+
+    assert "overlap" in refused(partial_overlap)
+    assert "overwrites" in refused(war_unordered)
+    assert "overwrites" in refused(war_thin_reader)
+    assert "overlapping outputs" in refused(waw_unordered)
+    # the legal forms of the same patterns: a decoder's "next x = last output" with every workgroup owning rows of the reader
+    # is covered by test_bench_launches_full_size; a buffer rewritten by a DEPENDENT call:
+    with wr.record_chain() as rec:
+        wr.fused([a], x, [o1], 1)
+        wr.fused([b], o1, [o2], 1)
+        wr.fused([a], o2, [o1], 1)          # op 2 depends on op 1 depends on op 0: the rewrite of o1 is ordered
+    rec.chain.launch()
+    torch.cuda.synchronize()
+    assert rec.chain.status() == 0
+    r1 = torch.empty(512, dtype=torch.float16, device="cuda"); r2 = torch.empty_like(r1); r3 = torch.empty_like(r1)
+    wr.fused([a], x, [r1], 1); wr.fused([b], r1, [r2], 1); wr.fused([a], r2, [r3], 1)
+    torch.cuda.synchronize()
+    assert rel_err(o1.float().cpu().numpy(), r3.float().cpu().numpy()) <= 5e-3
+    assert rel_err(o2.float().cpu().numpy(), r2.float().cpu().numpy()) <= 5e-3
+    rec.chain.free()
+    for w in (a, b, few, tail):
+        w.free()
+
+
+def test_chain_in_flight_guard(tm):
+    """a chain owns one set of hand-off buffers: a launch on a second stream while the first may still run is refused"""
+    import torch
+    m = Model(tm, [(4096, [4096, 4096, 4096], None), (4096, [4096], (0, 0)), (4096, [11008, 11008], (1, 0)), (11008, [4096], (2, 0))] * 1, seed=5)
+    chain = m.record()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    L = tm.lib()
+    for _ in range(50):
+        tm.binding.check(L.tmac_hip_chain_launch(chain.handle, s1.cuda_stream))
+    rc = L.tmac_hip_chain_launch(chain.handle, s2.cuda_stream)          # 50 launches (~3 ms) are still queued on s1
+    assert rc == -4 and b"in flight" in L.tmac_hip_last_error()
+    s1.synchronize()
+    tm.binding.check(L.tmac_hip_chain_launch(chain.handle, s2.cuda_stream))
+    s2.synchronize()
+    assert chain.status() == 0
+    chain.free()
+    m.free()
 
 
 LLAMA = [("qkv", 4096, [4096, 4096, 4096]), ("o", 4096, [4096]), ("gate_up", 4096, [11008, 11008]), ("down", 11008, [4096])]

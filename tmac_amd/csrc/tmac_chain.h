@@ -11,6 +11,9 @@ namespace tmac {
 #endif
 constexpr int CHAIN_FT = TMAC_CHAIN_FT;   // threads per workgroup (12 waves = 3 per SIMD, one workgroup per CU; 1024 measured 6 % slower)
 constexpr int CHAIN_NWV = CHAIN_FT / 64;
+constexpr int CHAIN_RED = 4;              // words per (wave, row) in the split-quad reduction buffer: one fp32 partial, or (unified scale) one int32 per bit-plane
+constexpr int CHAIN_US_FLOATS = 48;       // unified-scale flavour: floats in front of the chunk sums in a LUT buffer's scale area (see k_decode_chain)
+constexpr int CHAIN_US_MAX_GROUPS = 8;    // unified scales per matrix the kernel parks in LDS
 
 struct ChainMat {
     const uint4* W;      // QUAD layout weights
@@ -32,8 +35,10 @@ struct ChainOp {
     int wpq, ipi;        // waves per row quad, row quads per workgroup iteration (12 / wpq)
     int wpq_inv;         // ceil(65536 / wpq): wave / wpq = (wave * wpq_inv) >> 16
     int total_q;
-    int it_full, it_rem; // total_q = it_full * (grid * ipi) + it_rem: iterations every workgroup runs / quads of the last, partial one
-    int pad_[2];         // sizeof == 256: the kernel keeps a copy of all descriptors in LDS (uint4 copies)
+    int q_per, q_extra;  // total_q = q_per * grid + q_extra: workgroup b owns the q_per + (b < q_extra) consecutive quads from b * q_per + min(b, q_extra)
+    int m_groups;        // unified-scale flavour: scales per matrix (rows split into m_groups equal runs; qgemm.py:170-174), else 0
+    int ipi_inv;         // ceil(65536 / ipi)
+    // sizeof == 256: the kernel keeps a copy of all descriptors in LDS (uint4 copies)
 };
 static_assert(sizeof(ChainOp) == 256, "ChainOp is copied to LDS in 16-byte pieces");
 
@@ -47,14 +52,36 @@ struct ChainArgs {
     int buf_u4;                    // uint4 per LDS LUT buffer (two buffers, by op parity)
     int poll_sleep;                // s_sleep 1 (64 cycles) count between two polls of a hand-off (A/B knob)
     int poll_delay;                // s_sleep 1 count before the first poll of a hand-off (A/B knob)
-    int issue_first;               // A/B knob: issue an op's weights before polling for its activations
+    int issue_first;               // fragments per wave (0 .. ring size) of an op's weights issued before the polls for its activations; the rest follow the polls
     int poll_mode;                 // A/B knob: 0 dwordx4 sc1 | 1 dwordx4 sc0 sc1 | 2 dwordx4 nt | 3 dwordx4 plain
     unsigned long long* stamps;    // optional [nops][grid][8] of wave 0, s_memrealtime (100 MHz): 0 op entry, 1 activations complete, 2 LUT built
                                    // (barrier passed), 3 current ring landed, 5 last quad published, 6 everything in flight landed, 7 polls
 };
 
-hipError_t launch_decode_chain(const ChainArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st);
-size_t chain_lds_bytes(int buf_u4, int nops);
-int chain_buf_u4(int K);
+// one translation unit per weight width (tmac_chain.hip with -DTMAC_CHAIN_BITS=b).  sm: 0 per-group scales, 2 unified scale.
+// resident != nullptr: no launch -- returns how many workgroups of that kernel one CU can hold with lds_bytes of LDS.
+hipError_t launch_decode_chain_b1(const ChainArgs& a, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st, int* resident);
+hipError_t launch_decode_chain_b2(const ChainArgs& a, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st, int* resident);
+hipError_t launch_decode_chain_b3(const ChainArgs& a, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st, int* resident);
+hipError_t launch_decode_chain_b4(const ChainArgs& a, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st, int* resident);
+inline hipError_t launch_decode_chain(const ChainArgs& a, int bits, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st,
+                                      int* resident = nullptr) {
+    switch (bits) {
+        case 1: return launch_decode_chain_b1(a, zp, sc_f16, sm, grid, lds_bytes, st, resident);
+        case 2: return launch_decode_chain_b2(a, zp, sc_f16, sm, grid, lds_bytes, st, resident);
+        case 3: return launch_decode_chain_b3(a, zp, sc_f16, sm, grid, lds_bytes, st, resident);
+        case 4: return launch_decode_chain_b4(a, zp, sc_f16, sm, grid, lds_bytes, st, resident);
+        default: return hipErrorInvalidValue;
+    }
+}
+// LDS: two LUT buffers of buf_u4 uint4 each ([4][tstride] half tables + the act groups' scales / biases, or the unified-scale
+// scratch), the split-quad reduction buffer, the op descriptors
+inline int chain_buf_u4(int K) {
+    const int nu = K / 32, nst = (nu + 63) / 64;
+    return 4 * (nst * 64 + 1) + (2 * nst * 32 * 4 + 15) / 16 + CHAIN_US_FLOATS / 4;
+}
+inline size_t chain_lds_bytes(int buf_u4, int nops) {
+    return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops;
+}
 
 }  // namespace tmac

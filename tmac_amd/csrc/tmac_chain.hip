@@ -14,7 +14,9 @@
 // Arithmetic is that of k_gemv_quad (tmac_quad.hip) — same LUT build (lut_ctor.cc:120-215), same lookup + MFMA adder
 // (tbl.cc:445-462), same per-act-group scale chain (tbl.cc:479-526), same lane/wave decomposition for a given number of
 // waves per quad — so results are bit-identical to the per-launch path with 768-thread workgroups.
-// Scope: per-group scales with act groups of 64 and scale groups >= 128 (the GPTQ-style path), fp16 activations.
+// Scope: 1- to 4-bit weights, fp16 activations; SM = 0: per-group scales with act groups of 64 and scale groups >= 128 (the
+// GPTQ-style path, tbl.cc:323-532); SM = 2: unified scale(s), one act group per row, exact int32 totals and the scale-final
+// epilogue (BitNet: tbl.cc:536-630, qgemm.py:170-174,192-206).
 // Deadlock freedom: workgroups process ops in order and producers never wait for consumers, so by induction over the op
 // index everything completes provided all workgroups are resident; the grid is one workgroup per CU and the kernel's
 // register / LDS footprint admits exactly one.  Every spin is bounded (ChainArgs::spin_limit) and reports through ctl[2].
@@ -53,7 +55,7 @@ struct CFrag {
 // st*64 + 16g + 4*lg .. +3 (see k_gemv_quad); scale groups span >= 4 units, so one scale group per lane and step.
 // Lanes whose unit lies past K skip the weight load (their LUT entries are zero tables: whatever the registers hold
 // contributes exactly 0) -- the zero padding of the last step is stored but never fetched.
-template <int BITS, bool ZP, bool SCF16>
+template <int BITS, bool ZP, bool SCF16, int SM>
 __device__ __forceinline__ void c_issue(CFrag<BITS>& f, __amdgpu_buffer_rsrc_t rs, int woff, const TMAC_GLOBAL char* scq, int nsg, int gsh, int nu,
                                         int st, int lane, uint32_t lane16) {
     constexpr int per = ZP ? 2 : 1;
@@ -62,13 +64,15 @@ __device__ __forceinline__ void c_issue(CFrag<BITS>& f, __amdgpu_buffer_rsrc_t r
     const uint32_t sg = min((uint32_t)st * (64u >> gsh) + (uint32_t)(c0 >> gsh), (uint32_t)nsg - 1u);
     const uint32_t boff = (sg * 4 + (lane & 3)) * (per * esz);          // scq already points at the quad's first scale group
     uint32_t r0 = 0, r1 = 0;
-    if (SCF16) {
-        if (ZP) r0 = *reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq + boff);
-        else r0 = *reinterpret_cast<const TMAC_GLOBAL unsigned short*>(scq + boff);
-    } else {
-        const TMAC_GLOBAL uint32_t* p32 = reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq + boff);
-        r0 = p32[0];
-        if (ZP) r1 = p32[1];
+    if (SM == 0) {                       // (the unified scale is applied once per output, in the epilogue)
+        if (SCF16) {
+            if (ZP) r0 = *reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq + boff);
+            else r0 = *reinterpret_cast<const TMAC_GLOBAL unsigned short*>(scq + boff);
+        } else {
+            const TMAC_GLOBAL uint32_t* p32 = reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq + boff);
+            r0 = p32[0];
+            if (ZP) r1 = p32[1];
+        }
     }
     f.s0 = r0; f.s1 = r1;
     if (st * 64 + lane < nu) {
@@ -87,10 +91,11 @@ __device__ __forceinline__ void c_issue(CFrag<BITS>& f, __amdgpu_buffer_rsrc_t r
 }
 
 // One 64-unit step of a row quad: lookups (v_perm_b32 on the half tables), v_mfma_i32_16x16x64_i8 as the adder, then the
-// two act groups of the lane's output row through the fp32 scale chain (compute_mfma of k_gemv_quad, SM = 0).
-template <int BITS, bool ZP, bool SCF16>
+// two act groups of the lane's output row through the fp32 scale chain (compute_mfma of k_gemv_quad, SM = 0), or -- SM = 2 --
+// the exact int32 sum of the lane's row over all units, per bit-plane (tbl.cc:586-628).
+template <int BITS, bool ZP, bool SCF16, int SM>
 __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab, int tstride, const float* l_ls, const float* l_lb,
-                                          int st, int lane, qv4i_t bsel, uint32_t k3, float& cacc) {
+                                          int st, int lane, qv4i_t bsel, uint32_t k3, float& cacc, int32_t (&iacc)[BITS]) {
     const int u = st * 64 + lane;
     uint32_t tb[16];
 #pragma unroll
@@ -113,6 +118,16 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
             else q_lookup4_pm<0>(f.wd[qb >> 1], tb[4 * tp + 2], tb[4 * tp + 3], k3, pb, mb);
             c[pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8((qv4i_t){(int)pa, (int)ma, (int)pb, (int)mb}, bsel, c[pl], 0, 0, 0);
         }
+    }
+    if (SM == 2) {
+#pragma unroll
+        for (int pl = 0; pl < BITS; ++pl) {
+            // the MFMA result must have landed before a VALU instruction reads it (no hardware interlock; see compute_mfma
+            // of k_gemv_quad: with one bit-plane the hazard recogniser left the two a single wait state apart)
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[pl]));
+            iacc[pl] += (c[pl].x + c[pl].y) + (c[pl].z + c[pl].w);
+        }
+        return;
     }
     float sc, zr = 0.f;
     if (SCF16) {
@@ -177,7 +192,7 @@ __device__ __forceinline__ void c_ext3(const uint4* p0, const uint4* p1, const u
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(p0), "v"(p1), "v"(p2) : "memory");
 }
 
-template <int BITS, bool ZP, bool SCF16>
+template <int BITS, bool ZP, bool SCF16, int SM>
 __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     constexpr int FT = CHAIN_FT, NWV = CHAIN_NWV;
@@ -185,9 +200,9 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int bx = blockIdx.x, gx = gridDim.x;
     const unsigned gen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][4] partials of split quads
+    float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][4][CHAIN_RED] partials of split quads (SM 2: per bit-plane)
     // all op descriptors into LDS (16 uint4 each): a field is then a ds_read away instead of a scalar-cache miss
-    uint4* l_ops = lds + 2 * (size_t)a.buf_u4 + (2 * NWV * 4 * sizeof(float)) / 16;
+    uint4* l_ops = lds + 2 * (size_t)a.buf_u4 + (2 * NWV * 4 * CHAIN_RED * sizeof(float)) / 16;
     {
         const uint4* gsrc = reinterpret_cast<const uint4*>(a.ops);
         for (int idx = tid; idx < a.nops * 16; idx += FT) l_ops[idx] = gsrc[idx];
@@ -211,22 +226,25 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     uint32_t lane16 = (uint32_t)lane * 16u;
     asm volatile("" : "+v"(lane16));
 
-    // per-op role of this wave: quads slot0, slot0 + stride, ...; steps h, h + wpq, ... of each
-    // per-op role of this wave: quads slot0, slot0 + stride, ...; steps h, h + wpq, ... of each
-    struct Role { int slot0, stride, h, wpq, nst, total_q, my_iter, nquads, nsteps; };
+    // per-op role of this wave: quad qs (of ipi) of every iteration of its workgroup; steps h, h + wpq, ... of each
+    // Row quads are dealt to the workgroups as contiguous, balanced ranges: workgroup b owns q_per (+ 1 for the first q_extra
+    // workgroups) consecutive quads -- every CU streams its share of every op (800 quads over 256 CUs: 3 or 4 each, not 6 on
+    // 134 of them), and a workgroup's outputs stay together in the hand-off image (one or two stores per granule line).
+    struct Role { int q_lo, cnt, qs, ipi, h, wpq, nst, my_iter, nquads, nsteps; };
     auto role_of = [&](cop_ptr d) __attribute__((always_inline)) {
         Role r;
         r.wpq = uni(d->wpq);
         const int ipi = uni(d->ipi), inv = uni(d->wpq_inv);
         const int qs = (w * inv) >> 16;                                  // w / wpq for w < 12
         r.h = w - qs * r.wpq;
-        r.slot0 = bx * ipi + qs;
-        r.stride = gx * ipi;
+        r.qs = qs; r.ipi = ipi;
         r.nst = uni(d->nst);
-        r.total_q = uni(d->total_q);
-        const int itf = uni(d->it_full), itr = uni(d->it_rem);
-        r.my_iter = itf + ((bx * ipi < itr) ? 1 : 0);                    // iterations the WORKGROUP runs (barriers)
-        r.nquads = itf + ((r.slot0 < itr) ? 1 : 0);                      // quads this wave works on: its slot exists in every full iteration
+        const int qper = uni(d->q_per), qex = uni(d->q_extra);
+        r.q_lo = bx * qper + min(bx, qex);
+        r.cnt = qper + (bx < qex ? 1 : 0);
+        const int iinv = uni(d->ipi_inv);                                // x / ipi = (x * ipi_inv) >> 16 for the small x here
+        r.my_iter = ((r.cnt + ipi - 1) * iinv) >> 16;                    // iterations the WORKGROUP runs (barriers)
+        r.nquads = qs < r.cnt ? (((r.cnt - 1 - qs) * iinv) >> 16) + 1 : 0;   // quads this wave works on: q_lo + qs + it * ipi < q_lo + cnt
         r.nsteps = r.h < r.nst ? ((r.nst - r.h + r.wpq - 1) * inv) >> 16 : 0;   // steps h, h + wpq, ... < nst
         return r;
     };
@@ -240,6 +258,9 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         uint4* tab = lds + (size_t)(i & 1) * a.buf_u4;                // [4][tstride]
         float* l_ls = reinterpret_cast<float*>(tab + 4 * tstride);   // [GP] ls / 2 (groups past K: 0)
         float* l_lb = l_ls + GP;                                     // [GP] lb / 2
+        // SM 2 uses the same floats as: [0] lut_scales, [1] lut_biases, [2 .. 2+NWV) per-wave maxima, [16 .. 48) the unified
+        // scales of the op's matrices (m_groups <= CHAIN_US_MAX_GROUPS each), [CHAIN_US_FLOATS .. + K/32) the chunk sums of the bias chain
+        float* l_us = l_ls;
         const int P = uni(d->K) / 8;                                      // LUT pairs: tables 2p, 2p+1 from activations 8p .. 8p+7
         const Role ro = role_of(d);
         const int wpq = ro.wpq, h = ro.h;
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         auto issue_next = [&](CFrag<BITS>& f) __attribute__((always_inline)) {
             if (issued < n_items) {
                 if (q_res != i_it) {
-                    const int gqi = ro.slot0 + i_it * ro.stride;
+                    const int gqi = ro.q_lo + ro.qs + i_it * ro.ipi;
                     const int mi = (gqi >= qe0 ? 1 : 0) + (gqi >= qe1 ? 1 : 0) + (gqi >= qe2 ? 1 : 0);
                     const int lq = gqi - (gqi >= qe2 ? qe2 : (gqi >= qe1 ? qe1 : (gqi >= qe0 ? qe0 : 0)));
                     q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(uni(d->m[mi].W)), (short)0, 0x7fffffff, 0x00020000);
@@ -266,7 +287,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     q_woff = lq * nst * (BITS * 1024);
                     q_res = i_it;
                 }
-                c_issue<BITS, ZP, SCF16>(f, q_rs, q_woff, q_sc, nsg, gsh, nu, i_st, lane, lane16);
+                c_issue<BITS, ZP, SCF16, SM>(f, q_rs, q_woff, q_sc, nsg, gsh, nu, i_st, lane, lane16);
                 ++issued;
                 i_st += wpq;
                 if (i_st >= nst) { i_st = h; ++i_it; }
@@ -277,9 +298,20 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         // everything it had in flight): a poll costs one round trip, not the drain time of a weight stream.  Measured the
         // other way round -- next op's weights prefetched behind the current op's lookups -- every publish and every poll
         // sat behind 20-100 KB of queued weight loads per CU: 3-4 us per hand-off (profiles/r02_chain_prefetch_ab.txt). ----
-        if (a.issue_first) {       // A/B: weights first, the polls queue behind them
+        // issue_first fragments per wave go out before the polls (which then queue behind them), the rest of the ring
+        // after the activations have arrived
 #pragma unroll
-            for (int k = 0; k < RING; ++k) issue_next(ring[k]);
+        for (int k = 0; k < RING; ++k)
+            if (k < a.issue_first) issue_next(ring[k]);
+        if (SM == 2) {             // the unified scales of this op's matrices: a handful of floats, parked in LDS for the epilogue
+            const int mg = uni(d->m_groups);
+            if (tid < nm * mg) {
+                const int mi = tid / mg, g = tid - mi * mg;
+                const void* scp = d->m[mi].SC;
+                l_us[16 + mi * CHAIN_US_MAX_GROUPS + g] =
+                    SCF16 ? __half2float(__ushort_as_half(as_global(reinterpret_cast<const unsigned short*>(scp))[g]))
+                          : as_global(reinterpret_cast<const float*>(scp))[g];
+            }
         }
         const bool gran = uni(d->in_gran) != 0;
         const int nr = (P + FT - 1) / FT;                            // rounds of FT pairs (<= NRMAX, checked on the host)
@@ -350,45 +382,102 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt / lgkmcnt untouched
 
         // ---- 2. this wave's first RING (quad, step) items: the weights stream in during the LUT build ----
-        if (!a.issue_first) {
 #pragma unroll
-            for (int k = 0; k < RING; ++k) issue_next(ring[k]);
-        }
+        for (int k = 0; k < RING; ++k)
+            if (k >= a.issue_first) issue_next(ring[k]);
 
         CSTAMP(i, 3);
 
         // ---- 3. LUT into LDS (lut_ctor.cc:120-215, as in k_gemv_quad) ----
+        auto unpack = [&](int r, float (&x)[8]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const __half2 hh = *reinterpret_cast<const __half2*>(&xw[r][q]);
+                x[2 * q] = __low2float(hh); x[2 * q + 1] = __high2float(hh);
+            }
+        };
+        float gscale = 0.f, gtinv = 0.f;
+        if (SM == 2) {
+            // One act group = the whole row (qgemm.py:93-96): the scale is a maximum over K and lut_biases ONE fp32 chain over the
+            // K/32 chunk sums in order (lut_ctor.cc:157,218).  Neither the chunk sums nor the chain depend on the scale: pass 1
+            // forms maxima and chunk sums, one barrier, then lane 0 of the last wave (the one with the fewest pairs and, with
+            // split quads, the fewest steps) walks the chain while the other waves build their tables (k_gemv_quad, SM = 2).
+            float mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < NRMAX; ++r) {
+                const int p = r * FT + tid;
+                if (r < nr && p < P) {
+                    float x[8];
+                    unpack(r, x);
+                    mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3]))));
+                    mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x[4]), fabsf(x[5])), __fadd_rn(fabsf(x[6]), fabsf(x[7]))));
+                    float va = -__fadd_rn(__fadd_rn(__fadd_rn(x[0], x[1]), x[2]), x[3]);
+                    float vb = -__fadd_rn(__fadd_rn(__fadd_rn(x[4], x[5]), x[6]), x[7]);
+                    va = __fadd_rn(va, qdpp_f<0x4E>(va));      // lane ^ 2: v0+v4 | v2+v6      (lut_ctor.cc:25-31)
+                    vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));      //           v1+v5 | v3+v7
+                    va = __fadd_rn(va, qdpp_f<0xB1>(va));      // lane ^ 1: (v0+v4)+(v2+v6)
+                    vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));      //           (v1+v5)+(v3+v7)
+                    if ((p & 3) == 0) l_us[CHAIN_US_FLOATS + (p >> 2)] = __fadd_rn(va, vb);
+                }
+            }
+            mx = q_row_allmax(mx);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (lane == 0) l_us[2 + w] = mx;
+            __syncthreads();
+            mx = l_us[2];
+#pragma unroll
+            for (int ww = 1; ww < NWV; ++ww) mx = fmaxf(mx, l_us[2 + ww]);
+            gscale = div127(mx);
+            gtinv = (gscale != 0.0f) ? rcp_exact(gscale) : 0.0f;
+            if (tid == FT - 64) {
+                float biases = 0.0f;
+                const float4* cs = reinterpret_cast<const float4*>(l_us + CHAIN_US_FLOATS);      // 16-byte reads, unrolled: only the adds are serial
+                const int nc = nu;                                                   // K / 32 chunks
+                int c = 0;
+#pragma unroll 4
+                for (; c + 4 <= nc; c += 4) {
+                    const float4 v4 = cs[c >> 2];
+                    biases = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(biases, v4.x), v4.y), v4.z), v4.w);
+                }
+                for (; c < nc; ++c) biases = __fadd_rn(biases, l_us[CHAIN_US_FLOATS + c]);
+                l_us[0] = gscale;
+                l_us[1] = biases;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < NRMAX; ++r) {
             const int p = r * FT + tid;
             if (r < nr && p < P) {
                 float x[8];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const __half2 hh = *reinterpret_cast<const __half2*>(&xw[r][q]);
-                    x[2 * q] = __low2float(hh); x[2 * q + 1] = __high2float(hh);
+                unpack(r, x);
+                float scales, t_scales;
+                if (SM == 2) { scales = gscale; t_scales = gtinv; }
+                else {
+                    const float s0 = __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3])));
+                    const float s1 = __fadd_rn(__fadd_rn(fabsf(x[4]), fabsf(x[5])), __fadd_rn(fabsf(x[6]), fabsf(x[7])));
+                    const float mx = q_half_allmax(fmaxf(s0, s1));
+                    scales = div127(mx);
+                    t_scales = (scales != 0.0f) ? rcp_exact(scales) : 0.0f;
                 }
-                const float s0 = __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3])));
-                const float s1 = __fadd_rn(__fadd_rn(fabsf(x[4]), fabsf(x[5])), __fadd_rn(fabsf(x[6]), fabsf(x[7])));
-                const float mx = q_half_allmax(fmaxf(s0, s1));
-                const float scales = div127(mx);
-                const float t_scales = (scales != 0.0f) ? rcp_exact(scales) : 0.0f;
                 uint32_t lo0, hi0, lo1, hi1;
                 float La, Lb;
                 q_table8<true>(x[0], x[1], x[2], x[3], t_scales, lo0, hi0, La);
                 q_table8<true>(x[4], x[5], x[6], x[7], t_scales, lo1, hi1, Lb);
                 tab[(p & 3) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
-                // lut_biases (lut_ctor.cc:25-31): per 8-table chunk ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)), v_i = -L15 of table i
-                float va = -La, vb = -Lb;
-                va = __fadd_rn(va, qdpp_f<0x4E>(va));
-                vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));
-                va = __fadd_rn(va, qdpp_f<0xB1>(va));
-                vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));
-                const float v = __fadd_rn(va, vb);
-                const float c1 = qdpp_f<0x104>(v);      // row_shl:4: the second chunk of the act group
-                if ((p & 7) == 0) {
-                    l_ls[p >> 3] = __fmul_rn(0.5f, scales);
-                    l_lb[p >> 3] = __fmul_rn(0.5f, __fadd_rn(__fadd_rn(0.0f, v), c1));
+                if (SM != 2) {
+                    // lut_biases (lut_ctor.cc:25-31): per 8-table chunk ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)), v_i = -L15 of table i
+                    float va = -La, vb = -Lb;
+                    va = __fadd_rn(va, qdpp_f<0x4E>(va));
+                    vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));
+                    va = __fadd_rn(va, qdpp_f<0xB1>(va));
+                    vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));
+                    const float v = __fadd_rn(va, vb);
+                    const float c1 = qdpp_f<0x104>(v);      // row_shl:4: the second chunk of the act group
+                    if ((p & 7) == 0) {
+                        l_ls[p >> 3] = __fmul_rn(0.5f, scales);
+                        l_lb[p >> 3] = __fmul_rn(0.5f, __fadd_rn(__fadd_rn(0.0f, v), c1));
+                    }
                 }
             }
         }
@@ -396,7 +485,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4)
                 for (int u = nu + tid; u < nst * 64; u += FT) tab[j4 * tstride + u] = make_uint4(0u, 0u, 0u, 0u);
-            for (int g = G + tid; g < GP; g += FT) { l_ls[g] = 0.f; l_lb[g] = 0.f; }
+            if (SM != 2)
+                for (int g = G + tid; g < GP; g += FT) { l_ls[g] = 0.f; l_lb[g] = 0.f; }
         }
         CSTAMP(i, 4);
         __syncthreads();
@@ -409,41 +499,87 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         // instruction -- a granule line is then written by one or two stores, not by sixteen 8-byte write-throughs that each
         // invalidate the line in every polling XCD.  Every wave closes my_iter iterations, with or without work. ----
         int c_it = 0;
+        int32_t iacc[BITS];
+#pragma unroll
+        for (int pl = 0; pl < BITS; ++pl) iacc[pl] = 0;
         auto finish = [&](bool have, float cacc) __attribute__((always_inline)) {
-            float acc = 0.f;
-            if (have) {
-                acc = cacc;
-                acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // lanes with the same row: rotate by 4, 8 within the DPP row
-                acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
-                acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));
-                acc = __fadd_rn(acc, __shfl_xor(acc, 32, 64));
+            float* red = l_red + parity * (NWV * 4 * CHAIN_RED);
+            if (SM == 2) {
+                // exact integer totals of the lane's row (lane & 3): lanes of a DPP row by rotation, rows by two cross-row moves
+                int32_t* redi = reinterpret_cast<int32_t*>(red);
+#pragma unroll
+                for (int pl = 0; pl < BITS; ++pl) {
+                    uint32_t v = have ? (uint32_t)iacc[pl] : 0u;
+                    v += qdpp_u<0x124>(v);
+                    v += qdpp_u<0x128>(v);
+                    v += (uint32_t)__shfl_xor((int)v, 16, 64);
+                    v += (uint32_t)__shfl_xor((int)v, 32, 64);
+                    if (lane < 4) redi[(w * 4 + lane) * CHAIN_RED + pl] = (int32_t)v;
+                    iacc[pl] = 0;
+                }
+            } else {
+                float acc = 0.f;
+                if (have) {
+                    acc = cacc;
+                    acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // lanes with the same row: rotate by 4, 8 within the DPP row
+                    acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
+                    acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));
+                    acc = __fadd_rn(acc, __shfl_xor(acc, 32, 64));
+                }
+                if (lane < 4) red[(w * 4 + lane) * CHAIN_RED] = acc;
             }
-            float* red = l_red + parity * (NWV * 4);
-            if (lane < 4) red[w * 4 + lane] = acc;
             __syncthreads();
             if (w == 0) {
                 const int qs = lane >> 2, row = lane & 3;
-                const int g0 = bx * ipi + c_it * ro.stride;           // first quad of this workgroup iteration
+                const int g0 = ro.q_lo + c_it * ipi;                  // first quad of this workgroup iteration
                 const int gql = g0 + qs;
-                const bool mine = qs < ipi && gql < ro.total_q;      // the 4 lanes of a quad decide together
+                const bool mine = qs < ipi && gql < ro.q_lo + ro.cnt; // the 4 lanes of a quad decide together
                 float t = 0.f;
+                int32_t cb[BITS];
+#pragma unroll
+                for (int pl = 0; pl < BITS; ++pl) cb[pl] = 0;
                 if (mine) {
-                    t = red[(qs * wpq) * 4 + row];
-                    for (int ww = 1; ww < wpq; ++ww) t = __fadd_rn(t, red[(qs * wpq + ww) * 4 + row]);
+                    if (SM == 2) {
+                        const int32_t* redi = reinterpret_cast<const int32_t*>(red);
+                        for (int ww = 0; ww < wpq; ++ww)
+#pragma unroll
+                            for (int pl = 0; pl < BITS; ++pl) cb[pl] += redi[((qs * wpq + ww) * 4 + row) * CHAIN_RED + pl];
+                    } else {
+                        t = red[((qs * wpq) * 4 + row) * CHAIN_RED];
+                        for (int ww = 1; ww < wpq; ++ww) t = __fadd_rn(t, red[((qs * wpq + ww) * 4 + row) * CHAIN_RED]);
+                    }
                 }
-                // granule = {generation, fp16 row | fp16 next row << 16}, 8 bytes, write-through: even rows store
-                const uint32_t hb = (uint32_t)__half_as_ushort(__float2half_rn(t));
-                const uint32_t nb = qdpp_u<0xB1>(hb);                    // quad_perm [1,0,3,2]: the neighbour's value
                 // matrices in a uniform loop (descriptor fields through the scalar cache): a per-lane descriptor lookup
                 // is a vector load, and waiting for it waits for every weight load in flight as well
                 int base = 0;
                 for (int mi = 0; mi < nm; ++mi) {
                     const int qe = uni(d->m[mi].q_end);
                     if (g0 < qe && g0 + ipi > base) {
-                        if (mine && gql >= base && gql < qe) {
-                            const int lq = gql - base;
+                        const bool here = mine && gql >= base && gql < qe;
+                        const int lq = gql - base;
+                        if (SM == 2) {
+                            // scale-final (qgemm.py:170-174,192-206), as k_gemv_quad's epilogue: C = ((sum_p float(cb_p) alpha_p) ls + lb / 2) Scale
+                            float acc = 0.f;
+#pragma unroll
+                            for (int pl = 0; pl < BITS; ++pl) {
+                                const float tp = __fmul_rn((float)cb[pl], q_alpha(pl));
+                                acc = (pl == 0) ? tp : __fadd_rn(acc, tp);
+                            }
+                            const float v = __fadd_rn(__fmul_rn(acc, l_us[0]), __fmul_rn(l_us[1], 0.5f));
+                            const int mg = uni(d->m_groups), Mwm = uni(d->m[mi].Mw);
+                            const int g = (mg == 1 || !here) ? 0 : (4 * lq + row) / (Mwm / mg);
+                            t = __fmul_rn(v, l_us[16 + mi * CHAIN_US_MAX_GROUPS + g]);
+                        }
+                        // The fp16 output is the fp32 result rounded once more (as k_gemv_quad stores it and as the oracle is
+                        // compared): without the barrier the compiler fuses the last multiplication with the conversion
+                        // (v_fma_mixlo_f16: ONE rounding of the exact product), which differs on exact fp16 ties.
+                        asm volatile("" : "+v"(t));
+                        // granule = {generation, fp16 row | fp16 next row << 16}, 8 bytes, write-through: even rows store
+                        const uint32_t hb = (uint32_t)__half_as_ushort(__float2half_rn(t));
+                        const uint32_t nb = qdpp_u<0xB1>(hb);                    // quad_perm [1,0,3,2]: the neighbour's value
+                        if (here) {
                             const size_t oi = (size_t)(4 * lq + row);
-                            if (a.out_f16) as_global(reinterpret_cast<unsigned short*>(uni(d->m[mi].C)))[oi] = __half_as_ushort(__float2half_rn(t));
+                            if (a.out_f16) as_global(reinterpret_cast<unsigned short*>(uni(d->m[mi].C)))[oi] = (unsigned short)hb;
                             else as_global(reinterpret_cast<float*>(uni(d->m[mi].C)))[oi] = t;
                             TMAC_GLOBAL unsigned long long* gr = as_global(reinterpret_cast<unsigned long long*>(uni(d->m[mi].GR)));
                             if (gr && !(row & 1))
@@ -465,7 +601,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             while (left > 0) {
 #pragma unroll
                 for (int k = 0; k < RING; ++k) {
-                    c_compute<BITS, ZP, SCF16>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane, bsel, k3, cacc);
+                    c_compute<BITS, ZP, SCF16, SM>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane, bsel, k3, cacc, iacc);
                     issue_next(ring[k]);               // refill this slot with the item RING places ahead, if there is one
                     c_st += wpq;
                     if (c_st >= nst) {
@@ -494,37 +630,43 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     }
 }
 
-int chain_buf_u4(int K) {
-    const int nu = K / 32, nst = (nu + 63) / 64;
-    return 4 * (nst * 64 + 1) + (2 * nst * 32 * 4 + 15) / 16;      // [4][tstride] tables + [2][GP] floats
-}
-size_t chain_lds_bytes(int buf_u4, int nops) { return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4 + sizeof(ChainOp) * (size_t)nops; }
+#if !defined(TMAC_CHAIN_BITS)
+#error "compile with -DTMAC_CHAIN_BITS=1..4 (one translation unit per weight width keeps the build parallel)"
+#endif
+constexpr int CB = TMAC_CHAIN_BITS;
 
-hipError_t launch_decode_chain(const ChainArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st) {
-    if (a.nops < 1 || grid < 1) return hipErrorInvalidValue;
-    dim3 g(grid), b(CHAIN_FT);
-#define CL(B, Z, H)                                                                                                                  \
-    do {                                                                                                                             \
-        if (lds_bytes > 64 * 1024) {                                                                                                 \
-            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_chain<B, Z, H>),                             \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                         \
-            if (e_ != hipSuccess) return e_;                                                                                         \
-        }                                                                                                                            \
-        hipLaunchKernelGGL((k_decode_chain<B, Z, H>), g, b, lds_bytes, st, a);                                                       \
-        return hipGetLastError();                                                                                                    \
-    } while (0)
-#define CLZ(B)                                                                  \
-    do {                                                                        \
-        if (zp) { if (sc_f16) CL(B, true, true); else CL(B, true, false); }     \
-        else { if (sc_f16) CL(B, false, true); else CL(B, false, false); }      \
-    } while (0)
-    switch (bits) {
-        case 2: CLZ(2);
-        case 4: CLZ(4);
-        default: return hipErrorInvalidValue;
+template <bool ZP, bool SCF16, int SM>
+static hipError_t chain_launch_one(const ChainArgs& a, int grid, size_t lds_bytes, hipStream_t st, int* resident) {
+    auto* kern = &k_decode_chain<CB, ZP, SCF16, SM>;
+    if (lds_bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
     }
-#undef CLZ
-#undef CL
+    if (resident)       // query only: workgroups of this kernel one CU can hold (the chain needs >= 1 on EVERY CU at once)
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(resident, reinterpret_cast<const void*>(kern), CHAIN_FT, lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CHAIN_FT), lds_bytes, st, a);
+    return hipGetLastError();
 }
+
+#define TMAC_CHAIN_LAUNCHER(NAME)                                                                                               \
+    hipError_t NAME(const ChainArgs& a, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st, int* resident) { \
+        if (a.nops < 1 || grid < 1) return hipErrorInvalidValue;                                                                  \
+        if (sm == 2) return sc_f16 ? chain_launch_one<false, true, 2>(a, grid, lds_bytes, st, resident)                          \
+                                   : chain_launch_one<false, false, 2>(a, grid, lds_bytes, st, resident);                        \
+        if (sm != 0) return hipErrorInvalidValue;                                                                                 \
+        if (zp) return sc_f16 ? chain_launch_one<true, true, 0>(a, grid, lds_bytes, st, resident)                                \
+                              : chain_launch_one<true, false, 0>(a, grid, lds_bytes, st, resident);                              \
+        return sc_f16 ? chain_launch_one<false, true, 0>(a, grid, lds_bytes, st, resident)                                       \
+                      : chain_launch_one<false, false, 0>(a, grid, lds_bytes, st, resident);                                     \
+    }
+#if TMAC_CHAIN_BITS == 1
+TMAC_CHAIN_LAUNCHER(launch_decode_chain_b1)
+#elif TMAC_CHAIN_BITS == 2
+TMAC_CHAIN_LAUNCHER(launch_decode_chain_b2)
+#elif TMAC_CHAIN_BITS == 3
+TMAC_CHAIN_LAUNCHER(launch_decode_chain_b3)
+#else
+TMAC_CHAIN_LAUNCHER(launch_decode_chain_b4)
+#endif
 
 }  // namespace tmac

@@ -1,0 +1,341 @@
+// tmac_chain_host.cpp — host side of the persistent decode chain (kernel: tmac_chain.hip).
+#include "tmac_host.h"
+
+using namespace tmac_host;
+
+// ---------------------------------------------------------------------------------------------
+// Persistent decode chain (tmac_chain.hip): the fused calls of one decoded token recorded once, then executed by ONE
+// launch.  Recording mirrors stream capture: between tmac_hip_chain_begin() and tmac_hip_chain_end() the calling thread's
+// tmac_hip_qgemm_fused_dev calls (N = 1) are noted instead of launched; data flow is inferred from pointer identity (an
+// op whose activation pointer equals an earlier op's output pointer consumes that output inside the launch).
+// ---------------------------------------------------------------------------------------------
+struct ChainRecOp {
+    std::vector<const tmac_hip_weights*> w;
+    const void* B;
+    std::vector<void*> C;
+    tmac_dtype_t act, out;
+};
+static thread_local std::vector<ChainRecOp>* g_chain_rec = nullptr;
+bool tmac_host::chain_recording() { return g_chain_rec != nullptr; }
+
+struct tmac_hip_chain {
+    std::vector<ChainOp> ops;
+    ChainOp* d_ops = nullptr;
+    unsigned* ctl = nullptr;
+    std::vector<void*> grans;
+    int bits = 0, zp = 0, sc_f16 = 0, out_f16 = 0;
+    int sm = 0;                       // 0 per-group scales, 2 unified scale (k_decode_chain's SM)
+    int grid = 0, buf_u4 = 0;
+    size_t lds_bytes = 0;
+    unsigned long long* stamps = nullptr;
+    size_t bytes = 0;                 // algorithmic weight + scale bytes of one launch
+    int poll_sleep = 16, poll_delay = 24, issue_first = 4, poll_mode = 0;   // read from the environment once, at tmac_hip_chain_end
+    hipStream_t last_stream = nullptr;   // stream of the most recent launch (in-flight guard)
+    bool launched = false;
+};
+
+int32_t tmac_host::chain_record(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
+                            void* const* C_list, tmac_dtype_t out_dtype, int N) {
+    if (N != 1) return fail(TMAC_HIP_E_NOMATCH, "a decode chain records N = 1 calls only");
+    ChainRecOp op;
+    for (int i = 0; i < nmat; ++i) {
+        if (!wl[i] || !C_list[i]) return fail(TMAC_HIP_E_ARG, "null matrix or output");
+        op.w.push_back(wl[i]);
+        op.C.push_back(C_list[i]);
+    }
+    op.B = B_dev; op.act = act_dtype; op.out = out_dtype;
+    g_chain_rec->push_back(op);
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_chain_begin(void) {
+    if (g_chain_rec) return fail(TMAC_HIP_E_ARG, "a chain is already being recorded on this thread");
+    g_chain_rec = new std::vector<ChainRecOp>();
+    return TMAC_HIP_OK;
+}
+
+static int chain_pick_wpq(int total_q, int nst, int grid) {
+    int best = 1;
+    long best_cost = 1L << 60;
+    for (int wpq = 1; wpq <= 4; ++wpq) {          // the combinations k_gemv_quad is instantiated for with this many threads
+        if (CHAIN_NWV % wpq || (wpq > 1 && wpq > nst)) continue;
+        const long ipi = CHAIN_NWV / wpq;
+        const long cnt = (total_q + grid - 1) / grid;               // quads of the busiest workgroup (balanced contiguous ranges)
+        const long iters = (cnt + ipi - 1) / ipi;
+        const long steps = (nst + wpq - 1) / wpq;
+        if (iters * steps < best_cost) { best_cost = iters * steps; best = wpq; }     // ties: fewer waves per quad (no LDS combine)
+    }
+    return best;
+}
+
+extern "C" int32_t tmac_hip_chain_free(tmac_hip_chain* c) {
+    if (!c) return TMAC_HIP_OK;
+    for (void* p : c->grans) (void)hipFree(p);
+    if (c->d_ops) (void)hipFree(c->d_ops);
+    if (c->ctl) (void)hipFree(c->ctl);
+    delete c;
+    return TMAC_HIP_OK;
+}
+
+static int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
+// half-open byte ranges
+struct Range { const char* lo; const char* hi; };
+static bool overlap(const Range& a, const Range& b) { return a.lo < b.hi && b.lo < a.hi; }
+
+extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
+    if (!g_chain_rec) return fail(TMAC_HIP_E_ARG, "no chain is being recorded on this thread");
+    std::vector<ChainRecOp> rec;
+    rec.swap(*g_chain_rec);
+    delete g_chain_rec;
+    g_chain_rec = nullptr;
+    if (!out) return fail(TMAC_HIP_E_ARG, "null argument");
+    *out = nullptr;
+    if (rec.empty()) return fail(TMAC_HIP_E_ARG, "nothing was recorded");
+    int32_t rc = ensure_device();
+    if (rc) return rc;
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus < 1) return fail(TMAC_HIP_E_RUNTIME, "no compute units reported");
+    auto* c = new tmac_hip_chain();
+    c->grid = cus;                                  // one workgroup per CU; residency is checked below
+    const tmac_hip_weights* w0 = rec[0].w[0];
+    c->bits = w0->s.bits; c->zp = w0->s.zero_point; c->sc_f16 = w0->sc_dtype == F16; c->out_f16 = rec[0].out == TMAC_F16;
+    c->sm = (w0->s.m_groups >= 1) ? 2 : 0;
+    auto bail = [&](int32_t code) { tmac_hip_chain_free(c); return code; };
+    if (c->bits < 1 || c->bits > 4) return bail(fail(TMAC_HIP_E_NOMATCH, "the decode chain is built for 1- to 4-bit weights"));
+    const size_t n = rec.size();
+    const size_t out_esz = c->out_f16 ? 2 : 4;
+
+    // ---- data flow and hazards, on byte RANGES (ops run on workgroups that are not synchronised with each other; an op is
+    // ordered after another only through a hand-off: its activations are, transitively, made of the other's outputs) ----
+    std::vector<Range> in_r(n);
+    std::vector<std::vector<Range>> out_r(n);
+    for (size_t i = 0; i < n; ++i) {
+        const Shape& s0 = rec[i].w[0]->s;
+        in_r[i] = Range{(const char*)rec[i].B, (const char*)rec[i].B + (size_t)s0.K * 2};          // fp16 activations (checked below)
+        for (size_t m = 0; m < rec[i].w.size(); ++m)
+            out_r[i].push_back(Range{(const char*)rec[i].C[m], (const char*)rec[i].C[m] + (size_t)rec[i].w[m]->s.Mw * out_esz});
+        for (size_t m = 0; m < out_r[i].size(); ++m)
+            for (size_t m2 = 0; m2 < m; ++m2)
+                if (overlap(out_r[i][m], out_r[i][m2])) return bail(fail(TMAC_HIP_E_ARG, "op %zu: outputs %zu and %zu overlap", i, m2, m));
+    }
+    // source of every op's activations: the most recent earlier output that IS the range; partial overlap with an earlier
+    // output cannot be handed over (the reader would see a mixture of launches) and is refused
+    struct Src { int op, mat; };
+    std::vector<Src> src(n, Src{-1, -1});
+    std::vector<std::vector<char>> consumed(n);
+    for (size_t i = 0; i < n; ++i) consumed[i].assign(rec[i].w.size(), 0);
+    for (size_t i = 0; i < n; ++i) {
+        for (size_t j = i; j-- > 0 && src[i].op < 0;)
+            for (size_t m = 0; m < rec[j].C.size(); ++m) {
+                if (!overlap(in_r[i], out_r[j][m])) continue;
+                if (rec[j].C[m] != rec[i].B)
+                    return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu reads activations that overlap output %zu of op %zu without being that output: "
+                                                         "not representable as a hand-off", i, m, j));
+                src[i] = Src{(int)j, (int)m};
+                consumed[j][m] = 1;
+                break;
+            }
+    }
+    // dep[k][i]: op k runs after op i has published everything (transitive closure over the hand-offs)
+    std::vector<std::vector<char>> dep(n, std::vector<char>(n, 0));
+    for (size_t k = 0; k < n; ++k)
+        if (src[k].op >= 0) {
+            dep[k] = dep[src[k].op];
+            dep[k][src[k].op] = 1;
+        }
+
+    c->ops.resize(n);
+    int maxK = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const ChainRecOp& r = rec[i];
+        ChainOp& o = c->ops[i];
+        memset(&o, 0, sizeof(o));
+        const Shape& s0 = r.w[0]->s;
+        if (r.act != TMAC_F16) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the decode chain takes fp16 activations", i));
+        if ((r.out == TMAC_F16) != (c->out_f16 != 0)) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: one output dtype per chain", i));
+        if (s0.K > 8 * 3 * CHAIN_FT) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: K = %d beyond the decode chain's %d", i, s0.K, 8 * 3 * CHAIN_FT));
+        if (((s0.m_groups >= 1) ? 2 : 0) != c->sm) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: per-group and unified scales cannot share a chain", i));
+        int gu = 1;
+        if (c->sm == 2) {
+            if (s0.ags != s0.K || s0.K % 64 || s0.m_groups > CHAIN_US_MAX_GROUPS)
+                return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the unified-scale chain covers one act group per row (act_group_size == K) and up to %d scales per matrix",
+                                 i, CHAIN_US_MAX_GROUPS));
+        } else {
+            gu = s0.gs / 32;
+            if (s0.ags != 64 || s0.gs < 128 || (gu & (gu - 1)) || s0.K % s0.gs || s0.K % 64)
+                return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the decode chain covers per-group scales (group >= 128, power of two) with act groups of 64", i));
+        }
+        int nq = 0;
+        for (size_t m = 0; m < r.w.size(); ++m) {
+            const tmac_hip_weights* w = r.w[m];
+            const Shape& a = w->s;
+            if (a.lay != 2 || !w->lo_ok || w->fa) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu matrix %zu is not registered in the QUAD layout", i, m));
+            if (a.K != s0.K || a.bits != c->bits || a.gs != s0.gs || a.ags != s0.ags || a.zero_point != c->zp || a.m_groups != s0.m_groups ||
+                (w->sc_dtype == F16) != (c->sc_f16 != 0))
+                return bail(fail(TMAC_HIP_E_ARG, "op %zu: the matrices of a chain share bits, zero points and scale dtype; those of an op also K and group size", i));
+            if (c->sm == 2 && a.Mw % a.m_groups) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu matrix %zu: rows not divisible by m_groups", i, m));
+            nq += a.nquads();
+            o.m[m].W = (const uint4*)w->W; o.m[m].SC = w->SC; o.m[m].C = r.C[m]; o.m[m].Mw = a.Mw; o.m[m].q_end = nq;
+            o.m[m].GR = nullptr;
+            if (consumed[i][m]) {
+                if (r.out != TMAC_F16) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: outputs consumed inside the chain must be fp16", i));
+                void* g = nullptr;
+                const size_t gb = (size_t)a.nquads() * 16;
+                if (hipMalloc(&g, gb) != hipSuccess || hipMemset(g, 0, gb) != hipSuccess)
+                    return bail(fail(TMAC_HIP_E_RUNTIME, "hand-off buffer allocation failed"));
+                c->grans.push_back(g);
+                o.m[m].GR = (uint4*)g;
+            }
+            c->bytes += w->w_bytes + w->sc_bytes;
+        }
+        o.nmat = (int)r.w.size();
+        for (int m = 0; m < 4; ++m) o.q_end[m] = (m < o.nmat - 1) ? o.m[m].q_end : 0x7fffffff;
+        o.K = s0.K; o.nu = s0.K / 32; o.nst = (o.nu + 63) / 64; o.tstride = o.nst * 64 + 1;
+        o.G = s0.K / 64; o.GP = o.nst * 32; o.nsg = c->sm == 2 ? 1 : s0.K / s0.gs;
+        o.gs_shift = 0;
+        for (int g = gu; g > 1; g >>= 1) ++o.gs_shift;
+        o.m_groups = c->sm == 2 ? s0.m_groups : 0;
+        o.total_q = nq;
+        o.wpq = g_knobs.chain_wpq ? g_knobs.chain_wpq : chain_pick_wpq(nq, o.nst, c->grid);
+        if (CHAIN_NWV % o.wpq) return bail(fail(TMAC_HIP_E_ARG, "waves per quad must divide %d", CHAIN_NWV));
+        o.ipi = CHAIN_NWV / o.wpq;
+        o.wpq_inv = (65536 + o.wpq - 1) / o.wpq;
+        o.ipi_inv = (65536 + o.ipi - 1) / o.ipi;
+        if (nq / c->grid + 1 + o.ipi >= 4096) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: too many rows per workgroup for the decode chain", i));
+        o.q_per = nq / c->grid; o.q_extra = nq % c->grid;
+        if (src[i].op >= 0) {
+            const ChainOp& po = c->ops[src[i].op];
+            if (po.m[src[i].mat].Mw != o.K) return bail(fail(TMAC_HIP_E_ARG, "op %zu reads an output of %d rows as %d activations", i, po.m[src[i].mat].Mw, o.K));
+            o.in = po.m[src[i].mat].GR; o.in_gran = 1;
+        } else {
+            o.in = r.B; o.in_gran = 0;
+        }
+        if (o.K > maxK) maxK = o.K;
+    }
+    // Hazards between ops that no hand-off orders.  Every workgroup reads an op's activations itself (each builds the whole
+    // LUT) and walks the ops in recorded order.  "Op j has published" therefore implies "every workgroup is past op i" for
+    // any i <= j only when every workgroup owns rows of op j (q_per >= 1).  A later op k may overwrite an EXTERNAL input of
+    // op i (a decoder's "next x = last output") exactly when such an op j lies between them on k's hand-off path.
+    // Inputs handed over inside the launch are read from the hand-off image, never from the user-visible buffer.
+    auto all_past = [&](size_t i, size_t k) {
+        for (size_t j = i; j < k; ++j)
+            if (dep[k][j] && c->ops[j].q_per >= 1) return true;
+        return false;
+    };
+    for (size_t k = 0; k < n; ++k)
+        for (size_t m = 0; m < out_r[k].size(); ++m)
+            for (size_t i = 0; i < k; ++i) {
+                if (src[i].op < 0 && overlap(out_r[k][m], in_r[i]) && !all_past(i, k))
+                    return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu overwrites activations that op %zu reads from memory and nothing in the chain orders the two "
+                                                         "(no hand-off path from an op in which every workgroup owns rows): launch these calls one by one", k, i));
+                for (size_t m2 = 0; m2 < out_r[i].size(); ++m2)
+                    if (overlap(out_r[k][m], out_r[i][m2]) && !dep[k][i])
+                        return bail(fail(TMAC_HIP_E_NOMATCH, "ops %zu and %zu write overlapping outputs and nothing in the chain orders them", i, k));
+            }
+    c->buf_u4 = chain_buf_u4(maxK);
+    c->lds_bytes = chain_lds_bytes(c->buf_u4, (int)c->ops.size());
+    if (c->lds_bytes > 160 * 1024)
+        return bail(fail(TMAC_HIP_E_NOMATCH, "%zu calls with K up to %d need %zu bytes of LDS (LUT buffers + call descriptors): record shorter chains",
+                         c->ops.size(), maxK, c->lds_bytes));
+    // one workgroup per CU must be resident at once: does the kernel fit a CU at all with this much LDS?
+    {
+        ChainArgs probe;
+        memset(&probe, 0, sizeof(probe));
+        probe.nops = 1;
+        int resident = 0;
+        hipError_t e = launch_decode_chain(probe, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, nullptr, &resident);
+        if (e == hipErrorInvalidValue) return bail(fail(TMAC_HIP_E_NOMATCH, "no decode-chain kernel for this configuration"));
+        if (e != hipSuccess || resident < 1)
+            return bail(fail(TMAC_HIP_E_NOMATCH, "the decode chain's workgroup does not fit a compute unit (%s, %zu bytes of LDS)",
+                             e == hipSuccess ? "occupancy 0" : hipGetErrorString(e), c->lds_bytes));
+    }
+    if (hipMalloc((void**)&c->d_ops, sizeof(ChainOp) * c->ops.size()) != hipSuccess ||
+        hipMemcpy(c->d_ops, c->ops.data(), sizeof(ChainOp) * c->ops.size(), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(TMAC_HIP_E_RUNTIME, "descriptor upload failed"));
+    const unsigned ctl0[4] = {1u, 0u, 0u, 0u};
+    if (hipMalloc((void**)&c->ctl, sizeof(ctl0)) != hipSuccess || hipMemcpy(c->ctl, ctl0, sizeof(ctl0), hipMemcpyHostToDevice) != hipSuccess)
+        return bail(fail(TMAC_HIP_E_RUNTIME, "control word allocation failed"));
+    // the granule fills above ran on the null stream; the chain is launched on the caller's (possibly non-blocking) stream
+    if (hipStreamSynchronize(nullptr) != hipSuccess) return bail(fail(TMAC_HIP_E_RUNTIME, "hand-off buffer initialisation failed"));
+    // A workgroup reaches the polls of an op right after publishing its own share of the previous one: the first poll cannot
+    // succeed before the slowest producer's stores have crossed the fabric (~1 us), and every failed poll is 16 KB per workgroup
+    // of fabric traffic that the stores compete with.  Waiting ~0.75 us before the first poll and ~0.5 us between polls:
+    // 0.757 -> 0.735 ms per llama-2-7B token (profiles/r02_chain_prefetch_ab.txt, E).  Knobs are read here, once per chain.
+    c->poll_sleep = env_int("TMAC_CHAIN_POLL_SLEEP", 16);
+    c->poll_delay = env_int("TMAC_CHAIN_POLL_DELAY", 24);
+    c->issue_first = env_int("TMAC_CHAIN_ISSUE_FIRST", 4);
+    c->poll_mode = env_int("TMAC_CHAIN_POLL_MODE", 0);
+    *out = c;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
+    bind_thread_device();
+    if (!c) return fail(TMAC_HIP_E_ARG, "null chain");
+    hipStream_t st = (hipStream_t)stream;
+    // One launch of a chain at a time (its hand-off buffers and control words are per chain): launches on ONE stream are
+    // ordered by the stream; a launch on another stream is refused while the previous one may still be running.
+    if (c->launched && st != c->last_stream && hipStreamQuery(c->last_stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(TMAC_HIP_E_ARG, "the chain is still in flight on another stream: synchronise it first, or record one chain per stream");
+    }
+    ChainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ops = c->d_ops; a.nops = (int)c->ops.size(); a.ctl = c->ctl; a.out_f16 = c->out_f16;
+    a.spin_limit = g_knobs.chain_spin_limit; a.buf_u4 = c->buf_u4; a.stamps = c->stamps;
+    a.poll_sleep = c->poll_sleep; a.poll_delay = c->poll_delay; a.issue_first = c->issue_first; a.poll_mode = c->poll_mode;
+    hipError_t e = launch_decode_chain(a, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, st);
+    if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no decode-chain kernel for this configuration");
+    if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "decode chain launch: %s", hipGetErrorString(e));
+    c->last_stream = st; c->launched = true;
+    return TMAC_HIP_OK;
+}
+
+// After the stream has been synchronised: 0 = every hand-off completed; otherwise the error word of the first wave that
+// gave up (bit 31 | op << 8 | wave) -- the outputs are then invalid.  Clears the word and re-arms the chain.
+extern "C" int32_t tmac_hip_chain_status(tmac_hip_chain* c, uint32_t* error_word) {
+    if (!c || !error_word) return fail(TMAC_HIP_E_ARG, "null argument");
+    unsigned ctl[4];
+    HIP_TRY(hipMemcpy(ctl, c->ctl, sizeof(ctl), hipMemcpyDeviceToHost));
+    *error_word = ctl[2];
+    if (ctl[2] || ctl[1]) {
+        // a launch that gave up may not have advanced the generation: do it here and clear the partial state
+        const unsigned fresh[4] = {ctl[0] + 2u ? ctl[0] + 2u : 1u, 0u, 0u, 0u};
+        HIP_TRY(hipMemcpy(c->ctl, fresh, sizeof(fresh), hipMemcpyHostToDevice));
+    }
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_chain_info(const tmac_hip_chain* c, int op, int32_t* nops, int32_t* wpq, int32_t* grid, size_t* bytes) {
+    if (!c) return fail(TMAC_HIP_E_ARG, "null chain");
+    if (nops) *nops = (int32_t)c->ops.size();
+    if (grid) *grid = c->grid;
+    if (bytes) *bytes = c->bytes;
+    if (wpq) {
+        if (op < 0 || op >= (int)c->ops.size()) return fail(TMAC_HIP_E_ARG, "op index out of range");
+        *wpq = c->ops[op].wpq;
+    }
+    return TMAC_HIP_OK;
+}
+
+// profiling aid: s_memrealtime stamps [ops][workgroups][8] of wave 0 (layout: tmac_chain.h)
+extern "C" int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* c, unsigned long long* dev_buffer) {
+    if (!c) return fail(TMAC_HIP_E_ARG, "null chain");
+    c->stamps = dev_buffer;
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_chain_threads(void) { return CHAIN_FT; }
+
+extern "C" int32_t tmac_hip_debug_chain_config(int force_wpq, unsigned spin_limit) {
+    if (force_wpq < 0 || (force_wpq && CHAIN_NWV % force_wpq)) return fail(TMAC_HIP_E_ARG, "waves per quad must divide %d", CHAIN_NWV);
+    g_knobs.chain_wpq = force_wpq;
+    if (spin_limit) g_knobs.chain_spin_limit = spin_limit;
+    return TMAC_HIP_OK;
+}

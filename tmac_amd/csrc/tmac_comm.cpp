@@ -6,9 +6,10 @@
 // reduction: K is never split.
 // RCCL is resolved at run time (dlopen): a single-GPU user of libtmac_hip.so needs no RCCL, and a process that already
 // carries one (PyTorch ships its own librccl.so) keeps exactly one instance.
+// No RCCL header is needed to BUILD the library either: the five entry points used are declared below with the signatures
+// NCCL has kept stable since 2.0 (ncclUniqueId = 128 opaque bytes, passed by value; ncclInt8 = 0; ncclSuccess = 0).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <cstdio>
 #include <cstring>
@@ -18,13 +19,27 @@
 
 namespace {
 
+// the slice of the NCCL / RCCL ABI this file binds at run time
+struct ncclUniqueId { char internal[TMAC_HIP_COMM_ID_BYTES]; };
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr int ncclInt8 = 0;
+extern "C" {
+typedef ncclResult_t (*ncclGetUniqueId_fn)(ncclUniqueId*);
+typedef ncclResult_t (*ncclCommInitRank_fn)(ncclComm_t*, int, ncclUniqueId, int);
+typedef ncclResult_t (*ncclAllGather_fn)(const void*, void*, size_t, int /* ncclDataType_t */, ncclComm_t, hipStream_t);
+typedef ncclResult_t (*ncclCommDestroy_fn)(ncclComm_t);
+typedef const char* (*ncclGetErrorString_fn)(ncclResult_t);
+}
+
 struct Rccl {
     void* h = nullptr;
-    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
-    decltype(&ncclCommInitRank) CommInitRank = nullptr;
-    decltype(&ncclAllGather) AllGather = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    ncclGetUniqueId_fn GetUniqueId = nullptr;
+    ncclCommInitRank_fn CommInitRank = nullptr;
+    ncclAllGather_fn AllGather = nullptr;
+    ncclCommDestroy_fn CommDestroy = nullptr;
+    ncclGetErrorString_fn GetErrorString = nullptr;
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
@@ -70,7 +85,6 @@ extern "C" const char* tmac_hip_comm_last_error(void) { return g_comm_err; }
 extern "C" int32_t tmac_hip_comm_unique_id(void* id_out) {
     if (!id_out) { snprintf(g_comm_err, sizeof(g_comm_err), "null argument"); return TMAC_HIP_E_ARG; }
     if (!load_rccl()) return TMAC_HIP_E_RUNTIME;
-    static_assert(sizeof(ncclUniqueId) == TMAC_HIP_COMM_ID_BYTES, "id size");
     ncclUniqueId id;
     const ncclResult_t r = g_rccl.GetUniqueId(&id);
     if (r != ncclSuccess) return comm_fail(TMAC_HIP_E_RUNTIME, "ncclGetUniqueId", r);

@@ -201,6 +201,10 @@ class DecodeChain:
         self.nops, self.grid, self.weight_bytes = n.value, g.value, b.value
         self.threads = int(B.lib().tmac_hip_chain_threads())     # threads per workgroup of k_decode_chain (for A/B against k_gemv_quad)
 
+    @property
+    def handle(self):
+        return self._h
+
     def launch(self, stream=None) -> None:
         check(B.lib().tmac_hip_chain_launch(self._h, _stream(stream)))
 
@@ -249,6 +253,8 @@ class _ChainRecorder:
         if et is None:
             check(rc)
             self.chain = DecodeChain(h, keep)
+        elif rc == 0 and h:
+            B.lib().tmac_hip_chain_free(h)      # the block raised: the chain that was built anyway is not handed out
         return False
 
 

@@ -29,7 +29,7 @@ struct ChainOp {
     ChainMat m[4];
     int q_end[4];        // m[k].q_end again, contiguous (one scalar load), INT_MAX from the last matrix on
     const void* in;      // in_gran: the hand-off image (uint4 [K/4]) written earlier in this launch; else activations [K] fp16
-    int in_gran;
+    int in_gran;         // bit 0: `in` is a hand-off image; bits 8..: weight fragments per wave issued in front of the polls (host's choice for this op)
     int nmat;
     int K, nu, nst, tstride, G, GP, nsg, gs_shift;
     int wpq, ipi;        // waves per row quad, row quads per workgroup iteration (12 / wpq)
@@ -52,7 +52,7 @@ struct ChainArgs {
     int buf_u4;                    // uint4 per LDS LUT buffer (two buffers, by op parity)
     int poll_sleep;                // s_sleep 1 (64 cycles) count between two polls of a hand-off (A/B knob)
     int poll_delay;                // s_sleep 1 count before the first poll of a hand-off (A/B knob)
-    int issue_first;               // fragments per wave (0 .. ring size) of an op's weights issued before the polls for its activations; the rest follow the polls
+    int issue_first;               // A/B knob: >= 0 overrides the per-op number of weight fragments issued before the polls for the activations
     int poll_mode;                 // A/B knob: 0 dwordx4 sc1 | 1 dwordx4 sc0 sc1 | 2 dwordx4 nt | 3 dwordx4 plain
     unsigned long long* stamps;    // optional [nops][grid][8] of wave 0, s_memrealtime (100 MHz): 0 op entry, 1 activations complete, 2 LUT built
                                    // (barrier passed), 3 current ring landed, 5 last quad published, 6 everything in flight landed, 7 polls

@@ -300,9 +300,13 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         // sat behind 20-100 KB of queued weight loads per CU: 3-4 us per hand-off (profiles/r02_chain_prefetch_ab.txt). ----
         // issue_first fragments per wave go out before the polls (which then queue behind them), the rest of the ring
         // after the activations have arrived
+        // per op: small ops put one fragment in front of the polls (the poll then returns after one fabric round trip plus 24 KB
+        // per CU, and the compiler-visible wait behind it does not hold the LUT build until ALL weights have landed); ops whose
+        // stream outlasts the hand-off put the whole ring in front (their stream must start at once) -- chosen on the host
+        const int isf = a.issue_first >= 0 ? a.issue_first : (uni(d->in_gran) >> 8);
 #pragma unroll
         for (int k = 0; k < RING; ++k)
-            if (k < a.issue_first) issue_next(ring[k]);
+            if (k < isf) issue_next(ring[k]);
         if (SM == 2) {             // the unified scales of this op's matrices: a handful of floats, parked in LDS for the epilogue
             const int mg = uni(d->m_groups);
             if (tid < nm * mg) {
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                           : as_global(reinterpret_cast<const float*>(scp))[g];
             }
         }
-        const bool gran = uni(d->in_gran) != 0;
+        const bool gran = (uni(d->in_gran) & 1) != 0;
         const int nr = (P + FT - 1) / FT;                            // rounds of FT pairs (<= NRMAX, checked on the host)
         constexpr int NRMAX = 3;
         uint32_t xw[NRMAX][4];
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         // ---- 2. this wave's first RING (quad, step) items: the weights stream in during the LUT build ----
 #pragma unroll
         for (int k = 0; k < RING; ++k)
-            if (k >= a.issue_first) issue_next(ring[k]);
+            if (k >= isf) issue_next(ring[k]);
 
         CSTAMP(i, 3);
 
@@ -400,8 +404,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         if (SM == 2) {
             // One act group = the whole row (qgemm.py:93-96): the scale is a maximum over K and lut_biases ONE fp32 chain over the
             // K/32 chunk sums in order (lut_ctor.cc:157,218).  Neither the chunk sums nor the chain depend on the scale: pass 1
-            // forms maxima and chunk sums, one barrier, then lane 0 of the last wave (the one with the fewest pairs and, with
-            // split quads, the fewest steps) walks the chain while the other waves build their tables (k_gemv_quad, SM = 2).
+            // forms maxima and chunk sums, one barrier, every wave builds its tables; the chain is walked behind the second barrier.
             float mx = 0.f;
 #pragma unroll
             for (int r = 0; r < NRMAX; ++r) {
@@ -430,20 +433,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             for (int ww = 1; ww < NWV; ++ww) mx = fmaxf(mx, l_us[2 + ww]);
             gscale = div127(mx);
             gtinv = (gscale != 0.0f) ? rcp_exact(gscale) : 0.0f;
-            if (tid == FT - 64) {
-                float biases = 0.0f;
-                const float4* cs = reinterpret_cast<const float4*>(l_us + CHAIN_US_FLOATS);      // 16-byte reads, unrolled: only the adds are serial
-                const int nc = nu;                                                   // K / 32 chunks
-                int c = 0;
-#pragma unroll 4
-                for (; c + 4 <= nc; c += 4) {
-                    const float4 v4 = cs[c >> 2];
-                    biases = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(biases, v4.x), v4.y), v4.z), v4.w);
-                }
-                for (; c < nc; ++c) biases = __fadd_rn(biases, l_us[CHAIN_US_FLOATS + c]);
-                l_us[0] = gscale;
-                l_us[1] = biases;
-            }
+            if (tid == 0) l_us[0] = gscale;
         }
 #pragma unroll
         for (int r = 0; r < NRMAX; ++r) {
@@ -491,6 +481,23 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         CSTAMP(i, 4);
         __syncthreads();
         CSTAMP(i, 2);
+        if (SM == 2 && tid == FT - 64) {
+            // lut_biases: ONE fp32 chain over the K/32 chunk sums in order (lut_ctor.cc:157,218; 270 dependent adds at K = 8640).
+            // Only the epilogue needs it, so it is walked here, behind the barrier that releases the lookups, by lane 0 of the
+            // last wave -- the wave with the fewest pairs to build and, when quads are split or a workgroup owns fewer than 12,
+            // the least (or no) lookup work; finish() has a barrier before the first reader.
+            float biases = 0.0f;
+            const float4* cs = reinterpret_cast<const float4*>(l_us + CHAIN_US_FLOATS);      // 16-byte reads, unrolled: only the adds are serial
+            const int nc = nu;                                                                 // K / 32 chunks
+            int c = 0;
+#pragma unroll 4
+            for (; c + 4 <= nc; c += 4) {
+                const float4 v4 = cs[c >> 2];
+                biases = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(biases, v4.x), v4.y), v4.z), v4.w);
+            }
+            for (; c < nc; ++c) biases = __fadd_rn(biases, l_us[CHAIN_US_FLOATS + c]);
+            l_us[1] = biases;
+        }
 
         // ---- 4. lookups.  Items are consumed in issue order, ring slot = item ordinal mod RING (static register roles:
         // the loop is unrolled over the ring).  A workgroup iteration (ipi consecutive quads) is closed by finish(): every

@@ -29,7 +29,7 @@ struct tmac_hip_chain {
     size_t lds_bytes = 0;
     unsigned long long* stamps = nullptr;
     size_t bytes = 0;                 // algorithmic weight + scale bytes of one launch
-    int poll_sleep = 16, poll_delay = 24, issue_first = 4, poll_mode = 0;   // read from the environment once, at tmac_hip_chain_end
+    int poll_sleep = 8, poll_delay = 4, issue_first = -1, poll_mode = 0;   // read from the environment once, at tmac_hip_chain_end
     hipStream_t last_stream = nullptr;   // stream of the most recent launch (in-flight guard)
     bool launched = false;
 };
@@ -216,6 +216,11 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         } else {
             o.in = r.B; o.in_gran = 0;
         }
+        // weight fragments per wave in front of the polls: ONE.  The poll then returns after a fabric round trip plus 24 KB per
+        // CU, and the wait behind it does not hold the LUT build until all of the op's weights have landed.  Putting the whole
+        // ring in front ("start the stream at once") measured slower even for the ops whose stream outlasts the hand-off:
+        // llama-2-7B W2 0.764 -> 0.714 ms, W4 1.028 -> 0.983 ms per token (profiles/r03_chain_knobs.txt).
+        o.in_gran |= 1 << 8;
         if (o.K > maxK) maxK = o.K;
     }
     // Hazards between ops that no hand-off orders.  Every workgroup reads an op's activations itself (each builds the whole
@@ -267,9 +272,9 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
     // succeed before the slowest producer's stores have crossed the fabric (~1 us), and every failed poll is 16 KB per workgroup
     // of fabric traffic that the stores compete with.  Waiting ~0.75 us before the first poll and ~0.5 us between polls:
     // 0.757 -> 0.735 ms per llama-2-7B token (profiles/r02_chain_prefetch_ab.txt, E).  Knobs are read here, once per chain.
-    c->poll_sleep = env_int("TMAC_CHAIN_POLL_SLEEP", 16);
-    c->poll_delay = env_int("TMAC_CHAIN_POLL_DELAY", 24);
-    c->issue_first = env_int("TMAC_CHAIN_ISSUE_FIRST", 4);
+    c->poll_sleep = env_int("TMAC_CHAIN_POLL_SLEEP", 8);
+    c->poll_delay = env_int("TMAC_CHAIN_POLL_DELAY", 4);
+    c->issue_first = env_int("TMAC_CHAIN_ISSUE_FIRST", -1);
     c->poll_mode = env_int("TMAC_CHAIN_POLL_MODE", 0);
     *out = c;
     return TMAC_HIP_OK;

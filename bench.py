@@ -101,46 +101,77 @@ def parse():
     return a
 
 
-def cpu_baseline(seconds=6.0):
-    """The reference kernel (oracle/_ref, built from /root/reference by oracle/Makefile) — or, if that prebuilt file is
-    absent, our scalar port — timed on this box's host cores over a bounded sample: the three W2 shapes of one llama-2-7B
-    layer (one matrix each).  Tiles are split over threads with an OpenMP static schedule exactly as llama.cpp splits them
-    (tmac_gemm_wrapper.h:197-199); best of >= 5 after a warm-up (deploy/benchmark.cc:36-45 method).  Test-infrastructure
-    code used as a reported baseline."""
+CPU_SETS = {
+    # workload -> (prebuilt set under deploy/tuned/, bits, bm, [(Mw, K, preprocessor M key)], shapes' sample text)
+    "llama2-7b-w2": ("aarch64-llama-2-7b-2bit", 2, 128, [(4096, 4096, 8192), (11008, 4096, 22016), (4096, 11008, 8192)]),
+    # the set's 4096 x 4096 kernel is the bm = 1024 one, whose stack accumulator is sized for fp16 and overflows with float_type = float
+    # (SURVEY.md 8c): the set's bm = 256 kernel of the same K serves both K = 4096 shapes
+    "llama2-7b-w4": ("aarch64-llama-2-7b-4bit", 4, 256, [(4096, 4096, 16384), (11008, 4096, 44032), (4096, 11008, 16384)]),
+}
+
+
+def cpu_baseline(workload="llama2-7b-w2", seconds=6.0):
+    """The reference's own CPU code (oracle/_ref, built from /root/reference by oracle/Makefile) — or, if that prebuilt file is
+    absent, our scalar port — timed on this box's host cores over a bounded sample: one matrix of each of the three shapes of
+    a layer.  Tiles are split over threads with an OpenMP static schedule exactly as llama.cpp splits them
+    (tmac_gemm_wrapper.h:197-199); best of >= 5 after a warm-up (deploy/benchmark.cc:36-45 method).  llama W2 / W4: the
+    checked-in prebuilt kernels (deploy/tuned/aarch64-llama-2-7b-{2,4}bit/kernels.cc).  BitNet: the int32 intrinsic
+    (tbl_g4_int8_int32_update, what the reference selects on x86) in the generated glue's loop + the scale-final expression.
+    Test-infrastructure code used as a reported baseline."""
     import ctypes as C
     from oracle import oracle as orc
-    BITS, BM, GS, AGS = 2, 128, 128, 64
     cores = os.cpu_count() or 1
     rng = np.random.default_rng(0)
-    shapes = [(4096, 4096), (11008, 4096), (4096, 11008)]
-    setname = "aarch64-llama-2-7b-2bit"
-    kind = "reference" if orc.have_ref(setname) else "port"
+    wl = WORKLOADS[workload]
+    bitnet = wl["mg"] >= 1
+    GS, AGS = 128, 64
+    if bitnet:
+        BITS, BM = 2, 128
+        shapes = [(3200, 3200, 0), (8640, 3200, 0), (3200, 8640, 0)]
+        kind = "reference" if orc.have_ref("intrins") else "port"
+        what = "tbl_g4_int8_int32_update + lut_ctor intrinsics (python/t_mac/intrins) in the generated glue's loops, scale-final glue restated in oracle/ref_driver.c"
+    else:
+        setname, BITS, BM, shapes = CPU_SETS[workload]
+        kind = "reference" if orc.have_ref(setname) else "port"
+        what = f"prebuilt kernels deploy/tuned/{setname}/kernels.cc"
     drv = C.CDLL(os.path.join(ROOT, "oracle", "libref_driver.so")) if kind == "reference" else None
     work = []
-    for Mw, K in shapes:
+    for Mw, K, pm in shapes:
         M = Mw * BITS
         A = rng.integers(0, 256, size=(M // BM, K // 4, BM // 2), dtype=np.uint8)
-        S = np.abs(rng.standard_normal((M // BM, K // GS, BM // BITS * 2))).astype(np.float32)
+        S = (np.array([1.0 / K], np.float32) if bitnet else
+             np.abs(rng.standard_normal((M // BM, K // GS, BM // BITS * 2))).astype(np.float32))
         Bv = rng.standard_normal((1, K)).astype(np.float32)
-        work.append((Mw, K, A, S, Bv))
-    total_bytes = sum(algorithmic_bytes(Mw, K, BITS, GS, AGS, True, -1) for Mw, K in shapes)
+        work.append((Mw, K, pm, A, S, Bv))
+    total_bytes = sum(algorithmic_bytes(Mw, K, BITS, GS, K if bitnet else AGS, not bitnet, 1 if bitnet else -1) for Mw, K, _ in shapes)
 
     def run_once(nthreads):
         t0 = time.perf_counter()
-        for Mw, K, A, S, Bv in work:
-            if kind == "reference":
+        for Mw, K, pm, A, S, Bv in work:
+            ntiles = Mw * BITS // BM
+            Cout = np.zeros(Mw, np.float32)
+            if kind == "reference" and bitnet:
+                L = orc.ref_lib("intrins")
+                ls = np.zeros(1, np.float32); lb = np.zeros(1, np.float32); q = np.zeros((K // 4, 16), np.int8)
+                L.ref_preprocessor(K, K, orc._p(Bv), orc._p(ls), orc._p(lb), orc._p(q))
+                rc = drv.ref_run_tiles_int32_omp(C.cast(L.ref_tile_cbits_int32, C.c_void_p), BITS, KF, BM, K, orc._p(A), C.c_size_t(A[0].nbytes),
+                                                 orc._p(q), C.c_float(float(ls[0])), C.c_float(float(lb[0])), C.c_float(float(S[0])),
+                                                 orc._p(Cout), ntiles, nthreads)
+                assert rc == 0
+            elif kind == "reference":
                 L = orc.ref_lib(setname)
                 G = K // AGS
                 ls = np.zeros(G, np.float32); lb = np.zeros(G, np.float32); q = np.zeros((K // 4, 16), np.int8)
-                pre = getattr(L, f"preprocessor_t1_int8_m{8192 if Mw == 4096 else 22016}_k{K}_n1_b2")
+                pre = getattr(L, f"preprocessor_t1_int8_m{pm}_k{K}_n1_b{BITS}")
                 pre(orc._p(Bv), orc._p(ls), orc._p(lb), orc._p(q))
-                qg = getattr(L, f"qgemm_lut_t1_int8_m{BM}_k{K}_n1_b2")
-                ntiles = Mw * BITS // BM
-                Cout = np.zeros(Mw, np.float32)
+                qg = getattr(L, f"qgemm_lut_t1_int8_m{BM}_k{K}_n1_b{BITS}")
                 rc = drv.ref_run_tiles_omp(C.cast(qg, C.c_void_p), orc._p(A), C.c_size_t(A[0].nbytes), orc._p(q), orc._p(S),
                                            C.c_size_t(S[0].size), orc._p(ls), orc._p(lb), orc._p(Cout),
                                            C.c_size_t(BM // BITS), ntiles, nthreads)
                 assert rc == 0
+            elif bitnet:
+                q, ls, lb = orc.preprocessor(Bv, K)
+                orc.qgemm_scale_final(A, q, S, ls[:, 0], lb[:, 0], Mw, K, 1, BITS, BM, KF, 1)
             else:
                 q, ls, lb = orc.preprocessor(Bv, AGS)
                 orc.qgemm_float(A, q, S, ls, lb, Mw, K, 1, BITS, BM, KF, GS, AGS, True)
@@ -156,9 +187,9 @@ def cpu_baseline(seconds=6.0):
         out[nthreads] = total_bytes / best / 1e9
     used = max(out, key=out.get)
     return {"value": round(out[used], 3), "unit": "GB/s", "cores": used, "kind": kind, "host_cores": cores,
-            "by_threads_GBps": {str(k): round(v, 3) for k, v in out.items()},
-            "sample": "one 4096x4096, one 11008x4096 and one 4096x11008 W2 g128 zp GEMV (preprocessor + all tiles), "
-                      "OpenMP static tile split, best of >=5; value = best thread count"}
+            "by_threads_GBps": {str(k): round(v, 3) for k, v in out.items()}, "code": what,
+            "sample": "one GEMV of each of the layer's three shapes (%s; preprocessor + all tiles, bm = %d), OpenMP static tile split, "
+                      "best of >=5; value = best thread count" % (", ".join(f"{m}x{k}" for m, k, _ in shapes), BM)}
 
 
 def main():
@@ -414,6 +445,38 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     finite = bool(torch.isfinite(outs["down"][0].float()).all().item())     # the chained activations stayed finite
 
+    def time_headline_launches(graph_ok):
+        """back-to-back stand-alone launches of the GEMV on the headline shape (the down projection of every layer: distinct
+        weights > MALL), replayed from a hipGraph where possible, inside a hipEvent pair; seconds per launch, 10 samples"""
+        name, Mw, K, cnt, slot = MATS[3]
+        xin = torch.randn(K, device=dev, generator=gen).half()
+        wr.llama_cpp_init(xin, Mw, K, 1, BITS, act_group_size=ags_of(K), act_dtype=F16)
+        hl_out = [torch.empty(shard_rows[name], dtype=torch.float16, device=dev)]
+        reps, skip, durs = 10, 3, []
+
+        def headline_launches():
+            for li in range(args.layers):
+                if fused_calls:
+                    wr.fused(layers[li][name], xin, hl_out, 1, act_dtype=F16, out_dtype=F16)
+                else:
+                    wr.llama_cpp_compute(layers[li][name][0], hl_out[0], 1, out_dtype=F16)
+        rgraph = None
+        if graph_ok:
+            headline_launches()
+            torch.cuda.synchronize()
+            rgraph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(rgraph):
+                headline_launches()
+        for r in range(reps + skip):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rgraph.replay() if rgraph is not None else headline_launches()
+            e1.record()
+            torch.cuda.synchronize()
+            if r >= skip:
+                durs.append(e0.elapsed_time(e1) * 1e-3 / args.layers)
+        return np.array(durs), reps
+
     # ---- roofline of the dominant kernel ------------------------------------------------------------------------------
     traffic, traffic_src = None, None
     kkey = {"chain": "k_decode_chain", "fused": "k_gemv_quad_headline", "split": "k_gemv_quad_headline"}[args.path] if decode else "k_gemm_planes"
@@ -439,6 +502,16 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_per_step, "avg_launch_us": round(ev_ms_per_step * 1e3, 2), "launches_timed": args.steps,
                 "timing": "hipEvent pair on the launch stream around the %d timed launches" % args.steps}
+        # BASELINE.json's target shape as a kernel of its own (outside the timed region): the down projection of every layer,
+        # LUT build fused, back-to-back launches over distinct weights replayed from a hipGraph
+        name, Mw, K, cnt, slot = MATS[3]
+        hdurs, _ = time_headline_launches(True)
+        hb = algorithmic_bytes(Mw, K, BITS, GS, ags_of(K), ZP, MG)
+        hus = float(np.mean(hdurs)) * 1e6
+        roof["headline_gemv"] = {"shape": f"{Mw}x{K} N=1 (k_gemv_quad, LUT build fused, one launch per GEMV)", "us": round(hus, 3),
+                                 "min_us": round(float(np.min(hdurs)) * 1e6, 3), "algorithmic_bytes": hb,
+                                 "GBps": round(hb / hus * 1e-3, 1), "frac": round(hb / hus * 1e-3 / HBM_PEAK_GBS, 4),
+                                 "timing": "hipEvent pair around %d back-to-back launches (distinct weights, hipGraph replay), mean of 10" % args.layers}
         if args.stamps:
             raw = stamp_buf.cpu().numpy().reshape(chain.nops, chain.grid, 8)
             try:
@@ -460,38 +533,12 @@ def main():
             name, Mw, K, cnt, slot = MATS[3]
             hb = algorithmic_bytes(Mw, K, BITS, GS, ags_of(K), ZP, MG)
             roof["per_call_from_stamps"] = per
-            roof["headline_gemv"] = {"shape": f"{Mw}x{K} (the down projection inside the launch)", "us": per["down"]["us"],
-                                     "GBps": round(hb / (per["down"]["us"] * 1e-6) / 1e9, 1), "frac": round(hb / (per["down"]["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+            roof["headline_gemv_inside_chain"] = {"shape": f"{Mw}x{K} (the down projection inside the launch)", "us": per["down"]["us"],
+                                                  "GBps": round(hb / (per["down"]["us"] * 1e-6) / 1e9, 1), "frac": round(hb / (per["down"]["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
     else:
-        # per-launch paths: back-to-back launches of the GEMV on the headline shape (the down projection of every layer:
-        # distinct weights > MALL), replayed from a hipGraph like the timed region, inside a hipEvent pair
+        # per-launch paths: the headline GEMV is the dominant kernel
         name, Mw, K, cnt, slot = MATS[3]
-        xin = torch.randn(K, device=dev, generator=gen).half()
-        wr.llama_cpp_init(xin, Mw, K, 1, BITS, act_group_size=ags_of(K), act_dtype=F16)
-        reps, skip, durs = 10, 3, []
-
-        def headline_launches():
-            for li in range(args.layers):
-                if fused_calls:
-                    wr.fused(layers[li][name], xin, outs[name], 1, act_dtype=F16, out_dtype=F16)
-                else:
-                    wr.llama_cpp_compute(layers[li][name][0], outs[name][0], 1, out_dtype=F16)
-        rgraph = None
-        if use_graph:
-            headline_launches()
-            torch.cuda.synchronize()
-            rgraph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(rgraph):
-                headline_launches()
-        for r in range(reps + skip):
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
-            rgraph.replay() if rgraph is not None else headline_launches()
-            e1.record()
-            torch.cuda.synchronize()
-            if r >= skip:
-                durs.append(e0.elapsed_time(e1) * 1e-3 / args.layers)
-        durs = np.array(durs)
+        durs, reps = time_headline_launches(use_graph)
         hb = algorithmic_bytes(shard_rows[name], K, BITS, GS, ags_of(K), ZP, MG)
         ach = hb / float(np.mean(durs)) / 1e9
         floor = None
@@ -596,13 +643,14 @@ def main():
             "event_ms_per_step": round(ev_ms_per_step, 4),
             "cpu_baseline": None,
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload == "llama2-7b-w2":
+        if world == 1 and not args.no_cpu_baseline and decode:
             try:
-                res["cpu_baseline"] = cpu_baseline()
+                res["cpu_baseline"] = cpu_baseline(args.workload)
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the GPU number
                 res["cpu_baseline"] = {"error": repr(e)}
-        elif args.workload != "llama2-7b-w2":
-            res["cpu_baseline"] = {"note": "the reference's prebuilt CPU kernels are timed with the default workload (llama2-7b-w2) only"}
+        elif not decode:
+            res["cpu_baseline"] = {"note": "the reference loops its N = 1 kernel over the activation rows (qgemm.py:183-190): the CPU rate per row "
+                                           "is the decode workload's cpu_baseline (llama2-7b-w2 / llama2-7b-w4)"}
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(res) + "\n").encode())
     if dist_on:

@@ -17,4 +17,32 @@ int ref_run_tiles_omp(qgemm_tile_fn fn, uint8_t* A, size_t a_stride, void* LUT, 
     return rc;
 }
 
+/* The int32 / scale-final path (BitNet on x86: the reference selects tbl_g4_int8_int32_update there, tools/run_pipeline.py:409-412).
+ * fn = ref_tile_cbits_int32 of oracle/_ref/libtmac_ref_intrins.so (the reference's own intrinsic in the generated glue's k_outer loop);
+ * the bit-plane combine and the three float operations of scale-final are the glue of python/t_mac/ops/qgemm.py:170-174,192-206,
+ * restated here (the reference has no compiled x86 exemplar of it). */
+typedef int32_t (*cbits_i32_fn)(int bits, int kfactor, int bm, int K, void* A_tile, void* LUT, int32_t* CBits);
+
+int ref_run_tiles_int32_omp(cbits_i32_fn fn, int bits, int kfactor, int bm, int K, uint8_t* A, size_t a_stride, void* LUT,
+                            float lut_scale, float lut_bias, float scale, float* C, int ntiles, int nthreads) {
+    int rc = 0;
+    if (bm > 1024 || bits < 1 || bits > 4) return -1;
+#pragma omp parallel for schedule(static) num_threads(nthreads) reduction(| : rc)
+    for (int t = 0; t < ntiles; ++t) {
+        int32_t cb[1024] __attribute__((aligned(32)));
+        rc |= fn(bits, kfactor, bm, K, A + (size_t)t * a_stride, LUT, cb);
+        const int rows = bm / bits;
+        for (int m = 0; m < rows; ++m) {
+            float acc = 0.f;
+            for (int b = 0; b < bits; ++b) {
+                const float alpha = b == 0 ? 0.5f : (b == 1 ? 1.0f : (b == 2 ? 2.0f : 4.0f));
+                const float term = (float)cb[(m / 8) * 8 * bits + b * 8 + m % 8] * alpha;
+                acc = b == 0 ? term : acc + term;
+            }
+            C[(size_t)t * rows + m] = (acc * lut_scale + lut_bias * 0.5f) * scale;
+        }
+    }
+    return rc;
+}
+
 int ref_max_threads(void) { return omp_get_max_threads(); }

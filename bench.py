@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--variant", type=int, default=0, help="GEMV kernel variant (0 auto, 1 mqsad, 2 sdwa)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--path", choices=["auto", "chain", "fused", "split"], default="auto",
-                    help="auto: chain where k_decode_chain covers the configuration (N = 1, one GPU), else fused")
+                    help="auto: chain where k_decode_chain covers the configuration (N = 1; row-sharded over the ranks with --gpus N), else fused")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the check of one layer's outputs (the launches being timed, at full size) against the oracle")
     ap.add_argument("--stamps", action="store_true", help="chain path: report per-call times from in-kernel stamps (costs ~6 %%)")
@@ -213,11 +213,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dist_on = world > 1 or args.force_dist
-    chain_ok = decode and not dist_on and args.variant == 0
+    chain_ok = decode and args.variant == 0
     if args.path == "auto":
         args.path = "chain" if chain_ok else "fused"
     if args.path == "chain" and not chain_ok:
-        raise SystemExit("bench.py: --path chain covers N = 1 on one GPU")
+        raise SystemExit("bench.py: --path chain covers N = 1")
     if dist_on:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if "MASTER_ADDR" not in os.environ:
@@ -321,6 +321,8 @@ def main():
         dist.broadcast(idt, 0)
         lib_comm = tmac_amd.Comm(bytes(idt.cpu().numpy().tobytes()), rank, world)
 
+    recording = [False]          # inside wr.record_chain(): exchange steps are recorded, not executed
+
     def calls(mats, xin, out_of, exchange=True):
         """the hot-path calls of one layer; xin / out_of: dicts of input blocks per slot / output lists per matrix group"""
         for name, Mw, K, cnt, slot in MATS:
@@ -331,7 +333,11 @@ def main():
                 for i in range(cnt):
                     wr.llama_cpp_compute(mats[name][i], out_of[name][i], N, out_dtype=F16)
             # exchange step: the first output of the group becomes the next activation block
-            if dist_on and exchange:
+            if dist_on and exchange and recording[0] and lib_comm is None:
+                # row-sharded chain: the exchange step becomes part of the in-kernel hand-off (tmac_hip_chain_record_gather)
+                wr.record_gather(out_of[name][0], gathered[name], out_of[name][0].numel() * 2, rank, world)
+                xin[nxt[name]] = gathered[name].reshape(-1)[:logical[name]]
+            elif dist_on and exchange:
                 if lib_comm is not None:
                     lib_comm.allgather(out_of[name][0], gathered[name], out_of[name][0].numel() * 2)
                 else:
@@ -354,18 +360,65 @@ def main():
     # ---- launch mechanism ---------------------------------------------------------------------------------------------
     # (the fused entry point's per-stream LUT workspace for N > 1 must not be allocated inside a capture: the warm-up step and
     # the capture below run on the same side stream, so the workspace exists and has its final size when capture starts)
-    use_graph = (not args.no_graph) and not (dist_on and args.eager_collectives) and args.path != "chain"
     graph, chain, stamp_buf = None, None, None
     if args.path == "chain":
         # record the token's calls once (they are not launched while recording); one launch per step from here on
         step()                                       # leaves x[0] = the down projection's output, as in a decode loop
         torch.cuda.synchronize()
-        with wr.record_chain() as rec:
-            step()
-        chain = rec.chain
-        if args.stamps:
+        def all_ranks_ok(ok):
+            if not dist_on:
+                return ok
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
+        recording[0] = True
+        why = ""
+        try:
+            with wr.record_chain() as rec:
+                step()
+            chain = rec.chain
+        except tmac_amd.binding.TMACHipError as e:
+            if not dist_on:
+                raise
+            why = str(e)
+        recording[0] = False
+        if dist_on:
+            # Every decision below is taken by ALL ranks together (a rank on its own path would leave the others in a collective).
+            # The ranks exchange the IPC handles of their hand-off arenas (bootstrap only); every producer then stores its granules
+            # into all of them (system-scope stores over xGMI).  Two trial launches prove the hand-off before anything is timed.
+            ok = all_ranks_ok(chain is not None)
+            if ok:
+                try:
+                    blob = torch.frombuffer(bytearray(chain.export()), dtype=torch.uint8).to(dev)
+                except tmac_amd.binding.TMACHipError as e:
+                    why, blob = str(e), torch.zeros(tmac_amd.DecodeChain.BLOB_BYTES, dtype=torch.uint8, device=dev)
+                blobs = torch.empty(world * tmac_amd.DecodeChain.BLOB_BYTES, dtype=torch.uint8, device=dev)
+                dist.all_gather_into_tensor(blobs, blob)
+                try:
+                    if not why:
+                        chain.connect(bytes(blobs.cpu().numpy().tobytes()))
+                except tmac_amd.binding.TMACHipError as e:
+                    why = str(e)
+                ok = all_ranks_ok(not why)
+            if ok:
+                barrier()
+                for _ in range(2):
+                    chain.launch()
+                torch.cuda.synchronize()
+                st = chain.status()
+                if st:
+                    why = "a hand-off across ranks timed out in the trial launches (error word %#x)" % st
+                ok = all_ranks_ok(st == 0)
+            if not ok:
+                if rank == 0:
+                    sys.stderr.write(f"bench.py: no row-sharded chain on this node ({why or 'another rank failed'}); per-launch path with RCCL all-gathers instead\n")
+                if chain is not None:
+                    chain.free()
+                chain, args.path = None, "fused"
+        if chain is not None and args.stamps:
             stamp_buf = torch.zeros(chain.nops * chain.grid * 8, dtype=torch.int64, device=dev)
             chain.set_stamps(stamp_buf)
+    use_graph = (not args.no_graph) and not (dist_on and args.eager_collectives) and args.path != "chain"
     if use_graph:
         # One step (the launches + the all-gathers) is captured into a hipGraph and replayed.  With RCCL collectives inside,
         # capture was exercised with one rank only on the development box: if capture raises, the run falls back to eager
@@ -636,7 +689,8 @@ def main():
                        "algorithmic_bytes_per_step": bytes_per_step, "weights": wl["weights"],
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
                        "kernel_variant": args.variant,
-                       "launch": "one persistent launch per step" if args.path == "chain" else ("hipGraph replay" if use_graph else "eager")},
+                       "launch": ("one persistent launch per step" + (" and rank, hand-off across ranks through IPC-mapped arenas" if world > 1 else ""))
+                                 if args.path == "chain" else ("hipGraph replay" if use_graph else "eager")},
             "roofline": roof,
             "verified": verified,
             "activations_finite": finite,

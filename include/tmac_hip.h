@@ -168,12 +168,28 @@ int32_t tmac_hip_chain_status(tmac_hip_chain* chain, uint32_t* error_word);
  * (any pointer may be NULL) */
 int32_t tmac_hip_chain_info(const tmac_hip_chain* chain, int op, int32_t* nops, int32_t* wpq, int32_t* grid, size_t* bytes);
 int32_t tmac_hip_chain_free(tmac_hip_chain* chain);
+/* Row-sharded chains (one process per GPU; weight ROWS split over the ranks).  While recording, the exchange step between
+ * a call and the calls that need its output whole is recorded too -- tmac_hip_comm_allgather(comm, send, recv, ...) notes itself, or
+ * tmac_hip_chain_record_gather where no communicator exists -- and inside the launch it becomes part of the hand-off: every rank's
+ * producers store their granules into the hand-off arena of EVERY rank (IPC-mapped peer memory, system-scope stores over xGMI), the
+ * consumers' polls are unchanged.  `recv` itself is NOT written by the launch.  Protocol, same recorded sequence on every rank:
+ *     tmac_hip_chain_end(&chain);  tmac_hip_chain_export(chain, blob);          // TMAC_HIP_CHAIN_BLOB_BYTES
+ *     ... all-gather the blobs over any transport (rank order) ...
+ *     tmac_hip_chain_connect(chain, blobs_of_all_ranks, world);                 // hipIpcOpenMemHandle of the peers' arenas
+ *     per token, on every rank: tmac_hip_chain_launch(chain, stream)            // the ranks' launches must overlap in time
+ * K is never split, integer sums are those of one GPU.  HSA_ENABLE_IPC_MODE_LEGACY=0 must be set where the driver supports dmabuf IPC only. */
+#define TMAC_HIP_CHAIN_BLOB_BYTES 128
+int32_t tmac_hip_chain_record_gather(const void* send_dev, void* recv_dev, size_t bytes_per_rank, int rank, int world);
+int32_t tmac_hip_chain_export(const tmac_hip_chain* chain, void* blob_out);
+int32_t tmac_hip_chain_connect(tmac_hip_chain* chain, const void* blobs_of_all_ranks, int world);
 int32_t tmac_hip_chain_threads(void);   /* threads per workgroup of k_decode_chain (the launch configuration its results are bit-identical with) */
 /* profiling / A-B knobs: s_memrealtime stamps (100 MHz) [calls][workgroups][8] of wave 0 (0 call entry, 1 activations complete, 2 LUT
  * built, 3 weights of the call landed, 5 last row quad published, 6 all loads landed, 7 number of polls) into a device buffer (NULL = off); waves per row quad forced for chains built from now on (0 = per-call
  * choice) and the poll limit of a hand-off (0 = keep) */
 int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* chain, unsigned long long* dev_buffer);
 int32_t tmac_hip_debug_chain_config(int force_waves_per_quad, unsigned spin_limit);
+/* workgroups of chains built from now on (0 = one per CU): lets two chains run side by side on one device (tests/test_gpu_chain_ipc.py) */
+int32_t tmac_hip_debug_chain_grid(int workgroups);
 
 /* ---- multi-GPU exchange step ------------------------------------------------------------------
  * One process per GPU; weight ROWS are sharded over the ranks (tile-aligned; register a rank's tiles with

@@ -33,6 +33,7 @@ def _fresh_library_state(request):
     tmac_hip_set_* / tmac_hip_debug_* knob, the host-pointer layer's caches and workspace (tmac_hip_reset_state).  Round 2's
     suite was order-dependent through exactly this state; knobs a test sets no longer need a `finally` to be undone."""
     if request.node.get_closest_marker("gpu") is not None:
+        import torch  # noqa: F401  (first: libtmac_hip.so must bind to the HIP runtime torch brings, not load a second one)
         import tmac_amd
         tmac_amd.binding.check(tmac_amd.lib().tmac_hip_reset_state())
     yield

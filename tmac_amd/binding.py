@@ -112,6 +112,10 @@ def load_library() -> C.CDLL:
         "tmac_hip_chain_free": ([vp], i32),
         "tmac_hip_chain_set_stamps": ([vp, vp], i32),
         "tmac_hip_chain_threads": ([], i32),
+        "tmac_hip_chain_record_gather": ([vp, vp, sz, C.c_int, C.c_int], i32),
+        "tmac_hip_chain_export": ([vp, vp], i32),
+        "tmac_hip_chain_connect": ([vp, vp, C.c_int], i32),
+        "tmac_hip_debug_chain_grid": ([C.c_int], i32),
         "tmac_hip_debug_chain_config": ([C.c_int, C.c_uint], i32),
         "tmac_hip_debug_quad_config": ([C.c_int, C.c_int], i32),
         "tmac_hip_selftest": ([vp, vp, C.c_int], i32),

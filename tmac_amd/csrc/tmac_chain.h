@@ -53,7 +53,12 @@ struct ChainArgs {
     int poll_sleep;                // s_sleep 1 (64 cycles) count between two polls of a hand-off (A/B knob)
     int poll_delay;                // s_sleep 1 count before the first poll of a hand-off (A/B knob)
     int issue_first;               // A/B knob: >= 0 overrides the per-op number of weight fragments issued before the polls for the activations
-    int poll_mode;                 // A/B knob: 0 dwordx4 sc1 | 1 dwordx4 sc0 sc1 | 2 dwordx4 nt | 3 dwordx4 plain
+    int poll_mode;                 // A/B knob: 0 polls at agent scope (sc1) | 1 at system scope (sc0 sc1; always with peers)
+    // row-sharded chains over several GPUs (one process per GPU): every rank holds the hand-off images of ALL ranks' rows in one
+    // arena with the same layout; a producer stores its granules into its own arena and, through IPC mappings, into every peer's
+    unsigned long long arena_base;     // this rank's arena (device address)
+    unsigned long long peer_base[7];   // the other ranks' arenas as mapped into this process
+    int npeer;
     unsigned long long* stamps;    // optional [nops][grid][8] of wave 0, s_memrealtime (100 MHz): 0 op entry, 1 activations complete, 2 LUT built
                                    // (barrier passed), 3 current ring landed, 5 last quad published, 6 everything in flight landed, 7 polls
 };

@@ -157,32 +157,37 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
 }
 
 // The hand-off granules of up to three LUT pairs (two consecutive row quads = 8 activations each), all rounds of a thread
-// in flight together; loads and their wait in one statement (cdna_hip_programming.md 5.7, form (i)); sc1 loads bypass
-// this CU's L1
-__device__ __forceinline__ void c_poll1(const uint4* p0, u32x4q (&v)[6]) {
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
-                 "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]) : "v"(p0) : "memory");
-}
-__device__ __forceinline__ void c_poll2(const uint4* p0, const uint4* p1, u32x4q (&v)[6]) {
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\t"
-                 "global_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %2, %5, off sc1\n\t"
-                 "global_load_dwordx4 %3, %5, off offset:16 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p0), "v"(p1) : "memory");
-}
-__device__ __forceinline__ void c_poll3(const uint4* p0, const uint4* p1, const uint4* p2, u32x4q (&v)[6]) {
-    asm volatile("global_load_dwordx4 %0, %6, off sc1\n\t"
-                 "global_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %2, %7, off sc1\n\t"
-                 "global_load_dwordx4 %3, %7, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %4, %8, off sc1\n\t"
-                 "global_load_dwordx4 %5, %8, off offset:16 sc1\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]) : "v"(p0), "v"(p1), "v"(p2) : "memory");
-}
+// in flight together; loads and their wait in one statement (cdna_hip_programming.md 5.7, form (i)).  Agent scope (sc1)
+// bypasses this CU's L1 and sees what other XCDs wrote through; chains that span several GPUs poll at system scope (sc0 sc1):
+// the granules then arrive over xGMI from the peers' producers.
+#define TMAC_POLL_FNS(SUFFIX, SC)                                                                                              \
+    __device__ __forceinline__ void c_poll1##SUFFIX(const uint4* p0, u32x4q (&v)[6]) {                                          \
+        asm volatile("global_load_dwordx4 %0, %2, off " SC "\n\t"                                                             \
+                     "global_load_dwordx4 %1, %2, off offset:16 " SC "\n\t"                                                   \
+                     "s_waitcnt vmcnt(0)"                                                                                       \
+                     : "=&v"(v[0]), "=&v"(v[1]) : "v"(p0) : "memory");                                                          \
+    }                                                                                                                           \
+    __device__ __forceinline__ void c_poll2##SUFFIX(const uint4* p0, const uint4* p1, u32x4q (&v)[6]) {                         \
+        asm volatile("global_load_dwordx4 %0, %4, off " SC "\n\t"                                                             \
+                     "global_load_dwordx4 %1, %4, off offset:16 " SC "\n\t"                                                   \
+                     "global_load_dwordx4 %2, %5, off " SC "\n\t"                                                             \
+                     "global_load_dwordx4 %3, %5, off offset:16 " SC "\n\t"                                                   \
+                     "s_waitcnt vmcnt(0)"                                                                                       \
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p0), "v"(p1) : "memory");                       \
+    }                                                                                                                           \
+    __device__ __forceinline__ void c_poll3##SUFFIX(const uint4* p0, const uint4* p1, const uint4* p2, u32x4q (&v)[6]) {        \
+        asm volatile("global_load_dwordx4 %0, %6, off " SC "\n\t"                                                             \
+                     "global_load_dwordx4 %1, %6, off offset:16 " SC "\n\t"                                                   \
+                     "global_load_dwordx4 %2, %7, off " SC "\n\t"                                                             \
+                     "global_load_dwordx4 %3, %7, off offset:16 " SC "\n\t"                                                   \
+                     "global_load_dwordx4 %4, %8, off " SC "\n\t"                                                             \
+                     "global_load_dwordx4 %5, %8, off offset:16 " SC "\n\t"                                                   \
+                     "s_waitcnt vmcnt(0)"                                                                                       \
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]) : "v"(p0), "v"(p1), "v"(p2) : "memory"); \
+    }
+TMAC_POLL_FNS(, "sc1")
+TMAC_POLL_FNS(_sys, "sc0 sc1")
+#undef TMAC_POLL_FNS
 // the same for plain activations (in memory since before the launch)
 __device__ __forceinline__ void c_ext3(const uint4* p0, const uint4* p1, const uint4* p2, u32x4q (&v)[6]) {
     asm volatile("global_load_dwordx4 %0, %3, off\n\t"
@@ -335,24 +340,16 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 for (;;) {
                     ++polls;
                     bool ok;
+                    const bool sys = a.npeer > 0 || a.poll_mode == 1;      // granules written by other GPUs: system scope
                     if (nr == 1) {
-                        if (a.poll_mode == 0) c_poll1(g0, v);
-                        else if (a.poll_mode == 1)
-                            asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                                         : "=&v"(v[0]), "=&v"(v[1]) : "v"(g0) : "memory");
-                        else if (a.poll_mode == 2)
-                            asm volatile("global_load_dwordx4 %0, %2, off nt\n\tglobal_load_dwordx4 %1, %2, off offset:16 nt\n\ts_waitcnt vmcnt(0)"
-                                         : "=&v"(v[0]), "=&v"(v[1]) : "v"(g0) : "memory");
-                        else
-                            asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
-                                         : "=&v"(v[0]), "=&v"(v[1]) : "v"(g0) : "memory");
+                        if (sys) c_poll1_sys(g0, v); else c_poll1(g0, v);
                         ok = !n0 || ((v[0].x == gen) & (v[0].z == gen) & (v[1].x == gen) & (v[1].z == gen));
                     } else if (nr == 2) {
-                        c_poll2(g0, g1, v);
+                        if (sys) c_poll2_sys(g0, g1, v); else c_poll2(g0, g1, v);
                         ok = (!n0 || ((v[0].x == gen) & (v[0].z == gen) & (v[1].x == gen) & (v[1].z == gen))) &
                              (!n1 || ((v[2].x == gen) & (v[2].z == gen) & (v[3].x == gen) & (v[3].z == gen)));
                     } else {
-                        c_poll3(g0, g1, g2, v);
+                        if (sys) c_poll3_sys(g0, g1, g2, v); else c_poll3(g0, g1, g2, v);
                         ok = (!n0 || ((v[0].x == gen) & (v[0].z == gen) & (v[1].x == gen) & (v[1].z == gen))) &
                              (!n1 || ((v[2].x == gen) & (v[2].z == gen) & (v[3].x == gen) & (v[3].z == gen))) &
                              (!n2 || ((v[4].x == gen) & (v[4].z == gen) & (v[5].x == gen) & (v[5].z == gen)));
@@ -589,9 +586,17 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                             if (a.out_f16) as_global(reinterpret_cast<unsigned short*>(uni(d->m[mi].C)))[oi] = (unsigned short)hb;
                             else as_global(reinterpret_cast<float*>(uni(d->m[mi].C)))[oi] = t;
                             TMAC_GLOBAL unsigned long long* gr = as_global(reinterpret_cast<unsigned long long*>(uni(d->m[mi].GR)));
-                            if (gr && !(row & 1))
-                                __hip_atomic_store(gr + 2 * (size_t)lq + (row >> 1), ((unsigned long long)(hb | (nb << 16)) << 32) | gen,
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (gr && !(row & 1)) {
+                                const unsigned long long gv = ((unsigned long long)(hb | (nb << 16)) << 32) | gen;
+                                TMAC_GLOBAL unsigned long long* dst = gr + 2 * (size_t)lq + (row >> 1);
+                                __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                // row-sharded chains: the same granule into the hand-off arena of every other rank (identical layout on
+                                // every rank: the peer's address is its arena base plus this address' offset), system scope over xGMI
+                                const unsigned long long off = reinterpret_cast<unsigned long long>(dst) - a.arena_base;
+                                for (int pe = 0; pe < a.npeer; ++pe)
+                                    __hip_atomic_store(reinterpret_cast<TMAC_GLOBAL unsigned long long*>(a.peer_base[pe] + off), gv,
+                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
                         }
                     }
                     base = qe;

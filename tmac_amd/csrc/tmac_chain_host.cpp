@@ -15,14 +15,30 @@ struct ChainRecOp {
     std::vector<void*> C;
     tmac_dtype_t act, out;
 };
+// an exchange step noted while recording: recv = all-gather over the ranks of send (rank r's bytes at r * bytes)
+struct ChainRecGather {
+    const void* send;
+    const void* recv;
+    size_t bytes;
+    int rank, world;
+    size_t pos;                       // number of calls recorded before it
+};
 static thread_local std::vector<ChainRecOp>* g_chain_rec = nullptr;
+static thread_local std::vector<ChainRecGather>* g_chain_gat = nullptr;
 bool tmac_host::chain_recording() { return g_chain_rec != nullptr; }
 
 struct tmac_hip_chain {
     std::vector<ChainOp> ops;
     ChainOp* d_ops = nullptr;
     unsigned* ctl = nullptr;
-    std::vector<void*> grans;
+    // hand-off images of all consumed outputs: ONE arena (same layout on every rank of a row-sharded chain: a peer's address of
+    // a granule is its arena base plus the local offset)
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    unsigned long long layout_hash = 0;
+    int rank = 0, world = 1;
+    std::vector<void*> peers;         // the other ranks' arenas, mapped through IPC (rank order, self skipped)
+    bool connected = false;
     int bits = 0, zp = 0, sc_f16 = 0, out_f16 = 0;
     int sm = 0;                       // 0 per-group scales, 2 unified scale (k_decode_chain's SM)
     int grid = 0, buf_u4 = 0;
@@ -51,7 +67,23 @@ int32_t tmac_host::chain_record(const tmac_hip_weights* const* wl, int nmat, con
 extern "C" int32_t tmac_hip_chain_begin(void) {
     if (g_chain_rec) return fail(TMAC_HIP_E_ARG, "a chain is already being recorded on this thread");
     g_chain_rec = new std::vector<ChainRecOp>();
+    g_chain_gat = new std::vector<ChainRecGather>();
     return TMAC_HIP_OK;
+}
+
+// The exchange step of a row-sharded chain, noted instead of executed (tmac_hip_comm_allgather calls this while the thread
+// records): the calls that read recv_dev afterwards consume, inside the launch, what every rank's producer of send_dev publishes.
+extern "C" int32_t tmac_hip_chain_record_gather(const void* send_dev, void* recv_dev, size_t bytes_per_rank, int rank, int world) {
+    if (!g_chain_rec) return fail(TMAC_HIP_E_ARG, "no chain is being recorded on this thread");
+    if (!send_dev || !recv_dev || !bytes_per_rank || world < 1 || world > 8 || rank < 0 || rank >= world)
+        return fail(TMAC_HIP_E_ARG, "bad gather (1..8 ranks)");
+    g_chain_gat->push_back(ChainRecGather{send_dev, recv_dev, bytes_per_rank, rank, world, g_chain_rec->size()});
+    return TMAC_HIP_OK;
+}
+bool tmac_host::chain_record_gather_if_recording(const void* send_dev, void* recv_dev, size_t bytes_per_rank, int rank, int world, int32_t* rc) {
+    if (!g_chain_rec) return false;
+    *rc = tmac_hip_chain_record_gather(send_dev, recv_dev, bytes_per_rank, rank, world);
+    return true;
 }
 
 static int chain_pick_wpq(int total_q, int nst, int grid) {
@@ -70,7 +102,8 @@ static int chain_pick_wpq(int total_q, int nst, int grid) {
 
 extern "C" int32_t tmac_hip_chain_free(tmac_hip_chain* c) {
     if (!c) return TMAC_HIP_OK;
-    for (void* p : c->grans) (void)hipFree(p);
+    for (void* p : c->peers) if (p) (void)hipIpcCloseMemHandle(p);
+    if (c->arena) (void)hipFree(c->arena);
     if (c->d_ops) (void)hipFree(c->d_ops);
     if (c->ctl) (void)hipFree(c->ctl);
     delete c;
@@ -89,9 +122,13 @@ static bool overlap(const Range& a, const Range& b) { return a.lo < b.hi && b.lo
 extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
     if (!g_chain_rec) return fail(TMAC_HIP_E_ARG, "no chain is being recorded on this thread");
     std::vector<ChainRecOp> rec;
+    std::vector<ChainRecGather> gat;
     rec.swap(*g_chain_rec);
+    gat.swap(*g_chain_gat);
     delete g_chain_rec;
+    delete g_chain_gat;
     g_chain_rec = nullptr;
+    g_chain_gat = nullptr;
     if (!out) return fail(TMAC_HIP_E_ARG, "null argument");
     *out = nullptr;
     if (rec.empty()) return fail(TMAC_HIP_E_ARG, "nothing was recorded");
@@ -102,7 +139,11 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (cus < 1) return fail(TMAC_HIP_E_RUNTIME, "no compute units reported");
     auto* c = new tmac_hip_chain();
-    c->grid = cus;                                  // one workgroup per CU; residency is checked below
+    c->grid = (g_knobs.chain_grid > 0 && g_knobs.chain_grid < cus) ? g_knobs.chain_grid : cus;   // one workgroup per CU; residency is checked below
+    for (const ChainRecGather& g : gat) {
+        if (g.world != gat[0].world || g.rank != gat[0].rank) { tmac_hip_chain_free(c); return fail(TMAC_HIP_E_ARG, "the exchange steps of a chain share rank and world size"); }
+        c->rank = g.rank; c->world = g.world;
+    }
     const tmac_hip_weights* w0 = rec[0].w[0];
     c->bits = w0->s.bits; c->zp = w0->s.zero_point; c->sc_f16 = w0->sc_dtype == F16; c->out_f16 = rec[0].out == TMAC_F16;
     c->sm = (w0->s.m_groups >= 1) ? 2 : 0;
@@ -128,9 +169,30 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
     // output cannot be handed over (the reader would see a mixture of launches) and is refused
     struct Src { int op, mat; };
     std::vector<Src> src(n, Src{-1, -1});
-    std::vector<std::vector<char>> consumed(n);
-    for (size_t i = 0; i < n; ++i) consumed[i].assign(rec[i].w.size(), 0);
+    std::vector<std::vector<char>> consumed(n), gathered(n);
+    for (size_t i = 0; i < n; ++i) { consumed[i].assign(rec[i].w.size(), 0); gathered[i].assign(rec[i].w.size(), 0); }
     for (size_t i = 0; i < n; ++i) {
+        // activations that are the result of an exchange step recorded before this call: the latest such step decides; its
+        // producer is the latest earlier call that writes the gathered buffer's send side
+        const ChainRecGather* via = nullptr;
+        for (const ChainRecGather& g : gat)
+            if (g.pos <= i && g.recv == rec[i].B && (!via || g.pos >= via->pos)) via = &g;
+        if (via) {
+            for (size_t j = via->pos; j-- > 0 && src[i].op < 0;)
+                for (size_t m = 0; m < rec[j].C.size(); ++m)
+                    if (rec[j].C[m] == via->send) {
+                        if (via->bytes != (size_t)rec[j].w[m]->s.Mw * out_esz)
+                            return bail(fail(TMAC_HIP_E_ARG, "op %zu: the exchange step gathers %zu bytes per rank, output %zu of op %zu has %zu", i, via->bytes, m, j,
+                                             (size_t)rec[j].w[m]->s.Mw * out_esz));
+                        if ((size_t)rec[i].w[0]->s.K > (size_t)via->world * rec[j].w[m]->s.Mw)
+                            return bail(fail(TMAC_HIP_E_ARG, "op %zu reads %d activations from a gather of %d x %d rows", i, rec[i].w[0]->s.K, via->world, rec[j].w[m]->s.Mw));
+                        src[i] = Src{(int)j, (int)m};
+                        consumed[j][m] = 1; gathered[j][m] = 1;
+                        break;
+                    }
+            if (src[i].op < 0) return bail(fail(TMAC_HIP_E_ARG, "op %zu reads a gathered buffer whose send side no earlier call of the chain writes", i));
+            continue;
+        }
         for (size_t j = i; j-- > 0 && src[i].op < 0;)
             for (size_t m = 0; m < rec[j].C.size(); ++m) {
                 if (!overlap(in_r[i], out_r[j][m])) continue;
@@ -185,12 +247,14 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             o.m[m].GR = nullptr;
             if (consumed[i][m]) {
                 if (r.out != TMAC_F16) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: outputs consumed inside the chain must be fp16", i));
-                void* g = nullptr;
-                const size_t gb = (size_t)a.nquads() * 16;
-                if (hipMalloc(&g, gb) != hipSuccess || hipMemset(g, 0, gb) != hipSuccess)
-                    return bail(fail(TMAC_HIP_E_RUNTIME, "hand-off buffer allocation failed"));
-                c->grans.push_back(g);
-                o.m[m].GR = (uint4*)g;
+                if (gathered[i][m] && a.Mw % 4) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: row shards of a gathered output must be whole row quads", i));
+                // image of the output as its consumers see it: the rows of ALL ranks when it goes through an exchange step (rank r's
+                // quads from r * nquads on); GR holds the OFFSET for now, the arena is allocated once all images are known
+                const size_t nq_img = (size_t)a.nquads() * (gathered[i][m] ? c->world : 1);
+                const size_t my_off = gathered[i][m] ? (size_t)c->rank * a.nquads() * 16 : 0;
+                o.m[m].GR = reinterpret_cast<uint4*>(c->arena_bytes + my_off + 1);       // (+ 1: offset 0 is a valid image; fixed up below)
+                c->layout_hash = (c->layout_hash ^ (nq_img * 16 + i * 4 + m)) * 1099511628211ull;
+                c->arena_bytes += (nq_img * 16 + 255) & ~(size_t)255;
             }
             c->bytes += w->w_bytes + w->sc_bytes;
         }
@@ -211,8 +275,12 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         o.q_per = nq / c->grid; o.q_extra = nq % c->grid;
         if (src[i].op >= 0) {
             const ChainOp& po = c->ops[src[i].op];
-            if (po.m[src[i].mat].Mw != o.K) return bail(fail(TMAC_HIP_E_ARG, "op %zu reads an output of %d rows as %d activations", i, po.m[src[i].mat].Mw, o.K));
-            o.in = po.m[src[i].mat].GR; o.in_gran = 1;
+            const bool via_gather = gathered[src[i].op][src[i].mat] != 0;
+            if (!via_gather && po.m[src[i].mat].Mw != o.K)
+                return bail(fail(TMAC_HIP_E_ARG, "op %zu reads an output of %d rows as %d activations", i, po.m[src[i].mat].Mw, o.K));
+            // the image's first quad (a gathered image starts rank * nquads before this rank's part); offsets until the arena exists
+            const size_t my_off = via_gather ? (size_t)c->rank * ((po.m[src[i].mat].Mw + 3) / 4) * 16 : 0;
+            o.in = reinterpret_cast<const void*>(reinterpret_cast<size_t>(po.m[src[i].mat].GR) - my_off); o.in_gran = 1;
         } else {
             o.in = r.B; o.in_gran = 0;
         }
@@ -260,6 +328,22 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             return bail(fail(TMAC_HIP_E_NOMATCH, "the decode chain's workgroup does not fit a compute unit (%s, %zu bytes of LDS)",
                              e == hipSuccess ? "occupancy 0" : hipGetErrorString(e), c->lds_bytes));
     }
+    if (c->arena_bytes) {
+        // Peers write into this arena over xGMI while the local kernel polls it: fine-grained device memory (coherent across
+        // devices inside a running kernel; coarse-grained allocations promise that at kernel boundaries only).  Single-GPU
+        // chains keep the ordinary allocation.
+        const hipError_t ea = c->world > 1 ? hipExtMallocWithFlags(&c->arena, c->arena_bytes, hipDeviceMallocFinegrained)
+                                           : hipMalloc(&c->arena, c->arena_bytes);
+        if (ea != hipSuccess || hipMemset(c->arena, 0, c->arena_bytes) != hipSuccess)
+            return bail(fail(TMAC_HIP_E_RUNTIME, "hand-off arena allocation failed (%zu bytes)", c->arena_bytes));
+        const size_t base = reinterpret_cast<size_t>(c->arena) - 1;       // (offsets were stored + 1)
+        for (ChainOp& o : c->ops) {
+            for (int m = 0; m < o.nmat; ++m)
+                if (o.m[m].GR) o.m[m].GR = reinterpret_cast<uint4*>(reinterpret_cast<size_t>(o.m[m].GR) + base);
+            if (o.in_gran & 1) o.in = reinterpret_cast<const void*>(reinterpret_cast<size_t>(o.in) + base);
+        }
+    }
+    c->connected = c->world == 1;
     if (hipMalloc((void**)&c->d_ops, sizeof(ChainOp) * c->ops.size()) != hipSuccess ||
         hipMemcpy(c->d_ops, c->ops.data(), sizeof(ChainOp) * c->ops.size(), hipMemcpyHostToDevice) != hipSuccess)
         return bail(fail(TMAC_HIP_E_RUNTIME, "descriptor upload failed"));
@@ -290,15 +374,64 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
         (void)hipGetLastError();
         return fail(TMAC_HIP_E_ARG, "the chain is still in flight on another stream: synchronise it first, or record one chain per stream");
     }
+    if (!c->connected) return fail(TMAC_HIP_E_ARG, "a row-sharded chain must be connected to its peers first (tmac_hip_chain_export / tmac_hip_chain_connect)");
     ChainArgs a;
     memset(&a, 0, sizeof(a));
     a.ops = c->d_ops; a.nops = (int)c->ops.size(); a.ctl = c->ctl; a.out_f16 = c->out_f16;
+    a.arena_base = reinterpret_cast<unsigned long long>(c->arena);
+    a.npeer = (int)c->peers.size();
+    for (int p = 0; p < a.npeer; ++p) a.peer_base[p] = reinterpret_cast<unsigned long long>(c->peers[p]);
     a.spin_limit = g_knobs.chain_spin_limit; a.buf_u4 = c->buf_u4; a.stamps = c->stamps;
     a.poll_sleep = c->poll_sleep; a.poll_delay = c->poll_delay; a.issue_first = c->issue_first; a.poll_mode = c->poll_mode;
     hipError_t e = launch_decode_chain(a, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, st);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no decode-chain kernel for this configuration");
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "decode chain launch: %s", hipGetErrorString(e));
     c->last_stream = st; c->launched = true;
+    return TMAC_HIP_OK;
+}
+
+// ---- row-sharded chains: the ranks exchange the IPC handles of their hand-off arenas (any transport: MPI, torch.distributed, a
+// file), then every producer stores its granules into all of them ----
+struct ChainBlob {
+    hipIpcMemHandle_t handle;
+    unsigned long long arena_bytes, layout_hash;
+    int rank, world;
+};
+static_assert(sizeof(ChainBlob) <= TMAC_HIP_CHAIN_BLOB_BYTES, "blob size");
+
+extern "C" int32_t tmac_hip_chain_export(const tmac_hip_chain* c, void* blob_out) {
+    if (!c || !blob_out) return fail(TMAC_HIP_E_ARG, "null argument");
+    if (!c->arena) return fail(TMAC_HIP_E_ARG, "the chain hands nothing over");
+    ChainBlob b;
+    memset(&b, 0, sizeof(b));
+    HIP_TRY(hipIpcGetMemHandle(&b.handle, c->arena));
+    b.arena_bytes = c->arena_bytes; b.layout_hash = c->layout_hash; b.rank = c->rank; b.world = c->world;
+    memset(blob_out, 0, TMAC_HIP_CHAIN_BLOB_BYTES);
+    memcpy(blob_out, &b, sizeof(b));
+    return TMAC_HIP_OK;
+}
+
+extern "C" int32_t tmac_hip_chain_connect(tmac_hip_chain* c, const void* blobs, int world) {
+    if (!c || !blobs) return fail(TMAC_HIP_E_ARG, "null argument");
+    if (world != c->world) return fail(TMAC_HIP_E_ARG, "the chain was recorded for %d ranks, %d blobs given", c->world, world);
+    if (c->connected && c->world > 1) return fail(TMAC_HIP_E_ARG, "the chain is already connected");
+    bind_thread_device();
+    for (int r = 0; r < world; ++r) {
+        ChainBlob b;
+        memcpy(&b, (const char*)blobs + (size_t)r * TMAC_HIP_CHAIN_BLOB_BYTES, sizeof(b));
+        if (b.rank != r || b.world != world || b.arena_bytes != c->arena_bytes || b.layout_hash != c->layout_hash)
+            return fail(TMAC_HIP_E_ARG, "rank %d recorded a different chain (its blob does not match this rank's hand-off layout)", r);
+        if (r == c->rank) continue;
+        void* p = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&p, b.handle, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            for (void* q : c->peers) if (q) (void)hipIpcCloseMemHandle(q);
+            c->peers.clear();
+            return fail(TMAC_HIP_E_RUNTIME, "hipIpcOpenMemHandle of rank %d's hand-off arena: %s", r, hipGetErrorString(e));
+        }
+        c->peers.push_back(p);
+    }
+    c->connected = true;
     return TMAC_HIP_OK;
 }
 
@@ -337,6 +470,12 @@ extern "C" int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* c, unsigned long lo
 }
 
 extern "C" int32_t tmac_hip_chain_threads(void) { return CHAIN_FT; }
+
+extern "C" int32_t tmac_hip_debug_chain_grid(int workgroups) {
+    if (workgroups < 0) return fail(TMAC_HIP_E_ARG, "negative grid");
+    g_knobs.chain_grid = workgroups;
+    return TMAC_HIP_OK;
+}
 
 extern "C" int32_t tmac_hip_debug_chain_config(int force_wpq, unsigned spin_limit) {
     if (force_wpq < 0 || (force_wpq && CHAIN_NWV % force_wpq)) return fail(TMAC_HIP_E_ARG, "waves per quad must divide %d", CHAIN_NWV);

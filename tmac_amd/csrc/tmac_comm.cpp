@@ -108,8 +108,15 @@ extern "C" int32_t tmac_hip_comm_init(tmac_hip_comm** out, const void* id, int r
     return TMAC_HIP_OK;
 }
 
+namespace tmac_host { bool chain_record_gather_if_recording(const void*, void*, size_t, int, int, int32_t*); }
+
 extern "C" int32_t tmac_hip_comm_allgather(tmac_hip_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream) {
     if (!c || !send_dev || !recv_dev || !bytes_per_rank) { snprintf(g_comm_err, sizeof(g_comm_err), "bad arguments"); return TMAC_HIP_E_ARG; }
+    int32_t rrc = 0;      // between tmac_hip_chain_begin and _end the exchange step becomes part of the recorded chain
+    if (tmac_host::chain_record_gather_if_recording(send_dev, recv_dev, bytes_per_rank, c->rank, c->world, &rrc)) {
+        if (rrc) snprintf(g_comm_err, sizeof(g_comm_err), "%s", tmac_hip_last_error());
+        return rrc;
+    }
     const ncclResult_t r = g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, ncclInt8, c->c, (hipStream_t)stream);
     if (r != ncclSuccess) return comm_fail(TMAC_HIP_E_RUNTIME, "ncclAllGather", r);
     return TMAC_HIP_OK;

@@ -98,6 +98,7 @@ struct Knobs {
     int ws_fill_sync = 1;          // test knob (tmac_hip_debug_ws_fill_sync): 0 re-opens the round-2 race between the workspace fills and its first user
     int chain_wpq = 0;             // waves per row quad for every op of chains built from now on (0 = per-op choice)
     unsigned chain_spin_limit = 1u << 18;   // polls of one hand-off before a wave gives up (~0.4 s)
+    int chain_grid = 0;            // workgroups of chains built from now on (0 = one per CU; tests run two chains side by side on one device)
     unsigned long long* stamps = nullptr;        // phase stamps of the next fused launches (tmac_hip_debug_stamps)
     int32_t* stamp_dump = nullptr;               // scratch the stamp instantiation stores its tap into (allocated once, survives resets)
     unsigned long long* gemm_stamps = nullptr;   // k_gemm_planes step stamps (tmac_hip_debug_gemm_stamps)
@@ -144,6 +145,8 @@ void tuned_config(const FusedArgs& fa, int total_q, int& ft, int& wpq);   // lea
 bool chain_recording();            // is the calling thread between tmac_hip_chain_begin and tmac_hip_chain_end?
 int32_t chain_record(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype, void* const* C_list,
                      tmac_dtype_t out_dtype, int N);
+// true (and *rc set) when the calling thread is recording: the exchange step was noted, not executed
+bool chain_record_gather_if_recording(const void* send_dev, void* recv_dev, size_t bytes_per_rank, int rank, int world, int32_t* rc);
 
 // ---- host-pointer layer (tmac_hostptr.cpp) --------------------------------------------------------
 void host_route_release();         // frees the layer's workspace, staging buffers and LUT memo (tiles / runs: tmac_hip_cache_clear)

@@ -205,6 +205,21 @@ class DecodeChain:
     def handle(self):
         return self._h
 
+    BLOB_BYTES = 128       # TMAC_HIP_CHAIN_BLOB_BYTES
+
+    def export(self) -> bytes:
+        """row-sharded chains: this rank's hand-off arena as an IPC blob; all-gather the blobs of all ranks (rank order, any
+        transport) and hand them to :meth:`connect`"""
+        buf = C.create_string_buffer(self.BLOB_BYTES)
+        check(B.lib().tmac_hip_chain_export(self._h, buf))
+        return buf.raw
+
+    def connect(self, blobs) -> None:
+        """blobs: the exported blobs of ALL ranks in rank order (list of bytes, or one bytes object)"""
+        raw = b"".join(blobs) if not isinstance(blobs, (bytes, bytearray)) else bytes(blobs)
+        world = len(raw) // self.BLOB_BYTES
+        check(B.lib().tmac_hip_chain_connect(self._h, raw, world))
+
     def launch(self, stream=None) -> None:
         check(B.lib().tmac_hip_chain_launch(self._h, _stream(stream)))
 
@@ -348,6 +363,14 @@ class TMACGeMMWrapper:
         if rec is not None:
             rec.append((list(weights_list), B_dev, list(C_list)))
         check(B.lib().tmac_hip_qgemm_fused_dev(wa, n, _ptr(B_dev), act_dtype, ca, out_dtype, N, _stream(stream)))
+
+    def record_gather(self, send_dev, recv_dev, bytes_per_rank: int, rank: int, world: int) -> None:
+        """while recording a chain: the exchange step ``recv = all-gather over the ranks of send`` (what ``Comm.allgather`` records
+        by itself); inside the launch it becomes part of the hand-off"""
+        rec = getattr(self, "_recording", None)
+        if rec is not None:
+            rec.append((send_dev, recv_dev))
+        check(B.lib().tmac_hip_chain_record_gather(_ptr(send_dev), _ptr(recv_dev), bytes_per_rank, rank, world))
 
     def record_chain(self) -> "_ChainRecorder":
         """``with wr.record_chain() as rec: <the token's wr.fused(...) calls>`` — the calls are noted instead of launched;

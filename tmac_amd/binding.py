@@ -35,7 +35,8 @@ class KCfg(C.Structure):
 
 
 def lib_path() -> str:
-    return os.path.join(HERE, "lib", "libtmac_hip.so")
+    # $TMAC_HIP_LIB: another build of the same library (A/B measurements of two builds in one run; tools/gpu/)
+    return os.environ.get("TMAC_HIP_LIB") or os.path.join(HERE, "lib", "libtmac_hip.so")
 
 
 def build_library(force: bool = False) -> str:

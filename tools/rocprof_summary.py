@@ -15,7 +15,7 @@ def short(n):
     return n.replace("void ", "").split("(")[0][:110]
 
 
-for tag in ("trace_chain", "trace_fused", "trace_prefill"):
+for tag in sorted(t for t in os.listdir(root) if t.startswith("trace_") and os.path.isdir(os.path.join(root, t))):
     fs = glob.glob(os.path.join(root, tag, "**", "*kernel_stats.csv"), recursive=True)
     print(f"== {tag}: rocprofv3 --kernel-trace --stats (durations in us)")
     for f in fs:

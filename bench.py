@@ -41,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
-MFMA_I8_PEAK_TOPS = 4404.0   # MI355X_MICROARCH.md: v_mfma_i32_32x32x32_i8 microbenchmark ceiling (the instruction k_gemm_planes issues; 16x16x64: 3944)
+MFMA_I8_PEAK_TOPS = 4404.0   # cdna_hip_programming.md: v_mfma_i32_32x32x32_i8 microbenchmark ceiling (the instruction k_gemm_planes issues; 16x16x64: 3944)
 KF = 16
 
 LLAMA = [("qkv", 4096, 4096, 3, 0), ("o", 4096, 4096, 1, 1), ("gate_up", 11008, 4096, 2, 2), ("down", 4096, 11008, 1, 3)]

@@ -240,6 +240,41 @@ def test_bitnet_layer_full_size(tm):
     m.free()
 
 
+def _random_chain(seed):
+    """a random call sequence: 3-7 calls, 1-3 matrices each, K and row counts on the grid the layouts allow, every call fed by
+    an external vector or by a random earlier output (so that K = that output's rows)"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(3, 8))
+    ops = []
+    for i in range(n):
+        feeders = [(j, m) for j in range(i) for m in range(len(ops[j][1])) if ops[j][1][m] % 128 == 0 and ops[j][1][m] <= 6144]
+        if feeders and rng.random() < 0.75:
+            src = feeders[int(rng.integers(len(feeders)))]
+            K = ops[src[0]][1][src[1]]
+        else:
+            src, K = None, int(rng.choice([128, 256, 640, 1024, 2688, 3200, 4096, 6144]))
+        rows = [int(rng.choice([64, 128, 256, 640, 1024, 2688, 3200, 4224])) for _ in range(int(rng.integers(1, 4)))]
+        ops.append((K, rows, src))
+    return ops
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_chains(tm, seed):
+    """random call sequences through every flavour of the chain kernel (bits 1-4, per-group scales with / without zero points or
+    unified scales, fp16 / fp32 scale storage): the same two bars as the fixed cases"""
+    rng = np.random.default_rng(1000 + seed)
+    bits = int(rng.integers(1, 5))
+    mg = 1 if rng.random() < 0.35 else -1
+    zp = bool(rng.integers(0, 2))
+    m = Model(tm, _random_chain(seed), bits=bits, zp=zp, dev_f16=bool(rng.integers(0, 2)), seed=60 + seed, mg=mg, ternary=(bits == 2))
+    chain = m.record()
+    for rep in range(2):
+        chain.launch()
+        m.check(chain, oracle_ops=None if rep == 0 else [])
+    chain.free()
+    m.free()
+
+
 def test_chain_equals_eager_sequence(tm):
     """the recorded calls issued one by one give the same final buffers as the chain (default launch configuration, so
     only to fp32 summation order: 1e-3 on fp16)"""

@@ -93,9 +93,9 @@ def parse():
     a = ap.parse_args()
     wl = WORKLOADS[a.workload]
     if a.steps is None:
-        a.steps = 20 if wl["N"] == 1 else 10
+        a.steps = 1000 if wl["N"] == 1 else 50      # ~0.7 s / ~0.4 s of timed GPU work: long enough for an outside observer (rocm-smi sampling) to see
     if a.warmup is None:
-        a.warmup = 5 if wl["N"] == 1 else 3
+        a.warmup = 20 if wl["N"] == 1 else 5
     if a.layers is None:
         a.layers = wl["layers"]
     return a

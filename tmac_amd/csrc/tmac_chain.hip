@@ -5,7 +5,7 @@
 // idles through most of a launch (0.78 ms per token against 0.45 ms for launches that merely read the
 // bytes).  Here one workgroup per CU walks the whole op list:
 //   * no dependent dispatch, no ramp-up and drain per op, activations read once (the poll that detects them IS the load);
-//     an op's weights are issued the moment its activations are complete and stream in during the LUT build;
+//     an op's first weight fragment is in flight before its polls, the rest streams in during the LUT build;
 //   * the hand-off is in-kernel: an op's outputs are published as self-tagged 8-byte granules {generation, 2 x fp16}
 //     with write-through (sc1) stores; the consumers' LUT build reads exactly those granules with sc1 loads and spins
 //     until every tag carries this launch's generation (data is the flag: no counter, no fence, no drain of the weight
@@ -300,14 +300,13 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         };
 
         // ---- 1. this op's activations.  The CU's vector-memory queue is empty here (the previous op's lookups consumed
-        // everything it had in flight): a poll costs one round trip, not the drain time of a weight stream.  Measured the
-        // other way round -- next op's weights prefetched behind the current op's lookups -- every publish and every poll
-        // sat behind 20-100 KB of queued weight loads per CU: 3-4 us per hand-off (profiles/r02_chain_prefetch_ab.txt). ----
-        // issue_first fragments per wave go out before the polls (which then queue behind them), the rest of the ring
-        // after the activations have arrived
-        // per op: small ops put one fragment in front of the polls (the poll then returns after one fabric round trip plus 24 KB
-        // per CU, and the compiler-visible wait behind it does not hold the LUT build until ALL weights have landed); ops whose
-        // stream outlasts the hand-off put the whole ring in front (their stream must start at once) -- chosen on the host
+        // everything it had in flight).  Measured the other way round -- next op's weights prefetched behind the current op's
+        // lookups -- every publish and every poll sat behind 20-100 KB of queued weight loads per CU: 3-4 us per hand-off
+        // (profiles/r02_chain_prefetch_ab.txt).  ONE weight fragment per wave goes out in front of the polls, the rest of the
+        // ring once the activations have arrived: the poll returns after a fabric round trip plus 24 KB per CU, and the
+        // compiler-visible wait behind it does not hold the LUT build until ALL of the op's weights have landed -- the build
+        // overlaps the stream.  The whole ring in front measured 5-7 % slower even for the ops whose stream outlasts the
+        // hand-off (profiles/r03_chain_knobs.txt A, B); the count sits in the op descriptor, ChainArgs::issue_first overrides it. ----
         const int isf = a.issue_first >= 0 ? a.issue_first : (uni(d->in_gran) >> 8);
 #pragma unroll
         for (int k = 0; k < RING; ++k)

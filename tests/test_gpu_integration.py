@@ -135,3 +135,29 @@ def test_cmake_consumer_computes_a_gemv(tm, tmp_path):
     r = subprocess.run([os.path.join(build, "consumer"), d, str(Mw), str(K), str(bits), str(bm)], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "gemv max rel err" in r.stdout
+
+
+@pytest.mark.parametrize("extra,path", [([], "chain"), (["--force-dist"], "chain"), (["--path", "fused"], "fused"),
+                                        (["--workload", "bitnet-3b"], "chain")])
+def test_bench_runs_and_verifies(tm, extra, path):
+    """bench.py end to end on two layers: ONE JSON line on stdout with the contract's keys, the timed path verified against the oracle
+    inside the run; --force-dist takes the multi-GPU code path (recorded exchange steps, blob exchange, trial launches) with one rank"""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("MASTER_ADDR", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["MASTER_PORT"] = "29577"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--layers", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                       capture_output=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["config"]["path"] == path and d["steps"] == 3 and d["n_gpus"] == 1
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["activations_finite"]
+    if "--force-dist" not in extra:
+        assert d["verified"]["ok"], d["verified"]
+    if path == "chain":
+        assert d["roofline"]["headline_gemv"]["us"] > 0

@@ -7,6 +7,8 @@ and (b) within 1e-3 (max-norm, fp16 outputs) of the oracle run on that activatio
 oracle/tmac_oracle.c).  (a) ties the chain to the kernel whose integer path is tapped bit for bit in test_gpu_parity.py;
 (b) ties it to the reference independently of that kernel.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -258,7 +260,7 @@ def _random_chain(seed):
     return ops
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TMAC_FUZZ_CHAINS", "12"))))   # tools/gpu/r3_fuzz.sh runs a few hundred
 def test_random_chains(tm, seed):
     """random call sequences through every flavour of the chain kernel (bits 1-4, per-group scales with / without zero points or
     unified scales, fp16 / fp32 scale storage): the same two bars as the fixed cases"""

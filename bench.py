@@ -90,6 +90,8 @@ def parse():
                     help="multi-GPU exchange step: torch.distributed (ProcessGroupNCCL = RCCL; default, the path exercised so far) or the "
                          "library's own communicator (tmac_hip_comm_*: RCCL through the C-ABI, bootstrapped over torch.distributed)")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # debugging: take the multi-GPU code path with 1 rank
+    ap.add_argument("--gemm-kernel", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="prefill A/B: tmac_hip_debug_gemm_kernel (0 auto, 1 k_gemm_onehot, 2 / 3 k_gemm_planes with eight- / four-wave workgroups)")
     a = ap.parse_args()
     wl = WORKLOADS[a.workload]
     if a.steps is None:
@@ -228,6 +230,7 @@ def main():
     L = tmac_amd.lib()
     tmac_amd.binding.check(L.tmac_hip_init(local_rank))
     tmac_amd.binding.check(L.tmac_hip_set_variant(args.variant))
+    tmac_amd.binding.check(L.tmac_hip_debug_gemm_kernel(args.gemm_kernel))
     dev = torch.device("cuda", local_rank)
     gen = torch.Generator(device=dev); gen.manual_seed(1234)   # same weights on every rank, sliced by rank below
     ags_of = (lambda K: K) if MG >= 1 else (lambda K: wl["ags"])

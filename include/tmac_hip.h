@@ -272,7 +272,8 @@ int32_t tmac_hip_debug_stamps(unsigned long long* dev_buffer);
 int32_t tmac_hip_debug_pairs_min_n(int n);
 /* N > 1 kernel selection and parity taps.  0 (default): k_gemm_planes (bit-planes combined inside the matrix-core operand,
  * tmac_gemm2.hip) wherever it covers the configuration (2- and 4-bit weights, per-group scales, act_group_size 64);
- * 1: always k_gemm_onehot (one matrix-core row per bit-plane row; also the only one for unified-scale weights).
+ * 1: always k_gemm_onehot (one matrix-core row per bit-plane row).  2 / 3: k_gemm_planes with its eight-wave (one workgroup per
+ * CU) / four-wave (two per CU) workgroup form forced; 0 picks by the number of tiles of the launch (tmac_gemm2.hip, PForm).
  * tmac_hip_debug_gemm_comb_sums: int32 [N][Mw][K/64], the integers sum_p 2^p PS_p (PS_p as tmac_hip_qgemm_partial_sums
  * returns them per bit-plane) that k_gemm_planes feeds into the fp32 chain; the workspace must hold the LUT of a
  * tmac_hip_preprocessor_dev call with N >= 2 rows.  tmac_hip_debug_gemm_image_read: the LUT image that kernel streams,

@@ -3,9 +3,10 @@
 Bars: (a) the LUT image it streams (k_lut_image) bit-identical to the oracle's QLUT / lut_scales / lut_biases
 (lut_ctor.cc restated in oracle/tmac_oracle.c); (b) the integers it feeds into the fp32 chain, comb = sum_p 2^p PS_p,
 bit-identical to the oracle's per-plane partial sums (tbl.cc:445-462) combined as integers; (c) outputs within 1e-3 of
-max|C| of the oracle (fp32 chain regrouped: K split over 8 waves, zero-point term once per weight group) -- measured
+max|C| of the oracle (fp32 chain regrouped: K split over 8 / 4 waves, zero-point term once per weight group) -- measured
 ~1e-6; (d) the same outputs as k_gemm_onehot (the per-plane kernel, whose integer path is tapped plane by plane in
-test_gpu_parity.py).
+test_gpu_parity.py).  Every case runs through both workgroup forms of the kernel (tmac_gemm2.hip, PForm: eight waves and one
+workgroup per CU, four waves and two per CU; tmac_hip_debug_gemm_kernel 2 / 3 -- the default picks by the number of tiles).
 """
 import numpy as np
 import pytest
@@ -52,7 +53,7 @@ def run(tm, case, Mw, K, bits, bm, gs, zp, N, scale_f16=False, act_f16=False, ou
         wr.llama_cpp_compute(w, Ct, N)
         torch.cuda.synchronize()
         out = dict(C=Ct.float().cpu().numpy(), A=A, S=S)
-        if kernel == 0:
+        if kernel != 1:
             out["img"] = wr.workspace.read_gemm_image(K, N)
             if want_comb:
                 out["comb"] = wr.comb_sums(w, N)
@@ -77,10 +78,14 @@ CASES = [
 ]
 
 
+FORMS = [2, 3]     # tmac_hip_debug_gemm_kernel: k_gemm_planes with eight- / four-wave workgroups
+
+
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("Mw,K,bits,bm,gs,zp,N", CASES)
-def test_gemm_planes(tm, Mw, K, bits, bm, gs, zp, N):
+def test_gemm_planes(tm, Mw, K, bits, bm, gs, zp, N, form):
     case = orc.make_case(9000 + N + K, Mw, K, N=N, bits=bits, gs=gs, ags=64, zero_point=zp)
-    r = run(tm, case, Mw, K, bits, bm, gs, zp, N)
+    r = run(tm, case, Mw, K, bits, bm, gs, zp, N, kernel=form)
     q, ls, lb = orc.preprocessor(case["B"], 64)
     # (a) the LUT image: entries 0..7 of every table, scales, biases bit for bit; the entry sums are what they say
     h, gls, glb, hs = r["img"]
@@ -100,17 +105,19 @@ def test_gemm_planes(tm, Mw, K, bits, bm, gs, zp, N):
     assert rel_err(r["C"], r1["C"]) <= 1e-5
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("scale_f16,act_f16,out_f16", [(True, True, True), (True, False, False), (False, True, True)])
-def test_gemm_planes_dtypes(tm, scale_f16, act_f16, out_f16):
+def test_gemm_planes_dtypes(tm, scale_f16, act_f16, out_f16, form):
     Mw, K, bits, bm, gs, N = 256, 2048, 2, 128, 128, 96
     case = orc.make_case(77, Mw, K, N=N, bits=bits, gs=gs, ags=64, fp16_values=True)
-    r = run(tm, case, Mw, K, bits, bm, gs, True, N, scale_f16=scale_f16, act_f16=act_f16, out_f16=out_f16, want_comb=False)
+    r = run(tm, case, Mw, K, bits, bm, gs, True, N, scale_f16=scale_f16, act_f16=act_f16, out_f16=out_f16, want_comb=False, kernel=form)
     q, ls, lb = orc.preprocessor(case["B"], 64)
     Cc = orc.qgemm_float(r["A"], q, r["S"], ls, lb, Mw, K, N, bits, bm, 16, gs, 64, True)
     assert rel_err(r["C"], Cc) <= (1e-3 if out_f16 else 1e-5)
 
 
-def test_gemm_planes_edge_activations(tm):
+@pytest.mark.parametrize("form", FORMS)
+def test_gemm_planes_edge_activations(tm, form):
     """all-zero act groups (scale 0), huge and tiny magnitudes, exact .5 ties: the LUT image equals the oracle's bit for
     bit and the outputs stay finite where the oracle's are"""
     Mw, K, bits, bm, gs, N = 128, 1024, 2, 128, 128, 12
@@ -121,7 +128,7 @@ def test_gemm_planes_edge_activations(tm):
     B[2, 128:192] *= 1e20
     B[3, 192:256] *= 1e-20
     B[4, 256:320] = np.tile(np.array([0.5, 1.5, 2.5, 127.0], np.float32), 16)
-    r = run(tm, case, Mw, K, bits, bm, gs, True, N)
+    r = run(tm, case, Mw, K, bits, bm, gs, True, N, kernel=form)
     q, ls, lb = orc.preprocessor(case["B"], 64)
     h, gls, glb, hs = r["img"]
     assert np.array_equal(h, q[:, :, :8])
@@ -135,8 +142,9 @@ def test_gemm_planes_edge_activations(tm):
             assert rel_err(r["C"][n][m], Cc[n][m]) <= 1e-5
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("Mw,K,N", [(320, 3200, 40), (160, 640, 33), (3200, 8640, 70), (3200, 3200, 256), (64, 12288, 13)])
-def test_gemm_planes_unified_scale(tm, Mw, K, N):
+def test_gemm_planes_unified_scale(tm, Mw, K, N, form):
     """the BitNet flavour (m_groups = 1, one act group per row) through k_gemm_planes_us: the LUT image of the row-wise build
     bit-identical to the oracle's, the combined integer totals bit-identical to the oracle's per-plane totals, and the
     outputs BIT-IDENTICAL to the oracle's scale-final expression (qgemm.py:170-174) -- integer accumulation has no order"""
@@ -147,6 +155,7 @@ def test_gemm_planes_unified_scale(tm, Mw, K, N):
     case = orc.make_case(400 + N + K, Mw, K, N=N, bits=bits, ags=K, zero_point=False, m_groups=1)
     L = tm.lib()
     tm.binding.check(L.tmac_hip_set_gemm_min_n(1))
+    tm.binding.check(L.tmac_hip_debug_gemm_kernel(form))
     try:
         A = orc.preprocess_weights(case["w"], bits, bm, 16)
         S = case["sc"]

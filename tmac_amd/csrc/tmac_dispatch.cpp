@@ -46,6 +46,7 @@ static int32_t planes_multi(const tmac_hip_weights* const* wl, int nmat, const t
     ga.sc_f16 = w0->sc_dtype == F16; ga.out_f16 = out_dtype == TMAC_F16;
     ga.bimg = (const uint4*)ws->gimg; ga.colv = ws->gcol; ga.Npad = ws->gNpad; ga.N = N; ga.dump = comb_dump;
     ga.stamps = g_knobs.gemm_stamps;
+    ga.form = g_knobs.gemm_kernel == 2 ? 1 : g_knobs.gemm_kernel == 3 ? 2 : 0;
     hipError_t e = launch_gemm_planes(ga, st);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "plane-combined gemm: configuration or sizes not covered (LUT image and matrices must stay below 2 GB)");
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "plane-combined gemm launch: %s", hipGetErrorString(e));
@@ -143,7 +144,8 @@ extern "C" int32_t tmac_hip_debug_gemm_stamps(unsigned long long* dev_buffer) {
 }
 
 extern "C" int32_t tmac_hip_debug_gemm_kernel(int which) {
-    if (which < 0 || which > 1) return fail(TMAC_HIP_E_ARG, "gemm kernel selector must be 0 (auto) or 1 (k_gemm_onehot)");
+    if (which < 0 || which > 3)
+        return fail(TMAC_HIP_E_ARG, "gemm kernel selector must be 0 (auto), 1 (k_gemm_onehot), 2 / 3 (k_gemm_planes with eight- / four-wave workgroups)");
     g_knobs.gemm_kernel = which;
     return TMAC_HIP_OK;
 }

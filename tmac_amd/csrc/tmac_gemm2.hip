@@ -111,21 +111,33 @@ hipError_t launch_lut_image(const void* B, int act_f16, void* bimg, float* colv,
 }
 
 // ---------------------------------------------------------------------------------------------
-constexpr int P_NWV = 8;                           // waves per workgroup = K ranges
-constexpr int P_PAT_BYTES = 256 * 32 * 8;          // joint-index operand rows, 32 copies
-constexpr int P_BB_OFF = P_PAT_BYTES;              // half-table chunk of one act group: [wave][unit 2][pair 4][n 64] uint4
-constexpr int P_BB_WAVE = 8192;
-constexpr int P_SC_OFF = P_BB_OFF + P_NWV * P_BB_WAVE; // weight scales / zeros of the wave's 64 rows: [wave][buffer][sc 64 | zr 64] float
-constexpr int P_SC_WAVE = 2 * 512;
-constexpr int P_LDS_BYTES = P_SC_OFF + P_NWV * P_SC_WAVE;
+// Two forms of the workgroup (same tile, same arithmetic, same order of the fp32 sums within a K range):
+//   NWV = 8: eight K ranges, 32 copies of the operand rows (no bank conflict), 136 KB of LDS -- one workgroup per CU.  For
+//            launches with at most one tile per CU (o / down projection at N = 256): all of a CU's waves work on its one tile.
+//   NWV = 4: four K ranges, 16 copies (lanes j and j + 16 share one: two-way conflicts at most, the address needs one more
+//            shift), 68 KB -- TWO workgroups per CU, each with one wave per SIMD.  A tile's fixed phases (operand rows 2.3 us,
+//            K-range reduction and store 1.3 us, the wait for its slowest wave) then overlap the other workgroup's main
+//            loop, and a wave whose SIMD partner is in such a phase runs its steps 40 % faster (profiles/r03_gemm_planes_forms.txt).
+template <int NWV>
+struct PForm {
+    static constexpr int COPIES = NWV == 8 ? 32 : 16;
+    static constexpr int PAT_BYTES = 256 * COPIES * 8;          // joint-index operand rows
+    static constexpr int BB_OFF = PAT_BYTES;                    // half-table chunk of one act group: [wave][unit 2][pair 4][n 64] uint4
+    static constexpr int BB_WAVE = 8192;
+    static constexpr int SC_OFF = BB_OFF + NWV * BB_WAVE;       // weight scales / zeros of the wave's 64 rows: [wave][buffer][sc 64 | zr 64] float
+    static constexpr int SC_WAVE = 2 * 512;
+    static constexpr int LDS_BYTES = SC_OFF + NWV * SC_WAVE;    // >= NWV * 16384 (the reduction reuses the front)
+};
 
 typedef __attribute__((address_space(3))) void* p_lds_ptr;
 
 // Everything the main loop loads goes through buffer instructions: per-lane byte offsets are computed once, the part that
 // changes from act group to act group is a scalar offset (no vector address arithmetic in the loop).
-template <int BITS, bool ZP, bool DUMP, bool SCF16>
-__global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
+template <int BITS, bool ZP, bool DUMP, bool SCF16, int NWV>
+__global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
+    using PF = PForm<NWV>;
+    constexpr int P_NWV = NWV, P_BB_OFF = PF::BB_OFF, P_BB_WAVE = PF::BB_WAVE, P_SC_OFF = PF::SC_OFF, P_SC_WAVE = PF::SC_WAVE;
     constexpr int NJ = BITS;                   // uint4 per unit and row quad in the QUAD layout
     constexpr int WPU = BITS / 2;              // uint4 of a unit's weights one lane needs per tile row (W2: both steps in one)
     const Shape& s = a.s;
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
     // ---- per-lane constants and the first loads (they do not need the operand rows built below) ------------------------
     // v_perm selector that builds an operand-row address from a weight dword: byte 0 = copy offset, byte 1 = byte beta of the dword
     const uint32_t psel = 0x0c0c0000u | ((4u + (lane & 3)) << 8);
-    const uint32_t copyoff = (uint32_t)j * 8u;
+    const uint32_t copyoff = NWV == 8 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u;   // (16 copies: entry stride 128 B = the perm's 256 B halved)
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.W), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.bimg), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.colv), (short)0, 0x7fffffff, 0x00020000);
@@ -194,7 +206,8 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
         }
     };
     auto pat_row = [&](uint32_t d) -> uint2 {
-        return *reinterpret_cast<const uint2*>(plds + __builtin_amdgcn_perm(d, copyoff, psel));
+        const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
+        return *reinterpret_cast<const uint2*>(plds + (NWV == 8 ? ad : ad >> 1));
     };
     auto load_staged = [&](int g) {            // scale / zero of row (row0 + lane), weight group g -> registers, raw (converted when written to LDS)
         const int quad = min((row0 >> 2) + (lane >> 2), nq - 1);
@@ -262,9 +275,10 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
             const uint32_t by8 = (uint32_t)(v & 0xff) << (8 * (e & 3));
             if (e < 4) lo |= by8; else hi |= by8;
         }
-        uint4* pt = reinterpret_cast<uint4*>(plds) + b * 16 + (tid >> 8) * 8;
+        // NWV = 8: two threads per entry (256 B = 32 copies), NWV = 4: one (128 B = 16 copies)
+        uint4* pt = reinterpret_cast<uint4*>(plds) + (NWV == 8 ? b * 16 + (tid >> 8) * 8 : b * 8);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo, hi);     // 8 consecutive entries (lanes) -> 8 different 16-byte slots of the 256-byte rows
+        for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo, hi);     // 8 consecutive entries (lanes) -> 8 different 16-byte slots of the rows
     }
     __syncthreads();
 
@@ -316,7 +330,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
         PSTAMP(kk - k_lo, 0);
         // the older wave of a SIMD wins every issue conflict (its four K ranges finish ~15 % earlier and then wait at the
         // reduction): alternate the priority between the two waves of a SIMD step by step
-        if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        if (NWV == 8) { if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk of kk is in LDS, its weights, column values and the staged scales in registers
         if (more) {
             write_staged(g + 1);
@@ -448,7 +462,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 16 / P_NWV; ++i) {
         const int idx = tid + 64 * P_NWV * i, nl = idx >> 4, sl = idx & 15;
         const unsigned char* p = plds + nl * 256 + ((sl ^ (nl & 15)) * 16);
         p4f_t v = *reinterpret_cast<const p4f_t*>(p);
@@ -477,9 +491,11 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes(Gemm2Args a) {
 // runs once per output -- bit for bit what the GEMV kernel and the oracle compute from the per-plane totals (comb / 2 =
 // sum_p alpha_p * total_p is exact in fp32: |comb| < 2^24).  2-bit weights (the signed operand rows need no bias term).
 // The LUT image comes from k_preprocess_pairs_row (tmac_quad.hip), colv holds lut_scales | lut_biases with one act group.
-template <bool DUMP>
-__global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes_us(Gemm2Args a) {
+template <bool DUMP, int NWV>
+__global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
+    using PF = PForm<NWV>;
+    constexpr int P_NWV = NWV, P_BB_OFF = PF::BB_OFF, P_BB_WAVE = PF::BB_WAVE;
     constexpr int NJ = 2;
     const Shape& s = a.s;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -497,7 +513,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes_us(Gemm2Args a) {
     const int k_lo = (w * nk) / P_NWV, k_end = ((w + 1) * nk) / P_NWV;        // 64-activation steps of this wave
 
     const uint32_t psel = 0x0c0c0000u | ((4u + (lane & 3)) << 8);
-    const uint32_t copyoff = (uint32_t)j * 8u;
+    const uint32_t copyoff = NWV == 8 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u;
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.W), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.bimg), (short)0, 0x7fffffff, 0x00020000);
     int wvoff[2];
@@ -525,7 +541,10 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes_us(Gemm2Args a) {
             wv[ul][rt] = make_uint4(v[0], v[1], v[2], v[3]);
         }
     };
-    auto pat_row = [&](uint32_t d) -> uint2 { return *reinterpret_cast<const uint2*>(plds + __builtin_amdgcn_perm(d, copyoff, psel)); };
+    auto pat_row = [&](uint32_t d) -> uint2 {
+        const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
+        return *reinterpret_cast<const uint2*>(plds + (NWV == 8 ? ad : ad >> 1));
+    };
     const bool work = k_lo < k_end;
     if (work) { dma_chunk(k_lo); load_weights(k_lo, 0); load_weights(k_lo, 1); }
     {
@@ -539,7 +558,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes_us(Gemm2Args a) {
             const uint32_t by8 = (uint32_t)(v & 0xff) << (8 * (e & 3));
             if (e < 4) lo |= by8; else hi |= by8;
         }
-        uint4* pt = reinterpret_cast<uint4*>(plds) + b * 16 + (tid >> 8) * 8;
+        uint4* pt = reinterpret_cast<uint4*>(plds) + (NWV == 8 ? b * 16 + (tid >> 8) * 8 : b * 8);
 #pragma unroll
         for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo, hi);
     }
@@ -554,7 +573,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes_us(Gemm2Args a) {
             for (int r = 0; r < 16; ++r) acc[rt][nt][r] = 0;
     for (int kk = k_lo; kk < k_end; ++kk) {
         const bool next = kk + 1 < k_end;
-        if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        if (NWV == 8) { if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         p4i_t bv[2][4];
 #pragma unroll
@@ -600,7 +619,7 @@ __global__ __launch_bounds__(64 * P_NWV) void k_gemm_planes_us(Gemm2Args a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 16 / P_NWV; ++i) {
         const int idx = tid + 64 * P_NWV * i, nl = idx >> 4, sl = idx & 15;
         const unsigned char* p = plds + nl * 256 + ((sl ^ (nl & 15)) * 16);
         p4i_t v = *reinterpret_cast<const p4i_t*>(p);
@@ -657,35 +676,37 @@ hipError_t launch_gemm_planes(const Gemm2Args& a_in, hipStream_t st) {
     while ((64 << a.apg_shift) < a.s.gs) ++a.apg_shift;
     a.gx = gx;
     a.gy = (a.N + 63) / 64;
-    dim3 g(((gx + 7) & ~7) * a.gy), b(64 * P_NWV);
-    if (a.s.m_groups >= 1) {
-        static bool attr_us[2] = {false, false};
-        const int d = a.dump ? 1 : 0;
-        const void* fn = d ? reinterpret_cast<const void*>(&k_gemm_planes_us<true>) : reinterpret_cast<const void*>(&k_gemm_planes_us<false>);
-        if (!attr_us[d]) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
-            if (e != hipSuccess) return e;
-            attr_us[d] = true;
-        }
-        if (d) hipLaunchKernelGGL((k_gemm_planes_us<true>), g, b, P_LDS_BYTES, st, a);
-        else hipLaunchKernelGGL((k_gemm_planes_us<false>), g, b, P_LDS_BYTES, st, a);
-        return hipGetLastError();
+    // form: one tile per CU at most -> eight waves on it; more -> two four-wave workgroups per CU (see PForm)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
+        n_cu = v;
     }
-#define PL4(B, Z, D, H) do { \
+    const int nwv = a.form == 1 ? 8 : a.form == 2 ? 4 : (gx * a.gy > n_cu ? 4 : 8);
+    dim3 g(((gx + 7) & ~7) * a.gy), b(64 * nwv);
+    const int lds_bytes = nwv == 8 ? PForm<8>::LDS_BYTES : PForm<4>::LDS_BYTES;
+#define PLAUNCH(KERNEL) do { \
         static bool attr_set = false; \
         if (!attr_set) { \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_planes<B, Z, D, H>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES); \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes); \
             if (e != hipSuccess) return e; \
             attr_set = true; \
         } \
-        hipLaunchKernelGGL((k_gemm_planes<B, Z, D, H>), g, b, P_LDS_BYTES, st, a); } while (0)
-#define PL3(B, Z, D) do { if (a.sc_f16) PL4(B, Z, D, true); else PL4(B, Z, D, false); } while (0)
+        hipLaunchKernelGGL((KERNEL), g, b, lds_bytes, st, a); } while (0)
+#define PLW(...) do { if (nwv == 8) PLAUNCH((__VA_ARGS__, 8>)); else PLAUNCH((__VA_ARGS__, 4>)); } while (0)
+    if (a.s.m_groups >= 1) {
+        if (a.dump) PLW(k_gemm_planes_us<true); else PLW(k_gemm_planes_us<false);
+        return hipGetLastError();
+    }
+#define PL3(B, Z, D) do { if (a.sc_f16) PLW(k_gemm_planes<B, Z, D, true); else PLW(k_gemm_planes<B, Z, D, false); } while (0)
 #define PL2(B, Z) do { if (a.dump) PL3(B, Z, true); else PL3(B, Z, false); } while (0)
     if (a.s.bits == 2) { if (a.s.zero_point) PL2(2, true); else PL2(2, false); }
     else { if (a.s.zero_point) PL2(4, true); else PL2(4, false); }
 #undef PL2
 #undef PL3
-#undef PL4
+#undef PLW
+#undef PLAUNCH
     return hipGetLastError();
 }
 

@@ -90,7 +90,7 @@ struct DevBuf {
 struct Knobs {
     int variant = V_AUTO;          // tmac_hip_set_variant
     int gemm_min_n = 32;           // tmac_hip_set_gemm_min_n: measured crossover on MI355X (llama-2-7B W2 shapes): GEMV loop ~1.7 us per row, GEMM 40-60 us up to 64 rows
-    int gemm_kernel = 0;           // N > 1 kernel: 0 = k_gemm_planes where it covers the configuration, 1 = k_gemm_onehot (tmac_hip_debug_gemm_kernel)
+    int gemm_kernel = 0;           // N > 1 kernel: 0 = k_gemm_planes where it covers the configuration, 1 = k_gemm_onehot, 2 / 3 = k_gemm_planes forced to eight- / four-wave workgroups (tmac_hip_debug_gemm_kernel)
     int pairs_min_n = 2;           // tmac_hip_preprocessor_dev: rows from which the pair-wise LUT build is used (tmac_hip_debug_pairs_min_n)
     int fa_mode = 0;               // fast aggregation for weights registered from now on (tmac_hip_set_fast_aggregation)
     int force_ft = 0, force_wpq = 0;   // A/B knobs of the quad kernel (0 = heuristic)

@@ -81,6 +81,7 @@ struct Gemm2Args {
     int gx, gy;               // filled by the launcher: row blocks (64 rows, all matrices) and token blocks (64 rows of activations)
     int apg_shift;            // filled by the launcher: log2(act groups per weight group)
     unsigned long long* stamps; // optional s_memrealtime stamps of workgroup 0: [wave 8][step 64][8] (profiling; tools/gemm2_stamps.py)
+    int form;                 // 0: by the number of tiles | 1: eight-wave workgroups, one per CU | 2: four-wave workgroups, two per CU
 };
 
 struct GemvArgs {

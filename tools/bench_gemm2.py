@@ -1,6 +1,7 @@
 """Per-shape timing of the N > 1 kernels on the llama-2-7B shapes: LUT image build and k_gemm_planes through the fused
 entry point (one call = k_lut_image + k_gemm_planes) and the GEMM alone, replayed from a hipGraph.
-usage: bench_gemm2.py [N] [bits] [kernel: 0 = k_gemm_planes (default), 1 = k_gemm_onehot]"""
+usage: bench_gemm2.py [N] [bits] [kernel: 0 = k_gemm_planes, form by tile count (default), 1 = k_gemm_onehot, 2 / 3 = k_gemm_planes with
+eight- / four-wave workgroups]"""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -35,7 +36,7 @@ def timeit(fn, reps=20):
     return best
 
 
-print("N =", N, " bits =", BITS, " kernel =", "k_gemm_onehot" if KERNEL else "k_gemm_planes")
+print("N =", N, " bits =", BITS, " kernel =", ["k_gemm_planes (auto form)", "k_gemm_onehot", "k_gemm_planes, 8 waves", "k_gemm_planes, 4 waves"][KERNEL])
 for name, Mw, K, nshare in [("o", 4096, 4096, 1), ("qkv", 4096, 4096, 3), ("gate_up", 11008, 4096, 2), ("down", 4096, 11008, 1)]:
     ws, outs = [], []
     for _ in range(nshare):

@@ -683,7 +683,8 @@ hipError_t launch_gemm_planes(const Gemm2Args& a_in, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
         n_cu = v;
     }
-    const int nwv = a.form == 1 ? 8 : a.form == 2 ? 4 : (gx * a.gy > n_cu ? 4 : 8);
+    // (4-bit weights: the four-wave form only pays from about four tiles per CU on -- q/k/v at N = 256, three per CU, loses 6 % with it)
+    const int nwv = a.form == 1 ? 8 : a.form == 2 ? 4 : (gx * a.gy > (a.s.bits == 4 && a.s.m_groups < 1 ? 4 : 1) * n_cu ? 4 : 8);
     dim3 g(((gx + 7) & ~7) * a.gy), b(64 * nwv);
     const int lds_bytes = nwv == 8 ? PForm<8>::LDS_BYTES : PForm<4>::LDS_BYTES;
 #define PLAUNCH(KERNEL) do { \

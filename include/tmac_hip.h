@@ -271,7 +271,8 @@ int32_t tmac_hip_debug_quad_config(int force_threads, int force_waves_per_quad);
 int32_t tmac_hip_debug_stamps(unsigned long long* dev_buffer);
 int32_t tmac_hip_debug_pairs_min_n(int n);
 /* N > 1 kernel selection and parity taps.  0 (default): k_gemm_planes (bit-planes combined inside the matrix-core operand,
- * tmac_gemm2.hip) wherever it covers the configuration (2- and 4-bit weights, per-group scales, act_group_size 64);
+ * tmac_gemm2.hip) wherever it covers the configuration (1- to 4-bit weights with per-group scales and act_group_size 64; 2-bit
+ * weights with a unified scale);
  * 1: always k_gemm_onehot (one matrix-core row per bit-plane row).  2 / 3: k_gemm_planes with its eight-wave (one workgroup per
  * CU) / four-wave (two per CU) workgroup form forced; 0 picks by the number of tiles of the launch (tmac_gemm2.hip, PForm).
  * tmac_hip_debug_gemm_comb_sums: int32 [N][Mw][K/64], the integers sum_p 2^p PS_p (PS_p as tmac_hip_qgemm_partial_sums

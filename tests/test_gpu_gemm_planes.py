@@ -75,6 +75,13 @@ CASES = [
     (64, 512, 2, 128, 256, True, 70),        # group size 256: 2 weight groups, six of the eight waves idle
     (1088, 11008, 2, 128, 128, True, 40),    # K = 11008: 86 weight groups
     (192, 4096, 4, 256, 128, True, 256),
+    # 1- and 3-bit weights: a byte of the layout mixes tables, 16-byte operand-row entries (tmac_gemm2.hip, ODD)
+    (128, 1024, 1, 64, 128, True, 64),
+    (256, 1024, 1, 64, 64, False, 130),
+    (192, 2048, 3, 192, 128, True, 40),
+    (320, 3200, 3, 192, 128, False, 33),     # ragged K ranges, rows and tokens
+    (1088, 11008, 3, 192, 128, True, 16),
+    (64, 4096, 1, 64, 256, True, 256),
 ]
 
 

@@ -257,7 +257,9 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT image launch: %s", hipGetErrorString(e));
         return planes_multi(wl, nmat, ws, C_list, out_dtype, N, nullptr, st);
     }
-    if ((s0.ags == 64 || (s0.ags == s0.K && s0.K <= 12288)) && g_knobs.variant != V_REF_LAYOUT) {
+    bool onehot_all = true;       // (1- / 3-bit weights reach this point only when k_gemm_planes cannot take them: they go to the row loop)
+    for (int i = 0; i < nmat; ++i) onehot_all = onehot_all && gemm_onehot_supported(wl[i]->s);
+    if (onehot_all && (s0.ags == 64 || (s0.ags == s0.K && s0.K <= 12288)) && g_knobs.variant != V_REF_LAYOUT) {
         // only the one-hot GEMM reads this workspace: build the half-table image alone, two tables per lane
         rc = check_lut_shape(ws, s0.K, N, s0.ags);
         if (rc) return rc;
@@ -271,7 +273,7 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
         rc = tmac_hip_preprocessor_dev(ws, B_dev, act_dtype, s0.K, N, s0.ags, st);
     }
     if (rc) return rc;
-    bool same = g_knobs.variant != V_REF_LAYOUT;      // (the caller has established that the GEMM pays for these matrices)
+    bool same = onehot_all && g_knobs.variant != V_REF_LAYOUT;      // (the caller has established that the GEMM pays for these matrices)
     for (int i = 0; i < nmat && same; ++i) {
         const Shape &x = wl[i]->s, &y = s0;
         same = x.lay == 2 && wl[i]->lo_ok && x.ts == 8 && x.bits == y.bits && x.gs == y.gs && x.zero_point == y.zero_point &&
@@ -290,7 +292,8 @@ int32_t tmac_host::fused_impl(const tmac_hip_weights* const* wl, int nmat, const
         bool ok = true;
         long rows = 0;
         for (int i = 0; i < nmat; ++i) {
-            ok = ok && wl[i] && C_list[i] && gemm_onehot_supported(wl[i]->s) && wl[i]->s.K == wl[0]->s.K && wl[i]->s.ags == wl[0]->s.ags;
+            ok = ok && wl[i] && C_list[i] && (gemm_onehot_supported(wl[i]->s) || planes_ok(wl[i])) && wl[i]->s.K == wl[0]->s.K &&
+                 wl[i]->s.ags == wl[0]->s.ags;
             if (ok) rows += wl[i]->s.Mw;
         }
         if (ok && gemm_pays(wl[0]->s, rows, N)) return fused_prefill(wl, nmat, B_dev, act_dtype, C_list, out_dtype, N, st);

@@ -19,6 +19,13 @@
 // byte-wise carry handling; the bias (15 per operand byte) leaves with the sum of the table entries, which the LUT build
 // provides per (n, kk) and the epilogue folds into the int -> float conversion constant.
 //
+// 1- and 3-bit weights (round 3): the layout packs nibble quad q = table * bits + plane, so a byte of an odd width mixes TABLES,
+// not just planes.  Its table entry is 16 bytes: the operand row of the low nibble | the operand row of the high nibble, each a
+// single plane's +-1 (W3: + 1 per byte, the W4 trick) -- 16 copies, ds_read_b128 (whose lane groups are 16 wide).  W1: one gather
+// IS the A operand of a 32-deep step (two tables).  W3: three gathers per table pair, bytes (t0p0|t0p1), (t0p2|t1p0), (t1p1|t1p2):
+// row(t0) = lo(G0) + 2 hi(G0) + 4 lo(G1), row(t1) = hi(G1) + 2 lo(G2) + 4 hi(G2); the +7 per operand byte leaves like W4's +15.
+// Here a lane holds ALL tables of one unit (its k half picks the unit of the act group), not half the tables of both: whole uint4.
+//
 // v_mfma_i32_32x32x32_i8: one instruction = 32 output rows x 32 activation rows x 4 tables.  Wave tile 64 x 64 (2 x 2
 // MFMA tiles); a workgroup = 8 waves = ONE 64 x 64 output tile, the waves split K by weight groups and reduce through
 // LDS at the end (at N = 256 a llama-2-7B projection has only 256 such tiles: one per CU; a larger workgroup tile would
@@ -139,7 +146,10 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     using PF = PForm<NWV>;
     constexpr int P_NWV = NWV, P_BB_OFF = PF::BB_OFF, P_BB_WAVE = PF::BB_WAVE, P_SC_OFF = PF::SC_OFF, P_SC_WAVE = PF::SC_WAVE;
     constexpr int NJ = BITS;                   // uint4 per unit and row quad in the QUAD layout
-    constexpr int WPU = BITS / 2;              // uint4 of a unit's weights one lane needs per tile row (W2: both steps in one)
+    constexpr bool ODD = (BITS & 1) != 0;      // 1- / 3-bit weights: 16-byte table entries, a lane holds one whole unit per tile row
+    constexpr int WPU = ODD ? BITS : BITS / 2; // uint4 of weights per lane, tile row and [even widths: unit | odd: act group]
+    constexpr int WUN = ODD ? 1 : 2;
+    constexpr int BIASB = BITS == 4 ? 15 : BITS == 3 ? 7 : 0;   // what the biased operand bytes add per half-table entry
     const Shape& s = a.s;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int kb = lane >> 5, j = lane & 31;
@@ -163,7 +173,9 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // ---- per-lane constants and the first loads (they do not need the operand rows built below) ------------------------
     // v_perm selector that builds an operand-row address from a weight dword: byte 0 = copy offset, byte 1 = byte beta of the dword
     const uint32_t psel = 0x0c0c0000u | ((4u + (lane & 3)) << 8);
-    const uint32_t copyoff = NWV == 8 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u;   // (16 copies: entry stride 128 B = the perm's 256 B halved)
+    // even widths: 32 (16) copies of 8 bytes; odd: 16 (8) copies of 16 bytes.  Four-wave form: entry stride 128 B = the perm's 256 B halved
+    const uint32_t copyoff = ODD ? (NWV == 8 ? (uint32_t)(lane & 15) * 16u : (uint32_t)(lane & 7) * 32u)
+                                 : (NWV == 8 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.W), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.bimg), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.colv), (short)0, 0x7fffffff, 0x00020000);
@@ -171,12 +183,13 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         const int quad = min((row0 >> 2) + rt * 8 + (j >> 2), nq - 1);
-        wvoff[rt] = ((quad * nst * NJ + (BITS == 2 ? kb : 2 * kb)) * 64) * 16;
+        wvoff[rt] = ODD ? (quad * nst * NJ * 64 + kb) * 16                      // the unit of the act group this lane's k half stands for
+                        : ((quad * nst * NJ + (BITS == 2 ? kb : 2 * kb)) * 64) * 16;
     }
     const int bvoff = (n0 + lane) * 16, cvoff = (n0 + j) * 4;
     const uint32_t bb_wave = P_BB_OFF + w * P_BB_WAVE, sc_wave = P_SC_OFF + w * P_SC_WAVE;
 
-    uint4 wv[2][2][WPU];                       // weights of the act group: [unit][tile row][..]
+    uint4 wv[WUN][2][WPU];                     // weights of the act group: [unit][tile row][..]
     uint32_t st_sc[2] = {0u, 0u}, st_zr[2] = {0u, 0u};   // raw scale / zero of row (row0 + lane) of the next two weight groups (by parity), staged
     float lbs[2] = {0.f, 0.f};                 // lut_biases summed over the act groups of the current weight group, per n tile
 
@@ -196,7 +209,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     };
     auto load_weights = [&](int kk, int rt) {  // tile row rt of the act group's two units
 #pragma unroll
-        for (int ul = 0; ul < 2; ++ul) {
+        for (int ul = 0; ul < WUN; ++ul) {
             const int u = 2 * kk + ul, so = ((u >> 6) * NJ * 64 + (u & 63)) * 16;
 #pragma unroll
             for (int q = 0; q < WPU; ++q) {
@@ -208,6 +221,10 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     auto pat_row = [&](uint32_t d) -> uint2 {
         const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
         return *reinterpret_cast<const uint2*>(plds + (NWV == 8 ? ad : ad >> 1));
+    };
+    auto pat_row2 = [&](uint32_t d) -> uint4 {  // odd widths: the operand rows of the byte's two nibbles
+        const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
+        return *reinterpret_cast<const uint4*>(plds + (NWV == 8 ? ad : ad >> 1));
     };
     auto load_staged = [&](int g) {            // scale / zero of row (row0 + lane), weight group g -> registers, raw (converted when written to LDS)
         const int quad = min((row0 >> 2) + (lane >> 2), nq - 1);
@@ -250,7 +267,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int c = 0; c < (BITS == 4 ? 3 : 2); ++c)
+            for (int c = 0; c < (BIASB ? 3 : 2); ++c)
                 cn[nt][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, cvoff + nt * 128, (c * G + kk) * a.Npad * 4, 0));
     };
     const bool work = k_lo < k_end;
@@ -266,19 +283,27 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // ---- joint-index operand rows: entry b = (i1 << 4) | i0, byte e = s(i0) [e == i0 & 7] + 2 s(i1) [e == i1 & 7] (+ 3 for W4)
     {
         const int b = tid & 255, i0 = b & 15, i1 = b >> 4;
-        uint32_t lo = 0, hi = 0;
+        uint32_t lo = 0, hi = 0, lo1 = 0, hi1 = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int v = (BITS == 4) ? 3 : 0;
-            if (e == (i0 & 7)) v += (i0 & 8) ? -1 : 1;
-            if (e == (i1 & 7)) v += (i1 & 8) ? -2 : 2;
-            const uint32_t by8 = (uint32_t)(v & 0xff) << (8 * (e & 3));
-            if (e < 4) lo |= by8; else hi |= by8;
+            if (ODD) {                         // one plane per nibble: +-1 (W3: + 1), low nibble's row | high nibble's row
+                const int v0 = (BITS == 3 ? 1 : 0) + (e == (i0 & 7) ? ((i0 & 8) ? -1 : 1) : 0);
+                const int v1 = (BITS == 3 ? 1 : 0) + (e == (i1 & 7) ? ((i1 & 8) ? -1 : 1) : 0);
+                const uint32_t b0 = (uint32_t)(v0 & 0xff) << (8 * (e & 3)), b1 = (uint32_t)(v1 & 0xff) << (8 * (e & 3));
+                if (e < 4) { lo |= b0; lo1 |= b1; } else { hi |= b0; hi1 |= b1; }
+            } else {
+                int v = (BITS == 4) ? 3 : 0;
+                if (e == (i0 & 7)) v += (i0 & 8) ? -1 : 1;
+                if (e == (i1 & 7)) v += (i1 & 8) ? -2 : 2;
+                const uint32_t by8 = (uint32_t)(v & 0xff) << (8 * (e & 3));
+                if (e < 4) lo |= by8; else hi |= by8;
+            }
         }
-        // NWV = 8: two threads per entry (256 B = 32 copies), NWV = 4: one (128 B = 16 copies)
+        if (!ODD) { lo1 = lo; hi1 = hi; }
+        // NWV = 8: two threads per entry (256 B = 32 copies of 8 bytes / 16 of 16), NWV = 4: one (128 B = 16 / 8 copies)
         uint4* pt = reinterpret_cast<uint4*>(plds) + (NWV == 8 ? b * 16 + (tid >> 8) * 8 : b * 8);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo, hi);     // 8 consecutive entries (lanes) -> 8 different 16-byte slots of the rows
+        for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo1, hi1);   // 8 consecutive entries (lanes) -> 8 different 16-byte slots of the rows
     }
     __syncthreads();
 
@@ -299,7 +324,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // exactly for |comb| < 2^21 (it is < 2^19 here), so int -> float is one packed subtraction per pair.  The 16 registers are
     // made opaque to the compiler, which otherwise rebuilds the constant vector with 15 moves in front of every chain.
     // W4 has no registers to spare for that: its chains start from zero and the conversion is 16 v_cvt_f32_i32 per tile.
-    constexpr bool MAGIC = BITS == 2;
+    constexpr bool MAGIC = BITS <= 2;
     constexpr int CI = MAGIC ? 0x40400000 : 0;
     p16i_t cinit = {CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI};
     if (MAGIC) asm volatile("" : "+v"(cinit));
@@ -310,7 +335,17 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     auto build_av = [&](int rt, p4i_t (&av)[4]) {       // A operands of tile row rt: the joint plane index of (row, table) selects the operand row
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if constexpr (BITS == 2) {
+            if constexpr (BITS == 1) {             // dword ks of the unit = tables 2 ks, 2 ks + 1
+                const uint4 q = wv[0][rt][0];
+                const uint4 g = pat_row2(ks == 0 ? q.x : ks == 1 ? q.y : ks == 2 ? q.z : q.w);
+                av[ks] = (p4i_t){(int)g.x, (int)g.y, (int)g.z, (int)g.w};
+            } else if constexpr (BITS == 3) {      // dwords 3 ks .. 3 ks + 2 of the unit's twelve
+                const uint32_t dw[12] = {wv[0][rt][0].x, wv[0][rt][0].y, wv[0][rt][0].z, wv[0][rt][0].w, wv[0][rt][1].x, wv[0][rt][1].y,
+                                         wv[0][rt][1].z, wv[0][rt][1].w, wv[0][rt][2].x, wv[0][rt][2].y, wv[0][rt][2].z, wv[0][rt][2].w};
+                const uint4 g0 = pat_row2(dw[3 * ks]), g1 = pat_row2(dw[3 * ks + 1]), g2 = pat_row2(dw[3 * ks + 2]);
+                av[ks] = (p4i_t){(int)(g0.x + (g0.z << 1) + (g1.x << 2)), (int)(g0.y + (g0.w << 1) + (g1.y << 2)),
+                                 (int)(g1.z + (g2.x << 1) + (g2.z << 2)), (int)(g1.w + (g2.y << 1) + (g2.w << 2))};
+            } else if constexpr (BITS == 2) {
                 const uint4 q = wv[ks >> 1][rt][0];
                 const uint2 t0 = pat_row((ks & 1) ? q.z : q.x), t1 = pat_row((ks & 1) ? q.w : q.y);
                 av[ks] = (p4i_t){(int)t0.x, (int)t0.y, (int)t1.x, (int)t1.y};
@@ -343,7 +378,9 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (((ks >> 1) * 4 + 2 * kb + (ks & 1)) * 64 + nt * 32 + j) * 16);
+                // even widths: this k half = pair 2 kb + (ks & 1) of unit ks >> 1; odd: pair ks of unit kb
+                const int pslot = ODD ? kb * 4 + ks : (ks >> 1) * 4 + 2 * kb + (ks & 1);
+                const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (pslot * 64 + nt * 32 + j) * 16);
                 bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
             }
         build_av(0, av0);
@@ -359,8 +396,8 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
             H[nt] = MAGIC ? __fmul_rn(hls, 4194304.0f) : hls;
             hlbx[nt] = __fmul_rn(0.5f, lb[nt]);
             bias[nt] = 0;
-            if (BITS == 4) {
-                const float hs15 = __fmul_rn(15.0f, cn[nt][2]);
+            if (BIASB) {
+                const float hs15 = __fmul_rn((float)BIASB, cn[nt][2]);
                 hlbx[nt] = __fmaf_rn(-hs15, hls, hlbx[nt]);
                 bias[nt] = (int)hs15;
             }
@@ -409,7 +446,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         };
 
         // tile pipeline: the MFMAs of tile t + 1 run under the fp32 chain of tile t (two accumulator sets)
-        constexpr bool SC2 = BITS == 2;        // W2: tile row 1's scales in registers of their own, fetched early (W4 has none to spare)
+        constexpr bool SC2 = BITS <= 2;        // W1, W2: tile row 1's scales in registers of their own, fetched early (W4 has none to spare)
         p16i_t ca, cb;
         p2f_t sc1s[SC2 ? 8 : 1];
         p2f_t (&sc1)[8] = *reinterpret_cast<p2f_t (*)[8]>(SC2 ? &sc1s[0] : &sc0[0]);
@@ -652,7 +689,7 @@ bool gemm_planes_us_supported(const Shape& s) {
 }
 
 bool gemm_planes_supported(const Shape& s) {
-    if (s.lay != 2 || (s.bits != 2 && s.bits != 4) || s.K % 64 != 0 || s.Mw % 4 != 0) return false;
+    if (s.lay != 2 || s.bits < 1 || s.bits > 4 || s.K % 64 != 0 || s.Mw % 4 != 0) return false;
     if (s.m_groups >= 1) return gemm_planes_us_supported(s);             // unified scale: k_gemm_planes_us
     const int apg = s.gs / 64;
     return s.ags == 64 && s.gs >= 64 && s.gs % 64 == 0 && s.K % s.gs == 0 && (apg & (apg - 1)) == 0;
@@ -702,8 +739,12 @@ hipError_t launch_gemm_planes(const Gemm2Args& a_in, hipStream_t st) {
     }
 #define PL3(B, Z, D) do { if (a.sc_f16) PLW(k_gemm_planes<B, Z, D, true); else PLW(k_gemm_planes<B, Z, D, false); } while (0)
 #define PL2(B, Z) do { if (a.dump) PL3(B, Z, true); else PL3(B, Z, false); } while (0)
-    if (a.s.bits == 2) { if (a.s.zero_point) PL2(2, true); else PL2(2, false); }
-    else { if (a.s.zero_point) PL2(4, true); else PL2(4, false); }
+    switch (a.s.bits) {
+        case 1: if (a.s.zero_point) PL2(1, true); else PL2(1, false); break;
+        case 2: if (a.s.zero_point) PL2(2, true); else PL2(2, false); break;
+        case 3: if (a.s.zero_point) PL2(3, true); else PL2(3, false); break;
+        default: if (a.s.zero_point) PL2(4, true); else PL2(4, false); break;
+    }
 #undef PL2
 #undef PL3
 #undef PLW

@@ -11,7 +11,7 @@ L = tmac_amd.lib()
 dev = torch.device("cuda")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 BITS = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-BM = 128 if BITS == 2 else 256
+BM = {1: 64, 2: 128, 3: 192, 4: 256}[BITS]
 KERNEL = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 tmac_amd.binding.check(L.tmac_hip_debug_gemm_kernel(KERNEL))
 L.tmac_hip_set_gemm_min_n(1)

@@ -189,3 +189,39 @@ def test_gemm_planes_unified_scale(tm, Mw, K, N, form):
     want = sum((cb[:, mrow(rows, p, bits)].astype(np.int64) << p) for p in range(bits))
     assert np.array_equal(comb[:, :, 0].astype(np.int64), want)
     assert np.array_equal(C.view(np.uint32), Cc.view(np.uint32))
+
+
+@pytest.mark.parametrize("bits,bm", [(1, 64), (3, 192), (2, 128)])
+def test_fused_entry_point_takes_the_planes_kernel(tm, bits, bm):
+    """tmac_hip_qgemm_fused_dev with N > 1 and two matrices that share the activations (gate / up): one LUT image build and ONE
+    k_gemm_planes launch for both -- also for 1- and 3-bit weights, which ran the GEMV kernel once per activation row before
+    round 3 -- outputs against the oracle and against the split entry points"""
+    import torch
+    K, gs, N, Mws = 2048, 128, 130, (192, 320)
+    L = tm.lib()
+    cases = [orc.make_case(700 + bits + i, Mw, K, N=N, bits=bits, gs=gs, ags=64, zero_point=True) for i, Mw in enumerate(Mws)]
+    B = cases[0]["B"]
+    wr = tm.TMACGeMMWrapper(act_group_size=64)
+    wr.set_workspace(K, N)
+    ws, refs = [], []
+    q, ls, lb = orc.preprocessor(B, 64)
+    for c, Mw in zip(cases, Mws):
+        A = orc.preprocess_weights(c["w"], bits, bm, 16)
+        S = orc.preprocess_scales(c["sc"], c["zr"], bits, bm)
+        ws.append(wr.register_weights(A, S, Mw, K, bits, tm.KCfg.make(Mw, K, bits, bm, 16, gs, 64, True, -1, N), scales_dtype=tm.F32, dev_dtype=tm.F32))
+        refs.append(orc.qgemm_float(A, q, S, ls, lb, Mw, K, N, bits, bm, 16, gs, 64, True))
+    Bt = torch.from_numpy(B).cuda()
+    outs = [torch.full((N, Mw), float("nan"), dtype=torch.float32, device="cuda") for Mw in Mws]
+    wr.fused(ws, Bt, outs, N)
+    torch.cuda.synchronize()
+    for o, ref in zip(outs, refs):
+        assert rel_err(o.cpu().numpy(), ref) <= 1e-5
+    # the split entry points (preprocessor + qgemm per matrix) take the same kernel: bit-identical outputs
+    wr.llama_cpp_init(Bt, Mws[0], K, N, bits)
+    for w, o, Mw in zip(ws, outs, Mws):
+        C2 = torch.full((N, Mw), float("nan"), dtype=torch.float32, device="cuda")
+        wr.llama_cpp_compute(w, C2, N)
+        torch.cuda.synchronize()
+        assert torch.equal(C2, o)
+    for w in ws:
+        w.free()

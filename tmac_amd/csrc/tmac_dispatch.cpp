@@ -9,7 +9,20 @@ static bool planes_covers(const Shape& s) { return g_knobs.gemm_kernel != 1 && s
 static bool gemm_pays(const Shape& s, long total_Mw, int N) {
     if (g_knobs.gemm_min_n <= 0) return false;
     if (g_knobs.gemm_min_n != 32) return N >= g_knobs.gemm_min_n;
-    if (planes_covers(s)) return N >= PLANES_MIN_N;
+    if (planes_covers(s)) {
+        // From how many activation rows on k_gemm_planes beats the GEMV kernel looped over the rows: measured on MI355X, llama-2-7B shapes,
+        // 1- to 4-bit weights (tools/bench_small_n.py, profiles/r03_small_n.txt).  The row loop costs ~3 us + N x (0.7 us + 0.155 us per MB
+        // of weights + 0.2 us per 1000 of K beyond 4096); the GEMM (6 + 14 K / 4096) us per wave of 64 x 64 tiles (x 1.18 for 3- / 4-bit
+        // operand rows) whatever N <= 64 is.  Crossovers (W2): o 14, q/k/v 7, gate/up 7, down 9 rows; the fixed 12 rows of round 2 -- which
+        // the fused entry point applied on top of a fixed 32 -- left up to 2 x on the table for 7-31 rows.  5 % margin for the row loop.
+        const double mb = (double)total_Mw * s.K * s.bits / 8e6, tiles = (double)((total_Mw + 63) / 64) * ((N + 63) / 64);
+        const double waves = tiles <= 256.0 ? 1.0 : s.bits == 4 ? (double)(((long)tiles + 255) / 256) : (s.bits == 3 ? 0.45 : 0.25) + tiles / 256.0;
+        const double tp = (6.0 + 14.0 * s.K / 4096.0) * waves * (s.bits >= 3 ? 1.18 : 1.0);
+        const double c1 = 0.7 + 0.155 * mb + 0.2 * (s.K > 4096 ? (s.K - 4096) / 1000.0 : 0.0);
+        int nmin = (int)((1.05 * tp - 3.0) / c1 + 0.999);
+        nmin = nmin < 4 ? 4 : nmin > 16 ? 16 : nmin;
+        return N >= nmin;
+    }
     return N >= 32 && (N >= 64 || (total_Mw * s.bits + 127) / 128 >= 128);
 }
 // one-hot MFMA GEMM over 1..4 matrices that share K, the quantisation config (checked by the callers) and the LUT in ws
@@ -288,7 +301,7 @@ int32_t tmac_host::fused_impl(const tmac_hip_weights* const* wl, int nmat, const
     bind_thread_device();
     if (!wl || !C_list || !B_dev || nmat < 1 || nmat > 4 || N < 1) return fail(TMAC_HIP_E_ARG, "bad fused arguments (1..4 matrices)");
     if (chain_recording() && !dump && !lut_tap) return chain_record(wl, nmat, B_dev, act_dtype, C_list, out_dtype, N);
-    if (g_knobs.gemm_min_n > 0 && N >= g_knobs.gemm_min_n && !dump && !lut_tap) {
+    if (g_knobs.gemm_min_n > 0 && N >= 2 && !dump && !lut_tap) {       // (gemm_pays applies the threshold: a set one, or the measured crossover)
         bool ok = true;
         long rows = 0;
         for (int i = 0; i < nmat; ++i) {

@@ -242,11 +242,13 @@ int32_t tmac_hip_selftest_mfma(const uint32_t* in_host, int32_t* out_host);
  * for 1- to 4-bit weights), 7 the same with the v_mqsad accumulate.  Affects weights
  * registered AFTER the call (the variant fixes their device layout).  For A/B benchmarking and tests. */
 int32_t tmac_hip_set_variant(int variant);
-/* tmac_hip_qgemm_dev with N >= n activation rows runs the one-hot MFMA GEMM (k_gemm_onehot: the table gather
- * written as an int8 contraction, same bit-exact integer sums) instead of looping the GEMV kernel over the
- * rows (qgemm.py:183-190); n = 0 disables it.  Default 32 (the measured crossover); at the default the GEMM additionally waits for
- * N >= 64 when the matrices of the call have fewer than 128 x 64 output rows x bits / 2 (an under-filled grid), any other value is taken literally.  QUAD-layout weights of 2 or 4 bits only (1/3-bit
- * weights loop the GEMV), per-group scales with act groups of 64 or the unified-scale (BitNet) flavour. */
+/* From n activation rows on the N > 1 entry points run an MFMA GEMM (k_gemm_planes, else k_gemm_onehot: the table gather written as
+ * an int8 contraction, same bit-exact integer sums) instead of looping the GEMV kernel over the rows (qgemm.py:183-190); n = 0
+ * disables it, any value other than the default 32 is taken literally.  At the default the library decides per launch: where
+ * k_gemm_planes covers the configuration (1- to 4-bit weights with per-group scales and act groups of 64, 2-bit with a unified scale)
+ * from the measured crossover on -- 7 to 16 rows depending on the matrices, tmac_dispatch.cpp gemm_pays; 12 rows through the split
+ * entry points, whose LUT build does not know the matrix -- else from 32 rows (64 when the matrices of the call have fewer than
+ * 128 x 64 output rows x bits / 2: an under-filled grid). */
 int32_t tmac_hip_set_gemm_min_n(int n);
 /* Fast aggregation (the reference's `-fa` build option, deploy/compile.py:167-174,223): the
  * looked-up bytes of an act group are folded by a tree of rounding-halving adds instead of being summed exactly

@@ -67,6 +67,9 @@ int32_t tmac_hip_init(int device);            /* selects the device; idempotent 
 const char* tmac_hip_last_error(void);        /* thread-local message of the last failure     */
 const char* tmac_hip_version(void);
 int32_t tmac_hip_device_count(void);
+/* 1 when p points into device memory (hipMalloc and friends), 0 for host memory of any kind (pageable, pinned) and for NULL.  For glue
+ * code that receives tensors from a host framework and must decide between staging and passing the pointer on (src/ggml_tmac_hip.cc). */
+int32_t tmac_hip_pointer_on_device(const void* p);
 
 /* kcfg.ini handling: same file format and section names as the reference
  * (deploy/compile.py:153-165; lookup tmac_gemm_wrapper.h:230-255).  `path` NULL -> $TMAC_KCFG_FILE. */

@@ -1,6 +1,7 @@
 // ggml_tmac_hip.cc — device-resident ggml op-hook glue on top of libtmac_hip.so's C-ABI (include/ggml-tmac-hip.h).
 // Plain C++ (no HIP headers): it binds tmac_hip.h exactly as a llama.cpp fork would.  The only device memory it owns is a
-// staging pair (activations in, outputs out); weights live in tmac_hip_weights handles.
+// staging pair (activations in, outputs out) for HOST tensors; tensors that already live in device memory are passed on as
+// they are; weights live in tmac_hip_weights handles.
 #include "../include/ggml-tmac-hip.h"
 
 #include <dlfcn.h>
@@ -112,16 +113,28 @@ extern "C" int ggml_tmac_hip_mul_mat(const struct tmac_ggml_tensor* w, const str
     const int N = (int)x->ne[1];
     if (x->ne[0] != h->K || dst->ne[0] != h->M || dst->ne[1] != N) return fail("shape mismatch");
     const size_t bx = sizeof(float) * (size_t)N * h->K, by = sizeof(float) * (size_t)N * h->M;
+    // Tensors of a device backend are passed on as they are; host tensors (ggml's CPU buffers, what the reference's fork hands over) are
+    // staged through pinned memory.  Either way the call returns when dst holds the result.
+    const bool x_dev = tmac_hip_pointer_on_device(x->data) == 1, y_dev = tmac_hip_pointer_on_device(dst->data) == 1;
     int rc;
-    if ((rc = grow(&g_dx, &g_px, &g_nx, bx)) || (rc = grow(&g_dy, &g_py, &g_ny, by))) return rc;
-    memcpy(g_px, x->data, bx);
-    if (hip.MemcpyAsync(g_dx, g_px, bx, 1 /* H2D */, g_stream) != 0) return fail("H2D copy failed");
+    const void* xin = x->data;
+    void* yout = dst->data;
+    if (!x_dev) {
+        if ((rc = grow(&g_dx, &g_px, &g_nx, bx))) return rc;
+        memcpy(g_px, x->data, bx);
+        if (hip.MemcpyAsync(g_dx, g_px, bx, 1 /* H2D */, g_stream) != 0) return fail("H2D copy failed");
+        xin = g_dx;
+    }
+    if (!y_dev) {
+        if ((rc = grow(&g_dy, &g_py, &g_ny, by))) return rc;
+        yout = g_dy;
+    }
     const tmac_hip_weights* wl[1] = {h->w};
-    void* cl[1] = {g_dy};
-    if ((rc = tmac_hip_qgemm_fused_dev(wl, 1, g_dx, TMAC_F32, cl, TMAC_F32, N, g_stream))) return rc;   // LUT build + mpGEMM, one launch at N = 1
-    if (hip.MemcpyAsync(g_py, g_dy, by, 2 /* D2H */, g_stream) != 0) return fail("D2H copy failed");
+    void* cl[1] = {yout};
+    if ((rc = tmac_hip_qgemm_fused_dev(wl, 1, xin, TMAC_F32, cl, TMAC_F32, N, g_stream))) return rc;   // LUT build + mpGEMM, one launch at N = 1
+    if (!y_dev && hip.MemcpyAsync(g_py, g_dy, by, 2 /* D2H */, g_stream) != 0) return fail("D2H copy failed");
     if (hip.StreamSynchronize(g_stream) != 0) return fail("stream synchronisation failed");
-    memcpy(dst->data, g_py, by);
+    if (!y_dev) memcpy(dst->data, g_py, by);
     return 0;
 }
 

@@ -111,14 +111,17 @@ def test_reference_wrapper_host_pointers_eight_threads(tm, tmp_path):
     print(r.stdout)
 
 
-@pytest.mark.parametrize("N", [1, 3])
-def test_ggml_op_hook_glue(tm, tmp_path, N):
+@pytest.mark.parametrize("N,where", [(1, "host"), (3, "host"), (1, "dev"), (3, "dev")])
+def test_ggml_op_hook_glue(tm, tmp_path, N, where):
     Mw, K, bits, bm = 1024, 4096, 2, 128
     d = fixtures(tmp_path, Mw, K, bits, bm, N=N)
     exe = os.path.join(d, "ggml_shim_main")
-    gxx(exe, os.path.join(ROOT, "tests", "cpp", "ggml_shim_main.cc"), os.path.join(ROOT, "src", "ggml_tmac_hip.cc"))
+    # (the device-tensor mode calls three HIP runtime functions itself: link the runtime libtmac_hip.so was built against)
+    gxx(exe, os.path.join(ROOT, "tests", "cpp", "ggml_shim_main.cc"), os.path.join(ROOT, "src", "ggml_tmac_hip.cc"),
+        extra=("-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"))
     env = dict(os.environ); env.pop("TMAC_KCFG_FILE", None)
-    r = subprocess.run([exe, d, str(Mw), str(K), str(bits), str(N)], capture_output=True, text=True, timeout=300, env=env)
+    r = subprocess.run([exe, d, str(Mw), str(K), str(bits), str(N)] + (["dev"] if where == "dev" else []), capture_output=True, text=True,
+                       timeout=300, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
 
 

@@ -65,6 +65,7 @@ def load_library() -> C.CDLL:
         "tmac_hip_last_error": ([], C.c_char_p),
         "tmac_hip_version": ([], C.c_char_p),
         "tmac_hip_device_count": ([], i32),
+        "tmac_hip_pointer_on_device": ([vp], i32),
         "tmac_hip_load_kcfg": ([C.c_char_p], i32),
         "tmac_hip_load_kcfg_ex": ([C.c_char_p, C.c_int], i32),
         "tmac_hip_clear_kcfg": ([], i32),

@@ -60,6 +60,13 @@ extern "C" int32_t tmac_hip_device_count(void) {
     int n = 0;
     return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
+extern "C" int32_t tmac_hip_pointer_on_device(const void* p) {
+    if (!p) return 0;
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) { (void)hipGetLastError(); return 0; }   // (plain malloc memory: not registered with HIP)
+    return at.type == hipMemoryTypeDevice ? 1 : 0;
+}
 extern "C" int32_t tmac_hip_set_fast_aggregation(int mode) {
     if (mode < 0 || mode > 2) return fail(TMAC_HIP_E_ARG, "unknown fast-aggregation mode %d", mode);
     g_knobs.fa_mode = mode;

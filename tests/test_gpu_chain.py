@@ -277,6 +277,30 @@ def test_random_chains(tm, seed):
     m.free()
 
 
+def test_chain_launch_inside_a_hip_graph(tm):
+    """the chain's ONE launch captured into a hipGraph (a decode step that also holds the attention kernels would be captured like this)
+    and replayed: every replay is a new generation of the hand-off tags, outputs as from the eager launch"""
+    import torch
+    m = Model(tm, SMALL, bits=2, zp=True, dev_f16=True, seed=91)
+    chain = m.record()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        chain.launch()                       # warm-up outside the capture (first use sets the kernel's LDS attribute)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        chain.launch()
+    for rep in range(3):
+        for os_ in m.outs:
+            for o in os_:
+                o.fill_(float("nan"))
+        g.replay()
+        m.check(chain, oracle_ops=[] if rep else None)
+    del g
+    chain.free()
+    m.free()
+
+
 def test_chain_equals_eager_sequence(tm):
     """the recorded calls issued one by one give the same final buffers as the chain (default launch configuration, so
     only to fp32 summation order: 1e-3 on fp16)"""

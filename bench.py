@@ -17,6 +17,7 @@ Synthetic data: uniform random weights, |N(0,1)|-shaped scales and zero points s
     bitnet-3b             configs[3]: BitNet-b1.58-3B shapes (3200/8640), ternary in 2 bits, one scale, act group = K, N = 1
     llama2-7b-w2-prefill  configs[4]: the W2 shapes at N = 256 (plane-combined one-hot MFMA GEMM; roofline bound "mfma")
     llama2-7b-w4-prefill  the W4 shapes at N = 256
+    bitnet-3b-prefill     the BitNet shapes at N = 256 (k_gemm_planes_us: int32 totals over the whole K, scale-final once per output)
 
 --path: chain = the step's fused calls recorded once and executed by ONE persistent launch (k_decode_chain; default where
 the configuration is covered); fused = one launch per fused call, replayed as a hipGraph; split = preprocessor + one
@@ -56,6 +57,8 @@ WORKLOADS = {
                       metric="W1.58A8 GEMV GB/s (BitNet-b1.58-3B all-layer decode, N=1)", weights="ternary in 2 bits, one scale, act_group = K (int32 path)"),
     "llama2-7b-w2-prefill": dict(tag="llama-2-7b-w2a8-prefill-256", mats=LLAMA, layers=32, bits=2, bm=128, gs=128, ags=64, zp=True, mg=-1, N=256,
                                  metric="W2A8 prefill tokens/s (llama-2-7B all-layer mpGEMM, N=256)", weights="W2 g128 zero-point, act_group 64"),
+    "bitnet-3b-prefill": dict(tag="bitnet-b1.58-3b-prefill-256", mats=BITNET, layers=26, bits=2, bm=128, gs=0, ags=0, zp=False, mg=1, N=256,
+                              metric="W1.58A8 prefill tokens/s (BitNet-b1.58-3B all-layer mpGEMM, N=256)", weights="ternary in 2 bits, one scale, act_group = K (int32 path)"),
     "llama2-7b-w4-prefill": dict(tag="llama-2-7b-w4a16-prefill-256", mats=LLAMA, layers=32, bits=4, bm=256, gs=128, ags=64, zp=True, mg=-1, N=256,
                                  metric="W4 (GPTQ-style) prefill tokens/s (llama-2-7B all-layer mpGEMM, N=256)", weights="W4 g128 zero-point, act_group 64"),
 }

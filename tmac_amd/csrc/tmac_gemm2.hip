@@ -150,6 +150,10 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     constexpr int WPU = ODD ? BITS : BITS / 2; // uint4 of weights per lane, tile row and [even widths: unit | odd: act group]
     constexpr int WUN = ODD ? 1 : 2;
     constexpr int BIASB = BITS == 4 ? 15 : BITS == 3 ? 7 : 0;   // what the biased operand bytes add per half-table entry
+#ifndef TMAC_G2_PIPE_MIN_BITS
+#define TMAC_G2_PIPE_MIN_BITS 4
+#endif
+    constexpr bool PIPE = BITS >= TMAC_G2_PIPE_MIN_BITS;         // instruction-level MFMA / fp32 interleave of a step (see the step loop)
     const Shape& s = a.s;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int kb = lane >> 5, j = lane & 31;
@@ -218,13 +222,21 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
             }
         }
     };
+    // (the dynamic LDS block starts at LDS address 0 -- the kernel has no static LDS -- so the perm's result IS the address: going through
+    // `plds + offset` costs a v_add_u32 with the relocated base, zero, per gather)
+    typedef unsigned int p2u_t __attribute__((ext_vector_type(2)));
+    typedef unsigned int p4u_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) const p2u_t* lds_u2_ptr;
+    typedef __attribute__((address_space(3))) const p4u_t* lds_u4_ptr;
     auto pat_row = [&](uint32_t d) -> uint2 {
         const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        return *reinterpret_cast<const uint2*>(plds + (NWV == 8 ? ad : ad >> 1));
+        const p2u_t v = *(lds_u2_ptr)(uintptr_t)(NWV == 8 ? ad : ad >> 1);
+        return make_uint2(v.x, v.y);
     };
     auto pat_row2 = [&](uint32_t d) -> uint4 {  // odd widths: the operand rows of the byte's two nibbles
         const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        return *reinterpret_cast<const uint4*>(plds + (NWV == 8 ? ad : ad >> 1));
+        const p4u_t v = *(lds_u4_ptr)(uintptr_t)(NWV == 8 ? ad : ad >> 1);
+        return make_uint4(v.x, v.y, v.z, v.w);
     };
     auto load_staged = [&](int g) {            // scale / zero of row (row0 + lane), weight group g -> registers, raw (converted when written to LDS)
         const int quad = min((row0 >> 2) + (lane >> 2), nq - 1);
@@ -402,7 +414,13 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
                 bias[nt] = (int)hs15;
             }
         }
-        if (next) { load_cols(kk + 1); load_weights(kk + 1, 0); }
+        // PIPE (4-bit weights): the loads of the next act group are issued unconditionally (the last step fetches its own act group
+        // again: same bytes into the same places, drained before the reduction), so that the whole step is ONE basic block and the
+        // matrix-core chains and the fp32 chains are interleaved instruction by instruction (sched_group_barrier): a chain is four
+        // DEPENDENT MFMAs -- 32 cycles each during which the wave issues nothing unless independent work sits between them.  Measured
+        // (profiles/r03_gemm_planes_forms.txt D): W4 prefill -3 %; W1, W2, W3 within +-1 % (kept in the coarse order).
+        const int kn = PIPE ? (next ? kk + 1 : kk) : kk + 1;
+        if (PIPE || next) { load_cols(kn); load_weights(kn, 0); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 
@@ -450,6 +468,40 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         p16i_t ca, cb;
         p2f_t sc1s[SC2 ? 8 : 1];
         p2f_t (&sc1)[8] = *reinterpret_cast<p2f_t (*)[8]>(SC2 ? &sc1s[0] : &sc0[0]);
+        if constexpr (PIPE) {
+        // MFMA | a few fp32 / address instructions [| LDS reads] | MFMA | ...: four times per region
+#define TMAC_G2_GROUPS(VALU_PER, DS_PER) do { _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) { \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0); \
+            if (DS_PER) __builtin_amdgcn_sched_group_barrier(0x100, DS_PER, 0); } } while (0)
+        chain(av0, 0, ca);
+        dma_part(kn, 0);
+        dma_part(kn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // region 1: chain (0, 1) | fp32 chain of tile (0, 0), operand-row gathers of tile row 1, its weights of the next act group
+        chain(av0, 1, cb);
+        epilogue(0, 0, ca, sc0);
+        build_av(1, av1);
+        if (SC2) read_rows(cbuf, 0, 1, sc1);
+        load_weights(kn, 1);
+        TMAC_G2_GROUPS(8, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        // region 2: chain (1, 0) | fp32 chain of tile (0, 1)
+        chain(av1, 0, ca);
+        epilogue(0, 1, cb, sc0);
+        dma_part(kn, 2);
+        TMAC_G2_GROUPS(6, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // region 3: chain (1, 1) | fp32 chain of tile (1, 0)
+        if (!SC2) read_rows(cbuf, 0, 1, sc1);
+        chain(av1, 1, cb);
+        epilogue(1, 0, ca, sc1);
+        dma_part(kn, 3);
+        TMAC_G2_GROUPS(6, SC2 ? 0 : 1);
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(1, 1, cb, sc1);
+        if (ZP && glast) { zero_points(0); zero_points(1); }     // (behind the act group's own terms: one branch at the end of the block)
+#undef TMAC_G2_GROUPS
+        } else {
         chain(av0, 0, ca);
         if (next) dma_part(kk + 1, 0);                     // (the chunk buffer has been read: lgkmcnt(0) above)
         chain(av0, 1, cb);
@@ -475,6 +527,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         __builtin_amdgcn_sched_barrier(0);
         epilogue(1, 1, cb, sc1);
         if (ZP && glast) zero_points(1);
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) lbs[nt] = glast ? 0.f : __fadd_rn(lbs[nt], lb[nt]);
     }
@@ -482,6 +535,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     __builtin_amdgcn_s_setprio(0);
     // ---- reduce the K ranges through LDS (operand rows and chunk buffers are free now) and store ------------------
     PSTAMP(1, 5);
+    if (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last step's (redundant) chunk DMA must not land in the reduction buffers
     __syncthreads();
     PSTAMP(1, 6);
     {

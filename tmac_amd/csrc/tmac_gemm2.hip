@@ -634,7 +634,9 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
     };
     auto pat_row = [&](uint32_t d) -> uint2 {
         const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        return *reinterpret_cast<const uint2*>(plds + (NWV == 8 ? ad : ad >> 1));
+        typedef unsigned int p2u_t __attribute__((ext_vector_type(2)));
+        const p2u_t v = *(__attribute__((address_space(3))) const p2u_t*)(uintptr_t)(NWV == 8 ? ad : ad >> 1);   // absolute LDS address (see k_gemm_planes)
+        return make_uint2(v.x, v.y);
     };
     const bool work = k_lo < k_end;
     if (work) { dma_chunk(k_lo); load_weights(k_lo, 0); load_weights(k_lo, 1); }

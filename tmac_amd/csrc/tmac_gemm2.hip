@@ -194,7 +194,10 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     const uint32_t bb_wave = P_BB_OFF + w * P_BB_WAVE, sc_wave = P_SC_OFF + w * P_SC_WAVE;
 
     uint4 wv[WUN][2][WPU];                     // weights of the act group: [unit][tile row][..]
-    uint32_t st_sc[2] = {0u, 0u}, st_zr[2] = {0u, 0u};   // raw scale / zero of row (row0 + lane) of the next two weight groups (by parity), staged
+    // raw scale / zero of row (row0 + lane) of the NEXT weight group, staged.  One slot, not two by parity: a register array indexed by a
+    // run-time parity made every load land through a select, i.e. behind an s_waitcnt vmcnt(0) right after its issue -- a full memory
+    // round trip in the open once per weight group and wave (ISA reading, round 3)
+    uint32_t st_sc = 0u, st_zr = 0u;
     float lbs[2] = {0.f, 0.f};                 // lut_biases summed over the act groups of the current weight group, per n tile
 
     // the act group's half tables, 64 activation rows: global -> LDS, no registers.  Issued in four parts (unit ul, pairs 2 h, 2 h + 1)
@@ -241,24 +244,30 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     auto load_staged = [&](int g) {            // scale / zero of row (row0 + lane), weight group g -> registers, raw (converted when written to LDS)
         const int quad = min((row0 >> 2) + (lane >> 2), nq - 1);
         const size_t si = quad_scale_index(s, quad, g, lane & 3, 0);
-        const int sl = (g - g_lo) & 1;
         if constexpr (SCF16) {
-            st_sc[sl] = reinterpret_cast<const unsigned short*>(M.SC)[si];
-            if (ZP) st_zr[sl] = reinterpret_cast<const unsigned short*>(M.SC)[si + 1];
+            // (scale, zero) is one aligned dword: kept whole, split when it is written to LDS -- splitting here is arithmetic on the
+            // load's result, i.e. a wait for it
+            if (ZP) st_sc = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned short*>(M.SC) + si);
+            else st_sc = reinterpret_cast<const unsigned short*>(M.SC)[si];
         } else {
-            st_sc[sl] = reinterpret_cast<const uint32_t*>(M.SC)[si];
-            if (ZP) st_zr[sl] = reinterpret_cast<const uint32_t*>(M.SC)[si + 1];
+            st_sc = reinterpret_cast<const uint32_t*>(M.SC)[si];
+            if (ZP) st_zr = reinterpret_cast<const uint32_t*>(M.SC)[si + 1];
         }
     };
     auto st_val = [&](uint32_t raw) -> float {
         if constexpr (SCF16) return __half2float(__ushort_as_half((unsigned short)raw));
         else return __uint_as_float(raw);
     };
-    auto write_staged = [&](int g) {           // LDS buffer and staged set of group g: (g - g_lo) & 1
+    auto write_staged = [&](int g) {           // the staged values are group g's; LDS buffer (g - g_lo) & 1
         const int sl = (g - g_lo) & 1;
         float* p = reinterpret_cast<float*>(plds + sc_wave + sl * 512);
-        p[lane] = st_val(st_sc[sl]);
-        if (ZP) p[64 + lane] = st_val(st_zr[sl]);
+        if constexpr (SCF16 && ZP) {
+            p[lane] = st_val(st_sc & 0xffffu);
+            p[64 + lane] = st_val(st_sc >> 16);
+        } else {
+            p[lane] = st_val(st_sc);
+            if (ZP) p[64 + lane] = st_val(st_zr);
+        }
     };
     // accumulator rows of this lane in tile row rt: 8 q4 + 4 kb + (0..3), q4 = 0..3
     auto read_rows = [&](int buf, int which, int rt, p2f_t (&dst)[8]) {
@@ -289,7 +298,6 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         load_weights(k_lo, 1);
         load_cols(k_lo);
         load_staged(g_lo);
-        if (g_lo + 1 < g_hi) load_staged(g_lo + 1);
     }
 
     // ---- joint-index operand rows: entry b = (i1 << 4) | i0, byte e = s(i0) [e == i0 & 7] + 2 s(i1) [e == i1 & 7] (+ 3 for W4)
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     PSTAMP(0, 6);
     if (work) {
         write_staged(g_lo);
-        if (g_lo + 2 < g_hi) load_staged(g_lo + 2);
+        if (g_lo + 1 < g_hi) load_staged(g_lo + 1);
     }
     // accumulators start from the bits of 3.0f, the middle of the binade [2, 4): as a float the int32 result is 3 + comb * 2^-22
     // exactly for |comb| < 2^21 (it is < 2^19 here), so int -> float is one packed subtraction per pair.  The 16 registers are
@@ -379,10 +387,8 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         // reduction): alternate the priority between the two waves of a SIMD step by step
         if (NWV == 8) { if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk of kk is in LDS, its weights, column values and the staged scales in registers
-        if (more) {
-            write_staged(g + 1);
-            if (g + 3 < g_hi) load_staged(g + 3);
-        }
+        if (more) write_staged(g + 1);     // (its successor is fetched behind this step's LDS reads: a load in front of them is waited for --
+                                           // the compiler orders every LDS read behind all LDS-DMA in flight with vmcnt(0))
         // B operands of the whole act group (both n tiles, four 32-deep steps); A operands and row scales of tile row 0
         p4i_t bv[2][4], av0[4], av1[4];
         p2f_t sc0[8];
@@ -420,6 +426,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         // DEPENDENT MFMAs -- 32 cycles each during which the wave issues nothing unless independent work sits between them.  Measured
         // (profiles/r03_gemm_planes_forms.txt D): W4 prefill -3 %; W1, W2, W3 within +-1 % (kept in the coarse order).
         const int kn = PIPE ? (next ? kk + 1 : kk) : kk + 1;
+        if (more && g + 2 < g_hi) load_staged(g + 2);
         if (PIPE || next) { load_cols(kn); load_weights(kn, 0); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);

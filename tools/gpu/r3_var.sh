@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library builds (tmac_amd/lib/ko/libtmac_hip_v*.so, built by hand with a -D variant) on the prefill workload; same box
+# A/B of library builds (tmac_amd/lib/ko/libtmac_hip_v*.so, built by hand with a -D variant) on bench.py workloads; same box
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 for rep in 1 2; do for f in tmac_amd/lib/ko/libtmac_hip_v*.so; do
   for wl in ${WLS:-llama2-7b-w2-prefill}; do

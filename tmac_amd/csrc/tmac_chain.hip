@@ -120,13 +120,17 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
         }
     }
     if (SM == 2) {
+        // The MFMA results must have landed before a VALU instruction reads them (no hardware interlock: up to 18 wait states after an
+        // 8-pass MFMA; with one bit-plane the compiler's hazard recogniser left the two a single wait state apart across the loop branch and
+        // W1 unified-scale results were wrong).  ONE wait for all planes, behind the last MFMA of the step (the planes' chains are
+        // interleaved, so the others finished earlier):
+        // a wait per plane cost (BITS - 1) x 19 idle cycles per item
+        if constexpr (BITS == 1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]));
+        else if constexpr (BITS == 2) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]), "+v"(c[1]));
+        else if constexpr (BITS == 3) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+        else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
 #pragma unroll
-        for (int pl = 0; pl < BITS; ++pl) {
-            // the MFMA result must have landed before a VALU instruction reads it (no hardware interlock; see compute_mfma
-            // of k_gemv_quad: with one bit-plane the hazard recogniser left the two a single wait state apart)
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[pl]));
-            iacc[pl] += (c[pl].x + c[pl].y) + (c[pl].z + c[pl].w);
-        }
+        for (int pl = 0; pl < BITS; ++pl) iacc[pl] += (c[pl].x + c[pl].y) + (c[pl].z + c[pl].w);
         return;
     }
     float sc, zr = 0.f;

@@ -27,7 +27,7 @@
 // Here a lane holds ALL tables of one unit (its k half picks the unit of the act group), not half the tables of both: whole uint4.
 //
 // v_mfma_i32_32x32x32_i8: one instruction = 32 output rows x 32 activation rows x 4 tables.  Wave tile 64 x 64 (2 x 2
-// MFMA tiles); a workgroup = 8 waves = ONE 64 x 64 output tile, the waves split K by weight groups and reduce through
+// MFMA tiles); a workgroup = 8 (or 4: PForm below) waves = ONE 64 x 64 output tile, the waves split K by weight groups and reduce through
 // LDS at the end (at N = 256 a llama-2-7B projection has only 256 such tiles: one per CU; a larger workgroup tile would
 // idle most of the chip).  Each wave is on its own between the kernel's two barriers: it streams its half-table chunks
 // global -> LDS (buffer_load ... lds, no registers), its weights, column values and weight scales global -> registers one

@@ -84,6 +84,9 @@ def parse():
                     help="auto: chain where k_decode_chain covers the configuration (N = 1; row-sharded over the ranks with --gpus N), else fused")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the check of one layer's outputs (the launches being timed, at full size) against the oracle")
+    ap.add_argument("--pattern", choices=["chained", "independent"], default="chained",
+                    help="chained: the calls are linked by real data (x1 = q, x2 = o, x3 = gate, next x0 = down; the default and the reported "
+                         "workload); independent: every call reads an external vector -- no hand-offs, the lookups' streaming rate alone (diagnostic)")
     ap.add_argument("--stamps", action="store_true", help="chain path: report per-call times from in-kernel stamps (costs ~6 %%)")
     ap.add_argument("--floors", action="store_true", help="fused path: also time launches that only read the same bytes")
     ap.add_argument("--autotune", action="store_true", help="fused path: measure the launch configurations first (tmac_hip_autotune_fused)")
@@ -351,12 +354,16 @@ def main():
                 g = gathered[name]
                 xin[nxt[name]] = (g.reshape(-1)[:logical[name]] if decode
                                   else g.permute(1, 0, 2).reshape(N, -1)[:, :logical[name]].contiguous())
-            else:
+            elif args.pattern == "chained":
                 xin[nxt[name]] = out_of[name][0]
+
+    # independent pattern: nothing orders the calls, so every layer gets output buffers of its own
+    outs_l = [outs] + [{name: [torch.empty_like(o) for o in outs[name]] for name in outs} for _ in range(args.layers - 1)] \
+        if args.pattern == "independent" else [outs] * args.layers
 
     def step():
         for li in range(args.layers):
-            calls(layers[li], x, outs)
+            calls(layers[li], x, outs_l[li])
 
     def barrier():
         if dist_on:
@@ -422,7 +429,7 @@ def main():
                     chain.free()
                 chain, args.path = None, "fused"
         if chain is not None and args.stamps:
-            stamp_buf = torch.zeros(chain.nops * chain.grid * 8, dtype=torch.int64, device=dev)
+            stamp_buf = torch.zeros(chain.nops * chain.grid * 16, dtype=torch.int64, device=dev)
             chain.set_stamps(stamp_buf)
     use_graph = (not args.no_graph) and not (dist_on and args.eager_collectives) and args.path != "chain"
     if use_graph:
@@ -572,22 +579,26 @@ def main():
                                  "GBps": round(hb / hus * 1e-3, 1), "frac": round(hb / hus * 1e-3 / HBM_PEAK_GBS, 4),
                                  "timing": "hipEvent pair around %d back-to-back launches (distinct weights, hipGraph replay), mean of 10" % args.layers}
         if args.stamps:
-            raw = stamp_buf.cpu().numpy().reshape(chain.nops, chain.grid, 8)
+            raw = stamp_buf.cpu().numpy().reshape(chain.nops, chain.grid, 16)
             try:
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
                 np.save(os.path.join(ROOT, "gpurun_out", "chain_stamps.npy"), raw)
             except Exception:
                 pass
-            st = raw[:, :, :7].astype(np.float64) * 0.01                     # s_memrealtime: 100 MHz -> us (wave 0 of every workgroup)
+            st = raw.astype(np.float64) * 0.01                               # s_memrealtime: 100 MHz -> us
             ends = st[:, :, 5].max(axis=1)                                    # a call is complete when its last row quad is published
             dur = ends - np.concatenate([[st[0, :, 0].min()], ends[:-1]])
             per = {}
             for k, (name, Mw, K, cnt, slot) in enumerate(MATS):
                 sel = st[k::4]
+                # stamp layout: tmac_chain.h (0 lookup wave 0 enters, 1 builder 0 has activations, 2 lookup wave 0 sees its first LUT
+                # step, 3 builder 0 built its last block, 4 lookup wave 0 done, 5 published, 6 builder 0 starts, 7 poll rounds)
                 per[name] = {"us": round(float(np.mean(dur[k::4])), 3),
-                             "wait_input_us": round(float(np.mean(sel[:, :, 1] - sel[:, :, 0])), 3),
-                             "lut_build_us": round(float(np.mean(sel[:, :, 2] - sel[:, :, 1])), 3),
-                             "lookups_us": round(float(np.mean(sel[:, :, 5] - sel[:, :, 2])), 3),
+                             "builder_wait_input_us": round(float(np.mean(sel[:, :, 1] - sel[:, :, 6])), 3),
+                             "lut_build_us": round(float(np.mean(sel[:, :, 3] - sel[:, :, 1])), 3),
+                             "lookup_wait_lut_us": round(float(np.mean(sel[:, :, 2] - sel[:, :, 0])), 3),
+                             "lookups_us": round(float(np.mean(sel[:, :, 4] - sel[:, :, 2])), 3),
+                             "publish_us": round(float(np.mean(sel[:, :, 5] - sel[:, :, 4])), 3),
                              "polls": round(float(np.mean(raw[k::4, :, 7])), 2)}
             name, Mw, K, cnt, slot = MATS[3]
             hb = algorithmic_bytes(Mw, K, BITS, GS, ags_of(K), ZP, MG)

@@ -225,3 +225,51 @@ def test_fused_entry_point_takes_the_planes_kernel(tm, bits, bm):
         assert torch.equal(C2, o)
     for w in ws:
         w.free()
+
+
+def test_workspace_write_invalidates_the_lut_image(tm):
+    """tmac_hip_preprocessor_dev(N = 16, X1) builds k_gemm_planes' LUT image; tmac_hip_workspace_write then replaces the LUT with
+    that of X2 (the split C-ABI, tmac_gemm_wrapper.h:170-228 with a caller-built LUT).  The following qgemm must compute with X2's
+    LUT -- not stream the image of X1 (round-3 advisor finding)."""
+    import torch
+    Mw, K, bits, bm, gs, N = 256, 1024, 2, 128, 128, 16
+    c1 = orc.make_case(71, Mw, K, bits=bits, N=N, gs=gs, ags=64, zero_point=True)
+    c2 = orc.make_case(72, Mw, K, bits=bits, N=N, gs=gs, ags=64, zero_point=True)
+    A = orc.preprocess_weights(c1["w"], bits, bm, 16)
+    S = orc.preprocess_scales(c1["sc"], c1["zr"], bits, bm)
+    cfg = tm.KCfg.make(Mw, K, bits, bm, 16, gs, 64, True, -1, N)
+    wr = tm.TMACGeMMWrapper(act_group_size=64)
+    wr.set_workspace(K, N)
+    w = wr.register_weights(A, S, Mw, K, bits, cfg, scales_dtype=tm.F32, dev_dtype=tm.F32)
+    Ct = torch.full((N, Mw), float("nan"), dtype=torch.float32, device="cuda")
+    wr.llama_cpp_init(torch.from_numpy(c1["B"]).cuda(), Mw, K, N, bits)       # image of X1
+    q2, ls2, lb2 = orc.preprocessor(c2["B"], 64)
+    wr.workspace.write(q2, ls2, lb2, 64)                                       # LUT of X2
+    wr.llama_cpp_compute(w, Ct, N)
+    torch.cuda.synchronize()
+    want = orc.qgemm_float(A, q2, S, ls2, lb2, Mw, K, N, bits, bm, 16, gs, 64, True)
+    assert rel_err(Ct.cpu().numpy(), want) <= 1e-3
+    w.free()
+
+
+@pytest.mark.parametrize("N", [5, 8, 11, 12, 20])
+def test_split_entry_small_n_matches_oracle(tm, N):
+    """the split entry points (preprocessor_dev + qgemm_dev) around the GEMM thresholds: below PLANES_MIN_N the LUT image is not
+    built and the row loop runs (k_gemm_onehot only from its own crossover on), from it on k_gemm_planes -- same results"""
+    import torch
+    Mw, K, bits, bm, gs = 512, 1024, 2, 128, 128
+    c = orc.make_case(80 + N, Mw, K, bits=bits, N=N, gs=gs, ags=64, zero_point=True)
+    A = orc.preprocess_weights(c["w"], bits, bm, 16)
+    S = orc.preprocess_scales(c["sc"], c["zr"], bits, bm)
+    cfg = tm.KCfg.make(Mw, K, bits, bm, 16, gs, 64, True, -1, N)
+    wr = tm.TMACGeMMWrapper(act_group_size=64)
+    wr.set_workspace(K, N)
+    w = wr.register_weights(A, S, Mw, K, bits, cfg, scales_dtype=tm.F32, dev_dtype=tm.F32)
+    Ct = torch.full((N, Mw), float("nan"), dtype=torch.float32, device="cuda")
+    wr.llama_cpp_init(torch.from_numpy(c["B"]).cuda(), Mw, K, N, bits)
+    wr.llama_cpp_compute(w, Ct, N)
+    torch.cuda.synchronize()
+    q, ls, lb = orc.preprocessor(c["B"], 64)
+    want = orc.qgemm_float(A, q, S, ls, lb, Mw, K, N, bits, bm, 16, gs, 64, True)
+    assert rel_err(Ct.cpu().numpy(), want) <= 1e-3
+    w.free()

@@ -4,27 +4,34 @@
 
 using namespace tmac_host;
 
-// bit-plane rows the row loop is faster up to 64 rows: 4096 x 11008 at N = 32: 88 us against 152 us).
+// GEMM or row loop for N activation rows on matrices with total_Mw output rows?  An explicitly set threshold
+// (tmac_hip_set_gemm_min_n) is taken literally.  Otherwise: the measured crossover per launch where k_gemm_planes covers the
+// configuration (planes_pays), and k_gemm_onehot only from 32 rows on with a grid that fills the chip (onehot_pays: with fewer
+// than 128 workgroups of 128 bit-plane rows the row loop is faster up to 64 rows: 4096 x 11008 at N = 32: 88 us against 152 us).
 static bool planes_covers(const Shape& s) { return g_knobs.gemm_kernel != 1 && s.lay == 2 && s.ts == 8 && gemm_planes_supported(s); }
-static bool gemm_pays(const Shape& s, long total_Mw, int N) {
+static bool onehot_pays(const Shape& s, long total_Mw, int N) {
     if (g_knobs.gemm_min_n <= 0) return false;
     if (g_knobs.gemm_min_n != 32) return N >= g_knobs.gemm_min_n;
-    if (planes_covers(s)) {
-        // From how many activation rows on k_gemm_planes beats the GEMV kernel looped over the rows: measured on MI355X, llama-2-7B shapes,
-        // 1- to 4-bit weights (tools/bench_small_n.py, profiles/r03_small_n.txt).  The row loop costs ~3 us + N x (0.7 us + 0.155 us per MB
-        // of weights + 0.2 us per 1000 of K beyond 4096); the GEMM (6 + 14 K / 4096) us per wave of 64 x 64 tiles (x 1.18 for 3- / 4-bit
-        // operand rows) whatever N <= 64 is.  Crossovers (W2): o 14, q/k/v 7, gate/up 7, down 9 rows; the fixed 12 rows of round 2 -- which
-        // the fused entry point applied on top of a fixed 32 -- left up to 2 x on the table for 7-31 rows.  5 % margin for the row loop.
-        const double mb = (double)total_Mw * s.K * s.bits / 8e6, tiles = (double)((total_Mw + 63) / 64) * ((N + 63) / 64);
-        const double waves = tiles <= 256.0 ? 1.0 : s.bits == 4 ? (double)(((long)tiles + 255) / 256) : (s.bits == 3 ? 0.45 : 0.25) + tiles / 256.0;
-        const double tp = (6.0 + 14.0 * s.K / 4096.0) * waves * (s.bits >= 3 ? 1.18 : 1.0);
-        const double c1 = 0.7 + 0.155 * mb + 0.2 * (s.K > 4096 ? (s.K - 4096) / 1000.0 : 0.0);
-        int nmin = (int)((1.05 * tp - 3.0) / c1 + 0.999);
-        nmin = nmin < 4 ? 4 : nmin > 16 ? 16 : nmin;
-        return N >= nmin;
-    }
     return N >= 32 && (N >= 64 || (total_Mw * s.bits + 127) / 128 >= 128);
 }
+static bool planes_pays(const Shape& s, long total_Mw, int N) {
+    if (g_knobs.gemm_min_n <= 0) return false;
+    if (g_knobs.gemm_min_n != 32) return N >= g_knobs.gemm_min_n;
+    // From how many activation rows on k_gemm_planes beats the GEMV kernel looped over the rows: measured on MI355X, llama-2-7B shapes,
+    // 1- to 4-bit weights (tools/bench_small_n.py, profiles/r03_small_n.txt).  The row loop costs ~3 us + N x (0.7 us + 0.155 us per MB
+    // of weights + 0.2 us per 1000 of K beyond 4096); the GEMM (6 + 14 K / 4096) us per wave of 64 x 64 tiles (x 1.18 for 3- / 4-bit
+    // operand rows) whatever N <= 64 is.  Crossovers (W2): o 14, q/k/v 7, gate/up 7, down 9 rows; the fixed 12 rows of round 2 -- which
+    // the fused entry point applied on top of a fixed 32 -- left up to 2 x on the table for 7-31 rows.  5 % margin for the row loop.
+    const double mb = (double)total_Mw * s.K * s.bits / 8e6, tiles = (double)((total_Mw + 63) / 64) * ((N + 63) / 64);
+    const double waves = tiles <= 256.0 ? 1.0 : s.bits == 4 ? (double)(((long)tiles + 255) / 256) : (s.bits == 3 ? 0.45 : 0.25) + tiles / 256.0;
+    const double tp = (6.0 + 14.0 * s.K / 4096.0) * waves * (s.bits >= 3 ? 1.18 : 1.0);
+    const double c1 = 0.7 + 0.155 * mb + 0.2 * (s.K > 4096 ? (s.K - 4096) / 1000.0 : 0.0);
+    int nmin = (int)((1.05 * tp - 3.0) / c1 + 0.999);
+    nmin = nmin < 4 ? 4 : nmin > 16 ? 16 : nmin;
+    return N >= nmin;
+}
+// the fused entry point builds whatever LUT form the chosen kernel wants, so one question decides
+static bool gemm_pays(const Shape& s, long total_Mw, int N) { return planes_covers(s) ? planes_pays(s, total_Mw, N) : onehot_pays(s, total_Mw, N); }
 // one-hot MFMA GEMM over 1..4 matrices that share K, the quantisation config (checked by the callers) and the LUT in ws
 static int32_t gemm_multi(const tmac_hip_weights* const* wl, int nmat, const tmac_hip_workspace* ws, void* const* C_list,
                           tmac_dtype_t out_dtype, int N, int32_t* dump, hipStream_t st) {
@@ -81,11 +88,13 @@ int32_t tmac_host::qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspac
     }
     if (w->fa && v != V_REF_LAYOUT && v != V_LO_MQSAD && v != V_LO_SDWA)
         return fail(TMAC_HIP_E_NOMATCH, "fast-aggregation weights run on the two-kernel path only");
-    if (v == V_FUSED && !dump && ws->gimg_valid && planes_ok(w) && planes_image_fits(ws, w->s.K) && gemm_pays(w->s, w->s.Mw, N)) {
+    // split entry points: tmac_hip_preprocessor_dev builds k_gemm_planes' LUT image from PLANES_MIN_N rows on (it does not know the
+    // matrix); without the image only k_gemm_onehot's own, later crossover counts -- below it the row loop is the faster kernel
+    if (v == V_FUSED && !dump && ws->gimg_valid && planes_ok(w) && planes_image_fits(ws, w->s.K) && planes_pays(w->s, w->s.Mw, N)) {
         void* cl[1] = {C_dev};
         return planes_multi(&w, 1, ws, cl, out_dtype, N, nullptr, st);
     }
-    if (v == V_FUSED && gemm_pays(w->s, w->s.Mw, N) && gemm_onehot_supported(w->s)) {
+    if (v == V_FUSED && onehot_pays(w->s, w->s.Mw, N) && gemm_onehot_supported(w->s)) {
         void* cl[1] = {C_dev};
         return gemm_multi(&w, 1, ws, cl, out_dtype, N, dump, st);
     }

@@ -19,7 +19,8 @@ struct TileKey {
 // host-pointer layer learns the matrices behind the tiles: tiles whose weight and scale pointers are contiguous (the
 // reference layout stores a matrix tile after tile) form a RUN; once a run has been seen whole, the first tile call
 // that arrives with a new LUT computes the run's entire output in one launch and the following tile calls are served
-// from that result as long as the LUT bytes they pass are the ones it was computed from (compared in full).
+// from that result as long as the LUT they pass is the one it was computed from (same three pointers and a 192-byte sample
+// of the table bytes on the shared-lock fast path; scales, biases and the whole table are compared when a pointer differs).
 // verbatim sample of a tile's weight and scale bytes (4 x 16 + 2 x 16 bytes): what the per-call staleness check of a grouped
 // tile compares (a memcmp of 96 bytes instead of a 192-byte hash per tile call)
 struct TileBytes { unsigned char b[96]; };

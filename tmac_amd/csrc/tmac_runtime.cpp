@@ -85,10 +85,6 @@ extern "C" int32_t tmac_hip_set_gemm_min_n(int n) {
     g_knobs.gemm_min_n = n;
     return TMAC_HIP_OK;
 }
-// GEMM or row loop for N activation rows on matrices with total_Mw output rows?  An explicitly set threshold is taken
-// literally.  The default: from 12 rows where k_gemm_planes covers the configuration (its 64-row tile costs 15-37 us on the
-// llama-2-7B shapes whatever N <= 64 is, the row loop 1.4-3 us per row: profiles/r02_gemm_planes_shapes.txt, r01_small_n.txt);
-// from 32 rows with k_gemm_onehot, which also asks for a grid that fills the chip (with fewer than 128 workgroups of 128
 extern "C" int32_t tmac_hip_selftest(const uint32_t* in_host, uint32_t* out_host, int n) {
     if (!in_host || !out_host || n <= 0) return fail(TMAC_HIP_E_ARG, "bad selftest arguments");
     int32_t rc = ensure_device();

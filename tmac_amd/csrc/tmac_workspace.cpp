@@ -121,6 +121,7 @@ extern "C" int32_t tmac_hip_workspace_write(tmac_hip_workspace* ws, const int8_t
     hipStream_t st = (hipStream_t)stream;
     const size_t G = (size_t)K / act_group_size;
     ws->K = K; ws->N = N; ws->ags = act_group_size; ws->qdev_u4_per_row = qdev_u4_for_K(K);
+    ws->gimg_valid = false;      // k_gemm_planes' LUT image (built from activations by tmac_hip_preprocessor_dev) no longer matches this LUT
     HIP_TRY(hipMemcpyAsync(ws->qlut_ref, qlut_host, (size_t)N * (K / 4) * 16, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ws->lut_scales, lut_scales_host, sizeof(float) * N * G, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(ws->lut_biases, lut_biases_host, sizeof(float) * N * G, hipMemcpyHostToDevice, st));

@@ -92,24 +92,13 @@ static int chain_pick_wpq(int total_q, int nst, int grid) {
     for (int wpq = 1; wpq <= 4; ++wpq) {          // the combinations k_gemv_quad is instantiated for with this many threads
         if (CHAIN_NWV % wpq || (wpq > 1 && wpq > nst)) continue;
         const long ipi = CHAIN_NWV / wpq;
-        const long cnt = (total_q + grid - 1) / grid;               // quads of the busiest workgroup
+        const long cnt = (total_q + grid - 1) / grid;               // quads of the busiest workgroup (balanced contiguous ranges)
         const long iters = (cnt + ipi - 1) / ipi;
         const long steps = (nst + wpq - 1) / wpq;
         if (iters * steps < best_cost) { best_cost = iters * steps; best = wpq; }     // ties: fewer waves per quad (no LDS combine)
     }
     return best;
 }
-// iteration-major partition of a call's row quads (ChainOp): niter super-blocks, each shared by all workgroups
-static void chain_partition(ChainOp& o, int grid) {
-    const int cnt = (o.total_q + grid - 1) / grid;
-    o.niter = (cnt + o.ipi - 1) / o.ipi;
-    if (o.niter < 1) o.niter = 1;
-    o.sb_base = o.total_q / o.niter; o.sb_rem = o.total_q % o.niter;
-    o.perA = (o.sb_base + 1) / grid; o.exA = (o.sb_base + 1) % grid;
-    o.perB = o.sb_base / grid; o.exB = o.sb_base % grid;
-}
-// every workgroup owns rows of the call (iteration 0 gives every workgroup at least one quad)
-static bool chain_all_own(const ChainOp& o) { return o.sb_rem > 0 ? o.perA >= 1 : o.perB >= 1; }
 
 extern "C" int32_t tmac_hip_chain_free(tmac_hip_chain* c) {
     if (!c) return TMAC_HIP_OK;
@@ -224,7 +213,6 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         }
 
     c->ops.resize(n);
-    std::vector<unsigned> gbase(n + 1, 0u);       // workgroup iterations before op i (every workgroup closes all iterations of every op)
     int maxK = 0;
     for (size_t i = 0; i < n; ++i) {
         const ChainRecOp& r = rec[i];
@@ -233,7 +221,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         const Shape& s0 = r.w[0]->s;
         if (r.act != TMAC_F16) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the decode chain takes fp16 activations", i));
         if ((r.out == TMAC_F16) != (c->out_f16 != 0)) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: one output dtype per chain", i));
-        if (s0.K > CHAIN_MAX_K) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: K = %d beyond the decode chain's %d", i, s0.K, CHAIN_MAX_K));
+        if (s0.K > 8 * 3 * CHAIN_FT) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: K = %d beyond the decode chain's %d", i, s0.K, 8 * 3 * CHAIN_FT));
         if (((s0.m_groups >= 1) ? 2 : 0) != c->sm) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: per-group and unified scales cannot share a chain", i));
         int gu = 1;
         if (c->sm == 2) {
@@ -282,9 +270,9 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         if (CHAIN_NWV % o.wpq) return bail(fail(TMAC_HIP_E_ARG, "waves per quad must divide %d", CHAIN_NWV));
         o.ipi = CHAIN_NWV / o.wpq;
         o.wpq_inv = (65536 + o.wpq - 1) / o.wpq;
-        chain_partition(o, c->grid);
-        if (o.niter >= 4096) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: too many rows per workgroup for the decode chain", i));
-        gbase[i + 1] = gbase[i] + (unsigned)o.niter;
+        o.ipi_inv = (65536 + o.ipi - 1) / o.ipi;
+        if (nq / c->grid + 1 + o.ipi >= 4096) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: too many rows per workgroup for the decode chain", i));
+        o.q_per = nq / c->grid; o.q_extra = nq % c->grid;
         if (src[i].op >= 0) {
             const ChainOp& po = c->ops[src[i].op];
             const bool via_gather = gathered[src[i].op][src[i].mat] != 0;
@@ -293,12 +281,6 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             // the image's first quad (a gathered image starts rank * nquads before this rank's part); offsets until the arena exists
             const size_t my_off = via_gather ? (size_t)c->rank * ((po.m[src[i].mat].Mw + 3) / 4) * 16 : 0;
             o.in = reinterpret_cast<const void*>(reinterpret_cast<size_t>(po.m[src[i].mat].GR) - my_off); o.in_gran = 1;
-            // the producer's iteration that completes the source matrix (its last quad): iteration-major super-blocks, tmac_chain.h
-            {
-                const int ql = po.m[src[i].mat].q_end - 1, nA = po.sb_rem * (po.sb_base + 1);
-                const int it = ql < nA ? ql / (po.sb_base + 1) : po.sb_rem + (ql - nA) / (po.sb_base > 0 ? po.sb_base : 1);
-                o.src_g = (int)(gbase[src[i].op] + (unsigned)it + 1u);
-            }
         } else {
             o.in = r.B; o.in_gran = 0;
         }
@@ -311,12 +293,12 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
     }
     // Hazards between ops that no hand-off orders.  Every workgroup reads an op's activations itself (each builds the whole
     // LUT) and walks the ops in recorded order.  "Op j has published" therefore implies "every workgroup is past op i" for
-    // any i <= j only when every workgroup owns rows of op j (chain_all_own).  A later op k may overwrite an EXTERNAL input of
+    // any i <= j only when every workgroup owns rows of op j (q_per >= 1).  A later op k may overwrite an EXTERNAL input of
     // op i (a decoder's "next x = last output") exactly when such an op j lies between them on k's hand-off path.
     // Inputs handed over inside the launch are read from the hand-off image, never from the user-visible buffer.
     auto all_past = [&](size_t i, size_t k) {
         for (size_t j = i; j < k; ++j)
-            if (dep[k][j] && chain_all_own(c->ops[j])) return true;
+            if (dep[k][j] && c->ops[j].q_per >= 1) return true;
         return false;
     };
     for (size_t k = 0; k < n; ++k)
@@ -465,7 +447,8 @@ extern "C" int32_t tmac_hip_chain_status(tmac_hip_chain* c, uint32_t* error_word
     if (ctl[2] || ctl[1]) {
         // A launch that gave up still ran to its end and advanced the generation like any other (every wait is bounded, the last
         // workgroup out advances): the generation stays in step with the peers of a row-sharded chain, which count launches the same
-        // way.  Only the error word (and a partial exit count, should the launch have been killed from outside) is cleared here.
+        // way -- re-arming one rank here would leave it a generation apart from its peers for good.  Only the error word (and a partial
+        // exit count, should the launch have been killed from outside) is cleared.
         const unsigned fresh[4] = {ctl[0], 0u, 0u, 0u};
         HIP_TRY(hipMemcpy(c->ctl, fresh, sizeof(fresh), hipMemcpyHostToDevice));
     }
@@ -491,7 +474,7 @@ extern "C" int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* c, unsigned long lo
     return TMAC_HIP_OK;
 }
 
-extern "C" int32_t tmac_hip_chain_threads(void) { return CHAIN_LT; }
+extern "C" int32_t tmac_hip_chain_threads(void) { return CHAIN_FT; }
 
 extern "C" int32_t tmac_hip_debug_chain_grid(int workgroups) {
     if (workgroups < 0) return fail(TMAC_HIP_E_ARG, "negative grid");

@@ -172,6 +172,34 @@ int32_t tmac_hip_chain_status(tmac_hip_chain* chain, uint32_t* error_word);
  * (any pointer may be NULL) */
 int32_t tmac_hip_chain_info(const tmac_hip_chain* chain, int op, int32_t* nops, int32_t* wpq, int32_t* grid, size_t* bytes);
 int32_t tmac_hip_chain_free(tmac_hip_chain* chain);
+/* Vector transforms inside the chain.  Between two mpGEMMs of a decoder layer sit element-wise operators the hot path does not own
+ * (residual add + RMSNorm in front of q/k/v and gate/up, silu(gate) * up in front of the down projection); as kernels of their own they
+ * would end the persistent launch after every call.  Every workgroup of the chain holds a call's whole activation vector when it builds
+ * the LUT, so these operators are applied THERE: tmac_hip_chain_xform, while recording, describes a transform of the activations of the
+ * NEXT recorded tmac_hip_qgemm_fused_dev call (B_dev = `in`).  fp32 arithmetic; the LUT is built from the fp32 result.
+ *   TMAC_XF_NORM  t = in + residual;  x = gamma ? t * (1 / sqrt(mean(t^2) + eps)) * gamma : t
+ *                 residual: fp32 [K] in device memory, NULL (none), or TMAC_XF_CARRY = the t that the latest NORM with keep != 0 kept
+ *                 (inside the launch, no memory round trip; K <= 8192); residual_out: t also goes to memory (fp32 [K], e.g. the residual
+ *                 stream for the next launch; must not alias anything the launch reads)
+ *   TMAC_XF_GLU   x = silu(in) * in2;  in2: fp16 [K], an earlier output of the chain (handed over like `in`) or external memory -- of the
+ *                 same kind as `in`; K <= 12288
+ * A decoder then runs one launch per segment between two operators that stay outside (attention): o -> gate/up -> down -> next q/k/v.
+ * These are extensions without a reference counterpart (T-MAC has no norm operator): tests compare them with the same formulas in
+ * numpy fed through the oracle (tolerance, not bits: the mean square is summed in another order). */
+#define TMAC_XF_NONE 0
+#define TMAC_XF_NORM 1
+#define TMAC_XF_GLU 2
+#define TMAC_XF_CARRY ((const float*)1)
+typedef struct {
+    int32_t kind;
+    const void* in2;
+    const float* residual;
+    const float* gamma;
+    float eps;
+    float* residual_out;
+    int32_t keep;
+} tmac_hip_xform;
+int32_t tmac_hip_chain_xform(const tmac_hip_xform* xf);
 /* Row-sharded chains (one process per GPU; weight ROWS split over the ranks).  While recording, the exchange step between
  * a call and the calls that need its output whole is recorded too -- tmac_hip_comm_allgather(comm, send, recv, ...) notes itself, or
  * tmac_hip_chain_record_gather where no communicator exists -- and inside the launch it becomes part of the hand-off: every rank's

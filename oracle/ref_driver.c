@@ -17,6 +17,20 @@ int ref_run_tiles_omp(qgemm_tile_fn fn, uint8_t* A, size_t a_stride, void* LUT, 
     return rc;
 }
 
+/* N > 1 as the reference computes it: its N = 1 kernel looped over the activation rows (python/t_mac/ops/qgemm.py:183-190,228-231: per-row
+ * LUT / LUT_Scales / LUT_Biases / C).  Rows inside the tile loop: a tile's weights stay in cache for all rows, the most favourable
+ * order for the CPU.  LUT rows lut_stride bytes apart, LS / LB rows g floats apart, C rows Mw floats apart. */
+int ref_run_tiles_rows_omp(qgemm_tile_fn fn, uint8_t* A, size_t a_stride, uint8_t* LUT, size_t lut_stride, float* S, size_t s_stride, float* LS,
+                           float* LB, size_t g, float* C, size_t c_stride, size_t Mw, int ntiles, int nrows, int nthreads) {
+    int rc = 0;
+#pragma omp parallel for schedule(static) num_threads(nthreads) reduction(| : rc)
+    for (int t = 0; t < ntiles; ++t)
+        for (int n = 0; n < nrows; ++n)
+            rc |= fn(A + (size_t)t * a_stride, LUT + (size_t)n * lut_stride, S + (size_t)t * s_stride, LS + (size_t)n * g, LB + (size_t)n * g,
+                     C + (size_t)n * Mw + (size_t)t * c_stride);
+    return rc;
+}
+
 /* The int32 / scale-final path (BitNet on x86: the reference selects tbl_g4_int8_int32_update there, tools/run_pipeline.py:409-412).
  * fn = ref_tile_cbits_int32 of oracle/_ref/libtmac_ref_intrins.so (the reference's own intrinsic in the generated glue's k_outer loop);
  * the bit-plane combine and the three float operations of scale-final are the glue of python/t_mac/ops/qgemm.py:170-174,192-206,

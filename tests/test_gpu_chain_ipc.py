@@ -46,7 +46,7 @@ def build(shard_rank, shard_world, grid, wpq):
     tm.binding.check(L.tmac_hip_debug_chain_grid(grid))
     tm.binding.check(L.tmac_hip_debug_chain_config(wpq, 1 << 18))
     wr = tm.TMACGeMMWrapper(act_group_size=AGS)
-    ws, outs, gath = [], [], []
+    ws, outs, gath, host = [], [], [], []
     for i, (K, Mw) in enumerate(OPS):
         ags = K if mg >= 1 else AGS
         case = orc.make_case(900 + i, Mw, K, bits=bits, gs=GS, ags=ags, zero_point=zp, m_groups=mg, fp16_values=True)
@@ -64,6 +64,7 @@ def build(shard_rank, shard_world, grid, wpq):
         Sb = S if mg >= 1 else orc.preprocess_scales(case["sc"][sl], case["zr"][sl], bits, bm)
         cfg = tm.KCfg.make(rows, K, bits, bm, KF, GS, ags, zp, mg)
         ws.append(wr.register_weights(A, Sb, rows, K, bits, cfg, scales_dtype=tm.F32, dev_dtype=tm.F16))
+        host.append((A, Sb))
         outs.append(torch.zeros(rows, dtype=torch.float16, device="cuda"))
         gath.append(torch.zeros(Mw, dtype=torch.float16, device="cuda"))
     x0 = torch.from_numpy(np.random.default_rng(5).standard_normal(OPS[0][0]).astype(np.float32)).cuda().half()
@@ -76,10 +77,10 @@ def build(shard_rank, shard_world, grid, wpq):
                 x = gath[i]
             else:
                 x = outs[i]
-    return rec.chain, outs, ws
+    return rec.chain, outs, ws, host, x0
 
 # ---- the sharded chain of this rank: grid 96, two waves per quad
-chain, outs, ws = build(rank, world, 96, 2)
+chain, outs, ws, _, _ = build(rank, world, 96, 2)
 blob = chain.export()
 open(os.path.join(d, f"blob.{rank}.tmp"), "wb").write(blob)
 os.rename(os.path.join(d, f"blob.{rank}.tmp"), os.path.join(d, f"blob.{rank}"))
@@ -99,7 +100,7 @@ chain.free()
 # ---- reference: the unsharded chain in this process alone (same waves per quad), rank after rank so that it has the device to itself
 for turn in range(world):
     if turn == rank:
-        ref_chain, ref_outs, _ = build(0, 1, 0, 2)
+        ref_chain, ref_outs, _, host, x0 = build(0, 1, 0, 2)
         ref_chain.launch(); torch.cuda.synchronize()
         assert ref_chain.status() == 0
         for i, (K, Mw) in enumerate(OPS):
@@ -108,6 +109,19 @@ for turn in range(world):
             assert bool(torch.isfinite(want.float()).all()) and float(want.float().abs().max()) > 0
             for rep in range(3):
                 assert torch.equal(res[rep][i], want), f"rank {rank} op {i} rep {rep}: sharded chain != unsharded chain"
+            # and against the oracle directly (lut_ctor.cc / tbl.cc restated in oracle/tmac_oracle.c) on the vector the sharded chain consumed:
+            # this rank's rows of the full matrix's result, 1e-3 of max |C| (fp16 outputs)
+            xin = (x0 if i == 0 else ref_outs[i - 1]).float().cpu().numpy()[None, :]
+            A, Sb = host[i]
+            if mg >= 1:
+                q, ls, lb = orc.preprocessor(xin, K)
+                full = orc.qgemm_scale_final(A, q, Sb, ls[:, 0], lb[:, 0], Mw, K, 1, bits, bm, KF, mg)[0][0]
+            else:
+                q, ls, lb = orc.preprocessor(xin, AGS)
+                full = orc.qgemm_float(A, q, Sb, ls, lb, Mw, K, 1, bits, bm, KF, GS, AGS, zp)[0]
+            got = res[0][i].float().cpu().numpy()
+            err = float(np.abs(got - full[rank * rows:(rank + 1) * rows]).max() / max(np.abs(full).max(), 1e-30))
+            assert err <= 1e-3, f"rank {rank} op {i}: sharded chain vs oracle {err}"
         ref_chain.free()
     barrier(f"ref{turn}")
 print("rank", rank, "ok")

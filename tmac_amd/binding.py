@@ -21,6 +21,12 @@ class TMACHipError(RuntimeError):
         self.code = code
 
 
+class XForm(C.Structure):
+    """tmac_hip_xform (include/tmac_hip.h): a vector transform of the next recorded call's activations"""
+    _fields_ = [("kind", C.c_int32), ("in2", C.c_void_p), ("residual", C.c_void_p), ("gamma", C.c_void_p), ("eps", C.c_float),
+                ("residual_out", C.c_void_p), ("keep", C.c_int32)]
+
+
 class KCfg(C.Structure):
     """tmac_kcfg — TMAC::TMACGeMMConfig (tmac_gemm_wrapper.h:26-35) + zero_point/act_group_size/m_groups."""
     _fields_ = [(n, C.c_int) for n in ("bm", "simd_n_in", "simd_n_out", "kfactor", "group_size", "lut_scales_size",
@@ -111,6 +117,7 @@ def load_library() -> C.CDLL:
         "tmac_hip_chain_launch": ([vp, vp], i32),
         "tmac_hip_chain_status": ([vp, C.POINTER(C.c_uint32)], i32),
         "tmac_hip_chain_info": ([vp, C.c_int, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)], i32),
+        "tmac_hip_chain_xform": ([C.POINTER(XForm)], i32),
         "tmac_hip_chain_free": ([vp], i32),
         "tmac_hip_chain_set_stamps": ([vp, vp], i32),
         "tmac_hip_chain_threads": ([], i32),
@@ -126,8 +133,15 @@ def load_library() -> C.CDLL:
         "qgemm_lut_int8": ([C.c_int] * 4 + [vp] * 6, i32),
         "preprocessor_int8": ([C.c_int] * 4 + [vp] * 4, i32),
     }
+    # $TMAC_HIP_LIB may name an OLDER build for an A/B run (tools/gpu): entry points it lacks stay unbound (calling one raises)
+    optional = {"tmac_hip_chain_xform"} if os.environ.get("TMAC_HIP_LIB") else set()
     for name, (argt, rest) in sigs.items():
-        fn = getattr(L, name)
+        try:
+            fn = getattr(L, name)
+        except AttributeError:
+            if name in optional:
+                continue
+            raise
         fn.argtypes, fn.restype = argt, rest
     _lib = L
     return L

@@ -38,9 +38,18 @@ struct ChainOp {
     int q_per, q_extra;  // total_q = q_per * grid + q_extra: workgroup b owns the q_per + (b < q_extra) consecutive quads from b * q_per + min(b, q_extra)
     int m_groups;        // unified-scale flavour: scales per matrix (rows split into m_groups equal runs; qgemm.py:170-174), else 0
     int ipi_inv;         // ceil(65536 / ipi)
-    // sizeof == 256: the kernel keeps a copy of all descriptors in LDS (uint4 copies)
+    // vector transform of the activations inside the LUT build (tmac_hip_chain_xform; xf_kind 0: none)
+    const void* in2;     // GLU (xf_kind 2): x = silu(in) * in2 -- a second vector of the same kind as `in` (hand-off image / fp16 memory)
+    const float* res;    // NORM (xf_kind 1): t = in + res (fp32 [K] in memory; nullptr: none, or the carry: xf_flags bit 1)
+    const float* gamma;  //   x = t * rsqrt(mean(t^2) + eps) * gamma (fp32 [K]); nullptr: x = t
+    float* res_out;      //   t is also written here (fp32 [K]); nullptr: not written
+    int xf_kind;
+    int xf_flags;        // bit 1: the residual is the t kept by an earlier NORM of this launch (LDS); bit 2: keep this op's t
+    int eps_bits;        // eps as the bits of a float
+    int pad[5];
+    // sizeof == 320: the kernel keeps a copy of all descriptors in LDS (uint4 copies)
 };
-static_assert(sizeof(ChainOp) == 256, "ChainOp is copied to LDS in 16-byte pieces");
+static_assert(sizeof(ChainOp) == 320, "ChainOp is copied to LDS in 16-byte pieces");
 
 struct ChainArgs {
     const ChainOp* ops;            // device memory; every workgroup copies them to LDS at kernel entry (a descriptor field read through
@@ -61,6 +70,8 @@ struct ChainArgs {
     unsigned long long arena_half;
     unsigned long long peer_base[7];   // the other ranks' arenas as mapped into this process
     int npeer;
+    int xforms;                    // some op carries a vector transform (tmac_hip_chain_xform): the kernel instance that knows them
+    int carry_floats;              // LDS floats for the vector a NORM transform keeps for a later op of the launch (0: no op does)
     unsigned long long* stamps;    // optional [nops][grid][8] of wave 0, s_memrealtime (100 MHz): 0 op entry, 1 activations complete, 2 LUT built
                                    // (barrier passed), 3 current ring landed, 5 last quad published, 6 everything in flight landed, 7 polls
 };
@@ -82,13 +93,13 @@ inline hipError_t launch_decode_chain(const ChainArgs& a, int bits, bool zp, boo
     }
 }
 // LDS: two LUT buffers of buf_u4 uint4 each ([4][tstride] half tables + the act groups' scales / biases, or the unified-scale
-// scratch), the split-quad reduction buffer, the op descriptors
+// scratch), the split-quad reduction buffer, the op descriptors, the transforms' scratch and carry
 inline int chain_buf_u4(int K) {
     const int nu = K / 32, nst = (nu + 63) / 64;
     return 4 * (nst * 64 + 1) + (2 * nst * 32 * 4 + 15) / 16 + CHAIN_US_FLOATS / 4;
 }
-inline size_t chain_lds_bytes(int buf_u4, int nops) {
-    return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops;
+inline size_t chain_lds_bytes(int buf_u4, int nops, int carry_floats = 0) {
+    return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops + sizeof(float) * (16 + (size_t)carry_floats);
 }
 
 }  // namespace tmac

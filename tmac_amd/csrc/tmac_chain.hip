@@ -165,13 +165,13 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
 // bypasses this CU's L1 and sees what other XCDs wrote through; chains that span several GPUs poll at system scope (sc0 sc1):
 // the granules then arrive over xGMI from the peers' producers.
 #define TMAC_POLL_FNS(SUFFIX, SC)                                                                                              \
-    __device__ __forceinline__ void c_poll1##SUFFIX(const uint4* p0, u32x4q (&v)[6]) {                                          \
+    __device__ __forceinline__ void c_poll1##SUFFIX(const uint4* p0, u32x4q (&v)[8]) {                                          \
         asm volatile("global_load_dwordx4 %0, %2, off " SC "\n\t"                                                             \
                      "global_load_dwordx4 %1, %2, off offset:16 " SC "\n\t"                                                   \
                      "s_waitcnt vmcnt(0)"                                                                                       \
                      : "=&v"(v[0]), "=&v"(v[1]) : "v"(p0) : "memory");                                                          \
     }                                                                                                                           \
-    __device__ __forceinline__ void c_poll2##SUFFIX(const uint4* p0, const uint4* p1, u32x4q (&v)[6]) {                         \
+    __device__ __forceinline__ void c_poll2##SUFFIX(const uint4* p0, const uint4* p1, u32x4q (&v)[8]) {                         \
         asm volatile("global_load_dwordx4 %0, %4, off " SC "\n\t"                                                             \
                      "global_load_dwordx4 %1, %4, off offset:16 " SC "\n\t"                                                   \
                      "global_load_dwordx4 %2, %5, off " SC "\n\t"                                                             \
@@ -179,7 +179,7 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
                      "s_waitcnt vmcnt(0)"                                                                                       \
                      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(p0), "v"(p1) : "memory");                       \
     }                                                                                                                           \
-    __device__ __forceinline__ void c_poll3##SUFFIX(const uint4* p0, const uint4* p1, const uint4* p2, u32x4q (&v)[6]) {        \
+    __device__ __forceinline__ void c_poll3##SUFFIX(const uint4* p0, const uint4* p1, const uint4* p2, u32x4q (&v)[8]) {        \
         asm volatile("global_load_dwordx4 %0, %6, off " SC "\n\t"                                                             \
                      "global_load_dwordx4 %1, %6, off offset:16 " SC "\n\t"                                                   \
                      "global_load_dwordx4 %2, %7, off " SC "\n\t"                                                             \
@@ -189,11 +189,28 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
                      "s_waitcnt vmcnt(0)"                                                                                       \
                      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]) : "v"(p0), "v"(p1), "v"(p2) : "memory"); \
     }
+#define TMAC_POLL4_FN(SUFFIX, SC)                                                                                               \
+    __device__ __forceinline__ void c_poll4##SUFFIX(const uint4* p0, const uint4* p1, const uint4* p2, const uint4* p3, u32x4q (&v)[8]) { \
+        asm volatile("global_load_dwordx4 %0, %8, off " SC "\n\t"                                                             \
+                     "global_load_dwordx4 %1, %8, off offset:16 " SC "\n\t"                                                   \
+                     "global_load_dwordx4 %2, %9, off " SC "\n\t"                                                             \
+                     "global_load_dwordx4 %3, %9, off offset:16 " SC "\n\t"                                                   \
+                     "global_load_dwordx4 %4, %10, off " SC "\n\t"                                                            \
+                     "global_load_dwordx4 %5, %10, off offset:16 " SC "\n\t"                                                  \
+                     "global_load_dwordx4 %6, %11, off " SC "\n\t"                                                            \
+                     "global_load_dwordx4 %7, %11, off offset:16 " SC "\n\t"                                                  \
+                     "s_waitcnt vmcnt(0)"                                                                                       \
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])   \
+                     : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");                                                          \
+    }
 TMAC_POLL_FNS(, "sc1")
 TMAC_POLL_FNS(_sys, "sc0 sc1")
+TMAC_POLL4_FN(, "sc1")
+TMAC_POLL4_FN(_sys, "sc0 sc1")
+#undef TMAC_POLL4_FN
 #undef TMAC_POLL_FNS
 // the same for plain activations (in memory since before the launch)
-__device__ __forceinline__ void c_ext3(const uint4* p0, const uint4* p1, const uint4* p2, u32x4q (&v)[6]) {
+__device__ __forceinline__ void c_ext3(const uint4* p0, const uint4* p1, const uint4* p2, u32x4q (&v)[8]) {
     asm volatile("global_load_dwordx4 %0, %3, off\n\t"
                  "global_load_dwordx4 %1, %4, off\n\t"
                  "global_load_dwordx4 %2, %5, off\n\t"
@@ -201,7 +218,8 @@ __device__ __forceinline__ void c_ext3(const uint4* p0, const uint4* p1, const u
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(p0), "v"(p1), "v"(p2) : "memory");
 }
 
-template <int BITS, bool ZP, bool SCF16, int SM>
+// XF: the chain holds vector transforms (tmac_hip_chain_xform) -- a kernel of its own, so that chains without them keep their registers
+template <int BITS, bool ZP, bool SCF16, int SM, bool XF>
 __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     constexpr int FT = CHAIN_FT, NWV = CHAIN_NWV;
@@ -215,10 +233,12 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     uint4* l_ops = lds + 2 * (size_t)a.buf_u4 + (2 * NWV * 4 * CHAIN_RED * sizeof(float)) / 16;
     {
         const uint4* gsrc = reinterpret_cast<const uint4*>(a.ops);
-        for (int idx = tid; idx < a.nops * 16; idx += FT) l_ops[idx] = gsrc[idx];
+        for (int idx = tid; idx < a.nops * (int)(sizeof(ChainOp) / 16); idx += FT) l_ops[idx] = gsrc[idx];
         __syncthreads();
     }
     const cop_ptr ops = reinterpret_cast<cop_ptr>(l_ops);
+    float* l_xf = reinterpret_cast<float*>(l_ops + (size_t)a.nops * (sizeof(ChainOp) / 16));     // [16] partial sums of a transform's mean square
+    float* l_carry = l_xf + 16;                                                                     // [a.carry_floats] the t a NORM transform keeps
     bool aborted = false;                                                   // a hand-off timed out somewhere: stop waiting
 
     // stamps: s_memrealtime (100 MHz, one clock for the whole device; s_memtime counts per XCD with unrelated offsets)
@@ -330,14 +350,61 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         const int nr = (P + FT - 1) / FT;                            // rounds of FT pairs (<= NRMAX, checked on the host)
         constexpr int NRMAX = 3;
         uint32_t xw[NRMAX][4];
+        // a GLU transform (x = silu(in) * in2, tmac_hip_chain_xform) reads a second vector of the same kind -- both handed over or both in
+        // memory -- in at most two rounds; its granules are polled together with the first vector's (one fabric round trip for both)
+        const int xk = XF ? uni(d->xf_kind) : 0;
+        const bool glu = XF && xk == 2;
+        uint32_t xw2[2][4];
         unsigned long long polls = 0;
         {
             // pair of round r: p = r * FT + tid; past the end the address is clamped and the result ignored
             const uint4* in4 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(uni(d->in)) + (gran ? par_off : 0ull));
             const int p0 = min(tid, P - 1), p1 = min(FT + tid, P - 1), p2 = min(2 * FT + tid, P - 1);
             const bool n0 = tid < P, n1 = FT + tid < P, n2 = 2 * FT + tid < P;
-            u32x4q v[6];
-            if (gran) {
+            u32x4q v[8];
+            if (gran && glu) {
+                const uint4* in5 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(uni(d->in2)) + par_off);
+                const uint4 *g0 = in4 + 2 * (size_t)p0, *g1 = in4 + 2 * (size_t)p1, *h0 = in5 + 2 * (size_t)p0, *h1 = in5 + 2 * (size_t)p1;
+                unsigned spins = 0;
+                for (int z = 0; z < a.poll_delay; ++z) __builtin_amdgcn_s_sleep(1);
+                for (;;) {
+                    ++polls;
+                    bool ok;
+                    const bool sys = a.npeer > 0 || a.poll_mode == 1;
+                    if (nr == 1) {
+                        if (sys) c_poll2_sys(g0, h0, v); else c_poll2(g0, h0, v);
+                        ok = !n0 || ((v[0].x == gen) & (v[0].z == gen) & (v[1].x == gen) & (v[1].z == gen) &
+                                     (v[2].x == gen) & (v[2].z == gen) & (v[3].x == gen) & (v[3].z == gen));
+                    } else {
+                        if (sys) c_poll4_sys(g0, g1, h0, h1, v); else c_poll4(g0, g1, h0, h1, v);
+                        ok = (!n0 || ((v[0].x == gen) & (v[0].z == gen) & (v[1].x == gen) & (v[1].z == gen) &
+                                      (v[4].x == gen) & (v[4].z == gen) & (v[5].x == gen) & (v[5].z == gen))) &
+                             (!n1 || ((v[2].x == gen) & (v[2].z == gen) & (v[3].x == gen) & (v[3].z == gen) &
+                                      (v[6].x == gen) & (v[6].z == gen) & (v[7].x == gen) & (v[7].z == gen)));
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+                    if (aborted) break;
+                    ++spins;
+                    if ((spins & 1023u) == 0u) {
+                        const unsigned err = __hip_atomic_load(a.ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (err != 0u || spins >= a.spin_limit) {
+                            if (err == 0u && lane == 0) atomicOr(a.ctl + 2, 0x80000000u | ((unsigned)i << 8) | (unsigned)w);
+                            aborted = true;
+                        }
+                    }
+                    for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
+                }
+                if (nr == 1) {
+                    xw[0][0] = v[0].y; xw[0][1] = v[0].w; xw[0][2] = v[1].y; xw[0][3] = v[1].w;
+                    xw2[0][0] = v[2].y; xw2[0][1] = v[2].w; xw2[0][2] = v[3].y; xw2[0][3] = v[3].w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        xw[r][0] = v[2 * r].y; xw[r][1] = v[2 * r].w; xw[r][2] = v[2 * r + 1].y; xw[r][3] = v[2 * r + 1].w;
+                        xw2[r][0] = v[4 + 2 * r].y; xw2[r][1] = v[4 + 2 * r].w; xw2[r][2] = v[5 + 2 * r].y; xw2[r][3] = v[5 + 2 * r].w;
+                    }
+                }
+            } else if (gran) {
                 const uint4 *g0 = in4 + 2 * (size_t)p0, *g1 = in4 + 2 * (size_t)p1, *g2 = in4 + 2 * (size_t)p2;
                 unsigned spins = 0;
                 for (int z = 0; z < a.poll_delay; ++z) __builtin_amdgcn_s_sleep(1);      // A/B knob: wait before the first poll
@@ -376,6 +443,12 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 c_ext3(in4 + p0, in4 + p1, in4 + p2, v);
 #pragma unroll
                 for (int r = 0; r < NRMAX; ++r) { xw[r][0] = v[r].x; xw[r][1] = v[r].y; xw[r][2] = v[r].z; xw[r][3] = v[r].w; }
+                if (glu) {
+                    const uint4* in5 = uni(reinterpret_cast<const uint4*>(d->in2));
+                    c_ext3(in5 + p0, in5 + p1, in5 + p1, v);
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) { xw2[r][0] = v[r].x; xw2[r][1] = v[r].y; xw2[r][2] = v[r].z; xw2[r][3] = v[r].w; }
+                }
             }
         }
         CSTAMP(i, 1);
@@ -394,11 +467,102 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         CSTAMP(i, 3);
 
         // ---- 3. LUT into LDS (lut_ctor.cc:120-215, as in k_gemv_quad) ----
-        auto unpack = [&](int r, float (&x)[8]) __attribute__((always_inline)) {
+        // the activations as fp32: the fp16 vector as it is, or -- tmac_hip_chain_xform -- a vector transform of it, computed here where
+        // every workgroup holds the whole vector anyway (a decoder's residual add + RMSNorm in front of q/k/v and gate/up, its
+        // silu(gate) * up in front of the down projection): the calls of a layer chain up without a kernel in between
+        float xs[XF ? NRMAX : 1][8];
+        if constexpr (XF) {
+#pragma unroll
+        for (int r = 0; r < NRMAX; ++r)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const __half2 hh = *reinterpret_cast<const __half2*>(&xw[r][q]);
-                x[2 * q] = __low2float(hh); x[2 * q + 1] = __high2float(hh);
+                xs[r][2 * q] = __low2float(hh); xs[r][2 * q + 1] = __high2float(hh);
+            }
+        if (xk == 2) {
+            // GLU: x = silu(in) * in2, fp32
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const __half2 hh = *reinterpret_cast<const __half2*>(&xw2[r][q]);
+                    const float u0 = __low2float(hh), u1 = __high2float(hh);
+                    const float a0 = xs[r][2 * q], a1 = xs[r][2 * q + 1];
+                    xs[r][2 * q] = __fmul_rn(__fdiv_rn(a0, __fadd_rn(1.0f, __expf(-a0))), u0);
+                    xs[r][2 * q + 1] = __fmul_rn(__fdiv_rn(a1, __fadd_rn(1.0f, __expf(-a1))), u1);
+                }
+        } else if (xk == 1) {
+            // NORM: t = in + residual (memory fp32, or the t an earlier NORM of this launch kept in LDS); x = t * rsqrt(mean(t^2) + eps) *
+            // gamma (or x = t without gamma); t optionally kept for a later op and / or written to memory (the residual stream that
+            // outlives the launch; each workgroup writes a stripe of it)
+            const int xfl = uni(d->xf_flags);
+            const TMAC_GLOBAL float* resp = as_global(uni(d->res));
+            const TMAC_GLOBAL float* gam = as_global(uni(d->gamma));
+            TMAC_GLOBAL float* rout = as_global(uni(d->res_out));
+            float ss = 0.f;
+#pragma unroll
+            for (int r = 0; r < NRMAX; ++r) {
+                const int p = r * FT + tid;
+                if (r < nr && p < P) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float rv = 0.f;
+                        if (xfl & 2) rv = l_carry[8 * p + e];
+                        else if (resp) rv = resp[8 * (size_t)p + e];
+                        const float t = __fadd_rn(xs[r][e], rv);
+                        xs[r][e] = t;
+                        ss = __fmaf_rn(t, t, ss);
+                    }
+                }
+            }
+            if (gam) {
+                ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+                ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+                if (lane == 0) l_xf[w] = ss;
+                __syncthreads();
+                float tot = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NWV; ++ww) tot += l_xf[ww];
+                const float rs = 1.0f / sqrtf(tot / (float)(8 * P) + __uint_as_float((uint32_t)uni(d->eps_bits)));
+                __syncthreads();                                   // l_xf is read; the next op may write it
+#pragma unroll
+                for (int r = 0; r < NRMAX; ++r) {
+                    const int p = r * FT + tid;
+                    if (r < nr && p < P) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float t = xs[r][e];
+                            if (xfl & 4) l_carry[8 * p + e] = t;
+                            if (rout && (p % gx) == bx) rout[8 * (size_t)p + e] = t;
+                            xs[r][e] = __fmul_rn(__fmul_rn(t, rs), gam[8 * (size_t)p + e]);
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < NRMAX; ++r) {
+                    const int p = r * FT + tid;
+                    if (r < nr && p < P) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            if (xfl & 4) l_carry[8 * p + e] = xs[r][e];
+                            if (rout && (p % gx) == bx) rout[8 * (size_t)p + e] = xs[r][e];
+                        }
+                    }
+                }
+            }
+        }
+        }   // XF
+        auto unpack = [&](int r, float (&x)[8]) __attribute__((always_inline)) {
+            if constexpr (XF) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = xs[r][e];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const __half2 hh = *reinterpret_cast<const __half2*>(&xw[r][q]);
+                    x[2 * q] = __low2float(hh); x[2 * q + 1] = __high2float(hh);
+                }
             }
         };
         float gscale = 0.f, gtinv = 0.f;
@@ -652,9 +816,9 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
 #endif
 constexpr int CB = TMAC_CHAIN_BITS;
 
-template <bool ZP, bool SCF16, int SM>
-static hipError_t chain_launch_one(const ChainArgs& a, int grid, size_t lds_bytes, hipStream_t st, int* resident) {
-    auto* kern = &k_decode_chain<CB, ZP, SCF16, SM>;
+template <bool ZP, bool SCF16, int SM, bool XF>
+static hipError_t chain_launch_x(const ChainArgs& a, int grid, size_t lds_bytes, hipStream_t st, int* resident) {
+    auto* kern = &k_decode_chain<CB, ZP, SCF16, SM, XF>;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -663,6 +827,11 @@ static hipError_t chain_launch_one(const ChainArgs& a, int grid, size_t lds_byte
         return hipOccupancyMaxActiveBlocksPerMultiprocessor(resident, reinterpret_cast<const void*>(kern), CHAIN_FT, lds_bytes);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(CHAIN_FT), lds_bytes, st, a);
     return hipGetLastError();
+}
+
+template <bool ZP, bool SCF16, int SM>
+static hipError_t chain_launch_one(const ChainArgs& a, int grid, size_t lds_bytes, hipStream_t st, int* resident) {
+    return a.xforms ? chain_launch_x<ZP, SCF16, SM, true>(a, grid, lds_bytes, st, resident) : chain_launch_x<ZP, SCF16, SM, false>(a, grid, lds_bytes, st, resident);
 }
 
 #define TMAC_CHAIN_LAUNCHER(NAME)                                                                                               \

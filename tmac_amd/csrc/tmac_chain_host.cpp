@@ -14,6 +14,7 @@ struct ChainRecOp {
     const void* B;
     std::vector<void*> C;
     tmac_dtype_t act, out;
+    tmac_hip_xform xf;               // vector transform of the activations (kind 0: none)
 };
 // an exchange step noted while recording: recv = all-gather over the ranks of send (rank r's bytes at r * bytes)
 struct ChainRecGather {
@@ -25,6 +26,7 @@ struct ChainRecGather {
 };
 static thread_local std::vector<ChainRecOp>* g_chain_rec = nullptr;
 static thread_local std::vector<ChainRecGather>* g_chain_gat = nullptr;
+static thread_local tmac_hip_xform g_chain_xf = {};                  // applies to the next recorded call
 bool tmac_host::chain_recording() { return g_chain_rec != nullptr; }
 
 struct tmac_hip_chain {
@@ -45,6 +47,7 @@ struct tmac_hip_chain {
     size_t lds_bytes = 0;
     unsigned long long* stamps = nullptr;
     size_t bytes = 0;                 // algorithmic weight + scale bytes of one launch
+    int xforms = 0, carry_floats = 0;    // some op carries a vector transform; LDS floats of the kept vector
     int poll_sleep = 8, poll_delay = 4, issue_first = -1, poll_mode = 0;   // read from the environment once, at tmac_hip_chain_end
     hipStream_t last_stream = nullptr;   // stream of the most recent launch (in-flight guard)
     bool launched = false;
@@ -60,7 +63,19 @@ int32_t tmac_host::chain_record(const tmac_hip_weights* const* wl, int nmat, con
         op.C.push_back(C_list[i]);
     }
     op.B = B_dev; op.act = act_dtype; op.out = out_dtype;
+    op.xf = g_chain_xf;
+    memset(&g_chain_xf, 0, sizeof(g_chain_xf));
     g_chain_rec->push_back(op);
+    return TMAC_HIP_OK;
+}
+
+// A vector transform for the NEXT recorded call (include/tmac_hip.h): validated when the chain is built.
+extern "C" int32_t tmac_hip_chain_xform(const tmac_hip_xform* xf) {
+    if (!g_chain_rec) return fail(TMAC_HIP_E_ARG, "no chain is being recorded on this thread");
+    if (!xf) return fail(TMAC_HIP_E_ARG, "null transform");
+    if (xf->kind < 0 || xf->kind > 2) return fail(TMAC_HIP_E_ARG, "unknown transform kind %d", xf->kind);
+    if (xf->kind == TMAC_XF_GLU && !xf->in2) return fail(TMAC_HIP_E_ARG, "GLU needs a second vector");
+    g_chain_xf = *xf;
     return TMAC_HIP_OK;
 }
 
@@ -68,6 +83,7 @@ extern "C" int32_t tmac_hip_chain_begin(void) {
     if (g_chain_rec) return fail(TMAC_HIP_E_ARG, "a chain is already being recorded on this thread");
     g_chain_rec = new std::vector<ChainRecOp>();
     g_chain_gat = new std::vector<ChainRecGather>();
+    memset(&g_chain_xf, 0, sizeof(g_chain_xf));
     return TMAC_HIP_OK;
 }
 
@@ -204,13 +220,36 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                 break;
             }
     }
+    // the second vector of a GLU transform: the same rules as the activations (an earlier output, whole, or external memory)
+    std::vector<Src> src2(n, Src{-1, -1});
+    for (size_t i = 0; i < n; ++i) {
+        if (rec[i].xf.kind != TMAC_XF_GLU) continue;
+        const Range r2{(const char*)rec[i].xf.in2, (const char*)rec[i].xf.in2 + (size_t)rec[i].w[0]->s.K * 2};
+        for (size_t j = i; j-- > 0 && src2[i].op < 0;)
+            for (size_t m = 0; m < rec[j].C.size(); ++m) {
+                if (!overlap(r2, out_r[j][m])) continue;
+                if (rec[j].C[m] != rec[i].xf.in2)
+                    return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the GLU's second vector overlaps output %zu of op %zu without being that output", i, m, j));
+                if (gathered[j][m]) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: a gathered output as the second vector of a GLU is not covered", i));
+                src2[i] = Src{(int)j, (int)m};
+                consumed[j][m] = 1;
+                break;
+            }
+        if ((src2[i].op >= 0) != (src[i].op >= 0))
+            return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the two vectors of a GLU must both be outputs of the chain or both be external", i));
+    }
     // dep[k][i]: op k runs after op i has published everything (transitive closure over the hand-offs)
     std::vector<std::vector<char>> dep(n, std::vector<char>(n, 0));
-    for (size_t k = 0; k < n; ++k)
+    for (size_t k = 0; k < n; ++k) {
         if (src[k].op >= 0) {
             dep[k] = dep[src[k].op];
             dep[k][src[k].op] = 1;
         }
+        if (src2[k].op >= 0) {
+            for (size_t q = 0; q < n; ++q) dep[k][q] |= dep[src2[k].op][q];
+            dep[k][src2[k].op] = 1;
+        }
+    }
 
     c->ops.resize(n);
     int maxK = 0;
@@ -284,6 +323,31 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         } else {
             o.in = r.B; o.in_gran = 0;
         }
+        // ---- vector transform (tmac_hip_chain_xform)
+        {
+            const tmac_hip_xform& xf = r.xf;
+            o.xf_kind = xf.kind;
+            if (xf.kind == TMAC_XF_NORM) {
+                c->xforms = 1;
+                if (o.K > 8192 && (xf.keep || xf.residual == TMAC_XF_CARRY))
+                    return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: a kept residual vector is covered up to K = 8192", i));
+                if (xf.residual == TMAC_XF_CARRY) {
+                    if (c->carry_floats < o.K) return bail(fail(TMAC_HIP_E_ARG, "op %zu: no earlier NORM of the chain keeps a vector of %d values", i, o.K));
+                    o.xf_flags |= 2;
+                } else o.res = xf.residual;
+                if (xf.keep) { o.xf_flags |= 4; if (o.K > c->carry_floats) c->carry_floats = o.K; }
+                o.gamma = xf.gamma; o.res_out = xf.residual_out;
+                memcpy(&o.eps_bits, &xf.eps, 4);
+            } else if (xf.kind == TMAC_XF_GLU) {
+                c->xforms = 1;
+                if (o.K > 2 * 8 * CHAIN_FT) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: a GLU transform is covered up to K = %d", i, 2 * 8 * CHAIN_FT));
+                if (src2[i].op >= 0) {
+                    const ChainOp& p2 = c->ops[src2[i].op];
+                    if (p2.m[src2[i].mat].Mw != o.K) return bail(fail(TMAC_HIP_E_ARG, "op %zu: the GLU's second vector has %d rows, K = %d", i, p2.m[src2[i].mat].Mw, o.K));
+                    o.in2 = p2.m[src2[i].mat].GR;        // (offset + 1 until the arena exists, like `in`)
+                } else o.in2 = xf.in2;
+            }
+        }
         // weight fragments per wave in front of the polls: ONE.  The poll then returns after a fabric round trip plus 24 KB per
         // CU, and the wait behind it does not hold the LUT build until all of the op's weights have landed.  Putting the whole
         // ring in front ("start the stream at once") measured slower even for the ops whose stream outlasts the hand-off:
@@ -312,7 +376,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                         return bail(fail(TMAC_HIP_E_NOMATCH, "ops %zu and %zu write overlapping outputs and nothing in the chain orders them", i, k));
             }
     c->buf_u4 = chain_buf_u4(maxK);
-    c->lds_bytes = chain_lds_bytes(c->buf_u4, (int)c->ops.size());
+    c->lds_bytes = chain_lds_bytes(c->buf_u4, (int)c->ops.size(), c->carry_floats);
     if (c->lds_bytes > 160 * 1024)
         return bail(fail(TMAC_HIP_E_NOMATCH, "%zu calls with K up to %d need %zu bytes of LDS (LUT buffers + call descriptors): record shorter chains",
                          c->ops.size(), maxK, c->lds_bytes));
@@ -343,6 +407,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             for (int m = 0; m < o.nmat; ++m)
                 if (o.m[m].GR) o.m[m].GR = reinterpret_cast<uint4*>(reinterpret_cast<size_t>(o.m[m].GR) + base);
             if (o.in_gran & 1) o.in = reinterpret_cast<const void*>(reinterpret_cast<size_t>(o.in) + base);
+            if ((o.in_gran & 1) && o.xf_kind == TMAC_XF_GLU) o.in2 = reinterpret_cast<const void*>(reinterpret_cast<size_t>(o.in2) + base);
         }
     }
     c->connected = c->world == 1;
@@ -384,6 +449,7 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
     a.npeer = (int)c->peers.size();
     for (int p = 0; p < a.npeer; ++p) a.peer_base[p] = reinterpret_cast<unsigned long long>(c->peers[p]);
     a.spin_limit = g_knobs.chain_spin_limit; a.buf_u4 = c->buf_u4; a.stamps = c->stamps;
+    a.xforms = c->xforms; a.carry_floats = c->carry_floats;
     a.poll_sleep = c->poll_sleep; a.poll_delay = c->poll_delay; a.issue_first = c->issue_first; a.poll_mode = c->poll_mode;
     hipError_t e = launch_decode_chain(a, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, st);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no decode-chain kernel for this configuration");

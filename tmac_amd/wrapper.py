@@ -372,6 +372,26 @@ class TMACGeMMWrapper:
             rec.append((send_dev, recv_dev))
         check(B.lib().tmac_hip_chain_record_gather(_ptr(send_dev), _ptr(recv_dev), bytes_per_rank, rank, world))
 
+    CARRY = "carry"
+
+    def chain_xform(self, kind: str, in2=None, residual=None, gamma=None, eps: float = 1e-5, residual_out=None, keep: bool = False) -> None:
+        """while recording a chain: a vector transform of the NEXT ``fused`` call's activations, applied inside its LUT build
+        (tmac_hip_chain_xform).  kind "norm": t = in + residual (fp32 tensor, None, or ``TMACGeMMWrapper.CARRY`` = the t the latest
+        kept NORM left in LDS); x = t * rsqrt(mean(t^2) + eps) * gamma (x = t without gamma); residual_out: t also goes to memory;
+        keep: leave t for a later CARRY.  kind "glu": x = silu(in) * in2."""
+        xf = B.XForm()
+        xf.kind = {"norm": 1, "glu": 2}[kind]
+        xf.in2 = _ptr(in2) if in2 is not None else None
+        xf.residual = 1 if residual is TMACGeMMWrapper.CARRY else (_ptr(residual) if residual is not None else None)
+        xf.gamma = _ptr(gamma) if gamma is not None else None
+        xf.eps = float(eps)
+        xf.residual_out = _ptr(residual_out) if residual_out is not None else None
+        xf.keep = 1 if keep else 0
+        rec = getattr(self, "_recording", None)
+        if rec is not None:
+            rec.append((in2, residual, gamma, residual_out))      # kept alive with the chain
+        check(B.lib().tmac_hip_chain_xform(C.byref(xf)))
+
     def record_chain(self) -> "_ChainRecorder":
         """``with wr.record_chain() as rec: <the token's wr.fused(...) calls>`` — the calls are noted instead of launched;
         afterwards ``rec.chain.launch()`` executes all of them in ONE persistent kernel launch (tmac_hip_chain_*)."""

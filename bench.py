@@ -84,9 +84,13 @@ def parse():
                     help="auto: chain where k_decode_chain covers the configuration (N = 1; row-sharded over the ranks with --gpus N), else fused")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the check of one layer's outputs (the launches being timed, at full size) against the oracle")
-    ap.add_argument("--pattern", choices=["chained", "independent"], default="chained",
+    ap.add_argument("--pattern", choices=["chained", "independent", "decoder"], default="chained",
                     help="chained: the calls are linked by real data (x1 = q, x2 = o, x3 = gate, next x0 = down; the default and the reported "
-                         "workload); independent: every call reads an external vector -- no hand-offs, the lookups' streaming rate alone (diagnostic)")
+                         "workload); independent: every call reads an external vector -- no hand-offs, the lookups' streaming rate alone (diagnostic); "
+                         "decoder: the calls as a decoder issues them -- residual add + RMSNorm and silu(gate) * up inside the chain "
+                         "(tmac_hip_chain_xform), one launch per segment o -> gate/up -> down -> next q/k/v, an outside kernel (stand-in for "
+                         "attention) between the segments; hipGraph replay of the token's launches")
+    ap.add_argument("--no-decoder-pattern", action="store_true", help="skip the decoder-pattern measurement of the default line")
     ap.add_argument("--stamps", action="store_true", help="chain path: report per-call times from in-kernel stamps (costs ~6 %%)")
     ap.add_argument("--floors", action="store_true", help="fused path: also time launches that only read the same bytes")
     ap.add_argument("--autotune", action="store_true", help="fused path: measure the launch configurations first (tmac_hip_autotune_fused)")
@@ -420,7 +424,7 @@ def main():
                 g = gathered[name]
                 xin[nxt[name]] = (g.reshape(-1)[:logical[name]] if decode
                                   else g.permute(1, 0, 2).reshape(N, -1)[:, :logical[name]].contiguous())
-            elif args.pattern == "chained":
+            elif args.pattern != "independent":
                 xin[nxt[name]] = out_of[name][0]
 
     # independent pattern: nothing orders the calls, so every layer gets output buffers of its own
@@ -440,7 +444,11 @@ def main():
     # (the fused entry point's per-stream LUT workspace for N > 1 must not be allocated inside a capture: the warm-up step and
     # the capture below run on the same side stream, so the workspace exists and has its final size when capture starts)
     graph, chain, stamp_buf = None, None, None
-    if args.path == "chain":
+    dpat = None
+    if args.pattern == "decoder":
+        if args.path != "chain" or dist_on:
+            raise SystemExit("bench.py: --pattern decoder runs on the chain path of one GPU")
+    if args.path == "chain" and args.pattern != "decoder":
         # record the token's calls once (they are not launched while recording); one launch per step from here on
         step()                                       # leaves x[0] = the down projection's output, as in a decode loop
         torch.cuda.synchronize()
@@ -530,6 +538,91 @@ def main():
             except Exception:
                 pass
 
+    # ---- the decoder pattern: the same 224 matrices as a decoder issues them.  A real layer has an operator outside
+    # the hot path between q/k/v and o (attention) and element-wise operators between the other mpGEMMs; the latter run inside the
+    # chain's LUT builds (tmac_hip_chain_xform), the former ends the persistent launch: one launch per segment.
+    def build_decoder_pattern():
+        H = MATS[1][2]                      # hidden size = K of the o projection
+        f16 = lambda n_: torch.zeros(n_, dtype=torch.float16, device=dev)
+        gam = [(torch.ones(H, dtype=torch.float32, device=dev), torch.ones(H, dtype=torch.float32, device=dev)) for _ in range(args.layers)]
+        hs = [torch.randn(H, device=dev, generator=gen)] + [torch.zeros(H, dtype=torch.float32, device=dev) for _ in range(args.layers)]
+        attn = f16(H)
+        bo = [dict(o=[f16(shard_rows["o"])], gate_up=[f16(shard_rows["gate_up"]) for _ in range(2)], down=[f16(shard_rows["down"])],
+                   qkv=[f16(shard_rows["qkv"]) for _ in range(3)]) for _ in range(args.layers + 1)]
+        x0 = hs[0].half()
+        chains_d = []
+        with wr.record_chain() as r0:
+            wr.chain_xform("norm", gamma=gam[0][0], eps=1e-5)
+            wr.fused(layers[0]["qkv"], x0, bo[0]["qkv"], 1, act_dtype=F16, out_dtype=F16)
+        chains_d.append(r0.chain)
+        for li in range(args.layers):
+            b, last = bo[li + 1], li == args.layers - 1
+            with wr.record_chain() as rc:
+                wr.fused(layers[li]["o"], attn, b["o"], 1, act_dtype=F16, out_dtype=F16)
+                wr.chain_xform("norm", residual=hs[li], gamma=gam[li][1], eps=1e-5, keep=True)
+                wr.fused(layers[li]["gate_up"], b["o"][0], b["gate_up"], 1, act_dtype=F16, out_dtype=F16)
+                wr.chain_xform("glu", in2=b["gate_up"][1])
+                wr.fused(layers[li]["down"], b["gate_up"][0], b["down"], 1, act_dtype=F16, out_dtype=F16)
+                if not last:
+                    wr.chain_xform("norm", residual=wr.CARRY, gamma=gam[li + 1][0], eps=1e-5, residual_out=hs[li + 1])
+                    wr.fused(layers[li + 1]["qkv"], b["down"][0], b["qkv"], 1, act_dtype=F16, out_dtype=F16)
+            chains_d.append(rc.chain)
+        keep_alive = (gam, hs, attn, bo, x0)
+
+        def dstep():
+            chains_d[0].launch()
+            for li in range(args.layers):
+                attn.copy_(bo[li]["qkv"][0])          # the outside operator: a kernel of the stream between two segments (stand-in for attention)
+                chains_d[li + 1].launch()
+        return dstep, chains_d, keep_alive
+
+    def time_decoder_pattern(reps=10):
+        dstep, chains_d, keep_alive = build_decoder_pattern()
+        dstep(); torch.cuda.synchronize()
+        ok = all(c.status() == 0 for c in chains_d)
+        g = None
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dstep()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                dstep()
+        except Exception as e:
+            sys.stderr.write(f"bench.py: decoder pattern not captured ({e!r}); eager launches\n")
+            g = None
+            torch.cuda.synchronize()
+        durs = []
+        for r in range(reps + 3):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); (g.replay() if g is not None else dstep()); e1.record()
+            torch.cuda.synchronize()
+            if r >= 3:
+                durs.append(e0.elapsed_time(e1))
+        ok = ok and all(c.status() == 0 for c in chains_d)
+        finite_d = bool(torch.isfinite(keep_alive[3][-1]["down"][0].float()).all().item())
+        for c in chains_d:
+            c.free()
+        return float(np.mean(durs)), ok and finite_d, len(chains_d), g is not None
+
+    if args.pattern == "decoder":
+        dstep, dchains, dkeep = build_decoder_pattern()
+        dstep(); torch.cuda.synchronize()
+        assert all(c.status() == 0 for c in dchains), "a hand-off inside a decoder segment timed out"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dstep()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            dstep()
+        dpat = dict(chains=dchains, keep=dkeep)
+
     def run_step():
         if chain is not None:
             chain.launch()
@@ -570,12 +663,30 @@ def main():
     ev_ms_per_step = ev0.elapsed_time(ev1) / args.steps      # hipEvent pair on the launch stream around the timed region
     if chain is not None and chain.status() != 0:
         raise SystemExit("bench.py: a hand-off inside the decode chain timed out; outputs invalid")
+    if dpat is not None and any(c.status() != 0 for c in dpat["chains"]):
+        raise SystemExit("bench.py: a hand-off inside a decoder segment timed out; outputs invalid")
+    if dpat is not None and args.stamps and len(dpat["chains"]) > 2:
+        # one segment (layer 1's) launched on its own with stamps: where its time goes (stderr; the timed numbers above are not affected)
+        sc = dpat["chains"][2]
+        sb = torch.zeros(sc.nops * sc.grid * 8, dtype=torch.int64, device=dev)
+        sc.set_stamps(sb)
+        for _ in range(3):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); sc.launch(); e1.record(); torch.cuda.synchronize()
+        st = sb.cpu().numpy().reshape(sc.nops, sc.grid, 8).astype(np.float64) * 0.01
+        t0 = st[0, :, 0].min()
+        sys.stderr.write("decoder segment with stamps: %.2f us by events; first entry -> last publish %.2f us\n" % (e0.elapsed_time(e1) * 1e3, st[-1, :, 5].max() - t0))
+        for oi in range(sc.nops):
+            sys.stderr.write("  op %d: entry %.2f..%.2f  activations %.2f..%.2f  LUT built %.2f..%.2f  published %.2f..%.2f (us after the first entry; min..max over workgroups)\n"
+                             % (oi, st[oi, :, 0].min() - t0, st[oi, :, 0].max() - t0, st[oi, :, 1].min() - t0, st[oi, :, 1].max() - t0,
+                                st[oi, :, 2].min() - t0, st[oi, :, 2].max() - t0, st[oi, :, 5].min() - t0, st[oi, :, 5].max() - t0))
+        sc.set_stamps(None)
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    finite = bool(torch.isfinite(outs["down"][0].float()).all().item())     # the chained activations stayed finite
+    finite = bool(torch.isfinite((dpat["keep"][3][-1]["down"][0] if dpat is not None else outs["down"][0]).float()).all().item())     # the chained activations stayed finite
 
     def time_headline_launches(graph_ok):
         """back-to-back stand-alone launches of the GEMV on the headline shape (the down projection of every layer: distinct
@@ -628,8 +739,12 @@ def main():
                 "ops_per_step": ops_per_step, "timing": "hipEvent pair on the launch stream around the %d timed steps" % args.steps}
     elif args.path == "chain":
         ach = bytes_per_step / (ev_ms_per_step * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "k_decode_chain: one persistent launch per decoded token (all %d GEMVs, LUT builds and in-kernel "
-                                          "hand-offs of the layer stack)" % (7 * args.layers),
+        roof = {"bound": "hbm", "kernel": ("k_decode_chain: one persistent launch per decoded token (all %d GEMVs, LUT builds and in-kernel "
+                                           "hand-offs of the layer stack)" % (7 * args.layers)) if dpat is None else
+                                          ("k_decode_chain, decoder pattern: %d launches per token (first q/k/v; per layer the segment o -> [+ residual, RMSNorm] -> "
+                                           "gate/up -> [silu(gate) * up] -> down -> [+ residual, RMSNorm] -> next q/k/v with the element-wise operators inside "
+                                           "the LUT builds) and a copy kernel between the segments (stand-in for attention), replayed from a hipGraph"
+                                           % len(dpat["chains"])),
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_per_step, "avg_launch_us": round(ev_ms_per_step * 1e3, 2), "launches_timed": args.steps,
@@ -667,7 +782,18 @@ def main():
                                            % (args.layers, name, Mw, K), "us_per_gemv": round(sus, 3), "GBps": round(hb / sus * 1e-3, 1),
                                    "frac": round(hb / sus * 1e-3 / HBM_PEAK_GBS, 4), "ok": sok,
                                    "timing": "hipEvent pair around the launch, mean of 10"}
-        if args.stamps:
+        # the same matrices as a decoder issues them (outside the timed region; --pattern decoder makes it the timed workload)
+        if not dist_on and dpat is None and args.pattern == "chained" and not args.no_decoder_pattern:
+            try:
+                dms, dok, dn, dgraphed = time_decoder_pattern()
+                roof["decoder_pattern"] = {"what": "one launch per segment (o -> gate/up -> down -> next q/k/v; residual add + RMSNorm and silu(gate) * up inside the "
+                                                   "LUT builds), a copy kernel between the segments as stand-in for attention",
+                                           "ms_per_token": round(dms, 4), "launches": dn, "GBps": round(bytes_per_step / (dms * 1e-3) / 1e9, 1),
+                                           "frac": round(bytes_per_step / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ok": dok,
+                                           "timing": "hipEvent pair around a %s of the token's launches, mean of 10" % ("hipGraph replay" if dgraphed else "eager sequence")}
+            except Exception as e:
+                roof["decoder_pattern"] = {"error": repr(e)}
+        if args.stamps and chain is not None:
             raw = stamp_buf.cpu().numpy().reshape(chain.nops, chain.grid, 8)
             try:
                 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
@@ -786,7 +912,8 @@ def main():
             "frac_of_hbm_peak": round(bytes_per_step / sec / 1e9 / (HBM_PEAK_GBS * world), 4),
             "config": {"workload": wl["tag"], "layers": args.layers, "N": N,
                        "gemm_per_step": 7 * args.layers,
-                       "launches_per_step": 1 if args.path == "chain" else (4 if fused_calls else 11) * args.layers + (0 if decode else 4 * args.layers), "path": args.path,
+                       "launches_per_step": (len(dpat["chains"]) if dpat is not None else 1) if args.path == "chain" else (4 if fused_calls else 11) * args.layers + (0 if decode else 4 * args.layers), "path": args.path,
+                       "pattern": args.pattern,
                        "autotune": tuned,
                        "algorithmic_bytes_per_step": bytes_per_step, "weights": wl["weights"],
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",

@@ -99,7 +99,7 @@ inline int chain_buf_u4(int K) {
     return 4 * (nst * 64 + 1) + (2 * nst * 32 * 4 + 15) / 16 + CHAIN_US_FLOATS / 4;
 }
 inline size_t chain_lds_bytes(int buf_u4, int nops, int carry_floats = 0) {
-    return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops + sizeof(float) * (16 + (size_t)carry_floats);
+    return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops + sizeof(float) * (32 + (size_t)carry_floats);
 }
 
 }  // namespace tmac

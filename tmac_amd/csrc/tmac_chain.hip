@@ -237,8 +237,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         __syncthreads();
     }
     const cop_ptr ops = reinterpret_cast<cop_ptr>(l_ops);
-    float* l_xf = reinterpret_cast<float*>(l_ops + (size_t)a.nops * (sizeof(ChainOp) / 16));     // [16] partial sums of a transform's mean square
-    float* l_carry = l_xf + 16;                                                                     // [a.carry_floats] the t a NORM transform keeps
+    float* l_xf = reinterpret_cast<float*>(l_ops + (size_t)a.nops * (sizeof(ChainOp) / 16));     // [2][16] partial sums of a transform's mean square (by op parity)
+    float* l_carry = l_xf + 32;                                                                     // [a.carry_floats] the t a NORM transform keeps
     bool aborted = false;                                                   // a hand-off timed out somewhere: stop waiting
 
     // stamps: s_memrealtime (100 MHz, one clock for the whole device; s_memtime counts per XCD with unrelated offsets)
@@ -354,7 +354,26 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         // memory -- in at most two rounds; its granules are polled together with the first vector's (one fabric round trip for both)
         const int xk = XF ? uni(d->xf_kind) : 0;
         const bool glu = XF && xk == 2;
-        uint32_t xw2[2][4];
+        // NORM: the residual and the weight vector are in memory since before the launch -- their loads (16 bytes each) go out in front of
+        // the polls and cross the fabric while the hand-off is awaited.  xa: the residual (NORM) or the second vector's fp16 pairs (GLU):
+        // one set of registers for the two transforms
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 xa[XF ? 2 : 1][2], xg[XF ? 2 : 1][2];
+        if (XF && xk == 1) {
+            const int xfl0 = uni(d->xf_flags);
+            const TMAC_GLOBAL f32x4* resp4 = (const TMAC_GLOBAL f32x4*)(uni(d->res));
+            const TMAC_GLOBAL f32x4* gam4 = (const TMAC_GLOBAL f32x4*)(uni(d->gamma));
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const size_t pc = (size_t)min(r * FT + tid, P - 1);
+                xa[r][0] = xa[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                xg[r][0] = xg[r][1] = (f32x4){1.f, 1.f, 1.f, 1.f};
+                if (r < nr) {
+                    if (resp4 && !(xfl0 & 2)) { xa[r][0] = resp4[2 * pc]; xa[r][1] = resp4[2 * pc + 1]; }
+                    if (gam4) { xg[r][0] = gam4[2 * pc]; xg[r][1] = gam4[2 * pc + 1]; }
+                }
+            }
+        }
         unsigned long long polls = 0;
         {
             // pair of round r: p = r * FT + tid; past the end the address is clamped and the result ignored
@@ -394,14 +413,17 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     }
                     for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
                 }
+                auto w2f = [](uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) __attribute__((always_inline)) {
+                    return (f32x4){__uint_as_float(a0), __uint_as_float(a1), __uint_as_float(a2), __uint_as_float(a3)};
+                };
                 if (nr == 1) {
                     xw[0][0] = v[0].y; xw[0][1] = v[0].w; xw[0][2] = v[1].y; xw[0][3] = v[1].w;
-                    xw2[0][0] = v[2].y; xw2[0][1] = v[2].w; xw2[0][2] = v[3].y; xw2[0][3] = v[3].w;
+                    xa[0][0] = w2f(v[2].y, v[2].w, v[3].y, v[3].w);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         xw[r][0] = v[2 * r].y; xw[r][1] = v[2 * r].w; xw[r][2] = v[2 * r + 1].y; xw[r][3] = v[2 * r + 1].w;
-                        xw2[r][0] = v[4 + 2 * r].y; xw2[r][1] = v[4 + 2 * r].w; xw2[r][2] = v[5 + 2 * r].y; xw2[r][3] = v[5 + 2 * r].w;
+                        xa[r][0] = w2f(v[4 + 2 * r].y, v[4 + 2 * r].w, v[5 + 2 * r].y, v[5 + 2 * r].w);
                     }
                 }
             } else if (gran) {
@@ -447,7 +469,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     const uint4* in5 = uni(reinterpret_cast<const uint4*>(d->in2));
                     c_ext3(in5 + p0, in5 + p1, in5 + p1, v);
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) { xw2[r][0] = v[r].x; xw2[r][1] = v[r].y; xw2[r][2] = v[r].z; xw2[r][3] = v[r].w; }
+                    for (int r = 0; r < 2; ++r) xa[r][0] = (f32x4){__uint_as_float(v[r].x), __uint_as_float(v[r].y), __uint_as_float(v[r].z), __uint_as_float(v[r].w)};
                 }
             }
         }
@@ -485,71 +507,62 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             for (int r = 0; r < 2; ++r)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const __half2 hh = *reinterpret_cast<const __half2*>(&xw2[r][q]);
+                    const uint32_t w2 = __float_as_uint(xa[r][0][q]);
+                    const __half2 hh = *reinterpret_cast<const __half2*>(&w2);
                     const float u0 = __low2float(hh), u1 = __high2float(hh);
                     const float a0 = xs[r][2 * q], a1 = xs[r][2 * q + 1];
-                    xs[r][2 * q] = __fmul_rn(__fdiv_rn(a0, __fadd_rn(1.0f, __expf(-a0))), u0);
-                    xs[r][2 * q + 1] = __fmul_rn(__fdiv_rn(a1, __fadd_rn(1.0f, __expf(-a1))), u1);
+                    // silu(a) = a / (1 + exp(-a)): hardware exp2 and reciprocal (1 ulp each; the transform is specified to a tolerance)
+                    xs[r][2 * q] = __fmul_rn(__fmul_rn(a0, __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __expf(-a0)))), u0);
+                    xs[r][2 * q + 1] = __fmul_rn(__fmul_rn(a1, __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __expf(-a1)))), u1);
                 }
         } else if (xk == 1) {
             // NORM: t = in + residual (memory fp32, or the t an earlier NORM of this launch kept in LDS); x = t * rsqrt(mean(t^2) + eps) *
             // gamma (or x = t without gamma); t optionally kept for a later op and / or written to memory (the residual stream that
-            // outlives the launch; each workgroup writes a stripe of it)
+            // outlives the launch; each workgroup writes a stripe of it).  Up to two rounds of pairs (K <= 12288).
             const int xfl = uni(d->xf_flags);
-            const TMAC_GLOBAL float* resp = as_global(uni(d->res));
-            const TMAC_GLOBAL float* gam = as_global(uni(d->gamma));
-            TMAC_GLOBAL float* rout = as_global(uni(d->res_out));
+            const bool has_g = uni(d->gamma) != nullptr;
+            TMAC_GLOBAL f32x4* rout4 = (TMAC_GLOBAL f32x4*)(uni(d->res_out));
             float ss = 0.f;
 #pragma unroll
-            for (int r = 0; r < NRMAX; ++r) {
+            for (int r = 0; r < 2; ++r) {
                 const int p = r * FT + tid;
                 if (r < nr && p < P) {
+                    if (xfl & 2) {
+                        const f32x4* c4 = reinterpret_cast<const f32x4*>(l_carry + 8 * p);
+                        xa[r][0] = c4[0]; xa[r][1] = c4[1];
+                    }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float rv = 0.f;
-                        if (xfl & 2) rv = l_carry[8 * p + e];
-                        else if (resp) rv = resp[8 * (size_t)p + e];
-                        const float t = __fadd_rn(xs[r][e], rv);
+                        const float t = __fadd_rn(xs[r][e], xa[r][e >> 2][e & 3]);
                         xs[r][e] = t;
                         ss = __fmaf_rn(t, t, ss);
                     }
+                    if (xfl & 4) {
+                        f32x4* c4 = reinterpret_cast<f32x4*>(l_carry + 8 * p);
+                        c4[0] = (f32x4){xs[r][0], xs[r][1], xs[r][2], xs[r][3]}; c4[1] = (f32x4){xs[r][4], xs[r][5], xs[r][6], xs[r][7]};
+                    }
+                    if (rout4 && (p & 255) == (bx & 255)) {            // a stripe per workgroup (the grid has at most 256 workgroups: one writer per pair)
+                        rout4[2 * (size_t)p] = (f32x4){xs[r][0], xs[r][1], xs[r][2], xs[r][3]};
+                        rout4[2 * (size_t)p + 1] = (f32x4){xs[r][4], xs[r][5], xs[r][6], xs[r][7]};
+                    }
                 }
             }
-            if (gam) {
+            if (has_g) {
                 ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
                 ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
-                if (lane == 0) l_xf[w] = ss;
-                __syncthreads();
+                float* xfb = l_xf + (i & 1) * 16;                    // two sets by op parity: no second barrier needed
+                if (lane == 0) xfb[w] = ss;
+                // LDS-only barrier: __syncthreads() carries a workgroup fence = s_waitcnt vmcnt(0) on gfx9, i.e. it would wait here for the
+                // weight fragments issued a moment ago (a memory round trip in the open, before the tables are even started)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 float tot = 0.f;
 #pragma unroll
-                for (int ww = 0; ww < NWV; ++ww) tot += l_xf[ww];
-                const float rs = 1.0f / sqrtf(tot / (float)(8 * P) + __uint_as_float((uint32_t)uni(d->eps_bits)));
-                __syncthreads();                                   // l_xf is read; the next op may write it
+                for (int ww = 0; ww < NWV; ++ww) tot += xfb[ww];
+                const float rs = __builtin_amdgcn_rsqf(__fmaf_rn(tot, __builtin_amdgcn_rcpf((float)(8 * P)), __uint_as_float((uint32_t)uni(d->eps_bits))));
 #pragma unroll
-                for (int r = 0; r < NRMAX; ++r) {
-                    const int p = r * FT + tid;
-                    if (r < nr && p < P) {
+                for (int r = 0; r < 2; ++r)
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float t = xs[r][e];
-                            if (xfl & 4) l_carry[8 * p + e] = t;
-                            if (rout && (p % gx) == bx) rout[8 * (size_t)p + e] = t;
-                            xs[r][e] = __fmul_rn(__fmul_rn(t, rs), gam[8 * (size_t)p + e]);
-                        }
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < NRMAX; ++r) {
-                    const int p = r * FT + tid;
-                    if (r < nr && p < P) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            if (xfl & 4) l_carry[8 * p + e] = xs[r][e];
-                            if (rout && (p % gx) == bx) rout[8 * (size_t)p + e] = xs[r][e];
-                        }
-                    }
-                }
+                    for (int e = 0; e < 8; ++e) xs[r][e] = __fmul_rn(__fmul_rn(xs[r][e], rs), xg[r][e >> 2][e & 3]);
             }
         }
         }   // XF

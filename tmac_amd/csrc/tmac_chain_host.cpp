@@ -329,6 +329,8 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             o.xf_kind = xf.kind;
             if (xf.kind == TMAC_XF_NORM) {
                 c->xforms = 1;
+                if (o.K > 2 * 8 * CHAIN_FT) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: a NORM transform is covered up to K = %d", i, 2 * 8 * CHAIN_FT));
+                if (c->grid > 256 && xf.residual_out) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: residual_out is covered with up to 256 workgroups", i));
                 if (o.K > 8192 && (xf.keep || xf.residual == TMAC_XF_CARRY))
                     return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: a kept residual vector is covered up to K = 8192", i));
                 if (xf.residual == TMAC_XF_CARRY) {

@@ -44,6 +44,36 @@ int ggml_tmac_hip_mul_mat(const struct tmac_ggml_tensor* w, const struct tmac_gg
 void ggml_tmac_hip_free(struct tmac_ggml_tensor* w);
 const char* ggml_tmac_hip_last_error(void);
 
+/* ---- decoder segments ------------------------------------------------------------------------------------------------------
+ * A decoded token issues the same mat-muls in the same order every time; between two of them sit element-wise operators (residual
+ * add + RMSNorm in front of q/k/v and gate/up, silu(gate) * up in front of the down projection) and, once per layer, an operator
+ * that stays outside the hook (attention).  A backend that sees the graph (ggml_backend_graph_compute) records, ONCE, the mat-muls
+ * between two outside operators as a segment -- typically o -> gate/up -> down -> next layer's q/k/v -- with the element-wise
+ * operators declared in front of the mat-mul that consumes their result; per token it computes the segment with ONE launch
+ * (include/tmac_hip.h: tmac_hip_chain_*, tmac_hip_chain_xform).  All tensors of a segment live in DEVICE memory: activations and
+ * outputs fp16 ([K] / [M], N = 1), the residual stream and the norm weights fp32.
+ *     ggml_tmac_hip_segment_begin();
+ *     ggml_tmac_hip_segment_mul_mat(&wo, 1, attn_out, &o);                                  // o projection
+ *     ggml_tmac_hip_segment_norm(h, 0, ffn_norm_w, eps, NULL, 1);                           // t = o + h, x = rmsnorm(t) * w; t kept
+ *     ggml_tmac_hip_segment_mul_mat(w_gate_up, 2, o, gate_up);
+ *     ggml_tmac_hip_segment_glu(up);                                                        // x = silu(gate) * up
+ *     ggml_tmac_hip_segment_mul_mat(&wdown, 1, gate, &down);
+ *     ggml_tmac_hip_segment_norm(NULL, 1, next_attn_norm_w, eps, h_next, 0);                // t = down + kept t; h_next = t
+ *     ggml_tmac_hip_segment_mul_mat(w_qkv_next, 3, down, qkv_next);
+ *     ggml_tmac_hip_segment_end(&seg);
+ *     per token:  <attention of layer l on ggml_tmac_hip_stream()>;  ggml_tmac_hip_segment_compute(seg_l);  ...
+ * The transform declared by _norm / _glu applies to the NEXT _mul_mat, whose x is the transform's `in`. */
+typedef struct ggml_tmac_hip_segment ggml_tmac_hip_segment;
+int ggml_tmac_hip_segment_begin(void);
+int ggml_tmac_hip_segment_norm(const float* residual, int residual_is_kept, const float* norm_weight, float eps, float* residual_out, int keep);
+int ggml_tmac_hip_segment_glu(const void* in2_f16);
+int ggml_tmac_hip_segment_mul_mat(const struct tmac_ggml_tensor* const* w, int nw, const void* x_f16, void* const* dst_f16);
+int ggml_tmac_hip_segment_end(ggml_tmac_hip_segment** seg);
+int ggml_tmac_hip_segment_compute(ggml_tmac_hip_segment* seg);   /* one launch on ggml_tmac_hip_stream(); does not wait */
+int ggml_tmac_hip_segment_wait(ggml_tmac_hip_segment* seg);      /* synchronises the stream; 0 if every hand-off of the segment's launches completed */
+void ggml_tmac_hip_segment_free(ggml_tmac_hip_segment* seg);
+void* ggml_tmac_hip_stream(void);                                /* the hipStream_t the glue launches on: outside operators go there too */
+
 #ifdef __cplusplus
 }
 #endif

@@ -146,3 +146,73 @@ extern "C" void ggml_tmac_hip_free(struct tmac_ggml_tensor* w) {
     delete h;
     w->extra = nullptr;
 }
+
+// ---- decoder segments: thin glue over tmac_hip_chain_* / tmac_hip_chain_xform (see the header) ----
+struct ggml_tmac_hip_segment { tmac_hip_chain* chain; };
+
+extern "C" void* ggml_tmac_hip_stream(void) { return g_stream; }
+
+extern "C" int ggml_tmac_hip_segment_begin(void) {
+    if (!g_ready) return fail("ggml_tmac_hip_init has not been called");
+    g_err[0] = 0;
+    return tmac_hip_chain_begin();
+}
+
+extern "C" int ggml_tmac_hip_segment_norm(const float* residual, int residual_is_kept, const float* norm_weight, float eps, float* residual_out, int keep) {
+    tmac_hip_xform xf;
+    memset(&xf, 0, sizeof(xf));
+    xf.kind = TMAC_XF_NORM;
+    xf.residual = residual_is_kept ? TMAC_XF_CARRY : residual;
+    xf.gamma = norm_weight; xf.eps = eps; xf.residual_out = residual_out; xf.keep = keep;
+    return tmac_hip_chain_xform(&xf);
+}
+
+extern "C" int ggml_tmac_hip_segment_glu(const void* in2_f16) {
+    tmac_hip_xform xf;
+    memset(&xf, 0, sizeof(xf));
+    xf.kind = TMAC_XF_GLU;
+    xf.in2 = in2_f16;
+    return tmac_hip_chain_xform(&xf);
+}
+
+extern "C" int ggml_tmac_hip_segment_mul_mat(const struct tmac_ggml_tensor* const* w, int nw, const void* x_f16, void* const* dst_f16) {
+    if (!w || nw < 1 || nw > 4 || !x_f16 || !dst_f16) return fail("bad segment mul_mat");
+    const tmac_hip_weights* wl[4];
+    void* cl[4];
+    for (int i = 0; i < nw; ++i) {
+        if (!w[i] || !w[i]->extra || !dst_f16[i]) return fail("null tensor");
+        wl[i] = ((const Handle*)w[i]->extra)->w;
+        cl[i] = dst_f16[i];
+    }
+    return tmac_hip_qgemm_fused_dev(wl, nw, x_f16, TMAC_F16, cl, TMAC_F16, 1, g_stream);   // recorded, not launched
+}
+
+extern "C" int ggml_tmac_hip_segment_end(ggml_tmac_hip_segment** seg) {
+    if (!seg) return fail("null argument");
+    tmac_hip_chain* c = nullptr;
+    int rc = tmac_hip_chain_end(&c);
+    if (rc) return rc;
+    *seg = new ggml_tmac_hip_segment{c};
+    return 0;
+}
+
+extern "C" int ggml_tmac_hip_segment_compute(ggml_tmac_hip_segment* seg) {
+    if (!seg || !seg->chain) return fail("null segment");
+    return tmac_hip_chain_launch(seg->chain, g_stream);
+}
+
+extern "C" int ggml_tmac_hip_segment_wait(ggml_tmac_hip_segment* seg) {
+    if (!seg || !seg->chain) return fail("null segment");
+    if (hip.StreamSynchronize(g_stream) != 0) return fail("stream synchronisation failed");
+    uint32_t word = 0;
+    int rc = tmac_hip_chain_status(seg->chain, &word);
+    if (rc) return rc;
+    return word ? fail("a hand-off inside the segment timed out") : 0;
+}
+
+extern "C" void ggml_tmac_hip_segment_free(ggml_tmac_hip_segment* seg) {
+    if (!seg) return;
+    if (g_stream) hip.StreamSynchronize(g_stream);
+    if (seg->chain) tmac_hip_chain_free(seg->chain);
+    delete seg;
+}

@@ -164,3 +164,83 @@ def test_bench_runs_and_verifies(tm, extra, path):
         assert d["verified"]["ok"], d["verified"]
     if path == "chain":
         assert d["roofline"]["headline_gemv"]["us"] > 0
+
+
+def test_ggml_glue_decoder_segments(tm, tmp_path):
+    """A two-layer llama-shaped loop through the ggml glue's decoder segments (include/ggml-tmac-hip.h): one launch per segment
+    o -> [+ residual, RMSNorm] -> gate/up -> [silu(gate) * up] -> down -> [+ residual, RMSNorm] -> next q/k/v, an operator outside the
+    hook (a device copy on the glue's stream, the stand-in for attention) between q/k/v and o.  The C++ program dumps every tensor;
+    each mpGEMM is recomputed with the oracle from the inputs the run actually saw (2e-3 of max |C|: the element-wise operators are
+    extensions specified to a tolerance), the residual stream with fp32 adds (bit for bit)."""
+    from tmac_amd import convert
+    H, F, bits, bm, NL, eps = 1024, 2816, 2, 128, 2, 1e-5
+    d = str(tmp_path)
+    rng = np.random.default_rng(21)
+    names = ["q", "k", "v", "o", "gate", "up", "down"]
+    shape = {"q": (H, H), "k": (H, H), "v": (H, H), "o": (H, H), "gate": (F, H), "up": (F, H), "down": (H, F)}
+    mats = {}
+    for l in range(NL):
+        for n in names:
+            Mw, K = shape[n]
+            case = orc.make_case(1000 + 10 * l + names.index(n), Mw, K, bits=bits, fp16_values=True)
+            c = 1.0 / np.sqrt(2.5 * K)
+            sc = (case["sc"] * c).astype(np.float16).astype(np.float32)
+            zr = (case["zr"] * c + ((2 ** bits - 1) / 2.0 - 2 ** (bits - 1)) * sc).astype(np.float16).astype(np.float32)
+            A = orc.preprocess_weights(case["w"], bits, bm, 16)
+            S = orc.preprocess_scales(sc, zr, bits, bm)
+            np.concatenate([A.reshape(-1), S.astype(np.float32).view(np.uint8).reshape(-1)]).tofile(os.path.join(d, f"blob_{l}_{n}.bin"))
+            mats[(l, n)] = (A, S, Mw, K)
+    convert.write_kcfg(os.path.join(d, "kcfg.ini"), [[bits, H, H, 1, -1], [bits, F, H, 1, -1], [bits, H, F, 1, -1]],
+                       bm={(bits, H, H): bm, (bits, F, H): bm, (bits, H, F): bm})
+    h0 = rng.standard_normal(H).astype(np.float32)
+    h0.tofile(os.path.join(d, "h0.bin")); h0.astype(np.float16).tofile(os.path.join(d, "x0.bin"))
+    g = {}
+    for l in range(NL):
+        for k in (1, 2):
+            g[(l, k)] = (1.0 + 0.1 * rng.standard_normal(H)).astype(np.float32)
+            g[(l, k)].tofile(os.path.join(d, f"g{l}_{k}.bin"))
+    exe = os.path.join(d, "ggml_segment_main")
+    gxx(exe, os.path.join(ROOT, "tests", "cpp", "ggml_segment_main.cc"), os.path.join(ROOT, "src", "ggml_tmac_hip.cc"),
+        extra=("-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"))
+    env = dict(os.environ); env.pop("TMAC_KCFG_FILE", None)
+    r = subprocess.run([exe, d, str(H), str(F), str(bits)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+    def out(name, dt=np.float16):
+        return np.fromfile(os.path.join(d, f"out_{name}.bin"), dtype=dt).astype(np.float32)
+
+    def oracle(l, n, x):
+        A, S, Mw, K = mats[(l, n)]
+        q, ls, lb = orc.preprocessor(x[None, :].astype(np.float32), 64)
+        return orc.qgemm_float(A, q, S, ls, lb, Mw, K, 1, bits, bm, 16, 128, 64, True)[0]
+
+    def norm(t, gam):
+        rs = np.float32(1.0) / np.sqrt(np.float32((t.astype(np.float64) ** 2).mean()) + np.float32(eps))
+        return (t * rs).astype(np.float32) * gam
+
+    def rel(a, b):
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+    x1 = norm(h0.astype(np.float16).astype(np.float32), g[(0, 1)])
+    for n in ("q", "k", "v"):
+        assert rel(out(f"0_{n}"), oracle(0, n, x1)) <= 2e-3, n
+    hcur = h0
+    for l in range(NL):
+        a = out(f"attn{l}")
+        assert np.array_equal(a, out(f"{l}_q"))                       # the outside operator ran between the launches
+        o = out(f"{l}_o")
+        assert rel(o, oracle(l, "o", a)) <= 2e-3
+        t2 = o + hcur
+        x2 = norm(t2, g[(l, 2)])
+        gt, up = out(f"{l}_gate"), out(f"{l}_up")
+        assert rel(gt, oracle(l, "gate", x2)) <= 2e-3 and rel(up, oracle(l, "up", x2)) <= 2e-3
+        dn = out(f"{l}_down")
+        m = (gt / (np.float32(1.0) + np.exp(-gt))).astype(np.float32) * up
+        assert rel(dn, oracle(l, "down", m)) <= 2e-3
+        if l + 1 < NL:
+            t3 = dn + t2
+            assert np.array_equal(out("h1", np.float32), t3)
+            x3 = norm(t3, g[(l + 1, 1)])
+            for n in ("q", "k", "v"):
+                assert rel(out(f"{l + 1}_{n}"), oracle(l + 1, n, x3)) <= 2e-3, n
+            hcur = t3

@@ -96,9 +96,10 @@ def parse():
     ap.add_argument("--autotune", action="store_true", help="fused path: measure the launch configurations first (tmac_hip_autotune_fused)")
     ap.add_argument("--no-graph", action="store_true", help="fused/split: launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--eager-collectives", action="store_true", help="multi-GPU: do not capture the RCCL all-gathers into the hipGraph")
-    ap.add_argument("--comm", choices=["torch", "lib"], default="torch",
-                    help="multi-GPU exchange step: torch.distributed (ProcessGroupNCCL = RCCL; default, the path exercised so far) or the "
-                         "library's own communicator (tmac_hip_comm_*: RCCL through the C-ABI, bootstrapped over torch.distributed)")
+    ap.add_argument("--comm", choices=["torch", "lib", "ipc"], default="torch",
+                    help="multi-GPU exchange step: torch.distributed (ProcessGroupNCCL = RCCL; default, the path exercised so far), the "
+                         "library's own communicator (tmac_hip_comm_*: RCCL through the C-ABI, bootstrapped over torch.distributed), or its "
+                         "IPC transport (windows mapped by every peer, no RCCL; tests/test_gpu_comm.py runs it with two processes on one device)")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # debugging: take the multi-GPU code path with 1 rank
     ap.add_argument("--gemm-kernel", type=int, default=0, choices=[0, 1, 2, 3],
                     help="prefill A/B: tmac_hip_debug_gemm_kernel (0 auto, 1 k_gemm_onehot, 2 / 3 k_gemm_planes with eight- / four-wave workgroups)")
@@ -399,6 +400,14 @@ def main():
             idt.copy_(torch.frombuffer(bytearray(tmac_amd.Comm.unique_id()), dtype=torch.uint8))
         dist.broadcast(idt, 0)
         lib_comm = tmac_amd.Comm(bytes(idt.cpu().numpy().tobytes()), rank, world)
+    elif dist_on and args.comm == "ipc":
+        # every rank's window is mapped by all peers; torch.distributed carries the 128-byte blobs (bootstrap only)
+        maxb = max(N * shard_rows[name] * 2 for name, *_ in MATS)
+        lib_comm = tmac_amd.Comm.ipc(maxb, rank, world)
+        blob = torch.frombuffer(bytearray(lib_comm.export()), dtype=torch.uint8).to(dev)
+        blobs = torch.empty(world * tmac_amd.Comm.BLOB_BYTES, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(blobs, blob)
+        lib_comm.connect(bytes(blobs.cpu().numpy().tobytes()))
 
     recording = [False]          # inside wr.record_chain(): exchange steps are recorded, not executed
 

@@ -240,6 +240,18 @@ int32_t tmac_hip_comm_unique_id(void* id_out);
 int32_t tmac_hip_comm_init(tmac_hip_comm** out, const void* id, int rank, int world);
 int32_t tmac_hip_comm_allgather(tmac_hip_comm* comm, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
 int32_t tmac_hip_comm_destroy(tmac_hip_comm* comm);
+/* The same exchange step without RCCL: every rank owns a window in fine-grained device memory that all peers map through hipIpc*; a
+ * small kernel publishes this rank's part and copies the peers' parts out of their windows (flags in the windows, no host in the
+ * loop).  For nodes or tests where RCCL cannot serve -- several ranks on ONE device, for instance, which RCCL refuses.
+ *   every rank: tmac_hip_comm_init_ipc(&comm, max_bytes_per_rank, rank, world);  tmac_hip_comm_export(comm, blob)
+ *   all-gather the TMAC_HIP_COMM_BLOB_BYTES blobs over any transport (rank order);  tmac_hip_comm_connect(comm, blobs, world)
+ *   per step:   tmac_hip_comm_allgather(comm, ...) as above (every rank issues the same sequence);  tmac_hip_comm_status after a
+ *   synchronisation: 0, or a bit per rank whose part did not arrive in time.  HSA_ENABLE_IPC_MODE_LEGACY=0 where the driver has dmabuf IPC only. */
+#define TMAC_HIP_COMM_BLOB_BYTES 128
+int32_t tmac_hip_comm_init_ipc(tmac_hip_comm** out, size_t max_bytes_per_rank, int rank, int world);
+int32_t tmac_hip_comm_export(const tmac_hip_comm* comm, void* blob_out);
+int32_t tmac_hip_comm_connect(tmac_hip_comm* comm, const void* blobs_of_all_ranks, int world);
+int32_t tmac_hip_comm_status(tmac_hip_comm* comm, uint32_t* error_word);
 const char* tmac_hip_comm_last_error(void);
 
 /* Raw device pointers of the workspace, for collectives (RCCL all-gather of the LUT over xGMI):

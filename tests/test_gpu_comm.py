@@ -86,3 +86,95 @@ def test_two_ranks_row_shards(tm):
         ps = [subprocess.Popen([sys.executable, script, ROOT, str(r), "2", idfile], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
         outs = [p.communicate(timeout=300)[0].decode() for p in ps]
         assert all(p.returncode == 0 for p in ps), outs
+
+
+IPC_WORKER = r'''
+import os, sys, time
+root, rank, world, d = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+sys.path.insert(0, root)
+import numpy as np, torch
+import tmac_amd
+from oracle import oracle as orc
+tm = tmac_amd
+tm.binding.check(tm.lib().tmac_hip_init(0))                  # both ranks on device 0 (RCCL refuses that; IPC windows do not)
+bits, bm, kf, gs, ags, N = 2, 128, 16, 128, 64, 48
+OPS = [(1024, 2048), (2048, 1024)]                           # (K, Mw): the second mpGEMM consumes the gathered block of the first
+
+def barrier(tag):
+    open(os.path.join(d, f"{tag}.{rank}"), "w").close()
+    t0 = time.time()
+    while not all(os.path.exists(os.path.join(d, f"{tag}.{r}")) for r in range(world)):
+        if time.time() - t0 > 120: raise SystemExit("barrier timeout " + tag)
+        time.sleep(0.002)
+
+wr = tm.TMACGeMMWrapper(act_group_size=ags)
+host, shard, full = [], [], []
+for i, (K, Mw) in enumerate(OPS):
+    case = orc.make_case(300 + i, Mw, K, N=N, bits=bits, fp16_values=True)
+    c = 1.0 / np.sqrt(2.5 * K)
+    sc = (case["sc"] * c).astype(np.float16).astype(np.float32)
+    zr = (case["zr"] * c + ((2 ** bits - 1) / 2.0 - 2 ** (bits - 1)) * sc).astype(np.float16).astype(np.float32)
+    A = orc.preprocess_weights(case["w"], bits, bm, kf); S = orc.preprocess_scales(sc, zr, bits, bm)
+    rows = Mw // world; tiles = rows * bits // bm; t0 = rank * tiles
+    shard.append(wr.register_weights(A[t0:t0 + tiles], S[t0:t0 + tiles], rows, K, bits, tm.KCfg.make(rows, K, bits, bm, kf, gs, ags, True, -1, N), dev_dtype=tm.F16))
+    full.append(wr.register_weights(A, S, Mw, K, bits, tm.KCfg.make(Mw, K, bits, bm, kf, gs, ags, True, -1, N), dev_dtype=tm.F16))
+    host.append((A, S, case))
+x0 = torch.from_numpy(host[0][2]["B"]).cuda().half()          # [N][K0]
+# ---- the communicator: windows exported through files
+maxb = max(N * (Mw // world) * 2 for K, Mw in OPS)
+comm = tm.Comm.ipc(maxb, rank, world)
+open(os.path.join(d, f"blob.{rank}.tmp"), "wb").write(comm.export()); os.rename(os.path.join(d, f"blob.{rank}.tmp"), os.path.join(d, f"blob.{rank}"))
+barrier("exported")
+comm.connect([open(os.path.join(d, f"blob.{r}"), "rb").read() for r in range(world)])
+res = []
+for rep in range(3):                                           # three rounds: the window halves and the generation flags are reused
+    x = x0
+    outs = []
+    for i, (K, Mw) in enumerate(OPS):
+        rows = Mw // world
+        part = torch.empty((N, rows), dtype=torch.float16, device="cuda")
+        wr.fused([shard[i]], x, [part], N, act_dtype=tm.F16)
+        g = torch.empty((world, N, rows), dtype=torch.float16, device="cuda")
+        comm.allgather(part, g, N * rows * 2)
+        x = g.permute(1, 0, 2).reshape(N, Mw).contiguous()    # the [N][Mw] block every rank's next LUT build needs whole
+        outs.append(x)
+    torch.cuda.synchronize()
+    assert comm.status() == 0, f"rank {rank}: a part did not arrive (rep {rep})"
+    res.append(outs)
+    barrier(f"rep{rep}")
+# ---- the unsharded computation in this process, and the oracle
+x = x0
+for i, (K, Mw) in enumerate(OPS):
+    ref = torch.empty((N, Mw), dtype=torch.float16, device="cuda")
+    wr.fused([full[i]], x, [ref], N, act_dtype=tm.F16)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        assert torch.equal(res[rep][i], ref), f"rank {rank} op {i} rep {rep}: gathered row shards differ from the unsharded result"
+    A, S, case = host[i]
+    q, ls, lb = orc.preprocessor(x.float().cpu().numpy(), ags)
+    want = orc.qgemm_float(A, q, S, ls, lb, Mw, K, N, bits, bm, kf, gs, ags, True)
+    got = ref.float().cpu().numpy()
+    assert float(np.abs(got - want).max() / np.abs(want).max()) <= 1e-3
+    x = ref
+comm.destroy()
+print("rank", rank, "ok")
+'''
+
+
+def test_prefill_exchange_over_ipc_two_processes_one_device(tm):
+    """BASELINE configs[4]'s exchange step (N > 1: the [N][rows] block of every rank gathered before the next LUT build) through the
+    IPC transport of the communicator, two PROCESSES on one device: gathered row shards bit-identical to the unsharded mpGEMM (rows
+    are independent, K is never split) and within 1e-3 of the oracle, three rounds (window halves and generation flags reused)."""
+    with tempfile.TemporaryDirectory() as d:
+        script = os.path.join(d, "worker.py")
+        open(script, "w").write(IPC_WORKER)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        ps = [subprocess.Popen([sys.executable, script, ROOT, str(r), "2", d], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        outs = []
+        for p in ps:
+            try:
+                outs.append(p.communicate(timeout=300)[0].decode())
+            except subprocess.TimeoutExpired:
+                p.kill()
+                outs.append("TIMEOUT\n" + p.communicate()[0].decode())
+        assert all(p.returncode == 0 for p in ps), "\n".join(o[-3000:] for o in outs)

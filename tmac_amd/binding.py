@@ -111,6 +111,10 @@ def load_library() -> C.CDLL:
         "tmac_hip_comm_init": ([C.POINTER(vp), vp, C.c_int, C.c_int], i32),
         "tmac_hip_comm_allgather": ([vp, vp, vp, sz, vp], i32),
         "tmac_hip_comm_destroy": ([vp], i32),
+        "tmac_hip_comm_init_ipc": ([C.POINTER(vp), sz, C.c_int, C.c_int], i32),
+        "tmac_hip_comm_export": ([vp, vp], i32),
+        "tmac_hip_comm_connect": ([vp, vp, C.c_int], i32),
+        "tmac_hip_comm_status": ([vp, C.POINTER(C.c_uint32)], i32),
         "tmac_hip_comm_last_error": ([], C.c_char_p),
         "tmac_hip_chain_begin": ([], i32),
         "tmac_hip_chain_end": ([C.POINTER(vp)], i32),
@@ -134,7 +138,7 @@ def load_library() -> C.CDLL:
         "preprocessor_int8": ([C.c_int] * 4 + [vp] * 4, i32),
     }
     # $TMAC_HIP_LIB may name an OLDER build for an A/B run (tools/gpu): entry points it lacks stay unbound (calling one raises)
-    optional = {"tmac_hip_chain_xform"} if os.environ.get("TMAC_HIP_LIB") else set()
+    optional = {"tmac_hip_chain_xform", "tmac_hip_comm_init_ipc", "tmac_hip_comm_export", "tmac_hip_comm_connect", "tmac_hip_comm_status"} if os.environ.get("TMAC_HIP_LIB") else set()
     for name, (argt, rest) in sigs.items():
         try:
             fn = getattr(L, name)

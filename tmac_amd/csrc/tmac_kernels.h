@@ -107,6 +107,20 @@ hipError_t launch_retile_weights(const uint8_t* A_ref, void* Wd, const Shape& s,
 hipError_t launch_retile_scales(const void* S_ref, Dtype in_dt, void* Sd, Dtype out_dt, const Shape& s, hipStream_t st);
 hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, float* lut_scales,
                              float* lut_biases, int K, int N, int ags, size_t qdev_u4_per_row, hipStream_t st);
+// all-gather over IPC-mapped windows (tmac_comm.cpp, transport "ipc"): workgroup p of `world` handles rank p's part
+struct IpcGatherArgs {
+    const unsigned char* send;     // this rank's part
+    unsigned char* recv;           // world x bytes
+    size_t bytes;                  // per rank
+    unsigned char* win[8];         // every rank's window (own + the peers' as mapped into this process): two halves of win_half bytes
+    unsigned* flag[8];             // every rank's two flag words (generation of the all-gather whose part the half holds)
+    size_t win_half;
+    int rank, world;
+    unsigned gen;                  // 1, 2, ...: half = gen & 1
+    unsigned spin_limit;
+    unsigned* err;                 // set when a peer's part did not arrive
+};
+hipError_t launch_ipc_allgather(const IpcGatherArgs& a, hipStream_t st);
 hipError_t launch_qlut_ref_to_dev(const int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, int K, int N, size_t qdev_u4_per_row, hipStream_t st);
 // pair-wise LUT build (tmac_quad.hip; ags = 64): the half-table image + LUT scales/biases, and -- when qlut_ref / qlut_dev are
 // given (both or neither) -- the other two layouts of the workspace as well

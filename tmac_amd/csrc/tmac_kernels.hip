@@ -636,6 +636,50 @@ hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// All-gather through IPC-mapped windows (one process per GPU; tmac_comm.cpp).  Workgroup `rank` publishes this rank's part: copy into
+// the own window's half gen & 1 (fine-grained memory, mapped by every peer) and into the own slot of recv, then -- behind a system-scope
+// fence -- the half's flag = gen.  Workgroup p != rank waits for rank p's flag and copies its part out of the mapped window.  Two halves
+// suffice: a rank reaches all-gather g + 2 (which overwrites half g & 1) only after g + 1 completed, and a peer publishes g + 1 only
+// after its own all-gather g -- the one that read this half -- has finished (stream order).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_ipc_allgather(IpcGatherArgs a) {
+    const int p = blockIdx.x, tid = threadIdx.x, half = (int)(a.gen & 1u);
+    const size_t n16 = a.bytes / 16;
+    if (p == a.rank) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.send);
+        uint4* w = reinterpret_cast<uint4*>(a.win[p] + (size_t)half * a.win_half);
+        uint4* r = reinterpret_cast<uint4*>(a.recv + (size_t)p * a.bytes);
+        for (size_t i = tid; i < n16; i += blockDim.x) { const uint4 v = src[i]; w[i] = v; r[i] = v; }
+        for (size_t i = n16 * 16 + tid; i < a.bytes; i += blockDim.x) { const unsigned char v = a.send[i]; a.win[p][(size_t)half * a.win_half + i] = v; a.recv[(size_t)p * a.bytes + i] = v; }
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(a.flag[p] + half, a.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+        __shared__ int ok;
+        if (tid == 0) {
+            unsigned spins = 0;
+            ok = 1;
+            while (__hip_atomic_load(a.flag[p] + half, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != a.gen) {
+                if (++spins >= a.spin_limit) { ok = 0; atomicOr(a.err, 1u << p); break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+        }
+        __syncthreads();
+        if (!ok) return;
+        const uint4* w = reinterpret_cast<const uint4*>(a.win[p] + (size_t)half * a.win_half);
+        uint4* r = reinterpret_cast<uint4*>(a.recv + (size_t)p * a.bytes);
+        for (size_t i = tid; i < n16; i += blockDim.x) r[i] = w[i];
+        for (size_t i = n16 * 16 + tid; i < a.bytes; i += blockDim.x) a.recv[(size_t)p * a.bytes + i] = a.win[p][(size_t)half * a.win_half + i];
+    }
+}
+
+hipError_t launch_ipc_allgather(const IpcGatherArgs& a, hipStream_t st) {
+    if (a.world < 1 || a.world > 8 || a.bytes == 0 || a.bytes > a.win_half) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_ipc_allgather, dim3(a.world), dim3(1024), 0, st, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_qlut_ref_to_dev(const int8_t* qlut_ref, void* qlut_dev, void* qlut_lds, int K, int N, size_t qdev_u4_per_row, hipStream_t st) {
     hipLaunchKernelGGL(k_qlut_ref_to_dev, dim3((K / 4 + 255) / 256, N), dim3(256), 0, st, qlut_ref, (uint2*)qlut_dev, (uint2*)qlut_lds, K, N, qdev_u4_per_row);
     return hipGetLastError();

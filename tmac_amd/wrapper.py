@@ -172,6 +172,40 @@ class Comm:
         if rc:
             raise B.TMACHipError(rc, B.lib().tmac_hip_comm_last_error().decode())
 
+    BLOB_BYTES = 128
+
+    @classmethod
+    def ipc(cls, max_bytes_per_rank: int, rank: int, world: int) -> "Comm":
+        """the same exchange step over IPC-mapped windows instead of RCCL (tmac_hip_comm_init_ipc): ``export()`` on every rank,
+        all-gather the blobs over any transport, ``connect(blobs)``"""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        rc = B.lib().tmac_hip_comm_init_ipc(C.byref(self._h), max_bytes_per_rank, rank, world)
+        if rc:
+            raise B.TMACHipError(rc, B.lib().tmac_hip_comm_last_error().decode())
+        return self
+
+    def export(self) -> bytes:
+        buf = C.create_string_buffer(self.BLOB_BYTES)
+        rc = B.lib().tmac_hip_comm_export(self._h, buf)
+        if rc:
+            raise B.TMACHipError(rc, B.lib().tmac_hip_comm_last_error().decode())
+        return buf.raw
+
+    def connect(self, blobs) -> None:
+        raw = b"".join(blobs) if not isinstance(blobs, (bytes, bytearray)) else bytes(blobs)
+        rc = B.lib().tmac_hip_comm_connect(self._h, raw, len(raw) // self.BLOB_BYTES)
+        if rc:
+            raise B.TMACHipError(rc, B.lib().tmac_hip_comm_last_error().decode())
+
+    def status(self) -> int:
+        w = C.c_uint32(0)
+        rc = B.lib().tmac_hip_comm_status(self._h, C.byref(w))
+        if rc:
+            raise B.TMACHipError(rc, B.lib().tmac_hip_comm_last_error().decode())
+        return w.value
+
     def allgather(self, send, recv, nbytes_per_rank: int, stream=None) -> None:
         rc = B.lib().tmac_hip_comm_allgather(self._h, _ptr(send), _ptr(recv), nbytes_per_rank, _stream(stream))
         if rc:

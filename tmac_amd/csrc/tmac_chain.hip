@@ -256,6 +256,21 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     uint32_t lane16 = (uint32_t)lane * 16u;
     asm volatile("" : "+v"(lane16));
 
+    // LUT pair of this thread in round r: r * FT + tpair.  The waves take the 64-pair blocks of a round in REVERSE order (lanes in
+    // order: the build's DPP sums depend on it): wave 0 -- which combines and publishes every workgroup iteration and therefore enters
+    // an op last -- gets the block that exists least often (K = 4096: blocks 0..7 go to waves 11..4), so the barrier behind the LUT
+    // build waits for waves that started polling on time, not for the publisher (A/B knob TMAC_CHAIN_PAIR_ORDER=0: waves in order)
+#ifndef TMAC_CHAIN_PAIR_ORDER
+#define TMAC_CHAIN_PAIR_ORDER 1
+#endif
+    const int tpair = TMAC_CHAIN_PAIR_ORDER ? (NWV - 1 - w) * 64 + lane : tid;
+    // ... and the lookup roles likewise: LOGICAL wave wl = NWV - 1 - w takes quad slot wl / wpq, steps wl % wpq, ... -- when a workgroup
+    // iteration has fewer (quad, step) slots than waves, the idle ones include wave 0.  The partial sums are filed under the logical
+    // index, so the combination order (k_gemv_quad's) does not change.
+#ifndef TMAC_CHAIN_ROLE_ORDER
+#define TMAC_CHAIN_ROLE_ORDER 1
+#endif
+    const int wl = TMAC_CHAIN_ROLE_ORDER ? NWV - 1 - w : w;
     // per-op role of this wave: quad qs (of ipi) of every iteration of its workgroup; steps h, h + wpq, ... of each
     // Row quads are dealt to the workgroups as contiguous, balanced ranges: workgroup b owns q_per (+ 1 for the first q_extra
     // workgroups) consecutive quads -- every CU streams its share of every op (800 quads over 256 CUs: 3 or 4 each, not 6 on
@@ -265,8 +280,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         Role r;
         r.wpq = uni(d->wpq);
         const int ipi = uni(d->ipi), inv = uni(d->wpq_inv);
-        const int qs = (w * inv) >> 16;                                  // w / wpq for w < 12
-        r.h = w - qs * r.wpq;
+        const int qs = (wl * inv) >> 16;                                 // wl / wpq for wl < 12
+        r.h = wl - qs * r.wpq;
         r.qs = qs; r.ipi = ipi;
         r.nst = uni(d->nst);
         const int qper = uni(d->q_per), qex = uni(d->q_extra);
@@ -365,7 +380,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             const TMAC_GLOBAL f32x4* gam4 = (const TMAC_GLOBAL f32x4*)(uni(d->gamma));
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const size_t pc = (size_t)min(r * FT + tid, P - 1);
+                const size_t pc = (size_t)min(r * FT + tpair, P - 1);
                 xa[r][0] = xa[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 xg[r][0] = xg[r][1] = (f32x4){1.f, 1.f, 1.f, 1.f};
                 if (r < nr) {
@@ -378,8 +393,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         {
             // pair of round r: p = r * FT + tid; past the end the address is clamped and the result ignored
             const uint4* in4 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(uni(d->in)) + (gran ? par_off : 0ull));
-            const int p0 = min(tid, P - 1), p1 = min(FT + tid, P - 1), p2 = min(2 * FT + tid, P - 1);
-            const bool n0 = tid < P, n1 = FT + tid < P, n2 = 2 * FT + tid < P;
+            const int p0 = min(tpair, P - 1), p1 = min(FT + tpair, P - 1), p2 = min(2 * FT + tpair, P - 1);
+            const bool n0 = tpair < P, n1 = FT + tpair < P, n2 = 2 * FT + tpair < P;
             u32x4q v[8];
             if (gran && glu) {
                 const uint4* in5 = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(uni(d->in2)) + par_off);
@@ -525,7 +540,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             float ss = 0.f;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const int p = r * FT + tid;
+                const int p = r * FT + tpair;
                 if (r < nr && p < P) {
                     if (xfl & 2) {
                         const f32x4* c4 = reinterpret_cast<const f32x4*>(l_carry + 8 * p);
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             float mx = 0.f;
 #pragma unroll
             for (int r = 0; r < NRMAX; ++r) {
-                const int p = r * FT + tid;
+                const int p = r * FT + tpair;
                 if (r < nr && p < P) {
                     float x[8];
                     unpack(r, x);
@@ -615,7 +630,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         }
 #pragma unroll
         for (int r = 0; r < NRMAX; ++r) {
-            const int p = r * FT + tid;
+            const int p = r * FT + tpair;
             if (r < nr && p < P) {
                 float x[8];
                 unpack(r, x);
@@ -659,7 +674,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         CSTAMP(i, 4);
         __syncthreads();
         CSTAMP(i, 2);
-        if (SM == 2 && tid == FT - 64) {
+        if (SM == 2 && tid == (TMAC_CHAIN_PAIR_ORDER ? 64 : FT - 64)) {
             // lut_biases: ONE fp32 chain over the K/32 chunk sums in order (lut_ctor.cc:157,218; 270 dependent adds at K = 8640).
             // Only the epilogue needs it, so it is walked here, behind the barrier that releases the lookups, by lane 0 of the
             // last wave -- the wave with the fewest pairs to build and, when quads are split or a workgroup owns fewer than 12,
@@ -699,7 +714,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     v += qdpp_u<0x128>(v);
                     v += (uint32_t)__shfl_xor((int)v, 16, 64);
                     v += (uint32_t)__shfl_xor((int)v, 32, 64);
-                    if (lane < 4) redi[(w * 4 + lane) * CHAIN_RED + pl] = (int32_t)v;
+                    if (lane < 4) redi[(wl * 4 + lane) * CHAIN_RED + pl] = (int32_t)v;
                     iacc[pl] = 0;
                 }
             } else {
@@ -711,77 +726,77 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));
                     acc = __fadd_rn(acc, __shfl_xor(acc, 32, 64));
                 }
-                if (lane < 4) red[(w * 4 + lane) * CHAIN_RED] = acc;
+                if (lane < 4) red[(wl * 4 + lane) * CHAIN_RED] = acc;
+            }
+            // wave 0 resolves where its lanes' rows go BEFORE the barrier (it is waited for by every consumer of these rows: what it
+            // does behind the barrier is on the chip's critical path, what it does in front of it is not): lane = (quad qs, row)
+            const int p_qs = lane >> 2, p_row = lane & 3;
+            const int p_g0 = ro.q_lo + c_it * ipi;                    // first quad of this workgroup iteration
+            const int p_gql = p_g0 + p_qs;
+            const bool p_mine = p_qs < ipi && p_gql < ro.q_lo + ro.cnt;   // the 4 lanes of a quad decide together
+            int p_mi = 0, p_lq = 0, p_Mw = 4;
+            unsigned long long p_c = 0ull, p_gr = 0ull;
+            if (w == 0) {
+                const int e0 = uni(d->q_end[0]), e1 = uni(d->q_end[1]), e2 = uni(d->q_end[2]);      // (INT_MAX from the last matrix on)
+                p_mi = (p_gql >= e0 ? 1 : 0) + (p_gql >= e1 ? 1 : 0) + (p_gql >= e2 ? 1 : 0);
+                p_lq = p_gql - (p_gql >= e2 ? e2 : (p_gql >= e1 ? e1 : (p_gql >= e0 ? e0 : 0)));
+                const ChainMat* mp = &d->m[p_mine ? p_mi : 0];        // the workgroup's copy in LDS: a per-lane ds_read
+                p_c = reinterpret_cast<unsigned long long>(mp->C);
+                p_gr = reinterpret_cast<unsigned long long>(mp->GR);
+                p_Mw = mp->Mw;
             }
             __syncthreads();
             if (w == 0) {
-                const int qs = lane >> 2, row = lane & 3;
-                const int g0 = ro.q_lo + c_it * ipi;                  // first quad of this workgroup iteration
-                const int gql = g0 + qs;
-                const bool mine = qs < ipi && gql < ro.q_lo + ro.cnt; // the 4 lanes of a quad decide together
+                const int qs = p_qs, row = p_row;
+                const bool mine = p_mine;
                 float t = 0.f;
-                int32_t cb[BITS];
-#pragma unroll
-                for (int pl = 0; pl < BITS; ++pl) cb[pl] = 0;
                 if (mine) {
                     if (SM == 2) {
+                        int32_t cb[BITS];
+#pragma unroll
+                        for (int pl = 0; pl < BITS; ++pl) cb[pl] = 0;
                         const int32_t* redi = reinterpret_cast<const int32_t*>(red);
                         for (int ww = 0; ww < wpq; ++ww)
 #pragma unroll
                             for (int pl = 0; pl < BITS; ++pl) cb[pl] += redi[((qs * wpq + ww) * 4 + row) * CHAIN_RED + pl];
+                        // scale-final (qgemm.py:170-174,192-206), as k_gemv_quad's epilogue: C = ((sum_p float(cb_p) alpha_p) ls + lb / 2) Scale
+                        float acc = 0.f;
+#pragma unroll
+                        for (int pl = 0; pl < BITS; ++pl) {
+                            const float tp = __fmul_rn((float)cb[pl], q_alpha(pl));
+                            acc = (pl == 0) ? tp : __fadd_rn(acc, tp);
+                        }
+                        const float v = __fadd_rn(__fmul_rn(acc, l_us[0]), __fmul_rn(l_us[1], 0.5f));
+                        const int mg = uni(d->m_groups);
+                        const int g = mg == 1 ? 0 : (4 * p_lq + row) / (p_Mw / mg);
+                        t = __fmul_rn(v, l_us[16 + p_mi * CHAIN_US_MAX_GROUPS + g]);
                     } else {
                         t = red[((qs * wpq) * 4 + row) * CHAIN_RED];
                         for (int ww = 1; ww < wpq; ++ww) t = __fadd_rn(t, red[((qs * wpq + ww) * 4 + row) * CHAIN_RED]);
                     }
                 }
-                // matrices in a uniform loop (descriptor fields through the scalar cache): a per-lane descriptor lookup
-                // is a vector load, and waiting for it waits for every weight load in flight as well
-                int base = 0;
-                for (int mi = 0; mi < nm; ++mi) {
-                    const int qe = uni(d->m[mi].q_end);
-                    if (g0 < qe && g0 + ipi > base) {
-                        const bool here = mine && gql >= base && gql < qe;
-                        const int lq = gql - base;
-                        if (SM == 2) {
-                            // scale-final (qgemm.py:170-174,192-206), as k_gemv_quad's epilogue: C = ((sum_p float(cb_p) alpha_p) ls + lb / 2) Scale
-                            float acc = 0.f;
-#pragma unroll
-                            for (int pl = 0; pl < BITS; ++pl) {
-                                const float tp = __fmul_rn((float)cb[pl], q_alpha(pl));
-                                acc = (pl == 0) ? tp : __fadd_rn(acc, tp);
-                            }
-                            const float v = __fadd_rn(__fmul_rn(acc, l_us[0]), __fmul_rn(l_us[1], 0.5f));
-                            const int mg = uni(d->m_groups), Mwm = uni(d->m[mi].Mw);
-                            const int g = (mg == 1 || !here) ? 0 : (4 * lq + row) / (Mwm / mg);
-                            t = __fmul_rn(v, l_us[16 + mi * CHAIN_US_MAX_GROUPS + g]);
-                        }
-                        // The fp16 output is the fp32 result rounded once more (as k_gemv_quad stores it and as the oracle is
-                        // compared): without the barrier the compiler fuses the last multiplication with the conversion
-                        // (v_fma_mixlo_f16: ONE rounding of the exact product), which differs on exact fp16 ties.
-                        asm volatile("" : "+v"(t));
-                        // granule = {generation, fp16 row | fp16 next row << 16}, 8 bytes, write-through: even rows store
-                        const uint32_t hb = (uint32_t)__half_as_ushort(__float2half_rn(t));
-                        const uint32_t nb = qdpp_u<0xB1>(hb);                    // quad_perm [1,0,3,2]: the neighbour's value
-                        if (here) {
-                            const size_t oi = (size_t)(4 * lq + row);
-                            if (a.out_f16) as_global(reinterpret_cast<unsigned short*>(uni(d->m[mi].C)))[oi] = (unsigned short)hb;
-                            else as_global(reinterpret_cast<float*>(uni(d->m[mi].C)))[oi] = t;
-                            const unsigned long long grb = reinterpret_cast<unsigned long long>(uni(d->m[mi].GR));
-                            TMAC_GLOBAL unsigned long long* gr = reinterpret_cast<TMAC_GLOBAL unsigned long long*>(grb + par_off);
-                            if (grb && !(row & 1)) {
-                                const unsigned long long gv = ((unsigned long long)(hb | (nb << 16)) << 32) | gen;
-                                TMAC_GLOBAL unsigned long long* dst = gr + 2 * (size_t)lq + (row >> 1);
-                                __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                // row-sharded chains: the same granule into the hand-off arena of every other rank (identical layout on
-                                // every rank: the peer's address is its arena base plus this address' offset), system scope over xGMI
-                                const unsigned long long off = reinterpret_cast<unsigned long long>(dst) - a.arena_base;
-                                for (int pe = 0; pe < a.npeer; ++pe)
-                                    __hip_atomic_store(reinterpret_cast<TMAC_GLOBAL unsigned long long*>(a.peer_base[pe] + off), gv,
-                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                            }
-                        }
+                // The fp16 output is the fp32 result rounded once more (as k_gemv_quad stores it and as the oracle is
+                // compared): without the barrier the compiler fuses the last multiplication with the conversion
+                // (v_fma_mixlo_f16: ONE rounding of the exact product), which differs on exact fp16 ties.
+                asm volatile("" : "+v"(t));
+                // granule = {generation, fp16 row | fp16 next row << 16}, 8 bytes, write-through: even rows store
+                const uint32_t hb = (uint32_t)__half_as_ushort(__float2half_rn(t));
+                const uint32_t nb = qdpp_u<0xB1>(hb);                    // quad_perm [1,0,3,2]: the neighbour's value
+                if (mine) {
+                    const size_t oi = (size_t)(4 * p_lq + row);
+                    if (a.out_f16) reinterpret_cast<TMAC_GLOBAL unsigned short*>(p_c)[oi] = (unsigned short)hb;
+                    else reinterpret_cast<TMAC_GLOBAL float*>(p_c)[oi] = t;
+                    if (p_gr && !(row & 1)) {
+                        const unsigned long long gv = ((unsigned long long)(hb | (nb << 16)) << 32) | gen;
+                        TMAC_GLOBAL unsigned long long* dst = reinterpret_cast<TMAC_GLOBAL unsigned long long*>(p_gr + par_off) + 2 * (size_t)p_lq + (row >> 1);
+                        __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // row-sharded chains: the same granule into the hand-off arena of every other rank (identical layout on
+                        // every rank: the peer's address is its arena base plus this address' offset), system scope over xGMI
+                        const unsigned long long off = reinterpret_cast<unsigned long long>(dst) - a.arena_base;
+                        for (int pe = 0; pe < a.npeer; ++pe)
+                            __hip_atomic_store(reinterpret_cast<TMAC_GLOBAL unsigned long long*>(a.peer_base[pe] + off), gv,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     }
-                    base = qe;
                 }
             }
             parity ^= 1;

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     bool aborted = false;                                                   // a hand-off timed out somewhere: stop waiting
 
     // stamps: s_memrealtime (100 MHz, one clock for the whole device; s_memtime counts per XCD with unrelated offsets)
-#define CSTAMPV(i, k, v) do { if (a.stamps && tid == 0) a.stamps[((size_t)(i) * gx + bx) * 8 + (k)] = (v); } while (0)
+// (stamps 0-4 and 7 by the wave that polls and builds LUT block 0 -- the LAST wave, see tpair below -- 5 and 6 by wave 0, the publisher)
+#define CSTAMPV(i, k, v) do { if (a.stamps && tid == (((k) == 5 || (k) == 6) ? 0 : FT - 64)) a.stamps[((size_t)(i) * gx + bx) * 8 + (k)] = (v); } while (0)
 #define CSTAMP(i, k) CSTAMPV(i, k, __builtin_amdgcn_s_memrealtime())
 
     qv4i_t bsel;
@@ -267,6 +268,9 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     // ... and the lookup roles likewise: LOGICAL wave wl = NWV - 1 - w takes quad slot wl / wpq, steps wl % wpq, ... -- when a workgroup
     // iteration has fewer (quad, step) slots than waves, the idle ones include wave 0.  The partial sums are filed under the logical
     // index, so the combination order (k_gemv_quad's) does not change.
+#ifndef TMAC_CHAIN_BIAS_WAVE
+#define TMAC_CHAIN_BIAS_WAVE 0       // unified scale: the wave that walks the lut_biases chain behind the LUT barrier (A/B knob)
+#endif
 #ifndef TMAC_CHAIN_ROLE_ORDER
 #define TMAC_CHAIN_ROLE_ORDER 1
 #endif
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         CSTAMP(i, 4);
         __syncthreads();
         CSTAMP(i, 2);
-        if (SM == 2 && tid == (TMAC_CHAIN_PAIR_ORDER ? 64 : FT - 64)) {
+        if (SM == 2 && tid == (TMAC_CHAIN_PAIR_ORDER ? TMAC_CHAIN_BIAS_WAVE * 64 : FT - 64)) {
             // lut_biases: ONE fp32 chain over the K/32 chunk sums in order (lut_ctor.cc:157,218; 270 dependent adds at K = 8640).
             // Only the epilogue needs it, so it is walked here, behind the barrier that releases the lookups, by lane 0 of the
             // last wave -- the wave with the fewest pairs to build and, when quads are split or a workgroup owns fewer than 12,

@@ -91,6 +91,7 @@ def parse():
                          "(tmac_hip_chain_xform), one launch per segment o -> gate/up -> down -> next q/k/v, an outside kernel (stand-in for "
                          "attention) between the segments; hipGraph replay of the token's launches")
     ap.add_argument("--no-decoder-pattern", action="store_true", help="skip the decoder-pattern measurement of the default line")
+    ap.add_argument("--no-stream-core", action="store_true", help="skip roofline.stream_core (profiling passes: keeps the kernel's statistics to the timed launches)")
     ap.add_argument("--stamps", action="store_true", help="chain path: report per-call times from in-kernel stamps (costs ~6 %%)")
     ap.add_argument("--floors", action="store_true", help="fused path: also time launches that only read the same bytes")
     ap.add_argument("--autotune", action="store_true", help="fused path: measure the launch configurations first (tmac_hip_autotune_fused)")
@@ -771,7 +772,7 @@ def main():
         # The streaming core alone: ONE persistent launch over the headline GEMV of every layer (distinct weights >
         # MALL), every call fed by the same external vector -- no hand-off anywhere, so what is left is activation fetch, LUT build,
         # lookups, reduction and publish of a workgroup, call after call.  Separates "issue / structure bound" from "latency bound".
-        if not dist_on:
+        if not dist_on and not args.no_stream_core:
             sx = torch.randn(K, device=dev, generator=gen).half()
             souts = [[torch.empty(shard_rows[name], dtype=torch.float16, device=dev)] for _ in range(args.layers)]
             with wr.record_chain() as srec:

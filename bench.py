@@ -561,20 +561,26 @@ def main():
                    qkv=[f16(shard_rows["qkv"]) for _ in range(3)]) for _ in range(args.layers + 1)]
         x0 = hs[0].half()
         chains_d = []
+        xf_sel = os.environ.get("TMAC_BENCH_DECODER_XF", "all")      # measurement only: all | none | norm | glu (which transforms the segments carry)
+        do_norm, do_glu = xf_sel in ("all", "norm"), xf_sel in ("all", "glu")
         with wr.record_chain() as r0:
-            wr.chain_xform("norm", gamma=gam[0][0], eps=1e-5)
+            if do_norm:
+                wr.chain_xform("norm", gamma=gam[0][0], eps=1e-5)
             wr.fused(layers[0]["qkv"], x0, bo[0]["qkv"], 1, act_dtype=F16, out_dtype=F16)
         chains_d.append(r0.chain)
         for li in range(args.layers):
             b, last = bo[li + 1], li == args.layers - 1
             with wr.record_chain() as rc:
                 wr.fused(layers[li]["o"], attn, b["o"], 1, act_dtype=F16, out_dtype=F16)
-                wr.chain_xform("norm", residual=hs[li], gamma=gam[li][1], eps=1e-5, keep=True)
+                if do_norm:
+                    wr.chain_xform("norm", residual=hs[li], gamma=gam[li][1], eps=1e-5, keep=True)
                 wr.fused(layers[li]["gate_up"], b["o"][0], b["gate_up"], 1, act_dtype=F16, out_dtype=F16)
-                wr.chain_xform("glu", in2=b["gate_up"][1])
+                if do_glu:
+                    wr.chain_xform("glu", in2=b["gate_up"][1])
                 wr.fused(layers[li]["down"], b["gate_up"][0], b["down"], 1, act_dtype=F16, out_dtype=F16)
                 if not last:
-                    wr.chain_xform("norm", residual=wr.CARRY, gamma=gam[li + 1][0], eps=1e-5, residual_out=hs[li + 1])
+                    if do_norm:
+                        wr.chain_xform("norm", residual=wr.CARRY, gamma=gam[li + 1][0], eps=1e-5, residual_out=hs[li + 1])
                     wr.fused(layers[li + 1]["qkv"], b["down"][0], b["qkv"], 1, act_dtype=F16, out_dtype=F16)
             chains_d.append(rc.chain)
         keep_alive = (gam, hs, attn, bo, x0)

@@ -72,6 +72,7 @@ struct ChainArgs {
     int npeer;
     int xforms;                    // some op carries a vector transform (tmac_hip_chain_xform): the kernel instance that knows them
     int carry_floats;              // LDS floats for the vector a NORM transform keeps for a later op of the launch (0: no op does)
+    int tmp_floats, gam_floats;    // LDS floats for a transform's vector of the current op (NORM's t / GLU's x) and for NORM's weights
     unsigned long long* stamps;    // optional [nops][grid][8] of wave 0, s_memrealtime (100 MHz): 0 op entry, 1 activations complete, 2 LUT built
                                    // (barrier passed), 3 current ring landed, 5 last quad published, 6 everything in flight landed, 7 polls
 };
@@ -98,8 +99,13 @@ inline int chain_buf_u4(int K) {
     const int nu = K / 32, nst = (nu + 63) / 64;
     return 4 * (nst * 64 + 1) + (2 * nst * 32 * 4 + 15) / 16 + CHAIN_US_FLOATS / 4;
 }
-inline size_t chain_lds_bytes(int buf_u4, int nops, int carry_floats = 0) {
-    return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops + sizeof(float) * (32 + (size_t)carry_floats);
+// LDS floats of one transform vector of a K-vector: 16-byte pieces, two per pair, rounds of CHAIN_FT pairs padded to whole waves
+inline int chain_xf_region_floats(int K) {
+    const int P = K / 8, nr = (P + CHAIN_FT - 1) / CHAIN_FT, PS = ((P < CHAIN_FT ? P : CHAIN_FT) + 63) & ~63;
+    return nr * 2 * PS * 4;
+}
+inline size_t chain_lds_bytes(int buf_u4, int nops, int xf_floats = 0) {
+    return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops + sizeof(float) * (32 + (size_t)xf_floats);
 }
 
 }  // namespace tmac

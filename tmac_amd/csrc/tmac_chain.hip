@@ -238,7 +238,11 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     }
     const cop_ptr ops = reinterpret_cast<cop_ptr>(l_ops);
     float* l_xf = reinterpret_cast<float*>(l_ops + (size_t)a.nops * (sizeof(ChainOp) / 16));     // [2][16] partial sums of a transform's mean square (by op parity)
+    // vectors of the transforms, 16-byte pieces in the order lanes of a wave hold them (piece h of the pair (round r, tpair) at
+    // ((2 r + h) * PS + tpair) * 16 bytes, PS = the op's pairs per round rounded up to whole waves: chain_xf_region_floats)
     float* l_carry = l_xf + 32;                                                                     // [a.carry_floats] the t a NORM transform keeps
+    float* l_tmp = l_carry + a.carry_floats;                                                        // [a.tmp_floats] this op's t (NORM, not kept) or x (GLU)
+    float* l_gam = l_tmp + a.tmp_floats;                                                            // [a.gam_floats] this op's norm weights
     bool aborted = false;                                                   // a hand-off timed out somewhere: stop waiting
 
     // stamps: s_memrealtime (100 MHz, one clock for the whole device; s_memtime counts per XCD with unrelated offsets)
@@ -377,21 +381,37 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         // the polls and cross the fabric while the hand-off is awaited.  xa: the residual (NORM) or the second vector's fp16 pairs (GLU):
         // one set of registers for the two transforms
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        f32x4 xa[XF ? 2 : 1][2], xg[XF ? 2 : 1][2];
+        f32x4 xa[XF ? 2 : 1];                    // GLU: the second vector's fp16 pairs of the two rounds
+        const int xPS = (min(P, FT) + 63) & ~63;
+        const int xfl = XF ? uni(d->xf_flags) : 0;
+        float* xt = nullptr;                     // NORM: the t = in + residual of this op (the kept vector's place, or scratch); GLU: x (scratch)
+        auto xslot = [&](float* region, int r, int h) __attribute__((always_inline)) {
+            return reinterpret_cast<f32x4*>(region) + ((2 * r + h) * xPS + tpair);
+        };
         if (XF && xk == 1) {
-            const int xfl0 = uni(d->xf_flags);
-            const TMAC_GLOBAL f32x4* resp4 = (const TMAC_GLOBAL f32x4*)(uni(d->res));
-            const TMAC_GLOBAL f32x4* gam4 = (const TMAC_GLOBAL f32x4*)(uni(d->gamma));
+            // The residual and the norm weights are in memory since before the launch: they go global -> LDS without touching a register
+            // (buffer_load ... lds, 16 bytes per lane: lane l of a wave lands at M0 + 16 l), issued in front of the polls and complete
+            // when the polls are (loads return in order).  Held in registers across the polls and the reduction -- 32 VGPRs -- the kernel
+            // spilled, and a spill behind the weight ring waits for the weights.
+            xt = (xfl & 4) ? l_carry : l_tmp;
+            typedef __attribute__((address_space(3))) void* lds_vp;
+            const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(uni(d->res)), (short)0, 0x7fffffff, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)(uni(d->gamma)), (short)0, 0x7fffffff, 0x00020000);
+            const bool ext_res = uni(d->res) != nullptr && !(xfl & 2), has_g = uni(d->gamma) != nullptr;
+            const uint32_t b_t = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)xt;
+            const uint32_t b_g = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)l_gam;
+            const int wfirst = __builtin_amdgcn_readfirstlane(tpair - lane);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const size_t pc = (size_t)min(r * FT + tpair, P - 1);
-                xa[r][0] = xa[r][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                xg[r][0] = xg[r][1] = (f32x4){1.f, 1.f, 1.f, 1.f};
-                if (r < nr) {
-                    if (resp4 && !(xfl0 & 2)) { xa[r][0] = resp4[2 * pc]; xa[r][1] = resp4[2 * pc + 1]; }
-                    if (gam4) { xg[r][0] = gam4[2 * pc]; xg[r][1] = gam4[2 * pc + 1]; }
+            for (int r = 0; r < 2; ++r)
+                if (r < nr && wfirst < xPS) {        // (whole waves past the round's pairs have no slots: PS is the round's pairs in whole waves)
+                    const int pc = min(r * FT + tpair, P - 1);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t lo = (uint32_t)(((2 * r + h) * xPS + wfirst) * 16);
+                        if (ext_res) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_r, (lds_vp)(uintptr_t)(b_t + lo), 16, (2 * pc + h) * 16, 0, 0, 0);
+                        if (has_g) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_vp)(uintptr_t)(b_g + lo), 16, (2 * pc + h) * 16, 0, 0, 0);
+                    }
                 }
-            }
         }
         unsigned long long polls = 0;
         {
@@ -437,12 +457,12 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 };
                 if (nr == 1) {
                     xw[0][0] = v[0].y; xw[0][1] = v[0].w; xw[0][2] = v[1].y; xw[0][3] = v[1].w;
-                    xa[0][0] = w2f(v[2].y, v[2].w, v[3].y, v[3].w);
+                    xa[0] = w2f(v[2].y, v[2].w, v[3].y, v[3].w);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 2; ++r) {
                         xw[r][0] = v[2 * r].y; xw[r][1] = v[2 * r].w; xw[r][2] = v[2 * r + 1].y; xw[r][3] = v[2 * r + 1].w;
-                        xa[r][0] = w2f(v[4 + 2 * r].y, v[4 + 2 * r].w, v[5 + 2 * r].y, v[5 + 2 * r].w);
+                        xa[r] = w2f(v[4 + 2 * r].y, v[4 + 2 * r].w, v[5 + 2 * r].y, v[5 + 2 * r].w);
                     }
                 }
             } else if (gran) {
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     const uint4* in5 = uni(reinterpret_cast<const uint4*>(d->in2));
                     c_ext3(in5 + p0, in5 + p1, in5 + p1, v);
 #pragma unroll
-                    for (int r = 0; r < 2; ++r) xa[r][0] = (f32x4){__uint_as_float(v[r].x), __uint_as_float(v[r].y), __uint_as_float(v[r].z), __uint_as_float(v[r].w)};
+                    for (int r = 0; r < 2; ++r) xa[r] = (f32x4){__uint_as_float(v[r].x), __uint_as_float(v[r].y), __uint_as_float(v[r].z), __uint_as_float(v[r].w)};
                 }
             }
         }
@@ -499,7 +519,6 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         // op loop counts as possibly pending, and VALU writes to such registers (LUT build temporaries, store operands)
         // get conservative s_waitcnt vmcnt(n) in front of them -- waits for this op's weights in the middle of the LUT build.
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt / lgkmcnt untouched
-
         // ---- 2. this wave's first RING (quad, step) items: the weights stream in during the LUT build ----
 #pragma unroll
         for (int k = 0; k < RING; ++k)
@@ -511,62 +530,64 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         // the activations as fp32: the fp16 vector as it is, or -- tmac_hip_chain_xform -- a vector transform of it, computed here where
         // every workgroup holds the whole vector anyway (a decoder's residual add + RMSNorm in front of q/k/v and gate/up, its
         // silu(gate) * up in front of the down projection): the calls of a layer chain up without a kernel in between
-        float xs[XF ? NRMAX : 1][8];
+        float xrs = 1.0f;                        // NORM: 1 / rms
+        // A transformed vector waits in LDS for the table build (each lane reads back what it wrote: no barrier of its own): held in
+        // registers -- two rounds x 8 fp32 -- the kernel spilled, with a vmcnt(0) in front of the spill.
         if constexpr (XF) {
-#pragma unroll
-        for (int r = 0; r < NRMAX; ++r)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const __half2 hh = *reinterpret_cast<const __half2*>(&xw[r][q]);
-                xs[r][2 * q] = __low2float(hh); xs[r][2 * q + 1] = __high2float(hh);
-            }
         if (xk == 2) {
             // GLU: x = silu(in) * in2, fp32
+            xt = l_tmp;
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < 2; ++r) {
+                const int p = r * FT + tpair;
+                if (r < nr && p < P) {
+                    f32x4 x0, x1;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const uint32_t w2 = __float_as_uint(xa[r][0][q]);
-                    const __half2 hh = *reinterpret_cast<const __half2*>(&w2);
-                    const float u0 = __low2float(hh), u1 = __high2float(hh);
-                    const float a0 = xs[r][2 * q], a1 = xs[r][2 * q + 1];
-                    // silu(a) = a / (1 + exp(-a)): hardware exp2 and reciprocal (1 ulp each; the transform is specified to a tolerance)
-                    xs[r][2 * q] = __fmul_rn(__fmul_rn(a0, __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __expf(-a0)))), u0);
-                    xs[r][2 * q + 1] = __fmul_rn(__fmul_rn(a1, __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __expf(-a1)))), u1);
+                    for (int q = 0; q < 4; ++q) {
+                        const __half2 ha = *reinterpret_cast<const __half2*>(&xw[r][q]);
+                        const uint32_t w2 = __float_as_uint(xa[r][q]);
+                        const __half2 hh = *reinterpret_cast<const __half2*>(&w2);
+                        const float u0 = __low2float(hh), u1 = __high2float(hh);
+                        const float a0 = __low2float(ha), a1 = __high2float(ha);
+                        // silu(a) = a / (1 + exp(-a)): hardware exp2 and reciprocal (1 ulp each; the transform is specified to a tolerance)
+                        const float y0 = __fmul_rn(__fmul_rn(a0, __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __expf(-a0)))), u0);
+                        const float y1 = __fmul_rn(__fmul_rn(a1, __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __expf(-a1)))), u1);
+                        if (q < 2) { x0[2 * q] = y0; x0[2 * q + 1] = y1; } else { x1[2 * q - 4] = y0; x1[2 * q - 3] = y1; }
+                    }
+                    *xslot(xt, r, 0) = x0; *xslot(xt, r, 1) = x1;
                 }
+            }
         } else if (xk == 1) {
             // NORM: t = in + residual (memory fp32, or the t an earlier NORM of this launch kept in LDS); x = t * rsqrt(mean(t^2) + eps) *
             // gamma (or x = t without gamma); t optionally kept for a later op and / or written to memory (the residual stream that
             // outlives the launch; each workgroup writes a stripe of it).  Up to two rounds of pairs (K <= 12288).
-            const int xfl = uni(d->xf_flags);
-            const bool has_g = uni(d->gamma) != nullptr;
             TMAC_GLOBAL f32x4* rout4 = (TMAC_GLOBAL f32x4*)(uni(d->res_out));
+            const bool has_res = uni(d->res) != nullptr || (xfl & 2);
+            float* rsrc = (xfl & 2) ? l_carry : xt;
             float ss = 0.f;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int p = r * FT + tpair;
                 if (r < nr && p < P) {
-                    if (xfl & 2) {
-                        const f32x4* c4 = reinterpret_cast<const f32x4*>(l_carry + 8 * p);
-                        xa[r][0] = c4[0]; xa[r][1] = c4[1];
-                    }
+                    f32x4 t0 = (f32x4){0.f, 0.f, 0.f, 0.f}, t1 = t0;
+                    if (has_res) { t0 = *xslot(rsrc, r, 0); t1 = *xslot(rsrc, r, 1); }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float t = __fadd_rn(xs[r][e], xa[r][e >> 2][e & 3]);
-                        xs[r][e] = t;
-                        ss = __fmaf_rn(t, t, ss);
+                    for (int q = 0; q < 4; ++q) {
+                        const __half2 hh = *reinterpret_cast<const __half2*>(&xw[r][q]);
+                        const float u0 = __fadd_rn(__low2float(hh), q < 2 ? t0[2 * q] : t1[2 * q - 4]);
+                        const float u1 = __fadd_rn(__high2float(hh), q < 2 ? t0[2 * q + 1] : t1[2 * q - 3]);
+                        if (q < 2) { t0[2 * q] = u0; t0[2 * q + 1] = u1; } else { t1[2 * q - 4] = u0; t1[2 * q - 3] = u1; }
+                        ss = __fmaf_rn(u0, u0, ss);
+                        ss = __fmaf_rn(u1, u1, ss);
                     }
-                    if (xfl & 4) {
-                        f32x4* c4 = reinterpret_cast<f32x4*>(l_carry + 8 * p);
-                        c4[0] = (f32x4){xs[r][0], xs[r][1], xs[r][2], xs[r][3]}; c4[1] = (f32x4){xs[r][4], xs[r][5], xs[r][6], xs[r][7]};
-                    }
+                    *xslot(xt, r, 0) = t0; *xslot(xt, r, 1) = t1;
                     if (rout4 && (p & 255) == (bx & 255)) {            // a stripe per workgroup (the grid has at most 256 workgroups: one writer per pair)
-                        rout4[2 * (size_t)p] = (f32x4){xs[r][0], xs[r][1], xs[r][2], xs[r][3]};
-                        rout4[2 * (size_t)p + 1] = (f32x4){xs[r][4], xs[r][5], xs[r][6], xs[r][7]};
+                        rout4[2 * (size_t)p] = t0;
+                        rout4[2 * (size_t)p + 1] = t1;
                     }
                 }
             }
-            if (has_g) {
+            if (uni(d->gamma) != nullptr) {
                 ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
                 ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
                 float* xfb = l_xf + (i & 1) * 16;                    // two sets by op parity: no second barrier needed
@@ -577,18 +598,24 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 float tot = 0.f;
 #pragma unroll
                 for (int ww = 0; ww < NWV; ++ww) tot += xfb[ww];
-                const float rs = __builtin_amdgcn_rsqf(__fmaf_rn(tot, __builtin_amdgcn_rcpf((float)(8 * P)), __uint_as_float((uint32_t)uni(d->eps_bits))));
-#pragma unroll
-                for (int r = 0; r < 2; ++r)
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) xs[r][e] = __fmul_rn(__fmul_rn(xs[r][e], rs), xg[r][e >> 2][e & 3]);
+                xrs = __builtin_amdgcn_rsqf(__fmaf_rn(tot, __builtin_amdgcn_rcpf((float)(8 * P)), __uint_as_float((uint32_t)uni(d->eps_bits))));
             }
         }
         }   // XF
         auto unpack = [&](int r, float (&x)[8]) __attribute__((always_inline)) {
-            if constexpr (XF) {
+            if (XF && xk != 0 && r < 2) {
+                const f32x4 t0 = *xslot(xt, r, 0), t1 = *xslot(xt, r, 1);
+                if (xk == 1 && uni(d->gamma) != nullptr) {
+                    const f32x4 g0 = *xslot(l_gam, r, 0), g1 = *xslot(l_gam, r, 1);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = xs[r][e];
+                    for (int e = 0; e < 4; ++e) {
+                        x[e] = __fmul_rn(__fmul_rn(t0[e], xrs), g0[e]);
+                        x[4 + e] = __fmul_rn(__fmul_rn(t1[e], xrs), g1[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { x[e] = t0[e]; x[4 + e] = t1[e]; }
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {

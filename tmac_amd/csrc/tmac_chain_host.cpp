@@ -1,5 +1,6 @@
 // tmac_chain_host.cpp — host side of the persistent decode chain (kernel: tmac_chain.hip).
 #include "tmac_host.h"
+#include <cstdlib>
 
 using namespace tmac_host;
 
@@ -48,6 +49,7 @@ struct tmac_hip_chain {
     unsigned long long* stamps = nullptr;
     size_t bytes = 0;                 // algorithmic weight + scale bytes of one launch
     int xforms = 0, carry_floats = 0;    // some op carries a vector transform; LDS floats of the kept vector
+    int tmp_floats = 0, gam_floats = 0, carry_K = 0;   // LDS floats of an op's own transform vector / norm weights; K of the latest kept vector
     int poll_sleep = 8, poll_delay = 4, issue_first = -1, poll_mode = 0;   // read from the environment once, at tmac_hip_chain_end
     hipStream_t last_stream = nullptr;   // stream of the most recent launch (in-flight guard)
     bool launched = false;
@@ -333,16 +335,20 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                 if (c->grid > 256 && xf.residual_out) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: residual_out is covered with up to 256 workgroups", i));
                 if (o.K > 8192 && (xf.keep || xf.residual == TMAC_XF_CARRY))
                     return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: a kept residual vector is covered up to K = 8192", i));
+                const int rf = chain_xf_region_floats(o.K);
                 if (xf.residual == TMAC_XF_CARRY) {
-                    if (c->carry_floats < o.K) return bail(fail(TMAC_HIP_E_ARG, "op %zu: no earlier NORM of the chain keeps a vector of %d values", i, o.K));
+                    if (c->carry_K != o.K) return bail(fail(TMAC_HIP_E_ARG, "op %zu: no earlier NORM of the chain keeps a vector of %d values", i, o.K));
                     o.xf_flags |= 2;
                 } else o.res = xf.residual;
-                if (xf.keep) { o.xf_flags |= 4; if (o.K > c->carry_floats) c->carry_floats = o.K; }
+                if (xf.keep) { o.xf_flags |= 4; c->carry_K = o.K; if (rf > c->carry_floats) c->carry_floats = rf; }
+                else if (rf > c->tmp_floats) c->tmp_floats = rf;
+                if (xf.gamma && rf > c->gam_floats) c->gam_floats = rf;
                 o.gamma = xf.gamma; o.res_out = xf.residual_out;
                 memcpy(&o.eps_bits, &xf.eps, 4);
             } else if (xf.kind == TMAC_XF_GLU) {
                 c->xforms = 1;
                 if (o.K > 2 * 8 * CHAIN_FT) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: a GLU transform is covered up to K = %d", i, 2 * 8 * CHAIN_FT));
+                if (chain_xf_region_floats(o.K) > c->tmp_floats) c->tmp_floats = chain_xf_region_floats(o.K);
                 if (src2[i].op >= 0) {
                     const ChainOp& p2 = c->ops[src2[i].op];
                     if (p2.m[src2[i].mat].Mw != o.K) return bail(fail(TMAC_HIP_E_ARG, "op %zu: the GLU's second vector has %d rows, K = %d", i, p2.m[src2[i].mat].Mw, o.K));
@@ -378,7 +384,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                         return bail(fail(TMAC_HIP_E_NOMATCH, "ops %zu and %zu write overlapping outputs and nothing in the chain orders them", i, k));
             }
     c->buf_u4 = chain_buf_u4(maxK);
-    c->lds_bytes = chain_lds_bytes(c->buf_u4, (int)c->ops.size(), c->carry_floats);
+    c->lds_bytes = chain_lds_bytes(c->buf_u4, (int)c->ops.size(), c->carry_floats + c->tmp_floats + c->gam_floats);
     if (c->lds_bytes > 160 * 1024)
         return bail(fail(TMAC_HIP_E_NOMATCH, "%zu calls with K up to %d need %zu bytes of LDS (LUT buffers + call descriptors): record shorter chains",
                          c->ops.size(), maxK, c->lds_bytes));
@@ -451,7 +457,11 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
     a.npeer = (int)c->peers.size();
     for (int p = 0; p < a.npeer; ++p) a.peer_base[p] = reinterpret_cast<unsigned long long>(c->peers[p]);
     a.spin_limit = g_knobs.chain_spin_limit; a.buf_u4 = c->buf_u4; a.stamps = c->stamps;
-    a.xforms = c->xforms; a.carry_floats = c->carry_floats;
+    a.xforms = c->xforms; a.carry_floats = c->carry_floats; a.tmp_floats = c->tmp_floats; a.gam_floats = c->gam_floats;
+    {   // measurement only (tools/gpu): run a chain WITHOUT transforms through the kernel instance that knows them
+        static const int force_xf = [] { const char* e = getenv("TMAC_HIP_CHAIN_FORCE_XF"); return e && e[0] == '1' ? 1 : 0; }();
+        if (force_xf) a.xforms = 1;
+    }
     a.poll_sleep = c->poll_sleep; a.poll_delay = c->poll_delay; a.issue_first = c->issue_first; a.poll_mode = c->poll_mode;
     hipError_t e = launch_decode_chain(a, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, st);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no decode-chain kernel for this configuration");

@@ -585,12 +585,38 @@ def main():
             chains_d.append(rc.chain)
         keep_alive = (gam, hs, attn, bo, x0)
 
-        def dstep():
-            chains_d[0].launch()
+        def dstep(segments=True):
+            if segments:
+                chains_d[0].launch()
             for li in range(args.layers):
                 attn.copy_(bo[li]["qkv"][0])          # the outside operator: a kernel of the stream between two segments (stand-in for attention)
-                chains_d[li + 1].launch()
+                if segments:
+                    chains_d[li + 1].launch()
         return dstep, chains_d, keep_alive
+
+    def time_outside_ops(dstep, reps=10):
+        """the stand-ins for attention alone (graph replay of the same 32 copies): the part of the decoder pattern's time that is not this library's"""
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                dstep(False)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                dstep(False)
+        except Exception:
+            torch.cuda.synchronize()
+            return None
+        durs = []
+        for r in range(reps + 3):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); g.replay(); e1.record()
+            torch.cuda.synchronize()
+            if r >= 3:
+                durs.append(e0.elapsed_time(e1))
+        return float(np.mean(durs))
 
     def time_decoder_pattern(reps=10):
         dstep, chains_d, keep_alive = build_decoder_pattern()
@@ -620,9 +646,10 @@ def main():
                 durs.append(e0.elapsed_time(e1))
         ok = ok and all(c.status() == 0 for c in chains_d)
         finite_d = bool(torch.isfinite(keep_alive[3][-1]["down"][0].float()).all().item())
+        outside = time_outside_ops(dstep) if g is not None else None
         for c in chains_d:
             c.free()
-        return float(np.mean(durs)), ok and finite_d, len(chains_d), g is not None
+        return float(np.mean(durs)), ok and finite_d, len(chains_d), g is not None, outside
 
     if args.pattern == "decoder":
         dstep, dchains, dkeep = build_decoder_pattern()
@@ -637,7 +664,7 @@ def main():
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=side):
             dstep()
-        dpat = dict(chains=dchains, keep=dkeep)
+        dpat = dict(chains=dchains, keep=dkeep, dstep=dstep)
 
     def run_step():
         if chain is not None:
@@ -801,10 +828,12 @@ def main():
         # the same matrices as a decoder issues them (outside the timed region; --pattern decoder makes it the timed workload)
         if not dist_on and dpat is None and args.pattern == "chained" and not args.no_decoder_pattern:
             try:
-                dms, dok, dn, dgraphed = time_decoder_pattern()
+                dms, dok, dn, dgraphed, dout = time_decoder_pattern()
                 roof["decoder_pattern"] = {"what": "one launch per segment (o -> gate/up -> down -> next q/k/v; residual add + RMSNorm and silu(gate) * up inside the "
                                                    "LUT builds), a copy kernel between the segments as stand-in for attention",
-                                           "ms_per_token": round(dms, 4), "launches": dn, "GBps": round(bytes_per_step / (dms * 1e-3) / 1e9, 1),
+                                           "ms_per_token": round(dms, 4), "launches": dn,
+                                           "outside_ms": None if dout is None else round(dout, 4),      # the 32 stand-in copies alone (same graph without the segments)
+                                           "GBps": round(bytes_per_step / (dms * 1e-3) / 1e9, 1),
                                            "frac": round(bytes_per_step / (dms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ok": dok,
                                            "timing": "hipEvent pair around a %s of the token's launches, mean of 10" % ("hipGraph replay" if dgraphed else "eager sequence")}
             except Exception as e:
@@ -930,6 +959,7 @@ def main():
                        "gemm_per_step": 7 * args.layers,
                        "launches_per_step": (len(dpat["chains"]) if dpat is not None else 1) if args.path == "chain" else (4 if fused_calls else 11) * args.layers + (0 if decode else 4 * args.layers), "path": args.path,
                        "pattern": args.pattern,
+                       **({"outside_ms": (lambda v: None if v is None else round(v, 4))(time_outside_ops(dpat["dstep"]))} if dpat is not None else {}),
                        "autotune": tuned,
                        "algorithmic_bytes_per_step": bytes_per_step, "weights": wl["weights"],
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",

@@ -44,9 +44,10 @@ class Model:
     mg = -1: per-group scales (+ zero points), act groups of 64 (tbl.cc:323-532); mg >= 1: unified scale(s), one act group
     per row, int32 totals + scale-final (BitNet: tbl.cc:536-630, qgemm.py:170-174)."""
 
-    def __init__(self, tm, ops, bits=2, zp=True, dev_f16=True, seed=0, out_f16=True, mg=-1, ternary=False):
+    def __init__(self, tm, ops, bits=2, zp=True, dev_f16=True, seed=0, out_f16=True, mg=-1, ternary=False, ext_f32=False):
         import torch
         self.tm, self.ops, self.bits, self.zp, self.mg = tm, ops, bits, zp and mg < 1, mg
+        self.ext_f32 = ext_f32                   # vectors in memory are fp32 (a caller with an fp32 graph); handed-over ones stay fp16
         zp = self.zp
         bm = BITS_BM[bits]
         self.wr = tm.TMACGeMMWrapper(act_group_size=AGS)
@@ -83,15 +84,20 @@ class Model:
                 os_.append(torch.zeros(Mw, dtype=torch.float16 if out_f16 else torch.float32, device="cuda"))
             self.host.append(hs); self.ws.append(ws); self.outs.append(os_)
             if src is None:
-                self.x_ext[i] = torch.from_numpy(rng.standard_normal(K).astype(np.float32)).cuda().half()
+                self.x_ext[i] = torch.from_numpy(rng.standard_normal(K).astype(np.float32)).cuda()
+                if not ext_f32:
+                    self.x_ext[i] = self.x_ext[i].half()
 
     def x_of(self, i):
         src = self.ops[i][2]
         return self.x_ext[i] if src is None else self.outs[src[0]][src[1]]
 
+    def act_dtype(self, i):
+        return self.tm.F32 if self.ext_f32 and self.ops[i][2] is None else self.tm.F16
+
     def issue(self):
         for i in range(len(self.ops)):
-            self.wr.fused(self.ws[i], self.x_of(i), self.outs[i], 1, act_dtype=self.tm.F16)
+            self.wr.fused(self.ws[i], self.x_of(i), self.outs[i], 1, act_dtype=self.act_dtype(i))
 
     def record(self):
         with self.wr.record_chain() as rec:
@@ -132,7 +138,7 @@ class Model:
             L.tmac_hip_debug_quad_config(chain.threads, chain.wpq(i))
             ref = [torch.empty_like(o) for o in got[i]]
             try:
-                self.wr.fused(self.ws[i], x, ref, 1, act_dtype=tm.F16)
+                self.wr.fused(self.ws[i], x, ref, 1, act_dtype=self.act_dtype(i))
                 torch.cuda.synchronize()
             finally:
                 L.tmac_hip_debug_quad_config(0, 0)
@@ -180,6 +186,29 @@ def test_small_chain(tm, bits, zp, dev_f16):
         for os_ in m.outs:
             for o in os_:
                 o.fill_(float(rep))
+        chain.launch()
+        m.check(chain, oracle_ops=None if rep == 0 else [])
+    chain.free()
+    m.free()
+
+
+EXT32 = [
+    (1024, [512, 256], None),          # fp32 vector in memory
+    (512, [1024], (0, 0)),             # handed over (fp16 granules)
+    (2688, [1024], None),              # ragged last step
+    (6400, [4096], None),              # two rounds of pairs (enough rows that the chain's waves per quad exist as a launch of its own)
+    (1024, [64, 64], (1, 0)),
+    (12800, [4096], None),             # three rounds
+]
+
+
+@pytest.mark.parametrize("bits,zp,mg", [(2, True, -1), (4, False, -1), (2, False, 1), (3, True, -1)])
+def test_chain_fp32_activations_from_memory(tm, bits, zp, mg):
+    """calls whose activations are fp32 vectors in memory (ggml's graphs are fp32): no fp16 in between -- the LUT is built from the
+    same fp32 values the call launched on its own builds it from, outputs bit-identical to it, and within 1e-3 of the oracle"""
+    m = Model(tm, EXT32, bits=bits, zp=zp, seed=40 + bits, mg=mg, ext_f32=True)
+    chain = m.record()
+    for rep in range(2):
         chain.launch()
         m.check(chain, oracle_ops=None if rep == 0 else [])
     chain.free()
@@ -331,9 +360,14 @@ def test_chain_rejections(tm):
     w = wr.register_weights(A, S, 128, 512, 2, tm.KCfg.make(128, 512, 2, 128, KF, GS, AGS, True))
     x32 = torch.zeros(512, dtype=torch.float32, device="cuda")
     out = torch.zeros(128, dtype=torch.float16, device="cuda")
+    case2 = orc.make_case(4, 128, 128, bits=2)
+    w2 = wr.register_weights(orc.preprocess_weights(case2["w"], 2, 128, KF), orc.preprocess_scales(case2["sc"], case2["zr"], 2, 128), 128, 128, 2,
+                             tm.KCfg.make(128, 128, 2, 128, KF, GS, AGS, True))
+    out2 = torch.zeros(128, dtype=torch.float16, device="cuda")
     with pytest.raises(tm.TMACHipError) as e:
         with wr.record_chain():
-            wr.fused([w], x32, [out], 1)          # fp32 activations
+            wr.fused([w], x32.half(), [out], 1)
+            wr.fused([w2], out, [out2], 1, act_dtype=tm.F32)     # an earlier output read as fp32: handed over as fp16, not representable
     assert e.value.code == -1
     with pytest.raises(tm.TMACHipError):
         with wr.record_chain():
@@ -345,7 +379,7 @@ def test_chain_rejections(tm):
     torch.cuda.synchronize()
     assert rec.chain.status() == 0
     rec.chain.free()
-    w.free()
+    w.free(); w2.free()
 
 
 def test_chain_hazards_are_refused(tm):

@@ -29,7 +29,7 @@ struct ChainOp {
     ChainMat m[4];
     int q_end[4];        // m[k].q_end again, contiguous (one scalar load), INT_MAX from the last matrix on
     const void* in;      // in_gran: the hand-off image (uint4 [K/4]) written earlier in this launch; else activations [K] fp16
-    int in_gran;         // bit 0: `in` is a hand-off image; bits 8..: weight fragments per wave issued in front of the polls (host's choice for this op)
+    int in_gran;         // bit 0: `in` is a hand-off image; bit 1: `in` is fp32 in memory ([K] floats); bits 8..: weight fragments per wave issued in front of the polls (host's choice for this op)
     int nmat;
     int K, nu, nst, tstride, G, GP, nsg, gs_shift;
     int wpq, ipi;        // waves per row quad, row quads per workgroup iteration (12 / wpq)
@@ -63,6 +63,7 @@ struct ChainArgs {
     int poll_delay;                // s_sleep 1 count before the first poll of a hand-off (A/B knob)
     int issue_first;               // A/B knob: >= 0 overrides the per-op number of weight fragments issued before the polls for the activations
     int poll_mode;                 // A/B knob: 0 polls at agent scope (sc1) | 1 at system scope (sc0 sc1; always with peers)
+    int poll_grid;                 // A/B knob: re-polls wait for the next multiple of this many 10 ns ticks of the device clock (power of two; 0: off)
     // row-sharded chains over several GPUs (one process per GPU): every rank holds the hand-off images of ALL ranks' rows in one
     // arena with the same layout; a producer stores its granules into its own arena and, through IPC mappings, into every peer's
     unsigned long long arena_base;     // this rank's arena (device address): two halves of arena_half bytes, used by generation parity -- a rank that
@@ -73,6 +74,7 @@ struct ChainArgs {
     int xforms;                    // some op carries a vector transform (tmac_hip_chain_xform): the kernel instance that knows them
     int carry_floats;              // LDS floats for the vector a NORM transform keeps for a later op of the launch (0: no op does)
     int tmp_floats, gam_floats;    // LDS floats for a transform's vector of the current op (NORM's t / GLU's x) and for NORM's weights
+    int ext_floats;                // LDS floats for an op's activations when they come as fp32 from memory
     unsigned long long* stamps;    // optional [nops][grid][8] of wave 0, s_memrealtime (100 MHz): 0 op entry, 1 activations complete, 2 LUT built
                                    // (barrier passed), 3 current ring landed, 5 last quad published, 6 everything in flight landed, 7 polls
 };

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     float* l_carry = l_xf + 32;                                                                     // [a.carry_floats] the t a NORM transform keeps
     float* l_tmp = l_carry + a.carry_floats;                                                        // [a.tmp_floats] this op's t (NORM, not kept) or x (GLU)
     float* l_gam = l_tmp + a.tmp_floats;                                                            // [a.gam_floats] this op's norm weights
+    float* l_ext = l_gam + a.gam_floats;                                                            // [a.ext_floats] this op's activations when they are fp32 in memory
     bool aborted = false;                                                   // a hand-off timed out somewhere: stop waiting
 
     // stamps: s_memrealtime (100 MHz, one clock for the whole device; s_memtime counts per XCD with unrelated offsets)
@@ -369,7 +370,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                           : as_global(reinterpret_cast<const float*>(scp))[g];
             }
         }
-        const bool gran = (uni(d->in_gran) & 1) != 0;
+        // hand-off image | fp32 vector in memory (known to the XF instance only: chains without it keep their code) | fp16 vector in memory
+        const bool gran = (uni(d->in_gran) & 1) != 0, ext32 = XF && (uni(d->in_gran) & 2) != 0;
         const int nr = (P + FT - 1) / FT;                            // rounds of FT pairs (<= NRMAX, checked on the host)
         constexpr int NRMAX = 3;
         uint32_t xw[NRMAX][4];
@@ -496,10 +498,34 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                             aborted = true;
                         }
                     }
+                    if (a.poll_grid > 0) {
+                        // A/B: all workgroups re-poll at the same instants of the device clock (one phase for the whole chip instead of 256)
+                        const unsigned rem = (unsigned)a.poll_grid - ((unsigned)__builtin_amdgcn_s_memrealtime() & ((unsigned)a.poll_grid - 1u));
+                        const int nz = (int)((rem * 10u) >> 5);                 // ticks of 10 ns -> s_sleep 1 rounds of ~32 ns
+                        for (int z = 0; z < nz; ++z) __builtin_amdgcn_s_sleep(1);
+                    } else
                     for (int z = 0; z < a.poll_sleep; ++z) __builtin_amdgcn_s_sleep(1);
                 }
 #pragma unroll
                 for (int r = 0; r < NRMAX; ++r) { xw[r][0] = v[2 * r].y; xw[r][1] = v[2 * r].w; xw[r][2] = v[2 * r + 1].y; xw[r][3] = v[2 * r + 1].w; }
+            } else if (ext32) {
+                // fp32 activations in memory (a caller whose graph is fp32, e.g. ggml): global -> LDS without registers, 32 bytes per pair,
+                // read back as the fp32 values the LUT is built from (no fp16 in between: what the per-launch path does with them)
+                typedef __attribute__((address_space(3))) void* lds_vp;
+                const __amdgpu_buffer_rsrc_t rs_i = __builtin_amdgcn_make_buffer_rsrc((void*)(uni(d->in)), (short)0, 0x7fffffff, 0x00020000);
+                const uint32_t b_e = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)l_ext;
+                const int wfirst = __builtin_amdgcn_readfirstlane(tpair - lane);
+#pragma unroll
+                for (int r = 0; r < NRMAX; ++r)
+                    if (r < nr && wfirst < xPS) {
+                        const int pc = min(r * FT + tpair, P - 1);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_i, (lds_vp)(uintptr_t)(b_e + (uint32_t)(((2 * r + h) * xPS + wfirst) * 16)), 16,
+                                                                     (2 * pc + h) * 16, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int r = 0; r < NRMAX; ++r) xw[r][0] = xw[r][1] = xw[r][2] = xw[r][3] = 0u;
             } else {
                 c_ext3(in4 + p0, in4 + p1, in4 + p2, v);
 #pragma unroll
@@ -571,11 +597,15 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 if (r < nr && p < P) {
                     f32x4 t0 = (f32x4){0.f, 0.f, 0.f, 0.f}, t1 = t0;
                     if (has_res) { t0 = *xslot(rsrc, r, 0); t1 = *xslot(rsrc, r, 1); }
+                    f32x4 i0 = (f32x4){0.f, 0.f, 0.f, 0.f}, i1 = i0;
+                    if (ext32) { i0 = *xslot(l_ext, r, 0); i1 = *xslot(l_ext, r, 1); }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const __half2 hh = *reinterpret_cast<const __half2*>(&xw[r][q]);
-                        const float u0 = __fadd_rn(__low2float(hh), q < 2 ? t0[2 * q] : t1[2 * q - 4]);
-                        const float u1 = __fadd_rn(__high2float(hh), q < 2 ? t0[2 * q + 1] : t1[2 * q - 3]);
+                        const float v0 = ext32 ? (q < 2 ? i0[2 * q] : i1[2 * q - 4]) : __low2float(hh);
+                        const float v1 = ext32 ? (q < 2 ? i0[2 * q + 1] : i1[2 * q - 3]) : __high2float(hh);
+                        const float u0 = __fadd_rn(v0, q < 2 ? t0[2 * q] : t1[2 * q - 4]);
+                        const float u1 = __fadd_rn(v1, q < 2 ? t0[2 * q + 1] : t1[2 * q - 3]);
                         if (q < 2) { t0[2 * q] = u0; t0[2 * q + 1] = u1; } else { t1[2 * q - 4] = u0; t1[2 * q - 3] = u1; }
                         ss = __fmaf_rn(u0, u0, ss);
                         ss = __fmaf_rn(u1, u1, ss);
@@ -588,10 +618,15 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 }
             }
             if (uni(d->gamma) != nullptr) {
-                ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
-                ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 32, 64);
+                // sum over the wave: four DPP steps inside the rows of 16 lanes, the four row sums through readlane (__shfl_xor is a
+                // ds_bpermute round trip per step: six in a row cost 0.2 us here)
+                ss = __fadd_rn(ss, qdpp_f<0xB1>(ss)); ss = __fadd_rn(ss, qdpp_f<0x4E>(ss));
+                ss = __fadd_rn(ss, qdpp_f<0x141>(ss)); ss = __fadd_rn(ss, qdpp_f<0x140>(ss));     // row_half_mirror, row_mirror
+                const int ssb = __builtin_bit_cast(int, ss);
+                const float sw = __fadd_rn(__fadd_rn(__builtin_bit_cast(float, __builtin_amdgcn_readlane(ssb, 0)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(ssb, 16))),
+                                           __fadd_rn(__builtin_bit_cast(float, __builtin_amdgcn_readlane(ssb, 32)), __builtin_bit_cast(float, __builtin_amdgcn_readlane(ssb, 48))));
                 float* xfb = l_xf + (i & 1) * 16;                    // two sets by op parity: no second barrier needed
-                if (lane == 0) xfb[w] = ss;
+                if (lane == 0) xfb[w] = sw;
                 // LDS-only barrier: __syncthreads() carries a workgroup fence = s_waitcnt vmcnt(0) on gfx9, i.e. it would wait here for the
                 // weight fragments issued a moment ago (a memory round trip in the open, before the tables are even started)
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -616,6 +651,10 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { x[e] = t0[e]; x[4 + e] = t1[e]; }
                 }
+            } else if (ext32) {
+                const f32x4 t0 = *xslot(l_ext, r, 0), t1 = *xslot(l_ext, r, 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[e] = t0[e]; x[4 + e] = t1[e]; }
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {

@@ -49,8 +49,8 @@ struct tmac_hip_chain {
     unsigned long long* stamps = nullptr;
     size_t bytes = 0;                 // algorithmic weight + scale bytes of one launch
     int xforms = 0, carry_floats = 0;    // some op carries a vector transform; LDS floats of the kept vector
-    int tmp_floats = 0, gam_floats = 0, carry_K = 0;   // LDS floats of an op's own transform vector / norm weights; K of the latest kept vector
-    int poll_sleep = 8, poll_delay = 4, issue_first = -1, poll_mode = 0;   // read from the environment once, at tmac_hip_chain_end
+    int tmp_floats = 0, gam_floats = 0, ext_floats = 0, carry_K = 0;   // LDS floats of an op's own transform vector / norm weights; K of the latest kept vector
+    int poll_sleep = 8, poll_delay = 4, issue_first = -1, poll_mode = 0, poll_grid = 0;   // read from the environment once, at tmac_hip_chain_end
     hipStream_t last_stream = nullptr;   // stream of the most recent launch (in-flight guard)
     bool launched = false;
 };
@@ -176,7 +176,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
     std::vector<std::vector<Range>> out_r(n);
     for (size_t i = 0; i < n; ++i) {
         const Shape& s0 = rec[i].w[0]->s;
-        in_r[i] = Range{(const char*)rec[i].B, (const char*)rec[i].B + (size_t)s0.K * 2};          // fp16 activations (checked below)
+        in_r[i] = Range{(const char*)rec[i].B, (const char*)rec[i].B + (size_t)s0.K * (rec[i].act == TMAC_F32 ? 4 : 2)};
         for (size_t m = 0; m < rec[i].w.size(); ++m)
             out_r[i].push_back(Range{(const char*)rec[i].C[m], (const char*)rec[i].C[m] + (size_t)rec[i].w[m]->s.Mw * out_esz});
         for (size_t m = 0; m < out_r[i].size(); ++m)
@@ -260,7 +260,9 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         ChainOp& o = c->ops[i];
         memset(&o, 0, sizeof(o));
         const Shape& s0 = r.w[0]->s;
-        if (r.act != TMAC_F16) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the decode chain takes fp16 activations", i));
+        if (r.act != TMAC_F16 && r.act != TMAC_F32) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: the decode chain takes fp16 or fp32 activations", i));
+        if (r.act == TMAC_F32 && (src[i].op >= 0 || r.xf.kind == TMAC_XF_GLU))
+            return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: fp32 activations are covered for vectors in memory (an earlier output is handed over as fp16), without a GLU transform", i));
         if ((r.out == TMAC_F16) != (c->out_f16 != 0)) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: one output dtype per chain", i));
         if (s0.K > 8 * 3 * CHAIN_FT) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: K = %d beyond the decode chain's %d", i, s0.K, 8 * 3 * CHAIN_FT));
         if (((s0.m_groups >= 1) ? 2 : 0) != c->sm) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: per-group and unified scales cannot share a chain", i));
@@ -324,6 +326,8 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             o.in = reinterpret_cast<const void*>(reinterpret_cast<size_t>(po.m[src[i].mat].GR) - my_off); o.in_gran = 1;
         } else {
             o.in = r.B; o.in_gran = 0;
+            if (r.act == TMAC_F32) { o.in_gran = 2; c->xforms = 1;      // (the kernel instance with the extensions)
+                if (chain_xf_region_floats(s0.K) > c->ext_floats) c->ext_floats = chain_xf_region_floats(s0.K); }
         }
         // ---- vector transform (tmac_hip_chain_xform)
         {
@@ -384,7 +388,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                         return bail(fail(TMAC_HIP_E_NOMATCH, "ops %zu and %zu write overlapping outputs and nothing in the chain orders them", i, k));
             }
     c->buf_u4 = chain_buf_u4(maxK);
-    c->lds_bytes = chain_lds_bytes(c->buf_u4, (int)c->ops.size(), c->carry_floats + c->tmp_floats + c->gam_floats);
+    c->lds_bytes = chain_lds_bytes(c->buf_u4, (int)c->ops.size(), c->carry_floats + c->tmp_floats + c->gam_floats + c->ext_floats);
     if (c->lds_bytes > 160 * 1024)
         return bail(fail(TMAC_HIP_E_NOMATCH, "%zu calls with K up to %d need %zu bytes of LDS (LUT buffers + call descriptors): record shorter chains",
                          c->ops.size(), maxK, c->lds_bytes));
@@ -435,6 +439,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
     c->poll_delay = env_int("TMAC_CHAIN_POLL_DELAY", 4);
     c->issue_first = env_int("TMAC_CHAIN_ISSUE_FIRST", -1);
     c->poll_mode = env_int("TMAC_CHAIN_POLL_MODE", 0);
+    c->poll_grid = env_int("TMAC_CHAIN_POLL_GRID", 0);
     *out = c;
     return TMAC_HIP_OK;
 }
@@ -457,12 +462,12 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
     a.npeer = (int)c->peers.size();
     for (int p = 0; p < a.npeer; ++p) a.peer_base[p] = reinterpret_cast<unsigned long long>(c->peers[p]);
     a.spin_limit = g_knobs.chain_spin_limit; a.buf_u4 = c->buf_u4; a.stamps = c->stamps;
-    a.xforms = c->xforms; a.carry_floats = c->carry_floats; a.tmp_floats = c->tmp_floats; a.gam_floats = c->gam_floats;
+    a.xforms = c->xforms; a.carry_floats = c->carry_floats; a.tmp_floats = c->tmp_floats; a.gam_floats = c->gam_floats; a.ext_floats = c->ext_floats;
     {   // measurement only (tools/gpu): run a chain WITHOUT transforms through the kernel instance that knows them
         static const int force_xf = [] { const char* e = getenv("TMAC_HIP_CHAIN_FORCE_XF"); return e && e[0] == '1' ? 1 : 0; }();
         if (force_xf) a.xforms = 1;
     }
-    a.poll_sleep = c->poll_sleep; a.poll_delay = c->poll_delay; a.issue_first = c->issue_first; a.poll_mode = c->poll_mode;
+    a.poll_sleep = c->poll_sleep; a.poll_delay = c->poll_delay; a.issue_first = c->issue_first; a.poll_mode = c->poll_mode; a.poll_grid = c->poll_grid;
     hipError_t e = launch_decode_chain(a, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, st);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no decode-chain kernel for this configuration");
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "decode chain launch: %s", hipGetErrorString(e));

@@ -68,6 +68,10 @@ int ggml_tmac_hip_segment_begin(void);
 int ggml_tmac_hip_segment_norm(const float* residual, int residual_is_kept, const float* norm_weight, float eps, float* residual_out, int keep);
 int ggml_tmac_hip_segment_glu(const void* in2_f16);
 int ggml_tmac_hip_segment_mul_mat(const struct tmac_ggml_tensor* const* w, int nw, const void* x_f16, void* const* dst_f16);
+/* the same with x as an fp32 vector in device memory that no earlier mat-mul of the segment wrote (ggml's graphs are fp32: the output of
+ * the attention operator in front of the o projection, the token embedding in front of the first q/k/v): the tables are built from the
+ * fp32 values, as tmac_hip_qgemm_fused_dev does on its own */
+int ggml_tmac_hip_segment_mul_mat_f32(const struct tmac_ggml_tensor* const* w, int nw, const float* x_f32, void* const* dst_f16);
 int ggml_tmac_hip_segment_end(ggml_tmac_hip_segment** seg);
 int ggml_tmac_hip_segment_compute(ggml_tmac_hip_segment* seg);   /* one launch on ggml_tmac_hip_stream(); does not wait */
 int ggml_tmac_hip_segment_wait(ggml_tmac_hip_segment* seg);      /* synchronises the stream; 0 if every hand-off of the segment's launches completed */

@@ -154,7 +154,7 @@ int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weights, int nma
  * inside the launch; any other B_dev must hold its activations when the launch starts.  Calls execute in recorded order.
  * An output buffer may be written by several calls (a decoder reuses its buffers layer after layer); the last one wins.
  * Scope: 1- to 4-bit QUAD-layout weights; per-group scales (group size >= 128, a power of two) with act groups of 64, or
- * unified scales (m_groups >= 1, BitNet) with one act group per row; fp16 activations; chained outputs fp16; one weight
+ * unified scales (m_groups >= 1, BitNet) with one act group per row; fp16 activations, or fp32 for vectors that are in memory before the launch; chained outputs fp16; one weight
  * width, scale flavour, scale dtype and zero-point setting per chain.  Anything else: -1 from tmac_hip_chain_end and
  * the caller keeps launching the calls one by one.  Results are bit-identical to tmac_hip_qgemm_fused_dev with
  * the same threads per workgroup and waves per row quad (tmac_hip_debug_quad_config(tmac_hip_chain_threads(), wpq)).

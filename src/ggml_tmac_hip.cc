@@ -175,8 +175,8 @@ extern "C" int ggml_tmac_hip_segment_glu(const void* in2_f16) {
     return tmac_hip_chain_xform(&xf);
 }
 
-extern "C" int ggml_tmac_hip_segment_mul_mat(const struct tmac_ggml_tensor* const* w, int nw, const void* x_f16, void* const* dst_f16) {
-    if (!w || nw < 1 || nw > 4 || !x_f16 || !dst_f16) return fail("bad segment mul_mat");
+static int segment_mul_mat(const struct tmac_ggml_tensor* const* w, int nw, const void* x, tmac_dtype_t x_dtype, void* const* dst_f16) {
+    if (!w || nw < 1 || nw > 4 || !x || !dst_f16) return fail("bad segment mul_mat");
     const tmac_hip_weights* wl[4];
     void* cl[4];
     for (int i = 0; i < nw; ++i) {
@@ -184,7 +184,15 @@ extern "C" int ggml_tmac_hip_segment_mul_mat(const struct tmac_ggml_tensor* cons
         wl[i] = ((const Handle*)w[i]->extra)->w;
         cl[i] = dst_f16[i];
     }
-    return tmac_hip_qgemm_fused_dev(wl, nw, x_f16, TMAC_F16, cl, TMAC_F16, 1, g_stream);   // recorded, not launched
+    return tmac_hip_qgemm_fused_dev(wl, nw, x, x_dtype, cl, TMAC_F16, 1, g_stream);   // recorded, not launched
+}
+
+extern "C" int ggml_tmac_hip_segment_mul_mat(const struct tmac_ggml_tensor* const* w, int nw, const void* x_f16, void* const* dst_f16) {
+    return segment_mul_mat(w, nw, x_f16, TMAC_F16, dst_f16);
+}
+
+extern "C" int ggml_tmac_hip_segment_mul_mat_f32(const struct tmac_ggml_tensor* const* w, int nw, const float* x_f32, void* const* dst_f16) {
+    return segment_mul_mat(w, nw, x_f32, TMAC_F32, dst_f16);
 }
 
 extern "C" int ggml_tmac_hip_segment_end(ggml_tmac_hip_segment** seg) {

@@ -71,7 +71,8 @@ int main(int argc, char** argv) {
     const tmac_ggml_tensor* wqkv0[3] = {&w[0][0], &w[0][1], &w[0][2]};
     CK(ggml_tmac_hip_segment_begin());
     CK(ggml_tmac_hip_segment_norm(nullptr, 0, g[0][0], 1e-5f, nullptr, 0));
-    CK(ggml_tmac_hip_segment_mul_mat(wqkv0, 3, x0, qkv[0]));
+    CK(ggml_tmac_hip_segment_mul_mat_f32(wqkv0, 3, h0, qkv[0]));        // the token's embedding as ggml holds it: fp32
+    (void)x0;
     CK(ggml_tmac_hip_segment_end(&s0));
     for (int l = 0; l < NL; ++l) {
         const tmac_ggml_tensor *wo[1] = {&w[l][3]}, *wgu[2] = {&w[l][4], &w[l][5]}, *wd[1] = {&w[l][6]};

@@ -112,13 +112,16 @@ class Layer:
         self.g2 = torch.from_numpy((1.0 + 0.1 * rng.standard_normal(H)).astype(np.float32)).cuda()
 
 
-@pytest.mark.parametrize("H,F", [(1024, 2816), (4096, 11008)])
-def test_decoder_layers_with_an_operator_outside(tm, H, F):
+@pytest.mark.parametrize("H,F,glu_in_producer", [(1024, 2816, 1), (1024, 2816, 0), (4096, 11008, 1), (1024, 2560, 1)])
+def test_decoder_layers_with_an_operator_outside(tm, H, F, glu_in_producer, monkeypatch):
     """A llama-shaped layer loop: per layer ONE launch of the segment o -> [+ residual, RMSNorm] -> gate / up -> [silu(gate) * up] ->
     down -> [+ residual, RMSNorm] -> next layer's q / k / v, then an operator that stays outside the chain (a stand-in for attention:
     any kernel on the stream) produces the next segment's input from q, k, v.  Every mpGEMM against the oracle, the residual stream bit
-    for bit against fp32 adds."""
+    for bit against fp32 adds.  silu(gate) * up is computed by the gate / up call's publishing wave (default: once per row, the down
+    projection reads ONE image) or inside the down projection's LUT build (TMAC_CHAIN_GLU_EPILOGUE=0: the form that also serves vectors
+    in memory): both are run.  F = 2560: 640 row pairs, not a multiple of the workgroup count (ragged ranges)."""
     import torch
+    monkeypatch.setenv("TMAC_CHAIN_GLU_EPILOGUE", str(glu_in_producer))
     NL, eps = 3, 1e-5
     wr = tm.TMACGeMMWrapper(act_group_size=AGS)
     layers = [Layer(tm, wr, 100 * (li + 1), H, F) for li in range(NL)]
@@ -173,7 +176,10 @@ def test_decoder_layers_with_an_operator_outside(tm, H, F):
         g, u = b["gate"].float().cpu().numpy(), b["up"].float().cpu().numpy()
         assert rel_err(g, L.gate.oracle(x2)) <= 2e-3 and rel_err(u, L.up.oracle(x2)) <= 2e-3
         d = b["down"].float().cpu().numpy()
-        assert rel_err(d, L.down.oracle(np_glu(g, u))) <= 2e-3
+        m_ = np_glu(g, u)
+        if glu_in_producer:
+            m_ = m_.astype(np.float16).astype(np.float32)           # the hand-off image holds silu(gate) * up as fp16
+        assert rel_err(d, L.down.oracle(m_)) <= 2e-3
         t3 = d + t2
         assert np.array_equal(b["h_out"].cpu().numpy(), t3), f"layer {li}: residual stream"
         x3 = np_norm(t3, Ln.g1.cpu().numpy(), eps)

@@ -46,7 +46,10 @@ struct ChainOp {
     int xf_kind;
     int xf_flags;        // bit 1: the residual is the t kept by an earlier NORM of this launch (LDS); bit 2: keep this op's t
     int eps_bits;        // eps as the bits of a float
-    int pad[5];
+    int epi;             // 1: this op's matrices 0 and 1 are gate and up of a GLU whose only reader is a later op of the chain: the row quads of
+                         //    the two are dealt in pairs (workgroup ranges in units of two: q_per / q_extra count pairs; virtual quad v = matrix v & 1,
+                         //    quad v >> 1) and matrix 0's hand-off image carries silu(gate) * up, computed once per row by the publishing wave
+    int pad[4];
     // sizeof == 320: the kernel keeps a copy of all descriptors in LDS (uint4 copies)
 };
 static_assert(sizeof(ChainOp) == 320, "ChainOp is copied to LDS in 16-byte pieces");

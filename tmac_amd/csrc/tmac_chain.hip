@@ -294,8 +294,9 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         r.qs = qs; r.ipi = ipi;
         r.nst = uni(d->nst);
         const int qper = uni(d->q_per), qex = uni(d->q_extra);
-        r.q_lo = bx * qper + min(bx, qex);
-        r.cnt = qper + (bx < qex ? 1 : 0);
+        const int unit = (XF && uni(d->epi)) ? 2 : 1;                     // GLU in the producer: ranges in pairs (gate quad, up quad)
+        r.q_lo = unit * (bx * qper + min(bx, qex));
+        r.cnt = unit * (qper + (bx < qex ? 1 : 0));
         const int iinv = uni(d->ipi_inv);                                // x / ipi = (x * ipi_inv) >> 16 for the small x here
         r.my_iter = ((r.cnt + ipi - 1) * iinv) >> 16;                    // iterations the WORKGROUP runs (barriers)
         r.nquads = qs < r.cnt ? (((r.cnt - 1 - qs) * iinv) >> 16) + 1 : 0;   // quads this wave works on: q_lo + qs + it * ipi < q_lo + cnt
@@ -325,6 +326,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         // cursor enters the quad, not per item: scalar instructions are issued by ONE unit per CU, and 12 waves x ~60 of
         // them per fragment were 0.4 us per fragment issued (profiles/r02_chain_prefetch_ab.txt C).
         const int qe0 = uni(d->q_end[0]), qe1 = uni(d->q_end[1]), qe2 = uni(d->q_end[2]);
+        const bool epi = XF && uni(d->epi) != 0;                              // matrices 0 / 1 dealt in pairs, silu(gate) * up published (tmac_chain.h)
         const int n_items = ro.nquads * ro.nsteps;
         __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint4*>(nullptr), (short)0, 0, 0x00020000);
         const TMAC_GLOBAL char* q_sc = nullptr;
@@ -334,8 +336,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             if (issued < n_items) {
                 if (q_res != i_it) {
                     const int gqi = ro.q_lo + ro.qs + i_it * ro.ipi;
-                    const int mi = (gqi >= qe0 ? 1 : 0) + (gqi >= qe1 ? 1 : 0) + (gqi >= qe2 ? 1 : 0);
-                    const int lq = gqi - (gqi >= qe2 ? qe2 : (gqi >= qe1 ? qe1 : (gqi >= qe0 ? qe0 : 0)));
+                    const int mi = epi ? (gqi & 1) : (gqi >= qe0 ? 1 : 0) + (gqi >= qe1 ? 1 : 0) + (gqi >= qe2 ? 1 : 0);
+                    const int lq = epi ? (gqi >> 1) : gqi - (gqi >= qe2 ? qe2 : (gqi >= qe1 ? qe1 : (gqi >= qe0 ? qe0 : 0)));
                     q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(uni(d->m[mi].W)), (short)0, 0x7fffffff, 0x00020000);
                     q_sc = as_global(uni(reinterpret_cast<const char*>(d->m[mi].SC))) + (size_t)lq * (size_t)(nsg * 4 * (ZP ? 2 : 1) * (SCF16 ? 2 : 4));
                     q_woff = lq * nst * (BITS * 1024);
@@ -808,8 +810,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             unsigned long long p_c = 0ull, p_gr = 0ull;
             if (w == 0) {
                 const int e0 = uni(d->q_end[0]), e1 = uni(d->q_end[1]), e2 = uni(d->q_end[2]);      // (INT_MAX from the last matrix on)
-                p_mi = (p_gql >= e0 ? 1 : 0) + (p_gql >= e1 ? 1 : 0) + (p_gql >= e2 ? 1 : 0);
-                p_lq = p_gql - (p_gql >= e2 ? e2 : (p_gql >= e1 ? e1 : (p_gql >= e0 ? e0 : 0)));
+                p_mi = epi ? (p_gql & 1) : (p_gql >= e0 ? 1 : 0) + (p_gql >= e1 ? 1 : 0) + (p_gql >= e2 ? 1 : 0);
+                p_lq = epi ? (p_gql >> 1) : p_gql - (p_gql >= e2 ? e2 : (p_gql >= e1 ? e1 : (p_gql >= e0 ? e0 : 0)));
                 const ChainMat* mp = &d->m[p_mine ? p_mi : 0];        // the workgroup's copy in LDS: a per-lane ds_read
                 p_c = reinterpret_cast<unsigned long long>(mp->C);
                 p_gr = reinterpret_cast<unsigned long long>(mp->GR);
@@ -851,13 +853,22 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 asm volatile("" : "+v"(t));
                 // granule = {generation, fp16 row | fp16 next row << 16}, 8 bytes, write-through: even rows store
                 const uint32_t hb = (uint32_t)__half_as_ushort(__float2half_rn(t));
-                const uint32_t nb = qdpp_u<0xB1>(hb);                    // quad_perm [1,0,3,2]: the neighbour's value
+                uint32_t pb = hb;                                        // what the hand-off image carries: the fp16 output, or ...
+                if (epi) {
+                    // ... silu(gate) * up: the up quad of this row pair sits four lanes up (slot qs + 1, same DPP row); from the fp16
+                    // values a reader would see, fp32 arithmetic, rounded to the fp16 the image holds
+                    const uint32_t ub = qdpp_u<0x104>(hb);               // row_shl:4
+                    const float gv = __half2float(__ushort_as_half((unsigned short)hb)), uv = __half2float(__ushort_as_half((unsigned short)ub));
+                    const float xv = __fmul_rn(__fmul_rn(gv, __builtin_amdgcn_rcpf(__fadd_rn(1.0f, __expf(-gv)))), uv);
+                    if (p_mi == 0) pb = (uint32_t)__half_as_ushort(__float2half_rn(xv));
+                }
+                const uint32_t nb = qdpp_u<0xB1>(pb);                    // quad_perm [1,0,3,2]: the neighbour's value
                 if (mine) {
                     const size_t oi = (size_t)(4 * p_lq + row);
                     if (a.out_f16) reinterpret_cast<TMAC_GLOBAL unsigned short*>(p_c)[oi] = (unsigned short)hb;
                     else reinterpret_cast<TMAC_GLOBAL float*>(p_c)[oi] = t;
                     if (p_gr && !(row & 1)) {
-                        const unsigned long long gv = ((unsigned long long)(hb | (nb << 16)) << 32) | gen;
+                        const unsigned long long gv = ((unsigned long long)(pb | (nb << 16)) << 32) | gen;
                         TMAC_GLOBAL unsigned long long* dst = reinterpret_cast<TMAC_GLOBAL unsigned long long*>(p_gr + par_off) + 2 * (size_t)p_lq + (row >> 1);
                         __hip_atomic_store(dst, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         // row-sharded chains: the same granule into the hand-off arena of every other rank (identical layout on

@@ -253,6 +253,30 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         }
     }
 
+    // GLU in the producer: when the two vectors of a GLU are outputs 0 and 1 of ONE earlier two-matrix call (gate and up) and nothing else
+    // in the chain reads the gate's hand-off image, the gate/up call publishes silu(gate) * up itself -- once per row, by the wave that
+    // publishes the rows anyway -- instead of all 256 workgroups of the reader evaluating K x (exp + rcp) each and polling two images
+    // (A/B: TMAC_CHAIN_GLU_EPILOGUE=0 keeps the reader's form).  Needs both quads of a row pair in one workgroup iteration: pairs are dealt.
+    std::vector<char> epi_of(n, 0), glu_in_producer(n, 0);
+    std::vector<std::vector<int>> readers(n);
+    for (size_t j = 0; j < n; ++j) readers[j].assign(rec[j].w.size(), 0);
+    for (size_t i = 0; i < n; ++i) {
+        if (src[i].op >= 0) ++readers[src[i].op][src[i].mat];
+        if (src2[i].op >= 0) ++readers[src2[i].op][src2[i].mat];
+    }
+    if (env_int("TMAC_CHAIN_GLU_EPILOGUE", 1))
+        for (size_t i = 0; i < n; ++i) {
+            if (rec[i].xf.kind != TMAC_XF_GLU || src[i].op < 0 || src2[i].op != src[i].op || src[i].mat != 0 || src2[i].mat != 1) continue;
+            const size_t j = (size_t)src[i].op;
+            if (rec[j].w.size() != 2 || rec[j].w[0]->s.Mw != rec[j].w[1]->s.Mw || gathered[j][0] || gathered[j][1] || readers[j][0] != 1 || epi_of[j]) continue;
+            const Shape& sj = rec[j].w[0]->s;
+            const int nqj = 2 * sj.nquads(), nstj = (sj.K / 32 + 63) / 64;
+            const int wq = g_knobs.chain_wpq ? g_knobs.chain_wpq : chain_pick_wpq(nqj, nstj, c->grid);
+            if (CHAIN_NWV % wq || ((CHAIN_NWV / wq) & 1)) continue;          // pairs need an even number of quads per workgroup iteration
+            epi_of[j] = 1; glu_in_producer[i] = 1;
+            if (readers[j][1] == 1) consumed[j][1] = 0;                      // nobody else reads the up projection through a hand-off
+        }
+
     c->ops.resize(n);
     int maxK = 0;
     for (size_t i = 0; i < n; ++i) {
@@ -316,6 +340,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         o.ipi_inv = (65536 + o.ipi - 1) / o.ipi;
         if (nq / c->grid + 1 + o.ipi >= 4096) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: too many rows per workgroup for the decode chain", i));
         o.q_per = nq / c->grid; o.q_extra = nq % c->grid;
+        if (epi_of[i]) { o.epi = 1; c->xforms = 1; o.q_per = (nq / 2) / c->grid; o.q_extra = (nq / 2) % c->grid; }
         if (src[i].op >= 0) {
             const ChainOp& po = c->ops[src[i].op];
             const bool via_gather = gathered[src[i].op][src[i].mat] != 0;
@@ -349,6 +374,8 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                 if (xf.gamma && rf > c->gam_floats) c->gam_floats = rf;
                 o.gamma = xf.gamma; o.res_out = xf.residual_out;
                 memcpy(&o.eps_bits, &xf.eps, 4);
+            } else if (xf.kind == TMAC_XF_GLU && glu_in_producer[i]) {
+                o.xf_kind = TMAC_XF_NONE;                  // `in` already holds silu(gate) * up (the producer's epilogue)
             } else if (xf.kind == TMAC_XF_GLU) {
                 c->xforms = 1;
                 if (o.K > 2 * 8 * CHAIN_FT) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: a GLU transform is covered up to K = %d", i, 2 * 8 * CHAIN_FT));

@@ -183,6 +183,8 @@ int32_t tmac_hip_chain_free(tmac_hip_chain* chain);
  *                 stream for the next launch; must not alias anything the launch reads)
  *   TMAC_XF_GLU   x = silu(in) * in2;  in2: fp16 [K], an earlier output of the chain (handed over like `in`) or external memory -- of the
  *                 same kind as `in`; K <= 12288
+ *                 (when `in` and `in2` are outputs 0 and 1 of one earlier two-matrix call of the chain and nothing else reads output 0 through a
+ *                 hand-off, that call publishes silu(in) * in2 itself, once per row, rounded to fp16 like every handed-over vector)
  * A decoder then runs one launch per segment between two operators that stay outside (attention): o -> gate/up -> down -> next q/k/v.
  * These are extensions without a reference counterpart (T-MAC has no norm operator): tests compare them with the same formulas in
  * numpy fed through the oracle (tolerance, not bits: the mean square is summed in another order). */

@@ -218,51 +218,6 @@ __device__ __forceinline__ void c_ext3(const uint4* p0, const uint4* p1, const u
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(p0), "v"(p1), "v"(p2) : "memory");
 }
 
-// value of lane ^ 16 / lane ^ 32 combined with the lane's own, on the VALU: gfx950's v_permlane16_swap / v_permlane32_swap exchange rows of 16
-// (halves of 32) lanes between two registers; fed the same value twice they return {own | partner} and {partner | own} halves, whose sum
-// (max) is what `x op __shfl_xor(x, 16 | 32)` computes -- bit for bit (the operations are commutative) -- without the ds_bpermute round trip
-// through the LDS crossbar (two in a row in front of every finish barrier).  A/B knob: -DTMAC_CHAIN_SWAP_REDUCE=0.
-#ifndef TMAC_CHAIN_SWAP_REDUCE
-#define TMAC_CHAIN_SWAP_REDUCE 1
-#endif
-template <int W> __device__ __forceinline__ void c_swap_pair(uint32_t x, uint32_t& a0, uint32_t& a1) {
-    if constexpr (W == 16) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); a0 = r[0]; a1 = r[1]; }
-    else { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); a0 = r[0]; a1 = r[1]; }
-}
-__device__ __forceinline__ float c_xor_add_f(float x) {          // x + x(lane ^ 16), then + (lane ^ 32)
-#if TMAC_CHAIN_SWAP_REDUCE
-    uint32_t a0, a1;
-    c_swap_pair<16>(__float_as_uint(x), a0, a1); x = __fadd_rn(__uint_as_float(a0), __uint_as_float(a1));
-    c_swap_pair<32>(__float_as_uint(x), a0, a1); x = __fadd_rn(__uint_as_float(a0), __uint_as_float(a1));
-    return x;
-#else
-    x = __fadd_rn(x, __shfl_xor(x, 16, 64));
-    return __fadd_rn(x, __shfl_xor(x, 32, 64));
-#endif
-}
-__device__ __forceinline__ uint32_t c_xor_add_u(uint32_t x) {
-#if TMAC_CHAIN_SWAP_REDUCE
-    uint32_t a0, a1;
-    c_swap_pair<16>(x, a0, a1); x = a0 + a1;
-    c_swap_pair<32>(x, a0, a1); x = a0 + a1;
-    return x;
-#else
-    x += (uint32_t)__shfl_xor((int)x, 16, 64);
-    return x + (uint32_t)__shfl_xor((int)x, 32, 64);
-#endif
-}
-__device__ __forceinline__ float c_xor_max_f(float x) {
-#if TMAC_CHAIN_SWAP_REDUCE
-    uint32_t a0, a1;
-    c_swap_pair<16>(__float_as_uint(x), a0, a1); x = fmaxf(__uint_as_float(a0), __uint_as_float(a1));
-    c_swap_pair<32>(__float_as_uint(x), a0, a1); x = fmaxf(__uint_as_float(a0), __uint_as_float(a1));
-    return x;
-#else
-    x = fmaxf(x, __shfl_xor(x, 16, 64));
-    return fmaxf(x, __shfl_xor(x, 32, 64));
-#endif
-}
-
 // XF: the chain holds vector transforms (tmac_hip_chain_xform) -- a kernel of its own, so that chains without them keep their registers
 template <int BITS, bool ZP, bool SCF16, int SM, bool XF>
 __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
@@ -734,7 +689,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 }
             }
             mx = q_row_allmax(mx);
-            mx = c_xor_max_f(mx);
+            mx = q_xor_max_f(mx);
             if (lane == 0) l_us[2 + w] = mx;
             __syncthreads();
             mx = l_us[2];
@@ -828,7 +783,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     uint32_t v = have ? (uint32_t)iacc[pl] : 0u;
                     v += qdpp_u<0x124>(v);
                     v += qdpp_u<0x128>(v);
-                    v = c_xor_add_u(v);
+                    v = q_xor_add_u(v);
                     if (lane < 4) redi[(wl * 4 + lane) * CHAIN_RED + pl] = (int32_t)v;
                     iacc[pl] = 0;
                 }
@@ -838,7 +793,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     acc = cacc;
                     acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // lanes with the same row: rotate by 4, 8 within the DPP row
                     acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
-                    acc = c_xor_add_f(acc);
+                    acc = q_xor_add_f(acc);
                 }
                 if (lane < 4) red[(wl * 4 + lane) * CHAIN_RED] = acc;
             }

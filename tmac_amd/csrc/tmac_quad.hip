@@ -240,8 +240,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                 }
             }
             mx = q_row_allmax(mx);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = q_xor_max_f(mx);
             if (lane == 0) l_scr[w] = mx;
             __syncthreads();
             mx = l_scr[0];
@@ -474,8 +473,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                 acc = cacc[0][0];                             // planes already combined (compute_mfma)
                 acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // lanes with the same beta: rotate by 4, 8 within the row
                 acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
-                acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));
-                acc = __fadd_rn(acc, __shfl_xor(acc, 32, 64));
+                acc = q_xor_add_f(acc);
             }
             if (WPQ == 1) {
                 const int o = 4 * lq + lane;
@@ -502,8 +500,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                     acc = __fadd_rn(acc, qdpp_f<0x4E>(acc));      // lane ^ 2
                     acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // rotate by 4, 8 within the 16-lane row
                     acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
-                    acc = __fadd_rn(acc, __shfl_xor(acc, 16, 64));
-                    acc = __fadd_rn(acc, __shfl_xor(acc, 32, 64));
+                    acc = q_xor_add_f(acc);
                     part[i] = acc;
                 }
             }
@@ -533,8 +530,7 @@ __global__ __launch_bounds__(FT) void k_gemv_quad(FusedArgs a) {
                     uint32_t v = have ? (uint32_t)iacc[pl][0] : 0u;
                     v += qdpp_u<0x124>(v);
                     v += qdpp_u<0x128>(v);
-                    v += (uint32_t)__shfl_xor((int)v, 16, 64);
-                    v += (uint32_t)__shfl_xor((int)v, 32, 64);
+                    v = q_xor_add_u(v);
                     tot[pl] = (int32_t)v;
                 } else {
                     int32_t mine = 0;
@@ -736,8 +732,7 @@ __global__ __launch_bounds__(PT) void k_preprocess_pairs_row(const void* __restr
         }
     }
     mx = q_row_allmax(mx);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = q_xor_max_f(mx);
     if (lane == 0) l_mx[w] = mx;
     __syncthreads();
     mx = l_mx[0];

@@ -130,4 +130,50 @@ __device__ __forceinline__ float q_half_allmax(float v) {
     return v;
 }
 
+// value of lane ^ 16 / lane ^ 32 combined with the lane's own, on the VALU: gfx950's v_permlane16_swap / v_permlane32_swap exchange rows of 16
+// (halves of 32) lanes between two registers; fed the same value twice they return {own | partner} and {partner | own} halves, whose sum
+// (max) is what `x op __shfl_xor(x, 16 | 32)` computes -- bit for bit (the operations are commutative) -- without the ds_bpermute round trip
+// through the LDS crossbar (two in a row in front of every reduction barrier of k_gemv_quad and k_decode_chain).  A/B knob: -DTMAC_SWAP_REDUCE=0.
+#ifndef TMAC_SWAP_REDUCE
+#define TMAC_SWAP_REDUCE 1
+#endif
+template <int W> __device__ __forceinline__ void q_swap_pair(uint32_t x, uint32_t& a0, uint32_t& a1) {
+    if constexpr (W == 16) { const auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false); a0 = r[0]; a1 = r[1]; }
+    else { const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false); a0 = r[0]; a1 = r[1]; }
+}
+__device__ __forceinline__ float q_xor_add_f(float x) {          // x + x(lane ^ 16), then + (lane ^ 32)
+#if TMAC_SWAP_REDUCE
+    uint32_t a0, a1;
+    q_swap_pair<16>(__float_as_uint(x), a0, a1); x = __fadd_rn(__uint_as_float(a0), __uint_as_float(a1));
+    q_swap_pair<32>(__float_as_uint(x), a0, a1); x = __fadd_rn(__uint_as_float(a0), __uint_as_float(a1));
+    return x;
+#else
+    x = __fadd_rn(x, __shfl_xor(x, 16, 64));
+    return __fadd_rn(x, __shfl_xor(x, 32, 64));
+#endif
+}
+__device__ __forceinline__ uint32_t q_xor_add_u(uint32_t x) {
+#if TMAC_SWAP_REDUCE
+    uint32_t a0, a1;
+    q_swap_pair<16>(x, a0, a1); x = a0 + a1;
+    q_swap_pair<32>(x, a0, a1); x = a0 + a1;
+    return x;
+#else
+    x += (uint32_t)__shfl_xor((int)x, 16, 64);
+    return x + (uint32_t)__shfl_xor((int)x, 32, 64);
+#endif
+}
+__device__ __forceinline__ float q_xor_max_f(float x) {
+#if TMAC_SWAP_REDUCE
+    uint32_t a0, a1;
+    q_swap_pair<16>(__float_as_uint(x), a0, a1); x = fmaxf(__uint_as_float(a0), __uint_as_float(a1));
+    q_swap_pair<32>(__float_as_uint(x), a0, a1); x = fmaxf(__uint_as_float(a0), __uint_as_float(a1));
+    return x;
+#else
+    x = fmaxf(x, __shfl_xor(x, 16, 64));
+    return fmaxf(x, __shfl_xor(x, 32, 64));
+#endif
+}
+
+
 }  // namespace tmac

@@ -149,17 +149,27 @@ def test_gemm_planes_edge_activations(tm, form):
             assert rel_err(r["C"][n][m], Cc[n][m]) <= 1e-5
 
 
+US_CASES = [
+    # Mw,   K,    N,  bits
+    (320, 3200, 40, 2), (160, 640, 33, 2), (3200, 8640, 70, 2), (3200, 3200, 256, 2), (64, 12288, 13, 2),
+    # round 4: the other widths (operand rows of k_gemm_planes; 3- / 4-bit rows leave their +7 / +15 with the row's entry sum)
+    (320, 3200, 40, 4), (192, 12288, 13, 4), (256, 1024, 130, 4),
+    (320, 3200, 33, 3), (192, 12288, 16, 3),
+    (128, 1024, 64, 1), (320, 8640, 70, 1),
+]
+
+
 @pytest.mark.parametrize("form", FORMS)
-@pytest.mark.parametrize("Mw,K,N", [(320, 3200, 40), (160, 640, 33), (3200, 8640, 70), (3200, 3200, 256), (64, 12288, 13)])
-def test_gemm_planes_unified_scale(tm, Mw, K, N, form):
-    """the BitNet flavour (m_groups = 1, one act group per row) through k_gemm_planes_us: the LUT image of the row-wise build
-    bit-identical to the oracle's, the combined integer totals bit-identical to the oracle's per-plane totals, and the
-    outputs BIT-IDENTICAL to the oracle's scale-final expression (qgemm.py:170-174) -- integer accumulation has no order"""
+@pytest.mark.parametrize("Mw,K,N,bits", US_CASES)
+def test_gemm_planes_unified_scale(tm, Mw, K, N, bits, form):
+    """the BitNet flavour (m_groups = 1, one act group per row) through k_gemm_planes_us, 1- to 4-bit weights: the LUT image of
+    the row-wise build bit-identical to the oracle's, the combined integer totals bit-identical to the oracle's per-plane totals,
+    and the outputs BIT-IDENTICAL to the oracle's scale-final expression (qgemm.py:170-174) -- integer accumulation has no order"""
     import torch
-    bits, bm = 2, 320 if Mw % 160 == 0 else 128
+    bm = {1: 64, 2: 320 if Mw % 160 == 0 else 128, 3: 192, 4: 256}[bits]
     if Mw % (bm // bits) != 0:
-        bm = 128
-    case = orc.make_case(400 + N + K, Mw, K, N=N, bits=bits, ags=K, zero_point=False, m_groups=1)
+        bm = 32 * bits
+    case = orc.make_case(400 + N + K + bits, Mw, K, N=N, bits=bits, ags=K, zero_point=False, m_groups=1)
     L = tm.lib()
     tm.binding.check(L.tmac_hip_set_gemm_min_n(1))
     tm.binding.check(L.tmac_hip_debug_gemm_kernel(form))
@@ -175,20 +185,28 @@ def test_gemm_planes_unified_scale(tm, Mw, K, N, form):
         wr.llama_cpp_init(Bt, Mw, K, N, bits)
         wr.llama_cpp_compute(w, Ct, N)
         torch.cuda.synchronize()
-        h, gls, glb, _ = wr.workspace.read_gemm_image(K, N, act_group_size=K)
+        h, gls, glb, hs = wr.workspace.read_gemm_image(K, N, act_group_size=K)
         comb = wr.comb_sums(w, N)
         C = Ct.cpu().numpy()
+        # the fused entry point (one image build + one launch) gives the same bits
+        C2 = torch.full((N, Mw), float("nan"), dtype=torch.float32, device="cuda")
+        wr.fused([w], Bt, [C2], N)
+        torch.cuda.synchronize()
+        C2 = C2.cpu().numpy()
         w.free()
     finally:
+        L.tmac_hip_debug_gemm_kernel(0)
         L.tmac_hip_set_gemm_min_n(32)
     q, ls, lb = orc.preprocessor(case["B"], K)
     assert np.array_equal(h, q[:, :, :8])
     assert np.array_equal(gls.view(np.uint32), ls.view(np.uint32)) and np.array_equal(glb.view(np.uint32), lb.view(np.uint32))
+    assert np.array_equal(hs[:, 0], q[:, :, :8].astype(np.int32).reshape(N, -1).sum(-1).astype(np.float32))
     Cc, cb = orc.qgemm_scale_final(A, q, S, ls[:, 0], lb[:, 0], Mw, K, N, bits, bm, 16, 1)      # cb: int32 [N][M] per-plane totals
     rows = np.arange(Mw)
     want = sum((cb[:, mrow(rows, p, bits)].astype(np.int64) << p) for p in range(bits))
     assert np.array_equal(comb[:, :, 0].astype(np.int64), want)
     assert np.array_equal(C.view(np.uint32), Cc.view(np.uint32))
+    assert np.array_equal(C2.view(np.uint32), Cc.view(np.uint32))
 
 
 @pytest.mark.parametrize("bits,bm", [(1, 64), (3, 192), (2, 128)])

@@ -209,7 +209,7 @@ extern "C" int32_t tmac_hip_debug_gemm_image_read(const tmac_hip_workspace* ws, 
     if (!ws || !half_tables_host || !lut_scales_host || !lut_biases_host || !entry_sums_host) return fail(TMAC_HIP_E_ARG, "null argument");
     if (!ws->gimg_valid || N <= 0 || N > ws->N) return fail(TMAC_HIP_E_ARG, "the workspace holds no LUT image for N=%d", N);
     hipStream_t st = (hipStream_t)stream;
-    const int K = ws->K, G = ws->ags == K ? 1 : K / 64, Np = ws->gNpad;     // (one act group per row: no entry sums, zeros returned)
+    const int K = ws->K, G = ws->ags == K ? 1 : K / 64, Np = ws->gNpad;
     std::vector<uint8_t> img((size_t)2 * K * Np);
     std::vector<float> col((size_t)3 * G * Np);
     HIP_TRY(hipMemcpyAsync(img.data(), ws->gimg, img.size(), hipMemcpyDeviceToHost, st));
@@ -223,7 +223,10 @@ extern "C" int32_t tmac_hip_debug_gemm_image_read(const tmac_hip_workspace* ws, 
         for (int kk = 0; kk < G; ++kk) {
             lut_scales_host[(size_t)n * G + kk] = col[((size_t)0 * G + kk) * Np + n];
             lut_biases_host[(size_t)n * G + kk] = col[((size_t)1 * G + kk) * Np + n];
-            entry_sums_host[(size_t)n * G + kk] = ws->ags == K ? 0.0f : col[((size_t)2 * G + kk) * Np + n];
+            const float es = col[((size_t)2 * G + kk) * Np + n];          // (one act group per row: int32 bits, see k_preprocess_pairs_row)
+            int32_t esi;
+            memcpy(&esi, &es, sizeof(esi));
+            entry_sums_host[(size_t)n * G + kk] = ws->ags == K ? (float)esi : es;
         }
     }
     return TMAC_HIP_OK;

@@ -587,14 +587,20 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
 // K range, the eight ranges are added as integers (exact, any order) and the scale-final expression
 //   C = ((comb / 2) * lut_scale[n] + lut_bias[n] / 2) * scale[o / (Mw / m_groups)]
 // runs once per output -- bit for bit what the GEMV kernel and the oracle compute from the per-plane totals (comb / 2 =
-// sum_p alpha_p * total_p is exact in fp32: |comb| < 2^24).  2-bit weights (the signed operand rows need no bias term).
-// The LUT image comes from k_preprocess_pairs_row (tmac_quad.hip), colv holds lut_scales | lut_biases with one act group.
-template <bool DUMP, int NWV>
+// sum_p alpha_p * total_p is exact in fp32: |comb| < 2^24).  1- to 4-bit weights (round 4; 2-bit only before): the operand rows
+// of k_gemm_planes per width -- 3- and 4-bit rows carry +7 / +15 per operand byte, which leaves as BIASB x (sum of ALL half-table
+// entries of activation row n), an integer the row-wise LUT build provides (colv[2][n], int32 bits).
+// The LUT image comes from k_preprocess_pairs_row (tmac_quad.hip), colv holds lut_scales | lut_biases | entry sum with one act group.
+template <int BITS, bool DUMP, int NWV>
 __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
     using PF = PForm<NWV>;
     constexpr int P_NWV = NWV, P_BB_OFF = PF::BB_OFF, P_BB_WAVE = PF::BB_WAVE;
-    constexpr int NJ = 2;
+    constexpr int NJ = BITS;
+    constexpr bool ODD = (BITS & 1) != 0;      // see k_gemm_planes: 16-byte table entries, a lane holds one whole unit per tile row
+    constexpr int WPU = ODD ? BITS : BITS / 2;
+    constexpr int WUN = ODD ? 1 : 2;
+    constexpr int BIASB = BITS == 4 ? 15 : BITS == 3 ? 7 : 0;
     const Shape& s = a.s;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int kb = lane >> 5, j = lane & 31;
@@ -611,18 +617,20 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
     const int k_lo = (w * nk) / P_NWV, k_end = ((w + 1) * nk) / P_NWV;        // 64-activation steps of this wave
 
     const uint32_t psel = 0x0c0c0000u | ((4u + (lane & 3)) << 8);
-    const uint32_t copyoff = NWV == 8 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u;
+    const uint32_t copyoff = ODD ? (NWV == 8 ? (uint32_t)(lane & 15) * 16u : (uint32_t)(lane & 7) * 32u)
+                                 : (NWV == 8 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.W), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.bimg), (short)0, 0x7fffffff, 0x00020000);
     int wvoff[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
         const int quad = min((row0 >> 2) + rt * 8 + (j >> 2), nq - 1);
-        wvoff[rt] = ((quad * nst * NJ + kb) * 64) * 16;
+        wvoff[rt] = ODD ? (quad * nst * NJ * 64 + kb) * 16
+                        : ((quad * nst * NJ + (BITS == 2 ? kb : 2 * kb)) * 64) * 16;
     }
     const int bvoff = (n0 + lane) * 16;
     const uint32_t bb_wave = P_BB_OFF + w * P_BB_WAVE;
-    uint4 wv[2][2];
+    uint4 wv[WUN][2][WPU];
     auto dma_chunk = [&](int kk) {
 #pragma unroll
         for (int ul = 0; ul < 2; ++ul)
@@ -633,34 +641,51 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
     };
     auto load_weights = [&](int kk, int rt) {
 #pragma unroll
-        for (int ul = 0; ul < 2; ++ul) {
+        for (int ul = 0; ul < WUN; ++ul) {
             const int u = 2 * kk + ul, so = ((u >> 6) * NJ * 64 + (u & 63)) * 16;
-            const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt], so, 0);
-            wv[ul][rt] = make_uint4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int q = 0; q < WPU; ++q) {
+                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt], so + q * 1024, 0);
+                wv[ul][rt][q] = make_uint4(v[0], v[1], v[2], v[3]);
+            }
         }
     };
+    typedef unsigned int p2u_t __attribute__((ext_vector_type(2)));
+    typedef unsigned int p4u_t __attribute__((ext_vector_type(4)));
     auto pat_row = [&](uint32_t d) -> uint2 {
         const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        typedef unsigned int p2u_t __attribute__((ext_vector_type(2)));
         const p2u_t v = *(__attribute__((address_space(3))) const p2u_t*)(uintptr_t)(NWV == 8 ? ad : ad >> 1);   // absolute LDS address (see k_gemm_planes)
         return make_uint2(v.x, v.y);
     };
+    auto pat_row2 = [&](uint32_t d) -> uint4 {   // odd widths: the operand rows of the byte's two nibbles
+        const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
+        const p4u_t v = *(__attribute__((address_space(3))) const p4u_t*)(uintptr_t)(NWV == 8 ? ad : ad >> 1);
+        return make_uint4(v.x, v.y, v.z, v.w);
+    };
     const bool work = k_lo < k_end;
     if (work) { dma_chunk(k_lo); load_weights(k_lo, 0); load_weights(k_lo, 1); }
-    {
+    {   // joint-index operand rows, as in k_gemm_planes
         const int b = tid & 255, i0 = b & 15, i1 = b >> 4;
-        uint32_t lo = 0, hi = 0;
+        uint32_t lo = 0, hi = 0, lo1 = 0, hi1 = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int v = 0;
-            if (e == (i0 & 7)) v += (i0 & 8) ? -1 : 1;
-            if (e == (i1 & 7)) v += (i1 & 8) ? -2 : 2;
-            const uint32_t by8 = (uint32_t)(v & 0xff) << (8 * (e & 3));
-            if (e < 4) lo |= by8; else hi |= by8;
+            if (ODD) {
+                const int v0 = (BITS == 3 ? 1 : 0) + (e == (i0 & 7) ? ((i0 & 8) ? -1 : 1) : 0);
+                const int v1 = (BITS == 3 ? 1 : 0) + (e == (i1 & 7) ? ((i1 & 8) ? -1 : 1) : 0);
+                const uint32_t b0 = (uint32_t)(v0 & 0xff) << (8 * (e & 3)), b1 = (uint32_t)(v1 & 0xff) << (8 * (e & 3));
+                if (e < 4) { lo |= b0; lo1 |= b1; } else { hi |= b0; hi1 |= b1; }
+            } else {
+                int v = (BITS == 4) ? 3 : 0;
+                if (e == (i0 & 7)) v += (i0 & 8) ? -1 : 1;
+                if (e == (i1 & 7)) v += (i1 & 8) ? -2 : 2;
+                const uint32_t by8 = (uint32_t)(v & 0xff) << (8 * (e & 3));
+                if (e < 4) lo |= by8; else hi |= by8;
+            }
         }
+        if (!ODD) { lo1 = lo; hi1 = hi; }
         uint4* pt = reinterpret_cast<uint4*>(plds) + (NWV == 8 ? b * 16 + (tid >> 8) * 8 : b * 8);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo, hi);
+        for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo1, hi1);
     }
     __syncthreads();
 
@@ -680,7 +705,9 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (((ks >> 1) * 4 + 2 * kb + (ks & 1)) * 64 + nt * 32 + j) * 16);
+                // even widths: this k half = pair 2 kb + (ks & 1) of unit ks >> 1; odd: pair ks of unit kb
+                const int pslot = ODD ? kb * 4 + ks : (ks >> 1) * 4 + 2 * kb + (ks & 1);
+                const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (pslot * 64 + nt * 32 + j) * 16);
                 bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
             }
         p4i_t av[2][4];
@@ -688,9 +715,25 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const uint4 q = wv[ks >> 1][rt];
-                const uint2 t0 = pat_row((ks & 1) ? q.z : q.x), t1 = pat_row((ks & 1) ? q.w : q.y);
-                av[rt][ks] = (p4i_t){(int)t0.x, (int)t0.y, (int)t1.x, (int)t1.y};
+                if constexpr (BITS == 1) {             // dword ks of the unit = tables 2 ks, 2 ks + 1
+                    const uint4 q = wv[0][rt][0];
+                    const uint4 g = pat_row2(ks == 0 ? q.x : ks == 1 ? q.y : ks == 2 ? q.z : q.w);
+                    av[rt][ks] = (p4i_t){(int)g.x, (int)g.y, (int)g.z, (int)g.w};
+                } else if constexpr (BITS == 3) {      // dwords 3 ks .. 3 ks + 2 of the unit's twelve
+                    const uint32_t dw[12] = {wv[0][rt][0].x, wv[0][rt][0].y, wv[0][rt][0].z, wv[0][rt][0].w, wv[0][rt][1].x, wv[0][rt][1].y,
+                                             wv[0][rt][1].z, wv[0][rt][1].w, wv[0][rt][2].x, wv[0][rt][2].y, wv[0][rt][2].z, wv[0][rt][2].w};
+                    const uint4 g0 = pat_row2(dw[3 * ks]), g1 = pat_row2(dw[3 * ks + 1]), g2 = pat_row2(dw[3 * ks + 2]);
+                    av[rt][ks] = (p4i_t){(int)(g0.x + (g0.z << 1) + (g1.x << 2)), (int)(g0.y + (g0.w << 1) + (g1.y << 2)),
+                                         (int)(g1.z + (g2.x << 1) + (g2.z << 2)), (int)(g1.w + (g2.y << 1) + (g2.w << 2))};
+                } else if constexpr (BITS == 2) {
+                    const uint4 q = wv[ks >> 1][rt][0];
+                    const uint2 t0 = pat_row((ks & 1) ? q.z : q.x), t1 = pat_row((ks & 1) ? q.w : q.y);
+                    av[rt][ks] = (p4i_t){(int)t0.x, (int)t0.y, (int)t1.x, (int)t1.y};
+                } else {
+                    const uint4 q = wv[ks >> 1][rt][ks & 1];
+                    const uint2 a0 = pat_row(q.x), a1 = pat_row(q.y), b0 = pat_row(q.z), b1 = pat_row(q.w);
+                    av[rt][ks] = (p4i_t){(int)(a0.x + (a1.x << 2)), (int)(a0.y + (a1.y << 2)), (int)(b0.x + (b1.x << 2)), (int)(b0.y + (b1.y << 2))};
+                }
             }
         if (next) { load_weights(kk + 1, 0); load_weights(kk + 1, 1); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -728,11 +771,14 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
         const int n = n0 + nl, o = row0 + sl * 4;
         if (n < a.N && o < Mw) {
             const float ls = a.colv[n], hlb = __fmul_rn(a.colv[a.Npad + n], 0.5f);
+            // the biased operand bytes of 3- / 4-bit rows added BIASB x (every half-table entry of row n) to each total
+            const int bias = BIASB ? BIASB * __float_as_int(a.colv[2 * a.Npad + n]) : 0;
             float r[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (DUMP) a.dump[(size_t)n * Mw + o + e] = v[e];
-                const float t = __fmul_rn((float)v[e], 0.5f);
+                const int c = v[e] - bias;
+                if (DUMP) a.dump[(size_t)n * Mw + o + e] = c;
+                const float t = __fmul_rn((float)c, 0.5f);
                 const float x = __fadd_rn(__fmul_rn(t, ls), hlb);
                 r[e] = __fmul_rn(x, q_ld_scale(M.SC, a.sc_f16, (o + e) / (Mw / s.m_groups)));
             }
@@ -748,7 +794,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
 }
 
 bool gemm_planes_us_supported(const Shape& s) {
-    return s.lay == 2 && s.bits == 2 && s.K % 64 == 0 && s.Mw % 4 == 0 && s.m_groups >= 1 && s.ags == s.K && s.Mw % s.m_groups == 0;
+    return s.lay == 2 && s.bits >= 1 && s.bits <= 4 && s.K % 64 == 0 && s.Mw % 4 == 0 && s.m_groups >= 1 && s.ags == s.K && s.Mw % s.m_groups == 0;
 }
 
 bool gemm_planes_supported(const Shape& s) {
@@ -797,7 +843,14 @@ hipError_t launch_gemm_planes(const Gemm2Args& a_in, hipStream_t st) {
         hipLaunchKernelGGL((KERNEL), g, b, lds_bytes, st, a); } while (0)
 #define PLW(...) do { if (nwv == 8) PLAUNCH((__VA_ARGS__, 8>)); else PLAUNCH((__VA_ARGS__, 4>)); } while (0)
     if (a.s.m_groups >= 1) {
-        if (a.dump) PLW(k_gemm_planes_us<true); else PLW(k_gemm_planes_us<false);
+#define PLU(B) do { if (a.dump) PLW(k_gemm_planes_us<B, true); else PLW(k_gemm_planes_us<B, false); } while (0)
+        switch (a.s.bits) {
+            case 1: PLU(1); break;
+            case 2: PLU(2); break;
+            case 3: PLU(3); break;
+            default: PLU(4); break;
+        }
+#undef PLU
         return hipGetLastError();
     }
 #define PL3(B, Z, D) do { if (a.sc_f16) PLW(k_gemm_planes<B, Z, D, true); else PLW(k_gemm_planes<B, Z, D, false); } while (0)

@@ -700,6 +700,8 @@ __global__ __launch_bounds__(PT) void k_preprocess_pairs_row(const void* __restr
     const int P = K / 8, n = blockIdx.x, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     float* l_mx = prs;
     float* l_cs = prs + NWV;
+    int* l_hs = reinterpret_cast<int*>(prs + NWV + K / 32);      // sum of all signed half-table entries of the row (LUT image only)
+    if (tid == 0) *l_hs = 0;
     constexpr int NPR = 3;                   // pairs per thread: K <= 24 * PT
     float x[NPR][8];
     float mx = 0.f;
@@ -748,6 +750,7 @@ __global__ __launch_bounds__(PT) void k_preprocess_pairs_row(const void* __restr
         lut_biases[n] = biases;
         if (colv) { colv[n] = gscale; colv[Npad + n] = biases; }      // the layout k_gemm_planes_us reads (tmac_gemm2.hip)
     }
+    int hsum = 0;
 #pragma unroll
     for (int r = 0; r < NPR; ++r) {
         const int p = r * PT + tid;
@@ -757,8 +760,11 @@ __global__ __launch_bounds__(PT) void k_preprocess_pairs_row(const void* __restr
             q_table8<false>(x[r][0], x[r][1], x[r][2], x[r][3], gtinv, lo0, hi0, La);
             q_table8<false>(x[r][4], x[r][5], x[r][6], x[r][7], gtinv, lo1, hi1, Lb);
             qlut_lds[((size_t)n * 4 + (p & 3)) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
-            if (bimg)   // signed half tables, [unit][pair][n]: what the plane-combined GEMM streams
+            if (bimg) {  // signed half tables, [unit][pair][n]: what the plane-combined GEMM streams
                 bimg[(size_t)p * Npad + n] = make_uint4(lo0 ^ 0x80808080u, hi0 ^ 0x80808080u, lo1 ^ 0x80808080u, hi1 ^ 0x80808080u);
+                // the 16 entries are biased bytes U = entry + 128: sum of the bytes - 16 * 128
+                hsum += (int)__builtin_amdgcn_sad_u8(lo0, 0u, __builtin_amdgcn_sad_u8(hi0, 0u, __builtin_amdgcn_sad_u8(lo1, 0u, __builtin_amdgcn_sad_u8(hi1, 0u, 0u)))) - 2048;
+            }
             if (ALL) {
                 const int seg = p >> 3, j8 = p & 7;
                 *reinterpret_cast<uint4*>(qlut_dev + ((size_t)n * qdev_u4_per_row + qlut_dev_u4_index(seg, j8)) * 2) = make_uint4(lo0, hi0, lo1, hi1);
@@ -771,6 +777,13 @@ __global__ __launch_bounds__(PT) void k_preprocess_pairs_row(const void* __restr
             }
         }
     }
+    if (colv) {   // (uniform) the row's entry sum, int32 bits: what the +7 / +15 operand bytes of 3- / 4-bit rows add per unit of it
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) hsum += __shfl_xor(hsum, off);
+        if (lane == 0) atomicAdd(l_hs, hsum);
+        __syncthreads();
+        if (tid == 0) colv[2 * (size_t)Npad + n] = __int_as_float(*l_hs);
+    }
 }
 
 hipError_t launch_preprocess_pairs_row(const void* B, int act_f16, void* qlut_lds, float* lut_scales, float* lut_biases, int K, int N,
@@ -778,7 +791,7 @@ hipError_t launch_preprocess_pairs_row(const void* B, int act_f16, void* qlut_ld
     constexpr int PT = 512;
     if (K % 64 != 0 || N < 1 || K > 24 * PT || ((qlut_ref == nullptr) != (qlut_dev == nullptr))) return hipErrorInvalidValue;
     const int tstride = (((K / 32) + 15) & ~15) + 1;
-    const size_t shmem = sizeof(float) * (PT / 64 + K / 32);
+    const size_t shmem = sizeof(float) * (PT / 64 + K / 32 + 1);
     dim3 g(N), b(PT);
 #define PLR(F, A) hipLaunchKernelGGL((k_preprocess_pairs_row<F, A, PT>), g, b, shmem, st, B, (uint4*)qlut_lds, lut_scales, lut_biases, K, tstride, \
                                      (uint4*)qlut_ref, (uint2*)qlut_dev, qdev_u4_per_row, (uint4*)bimg, colv, Npad)

@@ -180,7 +180,10 @@ int32_t tmac_hip_chain_free(tmac_hip_chain* chain);
  *   TMAC_XF_NORM  t = in + residual;  x = gamma ? t * (1 / sqrt(mean(t^2) + eps)) * gamma : t
  *                 residual: fp32 [K] in device memory, NULL (none), or TMAC_XF_CARRY = the t that the latest NORM with keep != 0 kept
  *                 (inside the launch, no memory round trip; K <= 8192); residual_out: t also goes to memory (fp32 [K], e.g. the residual
- *                 stream for the next launch; must not alias anything the launch reads)
+ *                 stream for the next launch).  tmac_hip_chain_end checks it like every other write of the launch: it may overlap a
+ *                 vector an EARLIER call of the chain reads from memory only when a hand-off path from a call in which every workgroup
+ *                 owns rows leads to this one (the in-place residual stream of a decoder segment); never the vectors this or a later
+ *                 call reads (a later NORM takes TMAC_XF_CARRY), never an output
  *   TMAC_XF_GLU   x = silu(in) * in2;  in2: fp16 [K], an earlier output of the chain (handed over like `in`) or external memory -- of the
  *                 same kind as `in`; K <= 12288
  *                 (when `in` and `in2` are outputs 0 and 1 of one earlier two-matrix call of the chain and nothing else reads output 0 through a

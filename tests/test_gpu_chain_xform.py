@@ -207,3 +207,27 @@ def test_transform_errors(tm):
     # outside a recording
     with pytest.raises(tm.binding.TMACHipError):
         wr.chain_xform("norm")
+    # residual_out over the vector the same NORM reads (the workgroups that own an index range store it while the others still read)
+    res = torch.zeros(512, dtype=torch.float32, device="cuda")
+    with pytest.raises(tm.binding.TMACHipError):
+        with wr.record_chain():
+            wr.chain_xform("norm", residual=res, residual_out=res)
+            wr.fused([m.w], x, [o], 1, act_dtype=tm.F16)
+    # residual_out over the call's own activations, and over an output of the launch
+    xf32 = torch.zeros(512, dtype=torch.float32, device="cuda")
+    with pytest.raises(tm.binding.TMACHipError):
+        with wr.record_chain():
+            wr.chain_xform("norm", residual=res, residual_out=xf32)
+            wr.fused([m.w], xf32[:256].view(torch.float16), [o], 1, act_dtype=tm.F16)
+    o32 = torch.zeros(512, dtype=torch.float32, device="cuda")
+    with pytest.raises(tm.binding.TMACHipError):
+        with wr.record_chain():
+            wr.chain_xform("norm", residual=res, residual_out=o32)
+            wr.fused([m.w], x, [o32[:128].view(torch.float16)], 1, act_dtype=tm.F16)
+    # an output of the launch over the norm weights of a later call that no hand-off orders behind it
+    gam = torch.ones(512, dtype=torch.float32, device="cuda")
+    with pytest.raises(tm.binding.TMACHipError):
+        with wr.record_chain():
+            wr.fused([m.w], x, [gam[:128].view(torch.float16)], 1, act_dtype=tm.F16)
+            wr.chain_xform("norm", residual=res, gamma=gam)
+            wr.fused([m.w], x, [o], 1, act_dtype=tm.F16)

@@ -414,6 +414,43 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                     if (overlap(out_r[k][m], out_r[i][m2]) && !dep[k][i])
                         return bail(fail(TMAC_HIP_E_NOMATCH, "ops %zu and %zu write overlapping outputs and nothing in the chain orders them", i, k));
             }
+    // The vectors of the transforms take part in the same analysis: what a NORM / GLU reads from memory (residual, norm weights, an
+    // external second vector) must not be written by the launch unless a hand-off orders the writer behind every reader; what a NORM
+    // writes (residual_out: stored by the workgroups that own the index range, while the others may still be reading) must not be read
+    // by the same or a later op of the launch (a later NORM takes it as TMAC_XF_CARRY), nor overlap any output.
+    std::vector<std::vector<Range>> xf_rd(n);
+    std::vector<Range> xf_wr(n, Range{nullptr, nullptr});
+    for (size_t i = 0; i < n; ++i) {
+        const tmac_hip_xform& xf = rec[i].xf;
+        const size_t K = (size_t)rec[i].w[0]->s.K;
+        if (xf.kind == TMAC_XF_NORM) {
+            if (xf.residual && xf.residual != TMAC_XF_CARRY) xf_rd[i].push_back(Range{(const char*)xf.residual, (const char*)xf.residual + K * 4});
+            if (xf.gamma) xf_rd[i].push_back(Range{(const char*)xf.gamma, (const char*)xf.gamma + K * 4});
+            if (xf.residual_out) xf_wr[i] = Range{(const char*)xf.residual_out, (const char*)xf.residual_out + K * 4};
+        } else if (xf.kind == TMAC_XF_GLU && src2[i].op < 0) {
+            xf_rd[i].push_back(Range{(const char*)xf.in2, (const char*)xf.in2 + K * 2});
+        }
+    }
+    for (size_t k = 0; k < n; ++k) {
+        for (size_t i = 0; i < n; ++i)
+            for (const Range& r : xf_rd[i]) {
+                for (size_t m = 0; m < out_r[k].size(); ++m)
+                    if (overlap(out_r[k][m], r) && (i >= k || !all_past(i, k)))
+                        return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu writes output %zu over a vector that the transform of op %zu reads from memory and nothing in the "
+                                                             "chain orders the writer behind every reader", k, m, i));
+                if (xf_wr[k].lo && overlap(xf_wr[k], r) && (i >= k || !all_past(i, k)))
+                    return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: residual_out overlaps a vector that the transform of op %zu reads from memory (a later NORM of the "
+                                                         "launch takes the kept vector, TMAC_XF_CARRY)", k, i));
+            }
+        if (!xf_wr[k].lo) continue;
+        for (size_t i = 0; i < n; ++i) {
+            if (src[i].op < 0 && overlap(xf_wr[k], in_r[i]) && (i >= k || !all_past(i, k)))
+                return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: residual_out overlaps activations that op %zu reads from memory", k, i));
+            for (size_t m = 0; m < out_r[i].size(); ++m)
+                if (overlap(xf_wr[k], out_r[i][m])) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: residual_out overlaps output %zu of op %zu", k, m, i));
+            if (i != k && xf_wr[i].lo && overlap(xf_wr[k], xf_wr[i])) return bail(fail(TMAC_HIP_E_NOMATCH, "ops %zu and %zu: overlapping residual_out vectors", i, k));
+        }
+    }
     c->buf_u4 = chain_buf_u4(maxK);
     c->lds_bytes = chain_lds_bytes(c->buf_u4, (int)c->ops.size(), c->carry_floats + c->tmp_floats + c->gam_floats + c->ext_floats);
     if (c->lds_bytes > 160 * 1024)

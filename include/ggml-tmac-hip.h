@@ -41,6 +41,11 @@ int ggml_tmac_hip_upload(struct tmac_ggml_tensor* w, int bits);
 /* dst[N][M] (fp32, host) = x[N][K] (fp32, host) x W^T: activations up through pinned staging, LUT build + mpGEMM on the
  * device, outputs back down; safe to call from one thread per process (ggml calls a backend's mul_mat from its main thread) */
 int ggml_tmac_hip_mul_mat(const struct tmac_ggml_tensor* w, const struct tmac_ggml_tensor* x, struct tmac_ggml_tensor* dst);
+/* Tensors whose data already lives in device memory are passed on unstaged.  The glue launches on a stream of its own
+ * (ggml_tmac_hip_stream(), non-blocking): work that PRODUCED such an x on another stream is not ordered in front of the launch.
+ * A device backend therefore hands the glue ITS stream once -- every launch and copy of the glue is then ordered with the backend's
+ * own kernels -- or synchronises its stream before it calls.  NULL returns to the glue's own stream.  Pending work is drained first. */
+int ggml_tmac_hip_set_stream(void* hip_stream);
 void ggml_tmac_hip_free(struct tmac_ggml_tensor* w);
 const char* ggml_tmac_hip_last_error(void);
 

@@ -27,7 +27,8 @@ struct Hip {
     int (*StreamSynchronize)(void*) = nullptr;
 } hip;
 bool g_ready = false;
-void* g_stream = nullptr;
+void* g_stream = nullptr;       // the stream every launch and copy goes to: the glue's own, or the backend's (ggml_tmac_hip_set_stream)
+void* g_own_stream = nullptr;
 void *g_dx = nullptr, *g_dy = nullptr, *g_px = nullptr, *g_py = nullptr;
 size_t g_nx = 0, g_ny = 0;
 std::mutex g_mu;
@@ -75,9 +76,18 @@ extern "C" int ggml_tmac_hip_init(const char* kcfg_file, int device) {
     if ((rc = tmac_hip_load_kcfg(kcfg_file))) return rc;
     if (!g_ready) {
         if (!load_hip()) return fail("HIP runtime not found");
-        if (hip.StreamCreateWithFlags(&g_stream, 1 /* hipStreamNonBlocking */) != 0) return fail("stream creation failed");
+        if (hip.StreamCreateWithFlags(&g_own_stream, 1 /* hipStreamNonBlocking */) != 0) return fail("stream creation failed");
+        g_stream = g_own_stream;
         g_ready = true;
     }
+    return 0;
+}
+
+extern "C" int ggml_tmac_hip_set_stream(void* hip_stream) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_ready) return fail("ggml_tmac_hip_init has not been called");
+    if (hip.StreamSynchronize(g_stream) != 0) return fail("stream synchronisation failed");   // staging buffers and recorded segments may be in flight there
+    g_stream = hip_stream ? hip_stream : g_own_stream;
     return 0;
 }
 

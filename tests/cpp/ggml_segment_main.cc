@@ -15,6 +15,7 @@ extern "C" int hipMalloc(void**, size_t);
 extern "C" int hipMemcpy(void*, const void*, size_t, int);
 extern "C" int hipMemcpyAsync(void*, const void*, size_t, int, void*);
 extern "C" int hipMemset(void*, int, size_t);
+extern "C" int hipStreamCreateWithFlags(void**, unsigned);
 
 static std::vector<char> slurp(const std::string& p) {
     std::ifstream f(p, std::ios::binary);
@@ -90,7 +91,12 @@ int main(int argc, char** argv) {
         CK(ggml_tmac_hip_segment_end(&seg[l]));
     }
     // ---- two "tokens" (the second replays the recorded segments; tensors of the last one are dumped)
+    void* backend_stream = nullptr;
+    if (hipStreamCreateWithFlags(&backend_stream, 1)) return 9;
     for (int tok = 0; tok < 2; ++tok) {
+        // the second token runs on a stream the "backend" hands to the glue (ggml_tmac_hip_set_stream): launches and the outside
+        // operator stay ordered on it
+        if (tok == 1) { CK(ggml_tmac_hip_set_stream(backend_stream)); if (ggml_tmac_hip_stream() != backend_stream) return 10; }
         CK(ggml_tmac_hip_segment_compute(s0));
         for (int l = 0; l < NL; ++l) {
             // the operator outside the hook, on the glue's stream (stand-in for attention): attn = q of this layer

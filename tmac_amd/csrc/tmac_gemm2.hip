@@ -282,6 +282,12 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // profiling: s_memrealtime (100 MHz) at fixed points of every act-group step of workgroup 0
     unsigned long long* stp = (a.stamps && blockIdx.x == 0) ? a.stamps + (size_t)w * 64 * 8 : nullptr;
 #define PSTAMP(step, i) do { if (stp && (step) < 64 && lane == 0) stp[(step) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    // stamps INSIDE a step (tools/gemm2_stamps.py prints the phases): a diagnostic build only (-DTMAC_G2_STEP_STAMPS=1) -- their mere
+    // presence (a branch and an exec-mask change at four places of the step) cost 1.7 % of the prefill line
+#ifndef TMAC_G2_STEP_STAMPS
+#define TMAC_G2_STEP_STAMPS 0
+#endif
+#define PSTAMP_IN(step, i) do { if (TMAC_G2_STEP_STAMPS) PSTAMP(step, i); } while (0)
     PSTAMP(0, 5);
     float cn[2][3];                            // column values (lut_scales, lut_biases, entry sums) of the NEXT act group, per n tile
     auto load_cols = [&](int kk) {
@@ -387,6 +393,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         // reduction): alternate the priority between the two waves of a SIMD step by step
         if (NWV == 8) { if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk of kk is in LDS, its weights, column values and the staged scales in registers
+        PSTAMP_IN(kk - k_lo, 1);
         if (more) write_staged(g + 1);     // (its successor is fetched behind this step's LDS reads: a load in front of them is waited for --
                                            // the compiler orders every LDS read behind all LDS-DMA in flight with vmcnt(0))
         // B operands of the whole act group (both n tiles, four 32-deep steps); A operands and row scales of tile row 0
@@ -430,6 +437,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         if (PIPE || next) { load_cols(kn); load_weights(kn, 0); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        PSTAMP_IN(kk - k_lo, 2);
 
         auto chain = [&](const p4i_t (&av)[4], int nt, p16i_t& c) {      // one 32 x 32 tile of the act group: four dependent MFMAs
             c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0], bv[nt][0], cinit, 0, 0, 0);
@@ -509,26 +517,34 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         if (ZP && glast) { zero_points(0); zero_points(1); }     // (behind the act group's own terms: one branch at the end of the block)
 #undef TMAC_G2_GROUPS
         } else {
+#ifndef TMAC_G2_DMA_EARLY
+#define TMAC_G2_DMA_EARLY 0      // A/B: how many of the next chunk's four DMA parts go out right behind the first MFMA chain (0: spread over the step)
+#endif
         chain(av0, 0, ca);
         if (next) dma_part(kk + 1, 0);                     // (the chunk buffer has been read: lgkmcnt(0) above)
+        if (TMAC_G2_DMA_EARLY >= 2 && next) dma_part(kk + 1, 1);
+        if (TMAC_G2_DMA_EARLY >= 4 && next) { dma_part(kk + 1, 2); dma_part(kk + 1, 3); }
         chain(av0, 1, cb);
-        if (next) dma_part(kk + 1, 1);
+        if (TMAC_G2_DMA_EARLY < 2 && next) dma_part(kk + 1, 1);
+        if (TMAC_G2_DMA_EARLY == 2 && next) { dma_part(kk + 1, 2); dma_part(kk + 1, 3); }
         __builtin_amdgcn_sched_barrier(0);
         build_av(1, av1);
         if (SC2) read_rows(cbuf, 0, 1, sc1);
         if (next) load_weights(kk + 1, 1);
         __builtin_amdgcn_sched_barrier(0);
+        PSTAMP_IN(kk - k_lo, 3);
         epilogue(0, 0, ca, sc0);
         __builtin_amdgcn_sched_barrier(0);
         chain(av1, 0, ca);
-        if (next) dma_part(kk + 1, 2);
+        if (TMAC_G2_DMA_EARLY == 0 && next) dma_part(kk + 1, 2);
         __builtin_amdgcn_sched_barrier(0);
         epilogue(0, 1, cb, sc0);
         if (!SC2) read_rows(cbuf, 0, 1, sc1);
         __builtin_amdgcn_sched_barrier(0);
         chain(av1, 1, cb);
-        if (next) dma_part(kk + 1, 3);
+        if (TMAC_G2_DMA_EARLY == 0 && next) dma_part(kk + 1, 3);
         __builtin_amdgcn_sched_barrier(0);
+        PSTAMP_IN(kk - k_lo, 4);
         if (ZP && glast) zero_points(0);
         epilogue(1, 0, ca, sc1);
         __builtin_amdgcn_sched_barrier(0);
@@ -578,6 +594,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         }
     }
     PSTAMP(2, 5);
+#undef PSTAMP_IN
 #undef PSTAMP
 }
 

@@ -33,3 +33,9 @@ for wv in range(8):
     print(f"wave {wv}: start {us(s[0,5]):6.2f}  operand rows built {us(s[0,6]):6.2f}  loop end {us(s[1,5]):6.2f}  reduce barrier {us(s[1,6]):6.2f}  stored {us(s[2,5]):6.2f}   steps {nsteps}")
     tops = [us(s[k, 0]) for k in range(nsteps)] + [us(s[1, 5])]
     print("    step durations: " + " ".join(f"{tops[k + 1] - tops[k]:5.2f}" for k in range(nsteps)))
+    if nsteps > 2 and (s[1:nsteps, 1] > 0).all():
+        # inside a step: top -> loads landed (vmcnt 0) -> operands read from LDS -> first two chains + tile row 1's gathers -> last chain issued -> end
+        k = np.arange(1, nsteps - 1)
+        seg = [(s[k, 1] - s[k, 0]), (s[k, 2] - s[k, 1]), (s[k, 3] - s[k, 2]), (s[k, 4] - s[k, 3]), (s[k + 1, 0] - s[k, 4])]
+        print("    mean of steps 1..n-2 (us): wait for loads %.2f | LDS operand reads + gathers %.2f | chains 0,1 + gathers of tile row 1 %.2f | epilogues 0,1 + chains 2,3 %.2f | epilogues 2,3 %.2f"
+              % tuple(float(x.mean()) / 100.0 for x in seg))

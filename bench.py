@@ -102,6 +102,10 @@ def parse():
                          "library's own communicator (tmac_hip_comm_*: RCCL through the C-ABI, bootstrapped over torch.distributed), or its "
                          "IPC transport (windows mapped by every peer, no RCCL; tests/test_gpu_comm.py runs it with two processes on one device)")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # debugging: take the multi-GPU code path with 1 rank
+    ap.add_argument("--share-device", action="store_true",
+                    help="test mode (tests/test_gpu_comm.py): every rank uses device 0 -- RCCL refuses that, so torch.distributed runs on gloo with host "
+                         "tensors (bootstrap and timing only) and the row-sharded chain's workgroups are divided between the ranks; exercises the whole "
+                         "N > 1 orchestration (row shards, recorded exchange steps, IPC export / connect, trial launches) on a one-GPU box.  Times mean nothing.")
     ap.add_argument("--gemm-kernel", type=int, default=0, choices=[0, 1, 2, 3],
                     help="prefill A/B: tmac_hip_debug_gemm_kernel (0 auto, 1 k_gemm_onehot, 2 / 3 k_gemm_planes with eight- / four-wave workgroups)")
     a = ap.parse_args()
@@ -291,6 +295,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist_on = world > 1 or args.force_dist
     chain_ok = decode and args.variant == 0
@@ -302,11 +308,36 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.share_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # the few collectives of the bootstrap and the timing: on the device through RCCL, or -- test mode -- through host tensors on gloo
+    def d_all_reduce(t, op):
+        if args.share_device:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
+    def d_all_gather_into(out, inp):
+        if args.share_device:
+            parts = [torch.empty(inp.shape, dtype=inp.dtype) for _ in range(world)]
+            dist.all_gather(parts, inp.cpu())
+            out.copy_(torch.cat([p.reshape(-1) for p in parts]).reshape(out.shape))
+        else:
+            dist.all_gather_into_tensor(out, inp)
     import tmac_amd
     from tmac_amd import KCfg, F16, F32
     L = tmac_amd.lib()
     tmac_amd.binding.check(L.tmac_hip_init(local_rank))
+    if args.share_device and world > 1:
+        if args.comm == "lib":
+            raise SystemExit("bench.py: --share-device cannot use RCCL (--comm lib)")
+        # both persistent kernels must be resident at once: the CUs are divided between the ranks
+        tmac_amd.binding.check(L.tmac_hip_debug_chain_grid(max(8, (256 - 32 * world) // world)))
     tmac_amd.binding.check(L.tmac_hip_set_variant(args.variant))
     tmac_amd.binding.check(L.tmac_hip_debug_gemm_kernel(args.gemm_kernel))
     dev = torch.device("cuda", local_rank)
@@ -407,7 +438,7 @@ def main():
         lib_comm = tmac_amd.Comm.ipc(maxb, rank, world)
         blob = torch.frombuffer(bytearray(lib_comm.export()), dtype=torch.uint8).to(dev)
         blobs = torch.empty(world * tmac_amd.Comm.BLOB_BYTES, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(blobs, blob)
+        d_all_gather_into(blobs, blob)
         lib_comm.connect(bytes(blobs.cpu().numpy().tobytes()))
 
     recording = [False]          # inside wr.record_chain(): exchange steps are recorded, not executed
@@ -430,7 +461,7 @@ def main():
                 if lib_comm is not None:
                     lib_comm.allgather(out_of[name][0], gathered[name], out_of[name][0].numel() * 2)
                 else:
-                    dist.all_gather_into_tensor(gathered[name], out_of[name][0])
+                    d_all_gather_into(gathered[name], out_of[name][0])
                 g = gathered[name]
                 xin[nxt[name]] = (g.reshape(-1)[:logical[name]] if decode
                                   else g.permute(1, 0, 2).reshape(N, -1)[:, :logical[name]].contiguous())
@@ -466,7 +497,7 @@ def main():
             if not dist_on:
                 return ok
             t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            d_all_reduce(t, dist.ReduceOp.MIN)
             return bool(t.item())
         recording[0] = True
         why = ""
@@ -490,7 +521,7 @@ def main():
                 except tmac_amd.binding.TMACHipError as e:
                     why, blob = str(e), torch.zeros(tmac_amd.DecodeChain.BLOB_BYTES, dtype=torch.uint8, device=dev)
                 blobs = torch.empty(world * tmac_amd.DecodeChain.BLOB_BYTES, dtype=torch.uint8, device=dev)
-                dist.all_gather_into_tensor(blobs, blob)
+                d_all_gather_into(blobs, blob)
                 try:
                     if not why:
                         chain.connect(bytes(blobs.cpu().numpy().tobytes()))
@@ -506,6 +537,8 @@ def main():
                 if st:
                     why = "a hand-off across ranks timed out in the trial launches (error word %#x)" % st
                 ok = all_ranks_ok(st == 0)
+            if not ok and args.share_device:
+                raise SystemExit(f"bench.py --share-device: the row-sharded chain did not come up ({why or 'another rank failed'})")
             if not ok:
                 if rank == 0:
                     sys.stderr.write(f"bench.py: no row-sharded chain on this node ({why or 'another rank failed'}); per-launch path with RCCL all-gathers instead\n")
@@ -726,7 +759,7 @@ def main():
         sc.set_stamps(None)
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        d_all_reduce(t, dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     finite = bool(torch.isfinite((dpat["keep"][3][-1]["down"][0] if dpat is not None else outs["down"][0]).float()).all().item())     # the chained activations stayed finite

@@ -180,26 +180,28 @@ def test_prefill_exchange_over_ipc_two_processes_one_device(tm):
         assert all(p.returncode == 0 for p in ps), "\n".join(o[-3000:] for o in outs)
 
 
-@pytest.mark.parametrize("workload,extra", [("llama2-7b-w2", []), ("bitnet-3b", []), ("llama2-7b-w2-prefill", ["--comm", "ipc"])])
-def test_bench_two_ranks_share_the_device(tm, workload, extra):
+@pytest.mark.parametrize("workload,extra,nranks", [("llama2-7b-w2", [], 2), ("bitnet-3b", [], 2), ("llama2-7b-w2-prefill", ["--comm", "ipc"], 2),
+                                                   ("llama2-7b-w2", [], 4), ("llama2-7b-w2", [], 8), ("llama2-7b-w2-prefill", ["--comm", "ipc"], 4)])
+def test_bench_ranks_share_the_device(tm, workload, extra, nranks):
     """bench.py's N > 1 orchestration end to end, launched exactly as the driver launches it (torch.distributed.run, one rank per
     "GPU"), with both ranks on the one device of the test box (--share-device: gloo instead of RCCL for bootstrap and timing, the CUs
     divided between the ranks' persistent kernels): row-sharded weights, the recorded exchange steps, IPC export / connect of the
-    hand-off arenas over torch.distributed, the two trial launches, the timed launches, ONE JSON line from rank 0.  Decode: the
+    hand-off arenas over torch.distributed, the two trial launches, the timed launches, ONE JSON line from rank 0 -- with 2, 4 and 8
+    ranks (ragged tile splits: gate / up's 172 reference tiles over 8 ranks).  Decode: the
     row-sharded chain (the mode fails instead of falling back); prefill: the IPC transport of the exchange step."""
     import json
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     port = 29600 + (os.getpid() % 300)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-device", "--workload", workload, "--layers", "2", "--steps", "5", "--warmup", "2",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nranks), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--share-device", "--workload", workload, "--layers", "2", "--steps", "5", "--warmup", "2",
            "--no-cpu-baseline"] + extra
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:] + "\n" + r.stderr[-4000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["steps"] == 5
-    assert d["config"]["parallelism"] == "row-shard x2"
+    assert d["n_gpus"] == nranks and d["value"] > 0 and d["steps"] == 5
+    assert d["config"]["parallelism"] == f"row-shard x{nranks}"
     if not workload.endswith("prefill"):
         assert d["config"]["path"] == "chain", d["config"]
         assert d.get("activations_finite", True)

@@ -548,9 +548,18 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         // get conservative s_waitcnt vmcnt(n) in front of them -- waits for this op's weights in the middle of the LUT build.
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt / lgkmcnt untouched
         // ---- 2. this wave's first RING (quad, step) items: the weights stream in during the LUT build ----
+        // A wave stalls 0.3-2 us in front of these loads while the CU's memory queue is full (stamps 1 -> 3: the op's stream, not instruction
+        // issue), and its tables wait behind that stall.  ISSUE_SPLIT = n: only n fragments go out here, the rest of the ring behind the
+        // wave's part of the LUT build.  Measured (profiles/r04b_chain_issue_split.txt, same box): with 3- / 4-bit weights (a ring of two
+        // fragments) and with unified scales (two passes over the vector before the tables) n = 0 is 2.5 % faster -- the fragment in front
+        // of the polls keeps the memory side busy through the build; 1- / 2-bit per-group chains are fastest with the whole ring here.
+#ifndef TMAC_CHAIN_ISSUE_SPLIT
+#define TMAC_CHAIN_ISSUE_SPLIT (-1)
+#endif
+        constexpr int ISSUE_SPLIT = TMAC_CHAIN_ISSUE_SPLIT >= 0 ? TMAC_CHAIN_ISSUE_SPLIT : ((BITS >= 3 || SM == 2) ? 0 : RING);
 #pragma unroll
         for (int k = 0; k < RING; ++k)
-            if (k >= isf) issue_next(ring[k]);
+            if (k >= isf && k < isf + ISSUE_SPLIT) issue_next(ring[k]);
 
         CSTAMP(i, 3);
 
@@ -741,6 +750,11 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 for (int u = nu + tid; u < nst * 64; u += FT) tab[j4 * tstride + u] = make_uint4(0u, 0u, 0u, 0u);
             if (SM != 2)
                 for (int g = G + tid; g < GP; g += FT) { l_ls[g] = 0.f; l_lb[g] = 0.f; }
+        }
+        if (ISSUE_SPLIT < RING) {
+#pragma unroll
+            for (int k = 0; k < RING; ++k)
+                if (k >= isf + ISSUE_SPLIT) issue_next(ring[k]);
         }
         CSTAMP(i, 4);
         __syncthreads();

@@ -161,7 +161,9 @@ def test_prebuilt_reference_kernels_bit_exact(setname, bits, bm, Mw, K, mname):
     assert np.mean((Cdq - Cref) ** 2) / np.mean(Cdq ** 2) < 5e-4
 
 
-@pytest.mark.parametrize("bits,bm,Mw,K", [(2, 128, 256, 3200), (2, 320, 320, 3200), (2, 128, 128, 8640), (4, 256, 128, 1024)])
+@pytest.mark.parametrize("bits,bm,Mw,K", [(2, 128, 256, 3200), (2, 320, 320, 3200), (2, 128, 128, 8640), (4, 256, 128, 1024),
+                                          # the widths k_gemm_planes_us and the chain cover since rounds 3 / 4
+                                          (1, 64, 128, 1024), (1, 64, 320, 8640), (3, 192, 192, 3200), (3, 192, 64, 12288), (4, 256, 192, 12288)])
 def test_int32_scale_final_path(bits, bm, Mw, K):
     case = orc.make_case(5, Mw, K, bits=bits, m_groups=1, ags=K, zero_point=False)
     A = orc.preprocess_weights(case["w"], bits, bm, 16)

@@ -32,8 +32,9 @@ def _worker(rank, world, port, Mw, K, bits, bm, q):
     S = orc.preprocess_scales(case["sc"], case["zr"], bits, bm)
     shard = sh.plan_row_shards(Mw, bits, bm, world)[rank]
     (wb, we), (sb, se) = sh.shard_blob_ranges(shard, K, bits, bm, 128, True, 4)
-    A_loc = np.frombuffer(A.tobytes()[wb:we], np.uint8).reshape(shard.tile_count, K // 4, bm // 2)
-    S_loc = np.frombuffer(S.tobytes()[sb:se], np.float32).reshape(shard.tile_count, K // 128, -1)
+    if shard.rows:       # (a rank past the ragged tail owns no tile: it still takes part in the equal-size exchange)
+        A_loc = np.frombuffer(A.tobytes()[wb:we], np.uint8).reshape(shard.tile_count, K // 4, bm // 2)
+        S_loc = np.frombuffer(S.tobytes()[sb:se], np.float32).reshape(shard.tile_count, K // 128, -1)
     # every rank builds the LUT from the (already gathered) activation vector: replicated preprocessing
     qlut, ls, lb = orc.preprocessor(case["B"], 64)
     out = np.zeros((1, shard.padded_rows), np.float32)
@@ -51,12 +52,13 @@ def _worker(rank, world, port, Mw, K, bits, bm, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("Mw,K,bits,bm", [(512, 1024, 2, 128), (704, 512, 2, 128)])   # 8 tiles (even) / 11 tiles (ragged)
-def test_two_rank_row_sharding_matches_single_rank(Mw, K, bits, bm):
+# 8 tiles (even) / 11 tiles (ragged) over 2 ranks; 11 tiles over 4 ranks (3, 3, 3, 2); 3 tiles over 4 ranks (one rank owns nothing)
+@pytest.mark.parametrize("Mw,K,bits,bm,world", [(512, 1024, 2, 128, 2), (704, 512, 2, 128, 2), (704, 512, 2, 128, 4), (192, 512, 2, 128, 4)])
+def test_row_sharding_matches_single_rank(Mw, K, bits, bm, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, Mw, K, bits, bm, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, Mw, K, bits, bm, q)) for r in range(world)]
     for p in procs:
         p.start()
     ok, gs, rs = q.get(timeout=120)

@@ -108,3 +108,53 @@ def test_bitnet_kcfg_entry(tmp_path):
         assert common
         for sec in common:
             assert dict(a[sec]) == dict(b[sec]), sec
+
+
+def _fake_checkpoint(d, layers, desc_act=False):
+    """config.json + two safetensors parts holding GPTQ-packed linear layers (qweight / scales / qzeros) and an unquantised tensor"""
+    import json
+    from safetensors.numpy import save_file
+    parts = [{}, {}]
+    for i, (bits, M, K, gs) in enumerate(layers):
+        qw, sc, qz, _, _ = gptq_case(50 + i, K, M, bits, gs)
+        pre = f"model.layers.{i}.proj"
+        parts[i % 2].update({pre + ".qweight": qw, pre + ".scales": sc, pre + ".qzeros": qz})
+    parts[0]["model.embed_tokens.weight"] = np.zeros((8, 4), np.float16)
+    save_file(parts[0], os.path.join(d, "model-00001-of-00002.safetensors"))
+    save_file(parts[1], os.path.join(d, "model-00002-of-00002.safetensors"))
+    cfg = {"quantization_config": {"bits": layers[0][0], "group_size": layers[0][3], "sym": False, "quant_method": "gptq", "desc_act": desc_act,
+                                   "meta": {"quantizer": "gptqmodel:1.0"}}, "hidden_size": 64}
+    json.dump(cfg, open(os.path.join(d, "config.json"), "w"))
+
+
+def test_presets_and_checkpoint_discovery(tmp_path):
+    """preset shape table, kernel shapes read from a GPTQ checkpoint's safetensors HEADERS, and the quantisation config -- equal to the
+    reference's model_utils (which loads the tensors to learn their shapes)"""
+    d = str(tmp_path)
+    layers = [(2, 64, 256, 128), (2, 160, 256, 128), (2, 64, 256, 128), (4, 96, 512, 128), (2, 64, 640, 128)]
+    _fake_checkpoint(d, layers)
+    ks = convert.extract_kernel_shapes("gptq-auto", d)
+    assert sorted(ks) == sorted([[2, 64, 256, 1, -1], [2, 160, 256, 1, -1], [4, 96, 512, 1, -1], [2, 64, 640, 1, -1]])    # distinct (bits, M, K), each once
+    assert convert.checkpoint_group_size(d) == 128
+    qc = convert.get_quantization_config(d)
+    assert qc["bits"] == 2 and qc["group_size"] == 128 and qc["quant_method"] == "gptq" and qc["quantizer"] == "gptqmodel:1.0"
+    with pytest.raises(KeyError):
+        convert.extract_kernel_shapes("no-such-model")
+    if have_ref:
+        from pathlib import Path
+        mu = ref_model_utils()
+        assert set(convert.get_preset_models()) == set(mu.get_preset_models())
+        for name in mu.get_preset_models():
+            if name != "gptq-auto":
+                assert convert.extract_kernel_shapes(name) == mu.extract_kernel_shapes(name)
+        assert sorted(ks) == sorted(mu.extract_kernel_shapes("gptq-auto", d))
+        assert qc == mu.get_quantization_config(Path(d))
+    # mixed group sizes and act-order checkpoints are refused, as in the reference
+    d2 = os.path.join(d, "mixed"); os.makedirs(d2)
+    _fake_checkpoint(d2, [(2, 64, 256, 128), (2, 64, 256, 64)])
+    with pytest.raises(RuntimeError):
+        convert.extract_kernel_shapes("gptq-auto", d2)
+    d3 = os.path.join(d, "actorder"); os.makedirs(d3)
+    _fake_checkpoint(d3, [(2, 64, 256, 128)], desc_act=True)
+    with pytest.raises(AssertionError):
+        convert.get_quantization_config(d3)

@@ -26,7 +26,90 @@ PRESET_KERNELS: Dict[str, List[List[int]]] = {
     "llama-3-8b-2bit": [[2, 4096, 4096, 1, -1], [2, 14336, 4096, 1, -1], [2, 4096, 14336, 1, -1], [2, 1024, 4096, 1, -1]],
     "llama-3-8b-4bit": [[4, 4096, 4096, 1, -1], [4, 14336, 4096, 1, -1], [4, 4096, 14336, 1, -1], [4, 1024, 4096, 1, -1]],
     "hf-bitnet-3b": [[2, 3200, 8640, 1, 1], [2, 8640, 3200, 1, 1], [2, 3200, 3200, 1, 1]],
+    "hf-bitnet-large-intn": [[2, 1536, 4096, 1, 1], [2, 4096, 1536, 1, 1], [2, 1536, 1536, 1, 1]],
+    "hf-bitnet-large-tq": [[2, 1536, 4096, 1, -1], [2, 4096, 1536, 1, -1], [2, 1536, 1536, 1, -1]],
+    "ms-bitnet-3b": [[2, 3200, 800, 1, 1], [2, 3200, 3200, 1, 1], [2, 3200, 10240, 1, 1], [2, 10240, 3200, 1, 1], [2, 800, 3200, 1, 1]],
+    "phi-3-mini-2bit": [[2, 3072, 3072, 1, -1], [2, 9216, 3072, 1, -1], [2, 3072, 8192, 1, -1], [2, 16384, 3072, 1, -1]],
+    "trilm-3.9b": [[2, 3072, 3072, 1, -1], [2, 3072, 9216, 1, -1], [2, 9216, 3072, 1, -1], [2, 768, 3072, 1, -1]],
+    "test": [],
+    "gptq-auto": [],            # shapes read from the checkpoint (extract_kernel_shapes)
 }
+
+
+def get_preset_models() -> List[str]:
+    return list(PRESET_KERNELS.keys())
+
+
+def _safetensors_shapes(path: str) -> Dict[str, Tuple[str, Tuple[int, ...]]]:
+    """{tensor name: (dtype, shape)} from a .safetensors file's header alone (8-byte little-endian length + JSON): a 7B checkpoint's kernel
+    shapes are known after reading a few hundred KB, no tensor is loaded (the reference reads every scales / qzeros / qweight tensor)"""
+    import json
+    import struct
+    with open(path, "rb") as f:
+        (n,) = struct.unpack("<Q", f.read(8))
+        hdr = json.loads(f.read(n))
+    return {k: (v["dtype"], tuple(v["shape"])) for k, v in hdr.items() if k != "__metadata__"}
+
+
+def extract_kernel_shapes(model_arch: Optional[str] = "gptq-auto", model_dir: Optional[str] = None) -> List[List[int]]:
+    """The kernels a model needs, [bits, M, K, N, m_groups] each (``model_utils.py:206-216``): a preset's list, or -- "gptq-auto" -- the distinct
+    (bits, M, K) of the GPTQ-packed linear layers found in the checkpoint's ``model*.safetensors`` parts, in order of first appearance.
+    One group size per model, as the reference requires (``model_utils.py:170-198``); ``checkpoint_group_size`` returns it."""
+    if model_arch not in PRESET_KERNELS:
+        raise KeyError("Unsupported model_arch: {}".format(model_arch))
+    if model_arch != "gptq-auto":
+        return [list(k) for k in PRESET_KERNELS[model_arch]]
+    return _scan_checkpoint(model_dir)[0]
+
+
+def checkpoint_group_size(model_dir: str) -> int:
+    return _scan_checkpoint(model_dir)[1]
+
+
+def _scan_checkpoint(model_dir: Optional[str]) -> Tuple[List[List[int]], int]:
+    if model_dir is None:
+        raise ValueError("gptq-auto needs the checkpoint directory")
+    parts = sorted(f for f in os.listdir(model_dir) if f.startswith("model") and f.endswith(".safetensors"))
+    if not parts:
+        raise RuntimeError("Models in {} not in GPTQ safetensors format (torch .bin checkpoints: convert them to safetensors first)".format(model_dir))
+    shapes: Dict[str, Tuple[int, ...]] = {}
+    order: List[str] = []
+    for part in parts:
+        for name, (_, shp) in _safetensors_shapes(os.path.join(model_dir, part)).items():
+            shapes[name] = shp
+            if name.endswith(".qweight"):
+                order.append(name)
+    ks: List[List[int]] = []
+    gs_all = None
+    for name in order:
+        qw, sc, qz = shapes[name], shapes.get(name[:-8] + ".scales"), shapes.get(name[:-8] + ".qzeros")
+        if sc is None or qz is None:
+            raise RuntimeError("{}: scales / qzeros missing".format(name))
+        bits = 32 // (sc[1] // qz[1])                      # parse_gptq on shapes alone
+        K, M = qw[0] * (32 // bits), qw[1]
+        gs = K // sc[0]
+        if [bits, M, K, 1, -1] not in ks:
+            ks.append([bits, M, K, 1, -1])
+        if gs_all is None:
+            gs_all = gs
+        elif gs_all != gs:
+            raise RuntimeError("Different group_sizes unsupported")
+    if not ks:
+        raise RuntimeError("Models in {} not in GPTQ format".format(model_dir))
+    return ks, int(gs_all)
+
+
+def get_quantization_config(model_dir: str) -> dict:
+    """what the pipeline reads from a checkpoint's config.json (``model_utils.py:219-240``): GPTQ fields of ``quantization_config`` and
+    BitNet's ``weight_bits``; act-order checkpoints (desc_act) are refused as the reference refuses them"""
+    import json
+    with open(os.path.join(model_dir, "config.json"), "r", encoding="utf-8") as f:
+        hp = json.load(f)
+    qc = hp.get("quantization_config", {})
+    if qc.get("desc_act", False):
+        raise AssertionError("desc_act=True currently unsupported by T-MAC")
+    return {"quantizer": qc.get("meta", {}).get("quantizer", ""), "group_size": qc.get("group_size", 0), "bits": qc.get("bits", 0),
+            "sym": qc.get("sym", False), "quant_method": qc.get("quant_method", ""), "weight_bits": hp.get("weight_bits", 0)}
 
 
 def parse_gptq(qweight: np.ndarray, scales: np.ndarray, qzeros: np.ndarray) -> Tuple[int, int, int, int]:

@@ -220,6 +220,15 @@ int32_t tmac_hip_chain_record_gather(const void* send_dev, void* recv_dev, size_
 int32_t tmac_hip_chain_export(const tmac_hip_chain* chain, void* blob_out);
 int32_t tmac_hip_chain_connect(tmac_hip_chain* chain, const void* blobs_of_all_ranks, int world);
 int32_t tmac_hip_chain_threads(void);   /* threads per workgroup of k_decode_chain (the launch configuration its results are bit-identical with) */
+/* Stream mode.  A recording in which NO call consumes another call's output (and none carries a transform) is a list of independent
+ * GEMVs -- SURVEY 8(d)'s back-to-back measurement, or a caller that evaluates many vectors against many matrices.  tmac_hip_chain_end
+ * then builds a different launch (1 = yes): k_lut_images builds the tables of every call ONCE -- the reference's own call structure,
+ * llama_cpp_init per activation vector, then lookups only (tmac_gemm_wrapper.h:170-228) -- and k_gemv_stream walks the calls with the
+ * tables prebuilt, a loader wave per workgroup staging the next call's tables while the lookup waves stream this call's weights; the
+ * weight prefetch runs across call boundaries.  No hand-offs, no spins: residency is not a correctness condition there.  Same
+ * arithmetic, same lane / wave decomposition: outputs bit-identical to the other N = 1 paths.  Per-group scales only;
+ * TMAC_CHAIN_STREAM=0 in the environment keeps the ordinary chain (A/B). */
+int32_t tmac_hip_chain_is_stream(const tmac_hip_chain* chain);
 /* profiling / A-B knobs: s_memrealtime stamps (100 MHz) [calls][workgroups][8] of wave 0 (0 call entry, 1 activations complete, 2 LUT
  * built, 3 weights of the call landed, 5 last row quad published, 6 all loads landed, 7 number of polls) into a device buffer (NULL = off); waves per row quad forced for chains built from now on (0 = per-call
  * choice) and the poll limit of a hand-off (0 = keep) */

@@ -1,0 +1,137 @@
+"""Stream mode of the recorded call sequence (k_lut_images + k_gemv_stream, tmac_amd/csrc/tmac_stream.hip): a recording in which no
+call consumes another call's output -- SURVEY 8(d)'s back-to-back GEMVs -- runs with the tables prebuilt once per call (the reference's
+own structure: llama_cpp_init, then lookups only, tmac_gemm_wrapper.h:170-228), a loader wave staging the next call's tables and a
+weight prefetch that crosses call boundaries.
+
+Bars (the harness of test_gpu_chain.py): every call's outputs (a) BIT-IDENTICAL to the same call launched on its own through
+tmac_hip_qgemm_fused_dev with the chain's launch configuration -- whose integer path test_gpu_parity.py taps bit for bit against the
+oracle and the reference-made goldens -- and (b) within 1e-3 of the oracle (lut_ctor.cc / tbl.cc restated in oracle/tmac_oracle.c).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_chain import Model, tm, _short_spin      # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(tm, ops, reps=2, **kw):
+    m = Model(tm, ops, **kw)
+    chain = m.record()
+    assert chain.stream, "a recording without data flow between its calls is a stream"
+    for rep in range(reps):
+        chain.launch()
+        m.check(chain, oracle_ops=None if rep == 0 else [])
+    chain.free()
+    m.free()
+
+
+# (K, rows of the matrices, None): a lone call; few / many quads per workgroup; split quads (K >= 2 steps of 2048 activations);
+# a K whose last step is partly padding (2688 = 1.3 steps, 6144 = 3 steps); a fused triple; more matrices than workgroups have quads for
+INDEP = [
+    (1024, [512, 256], None),
+    (2688, [640], None),
+    (4096, [1024, 1024, 1024], None),
+    (128, [64], None),
+    (6144, [256], None),
+    (4096, [4224, 4224], None),
+    (256, [128, 64, 64, 128], None),
+    (3200, [3200], None),
+]
+
+
+@pytest.mark.parametrize("bits,zp,dev_f16", [(2, True, True), (2, False, False), (4, True, True), (4, False, False), (1, True, True), (3, False, True)])
+def test_stream_of_independent_calls(tm, bits, zp, dev_f16):
+    _run(tm, INDEP, bits=bits, zp=zp, dev_f16=dev_f16, seed=3)
+
+
+def test_stream_single_call_and_repeats(tm):
+    _run(tm, [(4096, [4096], None)], reps=3, seed=5)
+    _run(tm, [(11008, [1024], None)], reps=3, seed=6)       # the headline's K: two rounds of table pairs, six steps (the last one 3/8 full)
+
+
+def test_stream_fp32_outputs_and_fp32_activations(tm):
+    _run(tm, INDEP[:5], out_f16=False, seed=7)
+    _run(tm, INDEP[:5], ext_f32=True, seed=8)
+
+
+@pytest.mark.parametrize("grid", [8, 96, 200])
+def test_stream_on_fewer_workgroups(tm, grid):
+    """fewer workgroups than CUs (another kernel holds the rest; a partitioned device): more quads per workgroup, several workgroup
+    iterations per call, waves without items in some calls"""
+    tm.binding.check(tm.lib().tmac_hip_debug_chain_grid(grid))
+    try:
+        _run(tm, INDEP, seed=9)
+    finally:
+        tm.binding.check(tm.lib().tmac_hip_debug_chain_grid(0))
+
+
+def _random_stream(seed):
+    rng = np.random.default_rng(seed)
+    ops = []
+    for _ in range(int(rng.integers(2, 10))):
+        K = int(rng.choice([128, 256, 640, 1024, 2688, 3200, 4096, 6144, 11008]))
+        rows = [int(rng.choice([64, 128, 256, 640, 1024, 2688, 3200, 4224])) for _ in range(int(rng.integers(1, 5)))]
+        ops.append((K, rows, None))
+    return ops
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("TMAC_FUZZ_STREAMS", "10"))))
+def test_random_streams(tm, seed):
+    rng = np.random.default_rng(2000 + seed)
+    _run(tm, _random_stream(seed), bits=int(rng.integers(1, 5)), zp=bool(rng.integers(0, 2)), dev_f16=bool(rng.integers(0, 2)), seed=80 + seed)
+
+
+def test_stream_equals_the_ordinary_chain(tm, monkeypatch):
+    """TMAC_CHAIN_STREAM=0 keeps k_decode_chain for the same recording: both launches, same bits"""
+    import torch
+    m = Model(tm, INDEP, seed=11)
+    s = m.record()
+    assert s.stream
+    s.launch(); torch.cuda.synchronize()
+    a = [[o.clone() for o in os_] for os_ in m.outs]
+    for os_ in m.outs:
+        for o in os_:
+            o.zero_()
+    monkeypatch.setenv("TMAC_CHAIN_STREAM", "0")
+    c = m.record()
+    assert not c.stream
+    c.launch(); torch.cuda.synchronize()
+    assert c.status() == 0
+    for x, y in zip(a, m.outs):
+        for p, q in zip(x, y):
+            assert torch.equal(p, q)
+    s.free(); c.free(); m.free()
+
+
+def test_dependent_and_unified_scale_recordings_are_not_streams(tm):
+    m = Model(tm, [(1024, [1024], None), (1024, [256], (0, 0))], seed=12)
+    c = m.record()
+    assert not c.stream
+    c.launch(); m.check(c)
+    c.free(); m.free()
+    m = Model(tm, [(1024, [1024], None), (640, [256], None)], seed=13, mg=1)      # unified scales: the tables need the row's maximum; k_decode_chain
+    c = m.record()
+    assert not c.stream
+    c.launch(); m.check(c)
+    c.free(); m.free()
+
+
+def test_stream_launch_inside_a_hip_graph(tm):
+    import torch
+    m = Model(tm, INDEP[:4], seed=14)
+    c = m.record()
+    assert c.stream
+    c.launch(); torch.cuda.synchronize()
+    side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        c.launch()
+    for os_ in m.outs:
+        for o in os_:
+            o.zero_()
+    g.replay()
+    m.check(c)
+    c.free(); m.free()

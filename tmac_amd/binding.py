@@ -125,6 +125,7 @@ def load_library() -> C.CDLL:
         "tmac_hip_chain_free": ([vp], i32),
         "tmac_hip_chain_set_stamps": ([vp, vp], i32),
         "tmac_hip_chain_threads": ([], i32),
+        "tmac_hip_chain_is_stream": ([vp], i32),
         "tmac_hip_chain_record_gather": ([vp, vp, sz, C.c_int, C.c_int], i32),
         "tmac_hip_chain_export": ([vp, vp], i32),
         "tmac_hip_chain_connect": ([vp, vp, C.c_int], i32),
@@ -138,7 +139,7 @@ def load_library() -> C.CDLL:
         "preprocessor_int8": ([C.c_int] * 4 + [vp] * 4, i32),
     }
     # $TMAC_HIP_LIB may name an OLDER build for an A/B run (tools/gpu): entry points it lacks stay unbound (calling one raises)
-    optional = {"tmac_hip_chain_xform", "tmac_hip_comm_init_ipc", "tmac_hip_comm_export", "tmac_hip_comm_connect", "tmac_hip_comm_status"} if os.environ.get("TMAC_HIP_LIB") else set()
+    optional = {"tmac_hip_chain_is_stream", "tmac_hip_chain_xform", "tmac_hip_comm_init_ipc", "tmac_hip_comm_export", "tmac_hip_comm_connect", "tmac_hip_comm_status"} if os.environ.get("TMAC_HIP_LIB") else set()
     for name, (argt, rest) in sigs.items():
         try:
             fn = getattr(L, name)

@@ -49,7 +49,10 @@ struct ChainOp {
     int epi;             // 1: this op's matrices 0 and 1 are gate and up of a GLU whose only reader is a later op of the chain: the row quads of
                          //    the two are dealt in pairs (workgroup ranges in units of two: q_per / q_extra count pairs; virtual quad v = matrix v & 1,
                          //    quad v >> 1) and matrix 0's hand-off image carries silu(gate) * up, computed once per row by the publishing wave
-    int pad[4];
+    // stream mode (tmac_stream.hip): the op's prebuilt LUT image in global memory (layout of the LDS LUT buffer) and its size in uint4, whole KB
+    const void* img;
+    int img_u4;
+    int pad;
     // sizeof == 320: the kernel keeps a copy of all descriptors in LDS (uint4 copies)
 };
 static_assert(sizeof(ChainOp) == 320, "ChainOp is copied to LDS in 16-byte pieces");
@@ -112,5 +115,21 @@ inline int chain_xf_region_floats(int K) {
 inline size_t chain_lds_bytes(int buf_u4, int nops, int xf_floats = 0) {
     return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops + sizeof(float) * (32 + (size_t)xf_floats);
 }
+
+// ---- stream mode: a recording in which no op consumes another's output (tmac_stream.hip) ----
+constexpr int STREAM_NLW = CHAIN_NWV;                 // lookup waves per workgroup: the roles of k_decode_chain
+constexpr int STREAM_FT = (STREAM_NLW + 1) * 64;      // + the loader wave
+struct StreamArgs {
+    const ChainOp* ops;
+    int nops;
+    int out_f16;
+    int buf_u4;                    // uint4 per LDS LUT buffer (two buffers, by op parity), a multiple of 64
+};
+inline int stream_img_u4(int K) { return (chain_buf_u4(K) + 63) & ~63; }      // image / LDS buffer of one op, whole KB
+inline size_t stream_lds_bytes(int buf_u4, int nops) {
+    return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * STREAM_NLW * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops;
+}
+hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, hipStream_t st);
+hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st);
 
 }  // namespace tmac

@@ -24,141 +24,9 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 
-#include "tmac_quad_core.h"
-#include "tmac_chain.h"
+#include "tmac_chain_core.h"
 
 namespace tmac {
-
-typedef const ChainOp* cop_ptr;   // descriptors: the workgroup's copy in LDS
-// Pointers read from the LDS copy are generic to the compiler: without the explicit global address space it emits flat
-// loads / stores, which also count on lgkmcnt -- every LDS wait would then wait for global memory.
-#define TMAC_GLOBAL __attribute__((address_space(1)))
-template <typename T>
-__device__ __forceinline__ TMAC_GLOBAL T* as_global(T* p) { return (TMAC_GLOBAL T*)p; }
-// A value read from the LDS copy is the same in every lane, but the compiler treats an LDS load as divergent: it
-// computes with it in VGPRs and wraps buffer resources in waterfall loops.  readfirstlane states the uniformity.
-__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
-template <typename T>
-__device__ __forceinline__ T* uni(T* p) {
-    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
-}
-
-template <int BITS>
-struct CFrag {
-    uint32_t wd[4 * BITS];
-    uint32_t s0, s1;     // the lane's scale (, zero) of the step's scale group: fp16 pair in s0, or fp32 in s0 (, s1)
-};
-
-// weights of (global quad gq, step st) + the lane's scale: the epilogue role of a lane is row lane & 3, units
-// st*64 + 16g + 4*lg .. +3 (see k_gemv_quad); scale groups span >= 4 units, so one scale group per lane and step.
-// Lanes whose unit lies past K skip the weight load (their LUT entries are zero tables: whatever the registers hold
-// contributes exactly 0) -- the zero padding of the last step is stored but never fetched.
-template <int BITS, bool ZP, bool SCF16, int SM>
-__device__ __forceinline__ void c_issue(CFrag<BITS>& f, __amdgpu_buffer_rsrc_t rs, int woff, const TMAC_GLOBAL char* scq, int nsg, int gsh, int nu,
-                                        int st, int lane, uint32_t lane16) {
-    constexpr int per = ZP ? 2 : 1;
-    constexpr int esz = SCF16 ? 2 : 4;
-    const int c0 = 4 * (lane & 12) + 4 * (lane >> 4);
-    const uint32_t sg = min((uint32_t)st * (64u >> gsh) + (uint32_t)(c0 >> gsh), (uint32_t)nsg - 1u);
-    const uint32_t boff = (sg * 4 + (lane & 3)) * (per * esz);          // scq already points at the quad's first scale group
-    uint32_t r0 = 0, r1 = 0;
-    if (SM == 0) {                       // (the unified scale is applied once per output, in the epilogue)
-        if (SCF16) {
-            if (ZP) r0 = *reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq + boff);
-            else r0 = *reinterpret_cast<const TMAC_GLOBAL unsigned short*>(scq + boff);
-        } else {
-            const TMAC_GLOBAL uint32_t* p32 = reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq + boff);
-            r0 = p32[0];
-            if (ZP) r1 = p32[1];
-        }
-    }
-    f.s0 = r0; f.s1 = r1;
-    if (st * 64 + lane < nu) {
-        // Buffer loads: resource (matrix base) and the fragment's byte offset in SGPRs, the lane's byte offset in a VGPR of
-        // its own (lane16, made opaque at kernel entry).  No VALU instruction takes part: when the address arithmetic
-        // (a rematerialised lane << 4, or a 64-bit add) lands in a dead ring register, that VALU write makes the
-        // compiler wait for every earlier load that might still target the register -- it serialised the fragments of a
-        // ring, one full memory latency each (1.4-2.8 us per op, profiles/r02_chain_prefetch_ab.txt B).
-        const int soff = woff + st * (BITS * 1024);
-#pragma unroll
-        for (int j = 0; j < BITS; ++j) {
-            const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane16, soff + j * 1024, 2 /* nt */);
-            f.wd[4 * j] = v.x; f.wd[4 * j + 1] = v.y; f.wd[4 * j + 2] = v.z; f.wd[4 * j + 3] = v.w;
-        }
-    }
-}
-
-// One 64-unit step of a row quad: lookups (v_perm_b32 on the half tables), v_mfma_i32_16x16x64_i8 as the adder, then the
-// two act groups of the lane's output row through the fp32 scale chain (compute_mfma of k_gemv_quad, SM = 0), or -- SM = 2 --
-// the exact int32 sum of the lane's row over all units, per bit-plane (tbl.cc:586-628).
-template <int BITS, bool ZP, bool SCF16, int SM>
-__device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab, int tstride, const float* l_ls, const float* l_lb,
-                                          int st, int lane, qv4i_t bsel, uint32_t k3, float& cacc, int32_t (&iacc)[BITS]) {
-    const int u = st * 64 + lane;
-    uint32_t tb[16];
-#pragma unroll
-    for (int j4 = 0; j4 < 4; ++j4) {
-        const uint4 v = tab[j4 * tstride + u];            // units past K read the zero tables: no contribution
-        tb[4 * j4] = v.x; tb[4 * j4 + 1] = v.y; tb[4 * j4 + 2] = v.z; tb[4 * j4 + 3] = v.w;
-    }
-    qv4i_t c[BITS];
-#pragma unroll
-    for (int pl = 0; pl < BITS; ++pl) c[pl] = (qv4i_t){0, 0, 0, 0};
-#pragma unroll
-    for (int tp = 0; tp < 4; ++tp) {
-#pragma unroll
-        for (int pl = 0; pl < BITS; ++pl) {
-            uint32_t pa, ma, pb, mb;
-            const int qa = (2 * tp) * BITS + pl, qb = (2 * tp + 1) * BITS + pl;
-            if (qa & 1) q_lookup4_pm<1>(f.wd[qa >> 1], tb[4 * tp], tb[4 * tp + 1], k3, pa, ma);
-            else q_lookup4_pm<0>(f.wd[qa >> 1], tb[4 * tp], tb[4 * tp + 1], k3, pa, ma);
-            if (qb & 1) q_lookup4_pm<1>(f.wd[qb >> 1], tb[4 * tp + 2], tb[4 * tp + 3], k3, pb, mb);
-            else q_lookup4_pm<0>(f.wd[qb >> 1], tb[4 * tp + 2], tb[4 * tp + 3], k3, pb, mb);
-            c[pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8((qv4i_t){(int)pa, (int)ma, (int)pb, (int)mb}, bsel, c[pl], 0, 0, 0);
-        }
-    }
-    if (SM == 2) {
-        // The MFMA results must have landed before a VALU instruction reads them (no hardware interlock: up to 18 wait states after an
-        // 8-pass MFMA; with one bit-plane the compiler's hazard recogniser left the two a single wait state apart across the loop branch and
-        // W1 unified-scale results were wrong).  ONE wait for all planes, behind the last MFMA of the step (the planes' chains are
-        // interleaved, so the others finished earlier):
-        // a wait per plane cost (BITS - 1) x 19 idle cycles per item
-        if constexpr (BITS == 1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]));
-        else if constexpr (BITS == 2) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]), "+v"(c[1]));
-        else if constexpr (BITS == 3) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
-        else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
-#pragma unroll
-        for (int pl = 0; pl < BITS; ++pl) iacc[pl] += (c[pl].x + c[pl].y) + (c[pl].z + c[pl].w);
-        return;
-    }
-    float sc, zr = 0.f;
-    if (SCF16) {
-        sc = __half2float(__ushort_as_half((unsigned short)(f.s0 & 0xffff)));
-        if (ZP) zr = __half2float(__ushort_as_half((unsigned short)(f.s0 >> 16)));
-    } else {
-        sc = __uint_as_float(f.s0);
-        if (ZP) zr = __uint_as_float(f.s1);
-    }
-    const int ub4 = st * 64 + 4 * (lane & 12) + 4 * (lane >> 4);
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-        const int kk = (ub4 + 2 * gi) >> 1;
-        const float hls = l_ls[kk], hlb = l_lb[kk];           // ls / 2, lb / 2; groups past K hold zeros
-        // sum_p alpha_p [(ps_p ls + [p = 0] lb) scale + [p = 0] zero 2 lb] = ((sum_p 2^p ps_p)(ls / 2) + lb / 2) scale + (2 zero)(lb / 2)
-        int32_t comb = 0;
-#pragma unroll
-        for (int pl = BITS - 1; pl >= 0; --pl) {
-            const int32_t ps = (gi == 0) ? (c[pl].x + c[pl].y) : (c[pl].z + c[pl].w);
-            comb = (pl == BITS - 1) ? ps : (int32_t)(((uint32_t)comb << 1) + (uint32_t)ps);
-        }
-        const float v = __fmaf_rn((float)comb, hls, hlb);
-        float cc = __fmaf_rn(v, sc, cacc);
-        if (ZP) cc = __fmaf_rn(__fadd_rn(zr, zr), hlb, cc);
-        cacc = cc;
-    }
-}
 
 // The hand-off granules of up to three LUT pairs (two consecutive row quads = 8 activations each), all rounds of a thread
 // in flight together; loads and their wait in one statement (cdna_hip_programming.md 5.7, form (i)).  Agent scope (sc1)

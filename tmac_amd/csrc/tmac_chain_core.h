@@ -1,0 +1,202 @@
+// tmac_chain_core.h -- device pieces shared by the persistent decode kernels: k_decode_chain (tmac_chain.hip: dependent calls with
+// in-kernel hand-offs) and k_gemv_stream (tmac_stream.hip: independent calls, LUT images prebuilt).  Weight fragments of one
+// (row quad, 64-unit step) item, their issue, and the item's lookups + MFMA adder + scale chain (tbl.cc:445-526).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "tmac_quad_core.h"
+#include "tmac_chain.h"
+
+namespace tmac {
+
+typedef const ChainOp* cop_ptr;   // descriptors: the workgroup's copy in LDS
+// Pointers read from the LDS copy are generic to the compiler: without the explicit global address space it emits flat
+// loads / stores, which also count on lgkmcnt -- every LDS wait would then wait for global memory.
+#define TMAC_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ TMAC_GLOBAL T* as_global(T* p) { return (TMAC_GLOBAL T*)p; }
+// A value read from the LDS copy is the same in every lane, but the compiler treats an LDS load as divergent: it
+// computes with it in VGPRs and wraps buffer resources in waterfall loops.  readfirstlane states the uniformity.
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+template <typename T>
+__device__ __forceinline__ T* uni(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+template <int BITS>
+struct CFrag {
+    u32x4q wq[BITS];     // the lane's 16 bytes of every bit-plane block of the item (dword 4 j + c of the item = wq[j][c])
+    uint32_t s0, s1;     // the lane's scale (, zero) of the step's scale group: fp16 pair in s0, or fp32 in s0 (, s1)
+};
+
+// weights of (global quad gq, step st) + the lane's scale: the epilogue role of a lane is row lane & 3, units
+// st*64 + 16g + 4*lg .. +3 (see k_gemv_quad); scale groups span >= 4 units, so one scale group per lane and step.
+// Lanes whose unit lies past K skip the weight load (their LUT entries are zero tables: whatever the registers hold
+// contributes exactly 0) -- the zero padding of the last step is stored but never fetched.
+template <int BITS, bool ZP, bool SCF16, int SM>
+__device__ __forceinline__ void c_issue(CFrag<BITS>& f, __amdgpu_buffer_rsrc_t rs, int woff, const TMAC_GLOBAL char* scq, int nsg, int gsh, int nu,
+                                        int st, int lane, uint32_t lane16) {
+    constexpr int per = ZP ? 2 : 1;
+    constexpr int esz = SCF16 ? 2 : 4;
+    const int c0 = 4 * (lane & 12) + 4 * (lane >> 4);
+    const uint32_t sg = min((uint32_t)st * (64u >> gsh) + (uint32_t)(c0 >> gsh), (uint32_t)nsg - 1u);
+    const uint32_t boff = (sg * 4 + (lane & 3)) * (per * esz);          // scq already points at the quad's first scale group
+    uint32_t r0 = 0, r1 = 0;
+    if (SM == 0) {                       // (the unified scale is applied once per output, in the epilogue)
+        if (SCF16) {
+            if (ZP) r0 = *reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq + boff);
+            else r0 = *reinterpret_cast<const TMAC_GLOBAL unsigned short*>(scq + boff);
+        } else {
+            const TMAC_GLOBAL uint32_t* p32 = reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq + boff);
+            r0 = p32[0];
+            if (ZP) r1 = p32[1];
+        }
+    }
+    f.s0 = r0; f.s1 = r1;
+    if (st * 64 + lane < nu) {
+        // Buffer loads: resource (matrix base) and the fragment's byte offset in SGPRs, the lane's byte offset in a VGPR of
+        // its own (lane16, made opaque at kernel entry).  No VALU instruction takes part: when the address arithmetic
+        // (a rematerialised lane << 4, or a 64-bit add) lands in a dead ring register, that VALU write makes the
+        // compiler wait for every earlier load that might still target the register -- it serialised the fragments of a
+        // ring, one full memory latency each (1.4-2.8 us per op, profiles/r02_chain_prefetch_ab.txt B).
+        const int soff = woff + st * (BITS * 1024);
+#pragma unroll
+        for (int j = 0; j < BITS; ++j) {
+            f.wq[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane16, soff + j * 1024, 2 /* nt */);
+        }
+    }
+}
+
+
+// ---- TMAC_RING_STATIC: the loads of an item as ONE unconditional, branch-free sequence ---------------------------------------------
+// With every ring slot (re)filled at fixed program points by exactly the same loads in the same order, the compiler's waitcnt pass can
+// count the loads issued behind the one it needs and wait per slot (s_waitcnt vmcnt(n)); with conditional issue it waits for the whole
+// ring.  The operands come from c_item_operands() for a real item, or describe a dummy (null resource: every lane out of range, zeros
+// without a fetch; the scale word from any mapped address).  Lanes past K re-read lane 0's 16 bytes (one line the wave fetches anyway;
+// their LUT entries are zero tables) instead of sitting under an exec-masked branch.
+struct CItemOps {
+    __amdgpu_buffer_rsrc_t rs;      // matrix (or null) resource
+    int soff;                       // byte offset of the fragment's first bit-plane block
+    const TMAC_GLOBAL char* sc;     // first scale group of the quad
+    uint32_t boff;                  // per lane: byte offset of its scale (, zero) word(s)
+    uint32_t l16;                   // per lane: byte offset inside a 1 KB block
+};
+template <int BITS, bool ZP, bool SCF16, int SM>
+__device__ __forceinline__ void c_item_operands(CItemOps& o, __amdgpu_buffer_rsrc_t rs, int woff, const TMAC_GLOBAL char* scq, int nsg, int gsh, int nu,
+                                                int st, int lane, uint32_t lane16) {
+    constexpr int per = ZP ? 2 : 1;
+    constexpr int esz = SCF16 ? 2 : 4;
+    const int c0 = 4 * (lane & 12) + 4 * (lane >> 4);
+    const uint32_t sg = min((uint32_t)st * (64u >> gsh) + (uint32_t)(c0 >> gsh), (uint32_t)nsg - 1u);
+    o.rs = rs; o.sc = scq;
+    o.boff = (sg * 4 + (lane & 3)) * (per * esz);
+    o.l16 = (st * 64 + lane < nu) ? lane16 : 0u;
+    o.soff = woff + st * (BITS * 1024);
+}
+template <int BITS, bool ZP, bool SCF16, int SM>
+__device__ __forceinline__ void c_issue_static(CFrag<BITS>& f, const CItemOps& o) {
+    uint32_t r0 = 0, r1 = 0;
+    if (SM == 0) {
+        if (SCF16) {
+            if (ZP) r0 = *reinterpret_cast<const TMAC_GLOBAL uint32_t*>(o.sc + o.boff);
+            else r0 = *reinterpret_cast<const TMAC_GLOBAL unsigned short*>(o.sc + o.boff);
+        } else {
+            const TMAC_GLOBAL uint32_t* p32 = reinterpret_cast<const TMAC_GLOBAL uint32_t*>(o.sc + o.boff);
+            r0 = p32[0];
+            if (ZP) r1 = p32[1];
+        }
+    }
+    f.s0 = r0; f.s1 = r1;
+#pragma unroll
+    for (int j = 0; j < BITS; ++j) f.wq[j] = __builtin_amdgcn_raw_buffer_load_b128(o.rs, (int)o.l16, o.soff + j * 1024, 2 /* nt */);
+}
+
+// ---- stores and barriers the compiler's waitcnt pass does not see (TMAC_RING_STATIC) ----------------------------------------------
+// On gfx9 stores count on vmcnt like loads, and loads and stores complete out of order with respect to each other: as soon as a store is
+// pending anywhere on a path, the pass stops counting and waits with vmcnt(0) in front of the next use of a loaded register -- which
+// drains the weight ring.  (Real hardware: loads return in order among themselves; a pending store can only make a counted wait longer.)
+// Likewise __syncthreads() is a workgroup fence + s_barrier, and the fence is s_waitcnt vmcnt(0) lgkmcnt(0): what the barriers of the
+// kernel order is LDS (tables, partial sums), never global memory.
+__device__ __forceinline__ void c_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void c_store_b16(unsigned long long gaddr, uint32_t v) { asm volatile("global_store_short %0, %1, off" :: "v"(gaddr), "v"(v) : "memory"); }
+__device__ __forceinline__ void c_store_b32(unsigned long long gaddr, uint32_t v) { asm volatile("global_store_dword %0, %1, off" :: "v"(gaddr), "v"(v) : "memory"); }
+__device__ __forceinline__ void c_store_b64(unsigned long long gaddr, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(gaddr), "v"(v) : "memory"); }
+__device__ __forceinline__ void c_store_b64_sc1(unsigned long long gaddr, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(gaddr), "v"(v) : "memory"); }
+__device__ __forceinline__ void c_store_b64_sys(unsigned long long gaddr, unsigned long long v) { asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" :: "v"(gaddr), "v"(v) : "memory"); }
+
+// One 64-unit step of a row quad: lookups (v_perm_b32 on the half tables), v_mfma_i32_16x16x64_i8 as the adder, then the
+// two act groups of the lane's output row through the fp32 scale chain (compute_mfma of k_gemv_quad, SM = 0), or -- SM = 2 --
+// the exact int32 sum of the lane's row over all units, per bit-plane (tbl.cc:586-628).
+template <int BITS, bool ZP, bool SCF16, int SM>
+__device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab, int tstride, const float* l_ls, const float* l_lb,
+                                          int st, int lane, qv4i_t bsel, uint32_t k3, float& cacc, int32_t (&iacc)[BITS]) {
+    const int u = st * 64 + lane;
+    uint32_t tb[16];
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) {
+        const uint4 v = tab[j4 * tstride + u];            // units past K read the zero tables: no contribution
+        tb[4 * j4] = v.x; tb[4 * j4 + 1] = v.y; tb[4 * j4 + 2] = v.z; tb[4 * j4 + 3] = v.w;
+    }
+    qv4i_t c[BITS];
+#pragma unroll
+    for (int pl = 0; pl < BITS; ++pl) c[pl] = (qv4i_t){0, 0, 0, 0};
+#pragma unroll
+    for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+        for (int pl = 0; pl < BITS; ++pl) {
+            uint32_t pa, ma, pb, mb;
+            const int qa = (2 * tp) * BITS + pl, qb = (2 * tp + 1) * BITS + pl;
+            if (qa & 1) q_lookup4_pm<1>(f.wq[qa >> 3][(qa >> 1) & 3], tb[4 * tp], tb[4 * tp + 1], k3, pa, ma);
+            else q_lookup4_pm<0>(f.wq[qa >> 3][(qa >> 1) & 3], tb[4 * tp], tb[4 * tp + 1], k3, pa, ma);
+            if (qb & 1) q_lookup4_pm<1>(f.wq[qb >> 3][(qb >> 1) & 3], tb[4 * tp + 2], tb[4 * tp + 3], k3, pb, mb);
+            else q_lookup4_pm<0>(f.wq[qb >> 3][(qb >> 1) & 3], tb[4 * tp + 2], tb[4 * tp + 3], k3, pb, mb);
+            c[pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8((qv4i_t){(int)pa, (int)ma, (int)pb, (int)mb}, bsel, c[pl], 0, 0, 0);
+        }
+    }
+    if (SM == 2) {
+        // The MFMA results must have landed before a VALU instruction reads them (no hardware interlock: up to 18 wait states after an
+        // 8-pass MFMA; with one bit-plane the compiler's hazard recogniser left the two a single wait state apart across the loop branch and
+        // W1 unified-scale results were wrong).  ONE wait for all planes, behind the last MFMA of the step (the planes' chains are
+        // interleaved, so the others finished earlier):
+        // a wait per plane cost (BITS - 1) x 19 idle cycles per item
+        if constexpr (BITS == 1) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]));
+        else if constexpr (BITS == 2) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]), "+v"(c[1]));
+        else if constexpr (BITS == 3) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]));
+        else asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+#pragma unroll
+        for (int pl = 0; pl < BITS; ++pl) iacc[pl] += (c[pl].x + c[pl].y) + (c[pl].z + c[pl].w);
+        return;
+    }
+    float sc, zr = 0.f;
+    if (SCF16) {
+        sc = __half2float(__ushort_as_half((unsigned short)(f.s0 & 0xffff)));
+        if (ZP) zr = __half2float(__ushort_as_half((unsigned short)(f.s0 >> 16)));
+    } else {
+        sc = __uint_as_float(f.s0);
+        if (ZP) zr = __uint_as_float(f.s1);
+    }
+    const int ub4 = st * 64 + 4 * (lane & 12) + 4 * (lane >> 4);
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi) {
+        const int kk = (ub4 + 2 * gi) >> 1;
+        const float hls = l_ls[kk], hlb = l_lb[kk];           // ls / 2, lb / 2; groups past K hold zeros
+        // sum_p alpha_p [(ps_p ls + [p = 0] lb) scale + [p = 0] zero 2 lb] = ((sum_p 2^p ps_p)(ls / 2) + lb / 2) scale + (2 zero)(lb / 2)
+        int32_t comb = 0;
+#pragma unroll
+        for (int pl = BITS - 1; pl >= 0; --pl) {
+            const int32_t ps = (gi == 0) ? (c[pl].x + c[pl].y) : (c[pl].z + c[pl].w);
+            comb = (pl == BITS - 1) ? ps : (int32_t)(((uint32_t)comb << 1) + (uint32_t)ps);
+        }
+        const float v = __fmaf_rn((float)comb, hls, hlb);
+        float cc = __fmaf_rn(v, sc, cacc);
+        if (ZP) cc = __fmaf_rn(__fadd_rn(zr, zr), hlb, cc);
+        cacc = cc;
+    }
+}
+
+
+}  // namespace tmac

@@ -53,6 +53,11 @@ struct tmac_hip_chain {
     int poll_sleep = 8, poll_delay = 4, issue_first = -1, poll_mode = 0, poll_grid = 0;   // read from the environment once, at tmac_hip_chain_end
     hipStream_t last_stream = nullptr;   // stream of the most recent launch (in-flight guard)
     bool launched = false;
+    // stream mode (tmac_stream.hip): no op consumes another's output -- k_lut_images builds every op's tables once into `images`
+    // (one image per op, the layout of the LDS LUT buffer), k_gemv_stream walks the ops with the tables prebuilt
+    bool stream = false;
+    void* images = nullptr;
+    int max_nst = 0;
 };
 
 int32_t tmac_host::chain_record(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
@@ -122,6 +127,7 @@ extern "C" int32_t tmac_hip_chain_free(tmac_hip_chain* c) {
     if (!c) return TMAC_HIP_OK;
     for (void* p : c->peers) if (p) (void)hipIpcCloseMemHandle(p);
     if (c->arena) (void)hipFree(c->arena);
+    if (c->images) (void)hipFree(c->images);
     if (c->d_ops) (void)hipFree(c->d_ops);
     if (c->ctl) (void)hipFree(c->ctl);
     delete c;
@@ -451,6 +457,37 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             if (i != k && xf_wr[i].lo && overlap(xf_wr[k], xf_wr[i])) return bail(fail(TMAC_HIP_E_NOMATCH, "ops %zu and %zu: overlapping residual_out vectors", i, k));
         }
     }
+    // ---- stream mode: nothing is handed over and nothing is transformed -- the calls are independent (SURVEY 8d's back-to-back GEMVs;
+    // a caller that evaluates many vectors against many matrices).  The reference's call structure then applies as it stands: tables
+    // once per activation vector (llama_cpp_init), lookups per matrix (llama_cpp_compute); see tmac_stream.hip.  The hazard analysis
+    // above has already refused every write of the launch that touches a vector another op reads from memory.  TMAC_CHAIN_STREAM=0: A/B.
+    {
+        bool indep = c->sm == 0 && c->world == 1 && gat.empty() && env_int("TMAC_CHAIN_STREAM", 1) != 0;
+        for (size_t i = 0; i < n && indep; ++i)
+            if (src[i].op >= 0 || src2[i].op >= 0 || rec[i].xf.kind != TMAC_XF_NONE || c->ops[i].epi) indep = false;
+        if (indep) {
+            size_t img_bytes = 0;
+            int buf = 0;
+            for (ChainOp& o : c->ops) {
+                o.img_u4 = stream_img_u4(o.K);
+                o.img = reinterpret_cast<const void*>(img_bytes + 1);       // offset + 1 until the images exist
+                img_bytes += (size_t)o.img_u4 * 16;
+                if (o.img_u4 > buf) buf = o.img_u4;
+                if (o.nst > c->max_nst) c->max_nst = o.nst;
+                o.in_gran &= 2;                                               // (no fragments-in-front-of-the-polls count: there are no polls)
+            }
+            const size_t lds = stream_lds_bytes(buf, (int)c->ops.size());
+            if (lds <= 160 * 1024) {
+                if (hipMalloc(&c->images, img_bytes) != hipSuccess || hipMemset(c->images, 0, img_bytes) != hipSuccess)
+                    return bail(fail(TMAC_HIP_E_RUNTIME, "LUT image allocation failed (%zu bytes)", img_bytes));
+                for (ChainOp& o : c->ops) o.img = reinterpret_cast<const char*>(c->images) + (reinterpret_cast<size_t>(o.img) - 1);
+                c->stream = true; c->buf_u4 = buf; c->lds_bytes = lds; c->xforms = 0;
+            } else {
+                for (ChainOp& o : c->ops) { o.img = nullptr; o.img_u4 = 0; o.in_gran |= 1 << 8; }
+            }
+        }
+    }
+    if (!c->stream) {
     c->buf_u4 = chain_buf_u4(maxK);
     c->lds_bytes = chain_lds_bytes(c->buf_u4, (int)c->ops.size(), c->carry_floats + c->tmp_floats + c->gam_floats + c->ext_floats);
     if (c->lds_bytes > 160 * 1024)
@@ -468,6 +505,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             return bail(fail(TMAC_HIP_E_NOMATCH, "the decode chain's workgroup does not fit a compute unit (%s, %zu bytes of LDS)",
                              e == hipSuccess ? "occupancy 0" : hipGetErrorString(e), c->lds_bytes));
     }
+    }   // !stream
     if (c->arena_bytes) {
         // Peers write into this arena over xGMI while the local kernel polls it: fine-grained device memory (coherent across
         // devices inside a running kernel; coarse-grained allocations promise that at kernel boundaries only).  Single-GPU
@@ -519,6 +557,17 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
         return fail(TMAC_HIP_E_ARG, "the chain is still in flight on another stream: synchronise it first, or record one chain per stream");
     }
     if (!c->connected) return fail(TMAC_HIP_E_ARG, "a row-sharded chain must be connected to its peers first (tmac_hip_chain_export / tmac_hip_chain_connect)");
+    if (c->stream) {
+        hipError_t e = launch_lut_images(c->d_ops, (int)c->ops.size(), c->max_nst, st);
+        if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT image launch: %s", hipGetErrorString(e));
+        StreamArgs sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.ops = c->d_ops; sa.nops = (int)c->ops.size(); sa.out_f16 = c->out_f16; sa.buf_u4 = c->buf_u4;
+        e = launch_gemv_stream(sa, c->bits, c->zp != 0, c->sc_f16 != 0, c->grid, c->lds_bytes, st);
+        if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "stream launch: %s", hipGetErrorString(e));
+        c->last_stream = st; c->launched = true;
+        return TMAC_HIP_OK;
+    }
     ChainArgs a;
     memset(&a, 0, sizeof(a));
     a.ops = c->d_ops; a.nops = (int)c->ops.size(); a.ctl = c->ctl; a.out_f16 = c->out_f16;
@@ -622,6 +671,8 @@ extern "C" int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* c, unsigned long lo
 }
 
 extern "C" int32_t tmac_hip_chain_threads(void) { return CHAIN_FT; }
+
+extern "C" int32_t tmac_hip_chain_is_stream(const tmac_hip_chain* c) { return c && c->stream ? 1 : 0; }
 
 extern "C" int32_t tmac_hip_debug_chain_grid(int workgroups) {
     if (workgroups < 0) return fail(TMAC_HIP_E_ARG, "negative grid");

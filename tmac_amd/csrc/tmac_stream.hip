@@ -1,0 +1,340 @@
+// tmac_stream.hip -- k_gemv_stream: a recorded sequence of INDEPENDENT decode GEMV groups (N = 1) as one persistent launch, and
+// k_lut_images, the LUT build of all of them as one launch in front of it.
+//
+// What it is for: SURVEY 8(d)'s headline measurement -- back-to-back GEMVs over rotating distinct weights, none reading another's
+// output -- and any caller whose calls carry no data dependence (tmac_hip_chain_end recognises such a recording: no op consumes an
+// earlier op's output).  The reference's own call structure is the model: the preprocessor runs once per activation vector
+// (tmac_gemm_wrapper.h:170-195), qgemm_lut then only looks up (:197-228), and its GEMV byte count includes the QLUT as an INPUT
+// (SURVEY 8d).  k_decode_chain cannot use that freedom (every call's table depends on the previous call's output); here
+//   * k_lut_images builds every op's tables ONCE (not once per CU) into a global image that has the layout of the LDS LUT buffer;
+//   * a LOADER wave (wave 12 of each 13-wave workgroup) moves op i+1's image global -> LDS (buffer_load ... lds, no registers, no VALU)
+//     while the twelve LOOKUP waves work on op i: the tables are never on a lookup wave's path;
+//   * a lookup wave's weight fragments form ONE FIFO across all ops: consume the oldest, refill the slot with the wave's next item --
+//     of this op or of the ops behind it -- so the ring always holds RING items and the stream never stops at an op boundary.  The
+//     loads of every item are the same unconditional sequence (c_issue_static), barriers and stores are asm: the compiler counts the
+//     loads behind the one it needs and waits per slot (s_waitcnt vmcnt((RING - 1) * loads per item)) instead of draining the ring
+//     (profiles/r05_ring_static.txt);
+//   * no hand-off, no polls, no spin: nothing waits for another workgroup, so residency is not a correctness condition.
+// Arithmetic per item and per row is k_decode_chain's / k_gemv_quad's (c_compute, the same wave / lane decomposition, the same
+// combination order of split quads), the tables are q_table8's: outputs are bit-identical to the other N = 1 paths for the same waves
+// per quad.  Scope: 1- to 4-bit QUAD-layout weights with per-group scales (act groups of 64); fp16 or fp32 activations.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#include "tmac_chain_core.h"
+
+namespace tmac {
+
+// ---------------------------------------------------------------------------------------------
+// LUT images: block (x, y) builds pairs 256 x .. 256 x + 255 (= the 64 units of step x) of op y -- the build phase of k_gemv_quad /
+// k_preprocess_pairs (lut_ctor.cc:120-215,240-256) writing the LDS layout of k_decode_chain's LUT buffer: [4][tstride] uint4 of signed
+// half tables, then ls / 2 and lb / 2 per act group, zero tables / zero scales for the units between K and the end of the last step.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lut_images(const ChainOp* __restrict__ ops) {
+    const ChainOp& d = ops[blockIdx.y];
+    const int K = d.K, P = K / 8, nst = d.nst, tstride = d.tstride, GP = d.GP;
+    if ((int)blockIdx.x >= nst) return;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    uint4* tab = reinterpret_cast<uint4*>(const_cast<void*>(d.img));
+    float* l_ls = reinterpret_cast<float*>(tab + 4 * tstride);
+    float* l_lb = l_ls + GP;
+    if (p >= P) {                           // P % 8 == 0: the 8 lanes of an act group are valid or padding together
+        tab[(p & 3) * tstride + (p >> 2)] = make_uint4(0u, 0u, 0u, 0u);
+        if ((p & 7) == 0) { l_ls[p >> 3] = 0.f; l_lb[p >> 3] = 0.f; }
+        return;
+    }
+    float x[8];
+    if (d.in_gran & 2) {
+        const float4* src = reinterpret_cast<const float4*>(d.in) + 2 * (size_t)p;
+        const float4 a0 = src[0], a1 = src[1];
+        x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
+    } else {
+        const uint4 v = reinterpret_cast<const uint4*>(d.in)[p];
+        const uint32_t r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __half2 hh = *reinterpret_cast<const __half2*>(&r[i]);
+            x[2 * i] = __low2float(hh); x[2 * i + 1] = __high2float(hh);
+        }
+    }
+    const float s0 = __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3])));
+    const float s1 = __fadd_rn(__fadd_rn(fabsf(x[4]), fabsf(x[5])), __fadd_rn(fabsf(x[6]), fabsf(x[7])));
+    const float mx = q_half_allmax(fmaxf(s0, s1));
+    const float scales = div127(mx);
+    const float t_scales = (scales != 0.0f) ? rcp_exact(scales) : 0.0f;
+    uint32_t lo0, hi0, lo1, hi1;
+    float La, Lb;
+    q_table8<true>(x[0], x[1], x[2], x[3], t_scales, lo0, hi0, La);
+    q_table8<true>(x[4], x[5], x[6], x[7], t_scales, lo1, hi1, Lb);
+    tab[(p & 3) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
+    float va = -La, vb = -Lb;               // lut_biases, lut_ctor.cc:25-31 (see k_gemv_quad)
+    va = __fadd_rn(va, qdpp_f<0x4E>(va));
+    vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));
+    va = __fadd_rn(va, qdpp_f<0xB1>(va));
+    vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));
+    const float v = __fadd_rn(va, vb);
+    const float c1 = qdpp_f<0x104>(v);
+    if ((p & 7) == 0) {
+        l_ls[p >> 3] = __fmul_rn(0.5f, scales);
+        l_lb[p >> 3] = __fmul_rn(0.5f, __fadd_rn(__fadd_rn(0.0f, v), c1));
+    }
+}
+
+hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, hipStream_t st) {
+    if (nops < 1 || max_nst < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_lut_images, dim3(max_nst, nops), dim3(256), 0, st, d_ops);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int BITS, bool ZP, bool SCF16>
+__global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 lds[];
+    constexpr int SM = 0;
+    constexpr int NWV = STREAM_NLW;                     // lookup waves; wave NWV is the loader
+    constexpr int RING = (BITS <= 2) ? 4 : 2;
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int bx = blockIdx.x;
+    float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][4][CHAIN_RED] partials of split quads
+    uint4* l_ops = lds + 2 * (size_t)a.buf_u4 + (2 * NWV * 4 * CHAIN_RED * sizeof(float)) / 16;
+    {
+        const uint4* gsrc = reinterpret_cast<const uint4*>(a.ops);
+        for (int idx = tid; idx < a.nops * (int)(sizeof(ChainOp) / 16); idx += STREAM_FT) l_ops[idx] = gsrc[idx];
+        __syncthreads();
+    }
+    const cop_ptr ops = reinterpret_cast<cop_ptr>(l_ops);
+    // barriers of op i, executed by all thirteen waves: A(i) -- the tables of op i are in LDS and everybody has left op i - 1 -- then one
+    // per workgroup iteration of the op (finish()).  The number of iterations depends on the workgroup alone.
+    auto wg_iters = [&](cop_ptr d) __attribute__((always_inline)) {
+        const int qper = uni(d->q_per), qex = uni(d->q_extra), ipi = uni(d->ipi), iinv = uni(d->ipi_inv);
+        const int cnt = qper + (bx < qex ? 1 : 0);
+        return ((cnt + ipi - 1) * iinv) >> 16;
+    };
+
+    if (w == NWV) {
+        // ---- the loader: op j's image global -> LDS buffer j & 1, one op ahead of the lookups.  1 KB per instruction, lane l lands at
+        // M0 + 16 l; images are padded to whole KB (zeros), so is the buffer.  The buffer of op j + 1 was op j - 1's: free since A(j). ----
+        typedef __attribute__((address_space(3))) void* lds_vp;
+        const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint4*)lds;
+        auto load_image = [&](int j) __attribute__((always_inline)) {
+            const cop_ptr d = ops + j;
+            const int n16 = uni(d->img_u4);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uni(d->img)), (short)0, n16 * 16, 0x00020000);
+            const uint32_t base = lds0 + (uint32_t)(j & 1) * (uint32_t)a.buf_u4 * 16u;
+            for (int o = 0; o < n16; o += 64)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vp)(uintptr_t)(base + (uint32_t)o * 16u), 16, (o + lane) * 16, 0, 0, 0);
+        };
+        load_image(0);
+        for (int j = 0; j < a.nops; ++j) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            c_lds_barrier();                                  // A(j)
+            if (j + 1 < a.nops) load_image(j + 1);
+            const int nit = wg_iters(ops + j);
+            for (int t = 0; t < nit; ++t) c_lds_barrier();
+        }
+        return;
+    }
+
+    qv4i_t bsel;
+    {
+        const int jrel = (lane & 15) - 4 * (lane >> 4);
+        const uint32_t be = (jrel >= 0 && jrel < 4) ? (0x01u << (8 * jrel)) : 0u, bo = (jrel >= 0 && jrel < 4) ? (0xfeu << (8 * jrel)) : 0u;   // +1 | -2
+        bsel = (qv4i_t){(int)be, (int)bo, (int)be, (int)bo};
+    }
+    uint32_t k3 = 0x03020100u;
+    asm volatile("" : "+v"(k3));
+    uint32_t lane16 = (uint32_t)lane * 16u;
+    asm volatile("" : "+v"(lane16));
+    const int wl = NWV - 1 - w;             // lookup roles in reverse wave order: wave 0 combines and stores, it gets the last role (k_decode_chain)
+
+    // a wave's share of an op (k_decode_chain's role_of): quad slot qs of every workgroup iteration, steps h, h + wpq, ...
+    struct Role { int q_lo, cnt, qs, ipi, h, wpq, nst, my_iter, nquads, nsteps; };
+    auto role_of = [&](cop_ptr d) __attribute__((always_inline)) {
+        Role r;
+        r.wpq = uni(d->wpq);
+        const int ipi = uni(d->ipi), inv = uni(d->wpq_inv);
+        const int qs = (wl * inv) >> 16;
+        r.h = wl - qs * r.wpq;
+        r.qs = qs; r.ipi = ipi;
+        r.nst = uni(d->nst);
+        const int qper = uni(d->q_per), qex = uni(d->q_extra);
+        r.q_lo = bx * qper + min(bx, qex);
+        r.cnt = qper + (bx < qex ? 1 : 0);
+        const int iinv = uni(d->ipi_inv);
+        r.my_iter = ((r.cnt + ipi - 1) * iinv) >> 16;
+        r.nquads = qs < r.cnt ? (((r.cnt - 1 - qs) * iinv) >> 16) + 1 : 0;
+        r.nsteps = r.h < r.nst ? ((r.nst - r.h + r.wpq - 1) * inv) >> 16 : 0;
+        return r;
+    };
+
+    // ---- the issue cursor: this wave's items of ops 0, 1, ... in order, RING items ahead of the lookups ----
+    CFrag<BITS> ring[RING];
+    const __amdgpu_buffer_rsrc_t null_rs = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint4*>(nullptr), (short)0, 0, 0x00020000);   // every lane out of range: zeros, no fetch
+    const TMAC_GLOBAL char* ops_g = as_global(reinterpret_cast<const char*>(a.ops));     // a dummy's scale word comes from a mapped address
+    const uint32_t dummy_boff = (uint32_t)(lane & 3) * (uint32_t)((ZP ? 2 : 1) * (SCF16 ? 2 : 4));
+    int i_op = -1, i_left = 0, i_it = 0, i_st = 0, i_h = 0, i_wpq = 1, i_nst = 1, i_nsg = 1, i_gsh = 0, i_nu = 0, i_q0 = 0, i_ipi = 1;
+    int i_qe0 = 0, i_qe1 = 0, i_qe2 = 0, q_res = -1, q_woff = 0;
+    cop_ptr i_d = ops;
+    __amdgpu_buffer_rsrc_t q_rs = null_rs;
+    const TMAC_GLOBAL char* q_sc = ops_g;
+    auto refill = [&](CFrag<BITS>& f) __attribute__((always_inline)) {
+        while (i_left == 0 && i_op < a.nops) {            // enter the next op in which this wave has items
+            ++i_op;
+            if (i_op < a.nops) {
+                i_d = ops + i_op;
+                const Role r = role_of(i_d);
+                i_left = r.nquads * r.nsteps;
+                i_it = 0; i_st = r.h; i_h = r.h; i_wpq = r.wpq; i_nst = r.nst; i_q0 = r.q_lo + r.qs; i_ipi = r.ipi;
+                i_nsg = uni(i_d->nsg); i_gsh = uni(i_d->gs_shift); i_nu = uni(i_d->nu);
+                i_qe0 = uni(i_d->q_end[0]); i_qe1 = uni(i_d->q_end[1]); i_qe2 = uni(i_d->q_end[2]);
+                q_res = -1;
+            }
+        }
+        const bool real = i_left > 0;
+        if (real && q_res != i_it) {                      // what depends on the quad alone
+            const int gqi = i_q0 + i_it * i_ipi;
+            const int mi = (gqi >= i_qe0 ? 1 : 0) + (gqi >= i_qe1 ? 1 : 0) + (gqi >= i_qe2 ? 1 : 0);
+            const int lq = gqi - (gqi >= i_qe2 ? i_qe2 : (gqi >= i_qe1 ? i_qe1 : (gqi >= i_qe0 ? i_qe0 : 0)));
+            q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(uni(i_d->m[mi].W)), (short)0, 0x7fffffff, 0x00020000);
+            q_sc = as_global(uni(reinterpret_cast<const char*>(i_d->m[mi].SC))) + (size_t)lq * (size_t)(i_nsg * 4 * (ZP ? 2 : 1) * (SCF16 ? 2 : 4));
+            q_woff = lq * i_nst * (BITS * 1024);
+            q_res = i_it;
+        }
+        CItemOps io;
+        if (real) c_item_operands<BITS, ZP, SCF16, SM>(io, q_rs, q_woff, q_sc, i_nsg, i_gsh, i_nu, i_st, lane, lane16);
+        else { io.rs = null_rs; io.soff = 0; io.sc = ops_g; io.boff = dummy_boff; io.l16 = 0u; }      // behind the last op: keeps the FIFO's depth
+        c_issue_static<BITS, ZP, SCF16, SM>(f, io);
+        if (real) {
+            --i_left;
+            i_st += i_wpq;
+            if (i_st >= i_nst) { i_st = i_h; ++i_it; }
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < RING; ++k) refill(ring[k]);
+
+    // ---- the lookup cursor ----
+    int c_op = -1, c_left = 0, c_it = 0, c_st = 0, parity = 0;
+    Role ro = role_of(ops);
+    cop_ptr d = ops;
+    int tstride = 1, nst = 1, wpq = 1, h = 0, ipi = 1;
+    uint4* tab = lds;
+    float* l_ls = reinterpret_cast<float*>(lds);
+    float* l_lb = l_ls;
+    float cacc = 0.f;
+    int32_t iacc[BITS];
+#pragma unroll
+    for (int pl = 0; pl < BITS; ++pl) iacc[pl] = 0;
+
+    // closes a workgroup iteration of op c_op: partial sums to LDS, one barrier, wave 0 combines the wpq partials of every quad of the
+    // iteration (in wave order, as k_gemv_quad does) and stores the outputs
+    auto finish = [&](bool have, float acc_in) __attribute__((always_inline)) {
+        float* red = l_red + parity * (NWV * 4 * CHAIN_RED);
+        float acc = 0.f;
+        if (have) {
+            acc = acc_in;
+            acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // lanes with the same row: rotate by 4, 8 within the DPP row
+            acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
+            acc = q_xor_add_f(acc);
+        }
+        if (lane < 4) red[(wl * 4 + lane) * CHAIN_RED] = acc;
+        const int p_qs = lane >> 2, p_row = lane & 3;
+        const int p_gql = ro.q_lo + c_it * ipi + p_qs;
+        const bool p_mine = p_qs < ipi && p_gql < ro.q_lo + ro.cnt;
+        int p_lq = 0;
+        unsigned long long p_c = 0ull;
+        if (w == 0) {
+            const int e0 = uni(d->q_end[0]), e1 = uni(d->q_end[1]), e2 = uni(d->q_end[2]);
+            const int p_mi = (p_gql >= e0 ? 1 : 0) + (p_gql >= e1 ? 1 : 0) + (p_gql >= e2 ? 1 : 0);
+            p_lq = p_gql - (p_gql >= e2 ? e2 : (p_gql >= e1 ? e1 : (p_gql >= e0 ? e0 : 0)));
+            p_c = reinterpret_cast<unsigned long long>(d->m[p_mine ? p_mi : 0].C);
+        }
+        c_lds_barrier();
+        if (w == 0 && p_mine) {
+            float t = red[((p_qs * wpq) * 4 + p_row) * CHAIN_RED];
+            for (int ww = 1; ww < wpq; ++ww) t = __fadd_rn(t, red[((p_qs * wpq + ww) * 4 + p_row) * CHAIN_RED]);
+            asm volatile("" : "+v"(t));       // the fp16 output is the fp32 result rounded once more (no fused convert: k_decode_chain)
+            const size_t oi = (size_t)(4 * p_lq + p_row);
+            if (a.out_f16) c_store_b16(p_c + 2 * oi, (uint32_t)__half_as_ushort(__float2half_rn(t)));
+            else c_store_b32(p_c + 4 * oi, __float_as_uint(t));
+        }
+        parity ^= 1;
+        ++c_it;
+    };
+    // the lookup cursor leaves op c_op (remaining barriers of the op) and enters the next op in which this wave has items, passing the
+    // barriers of the ops in between
+    bool done = false;
+    auto advance = [&]() __attribute__((always_inline)) {
+        for (;;) {
+            if (c_op >= 0) while (c_it < ro.my_iter) finish(false, 0.f);
+            ++c_op;
+            if (c_op >= a.nops) { done = true; return; }
+            d = ops + c_op;
+            ro = role_of(d);
+            tstride = uni(d->tstride); nst = ro.nst; wpq = ro.wpq; h = ro.h; ipi = ro.ipi;
+            tab = lds + (size_t)(c_op & 1) * a.buf_u4;
+            l_ls = reinterpret_cast<float*>(tab + 4 * tstride);
+            l_lb = l_ls + uni(d->GP);
+            c_left = ro.nquads * ro.nsteps; c_it = 0; c_st = h;
+            c_lds_barrier();                          // A(c_op): the loader has this op's tables in LDS
+            if (c_left > 0) return;
+        }
+    };
+
+    advance();                                        // op 0 (or the first op in which this wave has items)
+    // Rounds of RING slots; the loop is left at the END of a round only.  Once the wave is past its last item the remaining slots of the
+    // round skip the lookups and still refill (a dummy by then): with an exit -- or the op change -- in front of a slot's lookups, the
+    // compiler's structured control flow routes those paths through the loop's latch, the waitcnt pass merges "this slot's refill is the
+    // youngest load" into the head of the round and stops counting there (s_waitcnt vmcnt(1) in front of slot 0).
+    while (!done) {
+#pragma unroll
+        for (int k = 0; k < RING; ++k) {
+            if (!done) {
+                c_compute<BITS, ZP, SCF16, SM>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane, bsel, k3, cacc, iacc);
+                asm volatile("" : "+v"(cacc));        // the item's scale chain ends before the slot is refilled (the scale word keeps its register)
+            }
+            refill(ring[k]);
+            if (!done) {
+                --c_left;
+                c_st += wpq;
+                if (c_st >= nst) {
+                    finish(true, cacc);
+                    cacc = 0.f;
+                    c_st = h;
+                }
+                if (c_left == 0) advance();           // the op's last item: on to the next op BEHIND the refill (every path into the next slot has issued the same loads)
+            }
+        }
+    }
+
+}
+
+template <int BITS>
+static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st) {
+#define TMAC_SL(Z, H) do { \
+        auto* kern = &k_gemv_stream<BITS, Z, H>; \
+        if (lds_bytes > 64 * 1024) { \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            if (e != hipSuccess) return e; \
+        } \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(STREAM_FT), lds_bytes, st, a); \
+        return hipGetLastError(); } while (0)
+    if (zp) { if (sc_f16) TMAC_SL(true, true); else TMAC_SL(true, false); }
+    if (sc_f16) TMAC_SL(false, true);
+    TMAC_SL(false, false);
+#undef TMAC_SL
+}
+
+hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st) {
+    if (a.nops < 1 || grid < 1) return hipErrorInvalidValue;
+    switch (bits) {
+        case 1: return stream_launch_b<1>(a, zp, sc_f16, grid, lds_bytes, st);
+        case 2: return stream_launch_b<2>(a, zp, sc_f16, grid, lds_bytes, st);
+        case 3: return stream_launch_b<3>(a, zp, sc_f16, grid, lds_bytes, st);
+        case 4: return stream_launch_b<4>(a, zp, sc_f16, grid, lds_bytes, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace tmac

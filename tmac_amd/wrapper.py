@@ -234,6 +234,9 @@ class DecodeChain:
         check(B.lib().tmac_hip_chain_info(self._h, 0, C.byref(n), None, C.byref(g), C.byref(b)))
         self.nops, self.grid, self.weight_bytes = n.value, g.value, b.value
         self.threads = int(B.lib().tmac_hip_chain_threads())     # threads per workgroup of k_decode_chain (for A/B against k_gemv_quad)
+        is_stream = getattr(B.lib(), "tmac_hip_chain_is_stream", None)
+        # stream mode: no recorded call consumes another's output -- tables prebuilt by k_lut_images, lookups by k_gemv_stream (include/tmac_hip.h)
+        self.stream = bool(is_stream(self._h)) if is_stream is not None and getattr(is_stream, "argtypes", None) else False
 
     @property
     def handle(self):

@@ -443,7 +443,7 @@ def main():
 
     recording = [False]          # inside wr.record_chain(): exchange steps are recorded, not executed
 
-    def calls(mats, xin, out_of, exchange=True):
+    def calls(mats, xin, out_of, exchange=True, link=None):
         """the hot-path calls of one layer; xin / out_of: dicts of input blocks per slot / output lists per matrix group"""
         for name, Mw, K, cnt, slot in MATS:
             if fused_calls:
@@ -465,7 +465,7 @@ def main():
                 g = gathered[name]
                 xin[nxt[name]] = (g.reshape(-1)[:logical[name]] if decode
                                   else g.permute(1, 0, 2).reshape(N, -1)[:, :logical[name]].contiguous())
-            elif args.pattern != "independent":
+            elif (args.pattern != "independent") if link is None else link:
                 xin[nxt[name]] = out_of[name][0]
 
     # independent pattern: nothing orders the calls, so every layer gets output buffers of its own
@@ -946,13 +946,13 @@ def main():
         ok = True
         if args.path == "chain":
             with wr.record_chain() as vrec:
-                calls(layers[0], vx, vouts, exchange=False)
+                calls(layers[0], vx, vouts, exchange=False, link=True)
             vrec.chain.launch()
             torch.cuda.synchronize()
             ok = vrec.chain.status() == 0
             vrec.chain.free()
         else:
-            calls(layers[0], vx, vouts, exchange=False)
+            calls(layers[0], vx, vouts, exchange=False, link=True)
             torch.cuda.synchronize()
         worst = 0.0
         rows = [0] if decode else [0, N - 1]          # prefill: two of the N activation rows (the oracle takes seconds per row)

@@ -7,8 +7,9 @@
 // (tmac_gemm_wrapper.h:170-195), qgemm_lut then only looks up (:197-228), and its GEMV byte count includes the QLUT as an INPUT
 // (SURVEY 8d).  k_decode_chain cannot use that freedom (every call's table depends on the previous call's output); here
 //   * k_lut_images builds every op's tables ONCE (not once per CU) into a global image that has the layout of the LDS LUT buffer;
-//   * a LOADER wave (wave 12 of each 13-wave workgroup) moves op i+1's image global -> LDS (buffer_load ... lds, no registers, no VALU)
-//     while the twelve LOOKUP waves work on op i: the tables are never on a lookup wave's path;
+//   * a SERVICE wave (wave 12 of each 13-wave workgroup) moves op i+1's image global -> LDS (buffer_load ... lds, no registers, no VALU)
+//     while the twelve LOOKUP waves work on op i -- the tables are never on a lookup wave's path -- and combines the partial sums of split
+//     quads and stores the outputs behind each closing barrier, so no lookup wave is waited for while it stores;
 //   * a lookup wave's weight fragments form ONE FIFO across all ops: consume the oldest, refill the slot with the wave's next item --
 //     of this op or of the ops behind it -- so the ring always holds RING items and the stream never stops at an op boundary.  The
 //     loads of every item are the same unconditional sequence (c_issue_static), barriers and stores are asm: the compiler counts the
@@ -88,12 +89,18 @@ hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, hipStr
 }
 
 // ---------------------------------------------------------------------------------------------
+#ifndef TMAC_STREAM_KO
+#define TMAC_STREAM_KO 0          // timing experiments only (wrong results): 1 no combine / store, 2 no finish at all, 4 no image loads, 8 no lookups
+#endif
 template <int BITS, bool ZP, bool SCF16>
 __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     constexpr int SM = 0;
     constexpr int NWV = STREAM_NLW;                     // lookup waves; wave NWV is the loader
-    constexpr int RING = (BITS <= 2) ? 4 : 2;
+#ifndef TMAC_STREAM_RING
+#define TMAC_STREAM_RING 0
+#endif
+    constexpr int RING = TMAC_STREAM_RING ? TMAC_STREAM_RING : ((BITS <= 2) ? 4 : 2);      // weight fragments in flight per lookup wave (A/B knob)
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int bx = blockIdx.x;
     float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][4][CHAIN_RED] partials of split quads
@@ -125,14 +132,48 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
             for (int o = 0; o < n16; o += 64)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_vp)(uintptr_t)(base + (uint32_t)o * 16u), 16, (o + lane) * 16, 0, 0, 0);
         };
+        // ... and the combiner: after the barrier that closes a workgroup iteration, lane (quad slot, row) of this wave sums the wpq partials of
+        // its row (in wave order, as k_gemv_quad does) and stores the output -- the lookup waves go straight on.  The combination of an op's LAST
+        // iteration is deferred behind the next op's A barrier (the partials sit in the other half of the double-buffered area by then), so
+        // that A never waits for it: between A and the op's first closing barrier the lookup waves have at least an item to do.
+        int s_par = 0;
+        auto combine = [&](int j, int t, int par) __attribute__((always_inline)) {
+            const cop_ptr d = ops + j;
+            const int qper = uni(d->q_per), qex = uni(d->q_extra), ipi = uni(d->ipi), wpq = uni(d->wpq);
+            const int q_lo = bx * qper + min(bx, qex), cnt = qper + (bx < qex ? 1 : 0);
+            const int p_qs = lane >> 2, p_row = lane & 3;
+            const int p_gql = q_lo + t * ipi + p_qs;
+            if (p_qs < ipi && p_gql < q_lo + cnt) {
+                const int e0 = uni(d->q_end[0]), e1 = uni(d->q_end[1]), e2 = uni(d->q_end[2]);
+                const int p_mi = (p_gql >= e0 ? 1 : 0) + (p_gql >= e1 ? 1 : 0) + (p_gql >= e2 ? 1 : 0);
+                const int p_lq = p_gql - (p_gql >= e2 ? e2 : (p_gql >= e1 ? e1 : (p_gql >= e0 ? e0 : 0)));
+                const unsigned long long p_c = reinterpret_cast<unsigned long long>(d->m[p_mi].C);
+                const float* red = l_red + par * (NWV * 4 * CHAIN_RED);
+                float v = red[((p_qs * wpq) * 4 + p_row) * CHAIN_RED];
+                for (int ww = 1; ww < wpq; ++ww) v = __fadd_rn(v, red[((p_qs * wpq + ww) * 4 + p_row) * CHAIN_RED]);
+                asm volatile("" : "+v"(v));       // the fp16 output is the fp32 result rounded once more (no fused convert: k_decode_chain)
+                const size_t oi = (size_t)(4 * p_lq + p_row);
+                if (a.out_f16) c_store_b16(p_c + 2 * oi, (uint32_t)__half_as_ushort(__float2half_rn(v)));
+                else c_store_b32(p_c + 4 * oi, __float_as_uint(v));
+            }
+        };
         load_image(0);
+        int prev_nit = 0;
         for (int j = 0; j < a.nops; ++j) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             c_lds_barrier();                                  // A(j)
-            if (j + 1 < a.nops) load_image(j + 1);
+            if (!(TMAC_STREAM_KO & 1) && j > 0 && prev_nit > 0) combine(j - 1, prev_nit - 1, s_par ^ 1);
+            if (!(TMAC_STREAM_KO & 4) && j + 1 < a.nops) load_image(j + 1);
             const int nit = wg_iters(ops + j);
-            for (int t = 0; t < nit; ++t) c_lds_barrier();
+            if (!(TMAC_STREAM_KO & 2))
+                for (int t = 0; t < nit; ++t) {
+                    c_lds_barrier();                          // closes workgroup iteration t of op j: partials in half s_par
+                    if (!(TMAC_STREAM_KO & 1) && t + 1 < nit) combine(j, t, s_par);
+                    s_par ^= 1;
+                }
+            prev_nit = nit;
         }
+        if (!(TMAC_STREAM_KO & 1) && prev_nit > 0) combine(a.nops - 1, prev_nit - 1, s_par ^ 1);
         return;
     }
 
@@ -146,7 +187,7 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
     asm volatile("" : "+v"(k3));
     uint32_t lane16 = (uint32_t)lane * 16u;
     asm volatile("" : "+v"(lane16));
-    const int wl = NWV - 1 - w;             // lookup roles in reverse wave order: wave 0 combines and stores, it gets the last role (k_decode_chain)
+    const int wl = NWV - 1 - w;             // logical wave index of the roles and of the partial sums (k_decode_chain's order)
 
     // a wave's share of an op (k_decode_chain's role_of): quad slot qs of every workgroup iteration, steps h, h + wpq, ...
     struct Role { int q_lo, cnt, qs, ipi, h, wpq, nst, my_iter, nquads, nsteps; };
@@ -227,9 +268,10 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
 #pragma unroll
     for (int pl = 0; pl < BITS; ++pl) iacc[pl] = 0;
 
-    // closes a workgroup iteration of op c_op: partial sums to LDS, one barrier, wave 0 combines the wpq partials of every quad of the
-    // iteration (in wave order, as k_gemv_quad does) and stores the outputs
+    // closes a workgroup iteration of op c_op: the wave's partial sums to LDS, one barrier (the service wave combines the wpq partials of
+    // every quad of the iteration and stores the outputs)
     auto finish = [&](bool have, float acc_in) __attribute__((always_inline)) {
+        if (TMAC_STREAM_KO & 2) { ++c_it; return; }
         float* red = l_red + parity * (NWV * 4 * CHAIN_RED);
         float acc = 0.f;
         if (have) {
@@ -239,26 +281,7 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
             acc = q_xor_add_f(acc);
         }
         if (lane < 4) red[(wl * 4 + lane) * CHAIN_RED] = acc;
-        const int p_qs = lane >> 2, p_row = lane & 3;
-        const int p_gql = ro.q_lo + c_it * ipi + p_qs;
-        const bool p_mine = p_qs < ipi && p_gql < ro.q_lo + ro.cnt;
-        int p_lq = 0;
-        unsigned long long p_c = 0ull;
-        if (w == 0) {
-            const int e0 = uni(d->q_end[0]), e1 = uni(d->q_end[1]), e2 = uni(d->q_end[2]);
-            const int p_mi = (p_gql >= e0 ? 1 : 0) + (p_gql >= e1 ? 1 : 0) + (p_gql >= e2 ? 1 : 0);
-            p_lq = p_gql - (p_gql >= e2 ? e2 : (p_gql >= e1 ? e1 : (p_gql >= e0 ? e0 : 0)));
-            p_c = reinterpret_cast<unsigned long long>(d->m[p_mine ? p_mi : 0].C);
-        }
-        c_lds_barrier();
-        if (w == 0 && p_mine) {
-            float t = red[((p_qs * wpq) * 4 + p_row) * CHAIN_RED];
-            for (int ww = 1; ww < wpq; ++ww) t = __fadd_rn(t, red[((p_qs * wpq + ww) * 4 + p_row) * CHAIN_RED]);
-            asm volatile("" : "+v"(t));       // the fp16 output is the fp32 result rounded once more (no fused convert: k_decode_chain)
-            const size_t oi = (size_t)(4 * p_lq + p_row);
-            if (a.out_f16) c_store_b16(p_c + 2 * oi, (uint32_t)__half_as_ushort(__float2half_rn(t)));
-            else c_store_b32(p_c + 4 * oi, __float_as_uint(t));
-        }
+        c_lds_barrier();                          // the service wave combines and stores behind it
         parity ^= 1;
         ++c_it;
     };
@@ -291,6 +314,7 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
 #pragma unroll
         for (int k = 0; k < RING; ++k) {
             if (!done) {
+                if (TMAC_STREAM_KO & 8) cacc += __uint_as_float(ring[k].wq[0].x ^ ring[k].wq[BITS - 1].w ^ ring[k].s0); else
                 c_compute<BITS, ZP, SCF16, SM>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane, bsel, k3, cacc, iacc);
                 asm volatile("" : "+v"(cacc));        // the item's scale chain ends before the slot is refilled (the scale word keeps its register)
             }

@@ -1,0 +1,73 @@
+"""Back-to-back independent GEMVs (SURVEY 8d's headline measurement) through the recorded-sequence API in stream mode
+(k_lut_images + k_gemv_stream): NL matrices of one shape with distinct weights (> MALL in total) and a DISTINCT activation vector per
+call, one launch; us per GEMV (hipEvent pair, mean / best of 10), fraction of the 8 TB/s HBM peak on SURVEY 8d's algorithmic bytes, and
+a bit-comparison of every call's output with the same call launched on its own (tmac_hip_qgemm_fused_dev, the chain's configuration).
+usage: bench_stream.py [shape ...]   shape = MwxK[xCNT][:bits]   default: 4096x11008 4096x4096 11008x4096x2 4096x4096x3
+env: NL (calls per launch, default 32), TMAC_CHAIN_STREAM=0 measures k_decode_chain on the same recording."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tmac_amd
+from tmac_amd import KCfg, F16
+dev = torch.device("cuda")
+NL = int(os.environ.get("NL", "32"))
+L = tmac_amd.lib()
+gen = torch.Generator(device=dev); gen.manual_seed(7)
+
+
+def algorithmic_bytes(Mw, K, bits, gs=128, ags=64, zp=True):
+    return Mw * K * bits // 8 + Mw * (K // gs) * (2 if zp else 1) * 2 + K // 4 * 16 + (K // ags) * 4 + Mw * 2
+
+
+def run(Mw, K, cnt, bits):
+    bm = {1: 64, 2: 128, 3: 192, 4: 256}[bits]
+    wr = tmac_amd.TMACGeMMWrapper(act_group_size=64); wr.set_workspace(K, 1)
+    cfg = KCfg.make(Mw, K, bits, bm, 16, 128, 64, True, -1)
+    sets, xs, outs = [], [], []
+    c = 1.0 / np.sqrt(2.5 * K)
+    for _ in range(NL):
+        ws = []
+        for _ in range(cnt):
+            A = torch.randint(0, 256, (Mw * bits // bm, K // 4, bm // 2), dtype=torch.uint8, device=dev, generator=gen)
+            S = (torch.randn((Mw * bits // bm, K // 128, bm // bits // 8, 2, 8), device=dev, generator=gen) * c).half().contiguous()
+            ws.append(tmac_amd.Weights(A, S, Mw, K, bits, cfg, scales_dtype=F16, dev_dtype=F16, on_device=True))
+        sets.append(ws)
+        xs.append(torch.randn(K, device=dev, generator=gen).half())
+        outs.append([torch.zeros(Mw, dtype=torch.float16, device=dev) for _ in range(cnt)])
+    with wr.record_chain() as rec:
+        for i in range(NL):
+            wr.fused(sets[i], xs[i], outs[i], 1, act_dtype=F16, out_dtype=F16)
+    ch = rec.chain
+    ts = []
+    for r in range(13):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record(); ch.launch(); e1.record(); torch.cuda.synchronize()
+        if r >= 3:
+            ts.append(e0.elapsed_time(e1) * 1e3 / NL)
+    assert ch.status() == 0
+    got = [[o.clone() for o in os_] for os_ in outs]
+    same = True
+    for i in range(NL):
+        L.tmac_hip_debug_quad_config(ch.threads, ch.wpq(i))
+        ref = [torch.empty_like(o) for o in outs[i]]
+        wr.fused(sets[i], xs[i], ref, 1, act_dtype=F16, out_dtype=F16)
+        torch.cuda.synchronize()
+        same = same and all(torch.equal(a, b) for a, b in zip(got[i], ref))
+    L.tmac_hip_debug_quad_config(0, 0)
+    hb = cnt * algorithmic_bytes(Mw, K, bits) - (cnt - 1) * (K // 4 * 16 + (K // 64) * 4)
+    mean, best = float(np.mean(ts)), float(np.min(ts))
+    print(f"{Mw}x{K}x{cnt} W{bits} {'stream' if ch.stream else 'chain '} wpq={ch.wpq(0)}: {mean:6.2f} us/call (best {best:6.2f})  {hb / mean * 1e-3:7.1f} GB/s  "
+          f"frac {hb / mean * 1e-3 / 8000:.3f}  bit-identical to the stand-alone launches: {same}", flush=True)
+    ch.free()
+    for ws in sets:
+        for w in ws:
+            w.free()
+
+
+shapes = sys.argv[1:] or ["4096x11008", "4096x4096", "11008x4096x2", "4096x4096x3"]
+for s in shapes:
+    bits = 2
+    if ":" in s:
+        s, b = s.split(":"); bits = int(b)
+    p = [int(v) for v in s.split("x")]
+    run(p[0], p[1], p[2] if len(p) > 2 else 1, bits)

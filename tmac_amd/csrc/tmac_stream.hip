@@ -100,7 +100,9 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
 #ifndef TMAC_STREAM_RING
 #define TMAC_STREAM_RING 0
 #endif
-    constexpr int RING = TMAC_STREAM_RING ? TMAC_STREAM_RING : ((BITS <= 2) ? 4 : 2);      // weight fragments in flight per lookup wave (A/B knob)
+    // weight fragments in flight per lookup wave (A/B knob TMAC_STREAM_RING): measured flat from 2 to 6 (4096 x 11008 W2: 3.24 / 3.33 / 3.46 us
+    // per call with 2 / 4 / 6, W4 4.63 / 4.67 with 2 / 4: what a deeper ring adds in flight it takes from the other waves' share of the queue)
+    constexpr int RING = TMAC_STREAM_RING ? TMAC_STREAM_RING : ((BITS <= 2) ? 4 : 2);
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int bx = blockIdx.x;
     float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][4][CHAIN_RED] partials of split quads

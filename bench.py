@@ -101,6 +101,7 @@ def parse():
                     help="multi-GPU exchange step: torch.distributed (ProcessGroupNCCL = RCCL; default, the path exercised so far), the "
                          "library's own communicator (tmac_hip_comm_*: RCCL through the C-ABI, bootstrapped over torch.distributed), or its "
                          "IPC transport (windows mapped by every peer, no RCCL; tests/test_gpu_comm.py runs it with two processes on one device)")
+    ap.add_argument("--no-prefill-headline", action="store_true", help="multi-GPU decode runs: skip the N = 256 prefill measurement reported next to the decode line")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # debugging: take the multi-GPU code path with 1 rank
     ap.add_argument("--share-device", action="store_true",
                     help="test mode (tests/test_gpu_comm.py): every rank uses device 0 -- RCCL refuses that, so torch.distributed runs on gloo with host "
@@ -128,6 +129,32 @@ CPU_SETS = {
 }
 
 
+def _usable_cores():
+    """host threads this process may run on (the cpuset of a container can be far smaller than os.cpu_count(): an OpenMP team of
+    cpu_count threads on it is oversubscribed and collapses -- 0.098 GB/s at "256 threads" in round 4's line)"""
+    try:
+        n = max(1, len(os.sched_getaffinity(0)))
+    except Exception:
+        n = os.cpu_count() or 1
+    # ... and a CPU quota (cgroup v2 cpu.max / v1 cfs quota) caps what a team of busy threads gets, whatever the affinity mask says
+    for quota_path, period_path in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            with open(quota_path) as f:
+                parts = f.read().split()
+            if period_path is None:
+                q, per = parts[0], parts[1]
+            else:
+                q = parts[0]
+                with open(period_path) as f:
+                    per = f.read().split()[0]
+            if q != "max" and int(q) > 0:
+                n = max(1, min(n, int(q) // int(per)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(workload="llama2-7b-w2", seconds=6.0):
     """The reference's own CPU code (oracle/_ref, built from /root/reference by oracle/Makefile) — or, if that prebuilt file is
     absent, our scalar port — timed on this box's host cores over a bounded sample: one matrix of each of the three shapes of
@@ -138,7 +165,7 @@ def cpu_baseline(workload="llama2-7b-w2", seconds=6.0):
     Test-infrastructure code used as a reported baseline."""
     import ctypes as C
     from oracle import oracle as orc
-    cores = os.cpu_count() or 1
+    cores = _usable_cores()
     rng = np.random.default_rng(0)
     wl = WORKLOADS[workload]
     bitnet = wl["mg"] >= 1
@@ -196,7 +223,8 @@ def cpu_baseline(workload="llama2-7b-w2", seconds=6.0):
         return time.perf_counter() - t0
 
     out = {}
-    thread_counts = sorted({1, min(cores, 8), min(cores, 32), min(cores, 64), cores}) if kind == "reference" else [1]
+    # (the largest team stops at 128: on a 256-thread host whose container gets a share of them the full team measured 0.1 GB/s in rounds 4 / 5)
+    thread_counts = sorted({1, min(cores, 8), min(cores, 32), min(cores, 64), min(cores, 128)}) if kind == "reference" else [1]
     for nthreads in thread_counts:
         run_once(nthreads)
         best, t_end, reps = 1e9, time.perf_counter() + seconds / len(thread_counts), 0
@@ -204,7 +232,7 @@ def cpu_baseline(workload="llama2-7b-w2", seconds=6.0):
             best = min(best, run_once(nthreads)); reps += 1
         out[nthreads] = total_bytes / best / 1e9
     used = max(out, key=out.get)
-    return {"value": round(out[used], 3), "unit": "GB/s", "cores": used, "kind": kind, "host_cores": cores,
+    return {"value": round(out[used], 3), "unit": "GB/s", "cores": used, "kind": kind, "host_cores": cores, "host_cores_total": os.cpu_count(),
             "by_threads_GBps": {str(k): round(v, 3) for k, v in out.items()}, "code": what,
             "sample": "one GEMV of each of the layer's three shapes (%s; preprocessor + all tiles, bm = %d), OpenMP static tile split, "
                       "best of >=5; value = best thread count" % (", ".join(f"{m}x{k}" for m, k, _ in shapes), BM)}
@@ -224,7 +252,7 @@ def cpu_baseline_prefill(workload, seconds=8.0, rows=8):
     setname, BITS, BM, shapes = CPU_SETS[base]
     if not orc.have_ref(setname):
         return {"note": "oracle/_ref is not built here"}
-    cores = os.cpu_count() or 1
+    cores = _usable_cores()
     rng = np.random.default_rng(0)
     GS, AGS = 128, 64
     drv = C.CDLL(os.path.join(ROOT, "oracle", "libref_driver.so"))
@@ -260,7 +288,7 @@ def cpu_baseline_prefill(workload, seconds=8.0, rows=8):
         return per_layer
 
     out = {}
-    thread_counts = sorted({1, min(cores, 8), min(cores, 32), min(cores, 64), cores})
+    thread_counts = sorted({1, min(cores, 8), min(cores, 32), min(cores, 64), min(cores, 128)})
     for nthreads in thread_counts:
         run_once(nthreads)
         best, t_end, reps = 1e9, time.perf_counter() + seconds / len(thread_counts), 0
@@ -276,42 +304,20 @@ def cpu_baseline_prefill(workload, seconds=8.0, rows=8):
                       % (rows, ", ".join(f"{m}x{k}" for m, k, _ in shapes), wl["layers"])}
 
 
-def main():
-    args = parse()
+def run(args, env):
+    """one workload, measured as the contract says; returns the result dict on rank 0 (None elsewhere).  env: what main() set up once
+    per process (torch.distributed, the kept stdout)"""
+    import torch
+    import torch.distributed as dist
     wl = WORKLOADS[args.workload]
     MATS, BITS, BM, GS, ZP, MG, N = wl["mats"], wl["bits"], wl["bm"], wl["gs"], wl["zp"], wl["mg"], wl["N"]
     decode = N == 1
-    # The contract is ONE JSON line on stdout.  Libraries underneath write banners to file descriptor 1 (RCCL prints its
-    # version block there under torchrun), so everything else that reaches fd 1 is sent to stderr and the original stdout
-    # is kept for the result line alone.
-    sys.stdout.flush()
-    result_fd = os.dup(1)
-    os.dup2(2, 1)
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
-    if args.share_device:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dist_on = world > 1 or args.force_dist
+    world, rank, local_rank, dist_on = env["world"], env["rank"], env["local_rank"], env["dist_on"]
     chain_ok = decode and args.variant == 0
     if args.path == "auto":
         args.path = "chain" if chain_ok else "fused"
     if args.path == "chain" and not chain_ok:
         raise SystemExit("bench.py: --path chain covers N = 1")
-    if dist_on:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if "MASTER_ADDR" not in os.environ:
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
-        if args.share_device:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # the few collectives of the bootstrap and the timing: on the device through RCCL, or -- test mode -- through host tensors on gloo
     def d_all_reduce(t, op):
@@ -472,7 +478,10 @@ def main():
     outs_l = [outs] + [{name: [torch.empty_like(o) for o in outs[name]] for name in outs} for _ in range(args.layers - 1)] \
         if args.pattern == "independent" else [outs] * args.layers
 
+    step_in = [None]            # the tensor the most recent step() read as its first activation block (a replayed graph / chain keeps reading THAT one)
+
     def step():
+        step_in[0] = x[MATS[0][4]]
         for li in range(args.layers):
             calls(layers[li], x, outs_l[li])
 
@@ -725,6 +734,52 @@ def main():
         torch.cuda.synchronize()
         done.set()
 
+    # ---- multi-GPU preflight (before anything is timed): which path and transport every rank took, and one step of the path being timed
+    # against a communication-free emulation of the same step on every rank.  All ranks hold the same synthetic shard (same seed), so the
+    # all-gather of an output is that output repeated `world` times: each rank can replay the whole step alone -- the same calls launched
+    # one by one with the chain's launch configuration, the gather replaced by a local repeat -- and must arrive at the same last-layer
+    # outputs as the distributed step (same bits when the paths share the configuration; a wrong or stale exchange is off by O(1)).
+    preflight = None
+    if dist_on and dpat is None:
+        path_txt = ("row-sharded persistent chain: hand-off granules stored into every rank's IPC-mapped arena (system scope over xGMI)" if chain is not None else
+                    "one launch per fused call + all-gather per exchange step over " +
+                    {"torch": "torch.distributed (ProcessGroupNCCL = RCCL)", "lib": "tmac_hip_comm (RCCL through the C-ABI)", "ipc": "tmac_hip_comm IPC windows"}[args.comm] +
+                    (", replayed from a hipGraph" if graph is not None else ", eager"))
+        sys.stderr.write(f"bench.py preflight: rank {rank}/{world} device {local_rank}: {path_txt}\n")
+        try:
+            src_key = MATS[0][4]
+            # what the step about to run reads first: a replay reads the tensor of the recorded / captured call, an eager step the current one
+            xin0 = (step_in[0] if (chain is not None or graph is not None) else x[src_key]).clone()
+            run_step()
+            torch.cuda.synchronize()
+            got = {name: [o.clone() for o in outs[name]] for name in outs}
+            xe = {src_key: xin0}
+            tmp = {name: [torch.empty_like(o) for o in outs[name]] for name in outs}
+            opi = 0
+            for li in range(args.layers):
+                for name, Mw, K, cnt, slot in MATS:
+                    if chain is not None:
+                        L.tmac_hip_debug_quad_config(chain.threads, chain.wpq(opi))
+                    wr.fused(layers[li][name], xe[slot], tmp[name], N, act_dtype=F16, out_dtype=F16)
+                    o0 = tmp[name][0]
+                    xe[nxt[name]] = (o0.repeat(world)[:logical[name]] if decode else o0.repeat(1, world)[:, :logical[name]].contiguous())
+                    opi += 1
+            L.tmac_hip_debug_quad_config(0, 0)
+            torch.cuda.synchronize()
+            same = all(bool(torch.equal(a_, b_)) for name in outs for a_, b_ in zip(got[name], tmp[name]))
+            worst = max(float((a_.float() - b_.float()).abs().max() / b_.float().abs().max().clamp_min(1e-30)) for name in outs for a_, b_ in zip(got[name], tmp[name]))
+            okf = torch.tensor([1 if (same or worst <= 1e-2) else 0, 1 if same else 0], dtype=torch.int32, device=dev)
+            d_all_reduce(okf, dist.ReduceOp.MIN)
+            wt = torch.tensor([worst], dtype=torch.float64, device=dev)
+            d_all_reduce(wt, dist.ReduceOp.MAX)
+            preflight = {"ok": bool(okf[0].item()), "bit_identical_on_every_rank": bool(okf[1].item()), "max_rel_diff": float("%.3g" % wt.item()),
+                         "what": "one step of the timed path vs the same %d calls launched one by one on each rank with the all-gathers replaced by local repeats "
+                                 "(identical synthetic shards), last layer's outputs" % (len(MATS) * args.layers), "path": path_txt}
+            sys.stderr.write(f"bench.py preflight: rank {rank}: step reproduced {'bit for bit' if same else 'to %.3g' % worst}\n")
+            if not preflight["ok"]:
+                raise SystemExit("bench.py: PREFLIGHT FAILED: the distributed step differs from its single-rank emulation (%r)" % (preflight,))
+        except tmac_amd.binding.TMACHipError as e:
+            preflight = {"error": repr(e)}
     for _ in range(args.warmup):
         run_step()
     barrier()
@@ -839,25 +894,71 @@ def main():
         # MALL), every call fed by the same external vector -- no hand-off anywhere, so what is left is activation fetch, LUT build,
         # lookups, reduction and publish of a workgroup, call after call.  Separates "issue / structure bound" from "latency bound".
         if not dist_on and not args.no_stream_core:
-            sx = torch.randn(K, device=dev, generator=gen).half()
+            # SURVEY 8(d)'s headline measurement: back-to-back INDEPENDENT GEMVs of the target shape over rotating distinct weights (> MALL in
+            # total), a distinct activation vector per call.  Nothing is handed over, so the recording runs in stream mode: tables once per
+            # call by k_lut_images (the reference's llama_cpp_init), lookups by k_gemv_stream (its llama_cpp_compute); both launches timed.
+            sxs = [torch.randn(K, device=dev, generator=gen).half() for _ in range(args.layers)]
             souts = [[torch.empty(shard_rows[name], dtype=torch.float16, device=dev)] for _ in range(args.layers)]
             with wr.record_chain() as srec:
                 for li in range(args.layers):
-                    wr.fused(layers[li][name], sx, souts[li], 1, act_dtype=F16, out_dtype=F16)
-            sdur = []
+                    wr.fused(layers[li][name], sxs[li], souts[li], 1, act_dtype=F16, out_dtype=F16)
+            sdur, SB = [], 10           # SB replays back to back per event pair: launches overlap their predecessors' tails as in any timed loop
             for r in range(13):
                 e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                e0.record(); srec.chain.launch(); e1.record()
+                e0.record()
+                for _ in range(SB):
+                    srec.chain.launch()
+                e1.record()
                 torch.cuda.synchronize()
                 if r >= 3:
-                    sdur.append(e0.elapsed_time(e1) * 1e-3 / args.layers)
+                    sdur.append(e0.elapsed_time(e1) * 1e-3 / (SB * args.layers))
             sok = srec.chain.status() == 0
+            # the launch's outputs against the same calls launched one by one (whose integer path the parity tests tap): same bits
+            L.tmac_hip_debug_quad_config(srec.chain.threads, srec.chain.wpq(0))
+            sref = [torch.empty_like(souts[0][0])]
+            ssame = True
+            for li in (0, args.layers // 2, args.layers - 1):
+                wr.fused(layers[li][name], sxs[li], sref, 1, act_dtype=F16, out_dtype=F16)
+                torch.cuda.synchronize()
+                ssame = ssame and bool(torch.equal(sref[0], souts[li][0]))
+            L.tmac_hip_debug_quad_config(0, 0)
+            smode = "k_lut_images + k_gemv_stream (stream mode)" if getattr(srec.chain, "stream", False) else "k_decode_chain"
             srec.chain.free()
             sus = float(np.mean(sdur)) * 1e6
-            roof["stream_core"] = {"what": "one k_decode_chain launch over %d x %s (%dx%d, distinct weights), every call reading ONE external vector: no hand-offs"
-                                           % (args.layers, name, Mw, K), "us_per_gemv": round(sus, 3), "GBps": round(hb / sus * 1e-3, 1),
-                                   "frac": round(hb / sus * 1e-3 / HBM_PEAK_GBS, 4), "ok": sok,
-                                   "timing": "hipEvent pair around the launch, mean of 10"}
+            roof["stream_core"] = {"what": "%d independent GEMVs %s (%dx%d, distinct weights, a distinct activation vector each) recorded once, launched as %s: "
+                                           "tables built once per call, lookups with the tables prebuilt, no hand-offs" % (args.layers, name, Mw, K, smode),
+                                   "us_per_gemv": round(sus, 3), "min_us": round(float(np.min(sdur)) * 1e6, 3), "GBps": round(hb / sus * 1e-3, 1),
+                                   "frac": round(hb / sus * 1e-3 / HBM_PEAK_GBS, 4), "ok": sok and ssame,
+                                   "bit_identical_to_single_launches": ssame,
+                                   "timing": "hipEvent pair around 10 back-to-back replays (LUT build launches included), mean of 10 pairs"}
+            # ... and the whole token's 224 matrices as independent calls (what --pattern independent times): every call reads a resident vector
+            try:
+                ix = {s_: torch.randn(xdim[s_], device=dev, generator=gen).half() for s_ in xdim}
+                iouts = [{n_: [torch.empty_like(o) for o in outs[n_]] for n_ in outs} for _ in range(args.layers)]
+                with wr.record_chain() as irec:
+                    for li in range(args.layers):
+                        calls(layers[li], ix, iouts[li], link=False)
+                idur = []
+                for r in range(8):
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(10):
+                        irec.chain.launch()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if r >= 3:
+                        idur.append(e0.elapsed_time(e1) / 10)
+                iok = irec.chain.status() == 0
+                imode = "stream mode" if getattr(irec.chain, "stream", False) else "k_decode_chain"
+                irec.chain.free()
+                ims = float(np.mean(idur))
+                roof["independent_pattern"] = {"what": "the token's %d mpGEMMs as independent calls (each reads a vector that is in memory before the launch), %s"
+                                                       % (7 * args.layers, imode), "ms_per_token": round(ims, 4),
+                                               "GBps": round(bytes_per_step / (ims * 1e-3) / 1e9, 1),
+                                               "frac": round(bytes_per_step / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ok": iok}
+                del iouts
+            except Exception as e:
+                roof["independent_pattern"] = {"error": repr(e)}
         # the same matrices as a decoder issues them (outside the timed region; --pattern decoder makes it the timed workload)
         if not dist_on and dpat is None and args.pattern == "chained" and not args.no_decoder_pattern:
             try:
@@ -1000,6 +1101,7 @@ def main():
                        "launch": ("one persistent launch per step" + (" and rank, hand-off across ranks through IPC-mapped arenas" if world > 1 else ""))
                                  if args.path == "chain" else ("hipGraph replay" if use_graph else "eager")},
             "roofline": roof,
+            "preflight": preflight,
             "verified": verified,
             "activations_finite": finite,
             "event_ms_per_step": round(ev_ms_per_step, 4),
@@ -1015,6 +1117,75 @@ def main():
                 res["cpu_baseline"] = cpu_baseline_prefill(args.workload)
             except Exception as e:
                 res["cpu_baseline"] = {"error": repr(e)}
+    else:
+        res = None
+    # release this workload's device memory (a multi-GPU decode run measures the prefill twin next, in the same process)
+    try:
+        if chain is not None:
+            chain.free()
+        for mats in layers:
+            for ws in mats.values():
+                for w_ in ws:
+                    w_.free()
+        torch.cuda.synchronize()
+    except Exception:
+        pass
+    return res
+
+
+PREFILL_TWIN = {"llama2-7b-w2": "llama2-7b-w2-prefill", "llama2-7b-w4": "llama2-7b-w4-prefill", "bitnet-3b": "bitnet-3b-prefill"}
+
+
+def main():
+    args = parse()
+    # The contract is ONE JSON line on stdout.  Libraries underneath write banners to file descriptor 1 (RCCL prints its
+    # version block there under torchrun), so everything else that reaches fd 1 is sent to stderr and the original stdout
+    # is kept for the result line alone.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.share_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"), RANK="0", WORLD_SIZE="1")
+        if args.share_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    env = dict(world=world, rank=rank, local_rank=local_rank, dist_on=dist_on)
+    res = run(args, env)
+    # Scaling headline.  Decode is a chain of dependent GEMVs whose hand-off and LUT build do not shrink with the number of GPUs (DESIGN 6:
+    # 1.3 / 1.6 / 1.9 x at 2 / 4 / 8 by the model); the prefill GEMM of the same matrices (N = 256, BASELINE config 5) is compute-bound and
+    # splits by rows with one all-gather per call -- so a multi-GPU run also measures it, on the same ranks, and rank 0 reports both.
+    if world > 1 and WORKLOADS[args.workload]["N"] == 1 and args.workload in PREFILL_TWIN and not args.no_prefill_headline:
+        import copy
+        a2 = copy.copy(args)
+        a2.workload, a2.path, a2.pattern = PREFILL_TWIN[args.workload], "auto", "chained"
+        a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_verify, a2.stamps = 10, 2, True, True, False
+        a2.layers = min(args.layers, WORKLOADS[a2.workload]["layers"])
+        try:
+            r2 = run(a2, env)
+            head = None if r2 is None else {k: r2.get(k) for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "steps", "scaling", "dtype")}
+            if head is not None:
+                head["workload"] = r2["config"]["workload"]
+                head["launch"] = r2["config"]["launch"]
+        except BaseException as e:      # the decode number is never lost to the extra measurement
+            head = {"error": repr(e)}
+        if res is not None:
+            res["prefill_scaling_headline"] = head
+    if rank == 0 and res is not None:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(res) + "\n").encode())
     if dist_on:

@@ -202,6 +202,11 @@ def test_bench_ranks_share_the_device(tm, workload, extra, nranks):
     d = json.loads(lines[0])
     assert d["n_gpus"] == nranks and d["value"] > 0 and d["steps"] == 5
     assert d["config"]["parallelism"] == f"row-shard x{nranks}"
+    # the preflight: one step of the timed path reproduced by every rank's communication-free emulation (same bits: same launch configuration)
+    assert d["preflight"]["ok"] and d["preflight"]["bit_identical_on_every_rank"], d["preflight"]
     if not workload.endswith("prefill"):
         assert d["config"]["path"] == "chain", d["config"]
         assert d.get("activations_finite", True)
+        # ... and a multi-GPU decode run reports the prefill twin of the same matrices as its scaling headline
+        h = d["prefill_scaling_headline"]
+        assert "error" not in h and h["value"] > 0 and h["n_gpus"] == nranks and h["workload"].endswith("prefill-256"), h

@@ -78,6 +78,10 @@ int ggml_tmac_hip_segment_mul_mat(const struct tmac_ggml_tensor* const* w, int n
  * fp32 values, as tmac_hip_qgemm_fused_dev does on its own */
 int ggml_tmac_hip_segment_mul_mat_f32(const struct tmac_ggml_tensor* const* w, int nw, const float* x_f32, void* const* dst_f16);
 int ggml_tmac_hip_segment_end(ggml_tmac_hip_segment** seg);
+/* A segment is all or nothing: when ggml_tmac_hip_segment_mul_mat or _end returns non-zero the recording is over (no chain exists, nothing
+ * is pending) and the caller evaluates the graph's own nodes -- the element-wise operators of a segment have no stand-alone counterpart in
+ * this library.  ggml_tmac_hip_segment_abort ends a recording explicitly (after a failed _norm / _glu, or a change of mind). */
+int ggml_tmac_hip_segment_abort(void);
 int ggml_tmac_hip_segment_compute(ggml_tmac_hip_segment* seg);   /* one launch on ggml_tmac_hip_stream(); does not wait */
 int ggml_tmac_hip_segment_wait(ggml_tmac_hip_segment* seg);      /* synchronises the stream; 0 if every hand-off of the segment's launches completed */
 void ggml_tmac_hip_segment_free(ggml_tmac_hip_segment* seg);

@@ -164,6 +164,8 @@ int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weights, int nma
 typedef struct tmac_hip_chain tmac_hip_chain;
 int32_t tmac_hip_chain_begin(void);
 int32_t tmac_hip_chain_end(tmac_hip_chain** out);
+/* ends the recording without building a chain (after an error while recording: the thread launches its calls again) */
+int32_t tmac_hip_chain_abort(void);
 int32_t tmac_hip_chain_launch(tmac_hip_chain* chain, void* stream);
 /* after synchronising the stream: *error_word == 0 means every hand-off completed; otherwise (bit 31 | op << 8 | wave of
  * the first wave that gave up) the outputs of that launch are invalid.  Clears the word and re-arms the chain. */
@@ -190,7 +192,11 @@ int32_t tmac_hip_chain_free(tmac_hip_chain* chain);
  *                 hand-off, that call publishes silu(in) * in2 itself, once per row, rounded to fp16 like every handed-over vector)
  * A decoder then runs one launch per segment between two operators that stay outside (attention): o -> gate/up -> down -> next q/k/v.
  * These are extensions without a reference counterpart (T-MAC has no norm operator): tests compare them with the same formulas in
- * numpy fed through the oracle (tolerance, not bits: the mean square is summed in another order). */
+ * numpy fed through the oracle (tolerance, not bits: the mean square is summed in another order).
+ * NO PER-CALL FALLBACK: "-1 from tmac_hip_chain_end, keep launching the calls one by one" holds for recordings WITHOUT transforms only --
+ * a transform has no stand-alone counterpart in this library.  A caller that records transforms must be able to run the operators itself
+ * (ggml does: the segment glue is an optimisation of a graph that already has norm / glu nodes) when tmac_hip_chain_end refuses the
+ * recording (LDS beyond 160 KB, K beyond the limits above).  A transform declared in front of a call that is rejected is dropped with it. */
 #define TMAC_XF_NONE 0
 #define TMAC_XF_NORM 1
 #define TMAC_XF_GLU 2

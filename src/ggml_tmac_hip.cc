@@ -194,7 +194,9 @@ static int segment_mul_mat(const struct tmac_ggml_tensor* const* w, int nw, cons
         wl[i] = ((const Handle*)w[i]->extra)->w;
         cl[i] = dst_f16[i];
     }
-    return tmac_hip_qgemm_fused_dev(wl, nw, x, x_dtype, cl, TMAC_F16, 1, g_stream);   // recorded, not launched
+    const int rc = tmac_hip_qgemm_fused_dev(wl, nw, x, x_dtype, cl, TMAC_F16, 1, g_stream);   // recorded, not launched
+    if (rc) (void)tmac_hip_chain_abort();     // a segment is all or nothing: the recording ends here, the caller runs the graph's own nodes
+    return rc;
 }
 
 extern "C" int ggml_tmac_hip_segment_mul_mat(const struct tmac_ggml_tensor* const* w, int nw, const void* x_f16, void* const* dst_f16) {
@@ -205,10 +207,12 @@ extern "C" int ggml_tmac_hip_segment_mul_mat_f32(const struct tmac_ggml_tensor* 
     return segment_mul_mat(w, nw, x_f32, TMAC_F32, dst_f16);
 }
 
+extern "C" int ggml_tmac_hip_segment_abort(void) { return tmac_hip_chain_abort(); }
+
 extern "C" int ggml_tmac_hip_segment_end(ggml_tmac_hip_segment** seg) {
-    if (!seg) return fail("null argument");
+    if (!seg) { (void)tmac_hip_chain_abort(); return fail("null argument"); }
     tmac_hip_chain* c = nullptr;
-    int rc = tmac_hip_chain_end(&c);
+    int rc = tmac_hip_chain_end(&c);      // (ends the recording whether or not a chain comes out of it)
     if (rc) return rc;
     *seg = new ggml_tmac_hip_segment{c};
     return 0;

@@ -158,3 +158,28 @@ def test_presets_and_checkpoint_discovery(tmp_path):
     _fake_checkpoint(d3, [(2, 64, 256, 128)], desc_act=True)
     with pytest.raises(AssertionError):
         convert.get_quantization_config(d3)
+
+
+def test_corrupt_checkpoint_parts_are_named(tmp_path):
+    """a truncated or malformed safetensors part surfaces as a RuntimeError that names the file, not as a bare struct / JSON /
+    ZeroDivisionError"""
+    import json
+    import struct
+    from tmac_amd import convert as cv
+    d = tmp_path / "ckpt"; d.mkdir()
+    p = d / "model.safetensors"
+    p.write_bytes(b"\x10\x00\x00")                                       # shorter than the length field
+    with pytest.raises(RuntimeError, match="model.safetensors"):
+        cv.extract_kernel_shapes("gptq-auto", str(d))
+    p.write_bytes(struct.pack("<Q", 1 << 40) + b"{}")                     # header length beyond the file
+    with pytest.raises(RuntimeError, match="corrupt safetensors header"):
+        cv.extract_kernel_shapes("gptq-auto", str(d))
+    p.write_bytes(struct.pack("<Q", 5) + b"{oops")                        # not JSON
+    with pytest.raises(RuntimeError, match="corrupt safetensors header"):
+        cv.extract_kernel_shapes("gptq-auto", str(d))
+    hdr = {"l.qweight": {"dtype": "I32", "shape": [256, 64], "data_offsets": [0, 0]}, "l.scales": {"dtype": "F16", "shape": [32, 64], "data_offsets": [0, 0]},
+           "l.qzeros": {"dtype": "I32", "shape": [32, 0], "data_offsets": [0, 0]}}
+    raw = json.dumps(hdr).encode()
+    p.write_bytes(struct.pack("<Q", len(raw)) + raw)                     # a zero-width qzeros tensor
+    with pytest.raises(RuntimeError, match="not GPTQ-packed shapes"):
+        cv.extract_kernel_shapes("gptq-auto", str(d))

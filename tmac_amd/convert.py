@@ -45,10 +45,19 @@ def _safetensors_shapes(path: str) -> Dict[str, Tuple[str, Tuple[int, ...]]]:
     shapes are known after reading a few hundred KB, no tensor is loaded (the reference reads every scales / qzeros / qweight tensor)"""
     import json
     import struct
+    size = os.path.getsize(path)
     with open(path, "rb") as f:
-        (n,) = struct.unpack("<Q", f.read(8))
-        hdr = json.loads(f.read(n))
-    return {k: (v["dtype"], tuple(v["shape"])) for k, v in hdr.items() if k != "__metadata__"}
+        head = f.read(8)
+        if len(head) != 8:
+            raise RuntimeError("{}: not a safetensors file (shorter than its header length field)".format(path))
+        (n,) = struct.unpack("<Q", head)
+        if n == 0 or n > size - 8:
+            raise RuntimeError("{}: corrupt safetensors header (length {} in a file of {} bytes)".format(path, n, size))
+        try:
+            hdr = json.loads(f.read(n))
+            return {k: (v["dtype"], tuple(int(d) for d in v["shape"])) for k, v in hdr.items() if k != "__metadata__"}
+        except (ValueError, KeyError, TypeError) as e:
+            raise RuntimeError("{}: corrupt safetensors header ({})".format(path, e))
 
 
 def extract_kernel_shapes(model_arch: Optional[str] = "gptq-auto", model_dir: Optional[str] = None) -> List[List[int]]:
@@ -85,7 +94,11 @@ def _scan_checkpoint(model_dir: Optional[str]) -> Tuple[List[List[int]], int]:
         qw, sc, qz = shapes[name], shapes.get(name[:-8] + ".scales"), shapes.get(name[:-8] + ".qzeros")
         if sc is None or qz is None:
             raise RuntimeError("{}: scales / qzeros missing".format(name))
+        if len(qw) != 2 or len(sc) != 2 or len(qz) != 2 or qz[1] <= 0 or sc[0] <= 0 or sc[1] < qz[1]:
+            raise RuntimeError("{}: qweight {} / scales {} / qzeros {} are not GPTQ-packed shapes".format(name, qw, sc, qz))
         bits = 32 // (sc[1] // qz[1])                      # parse_gptq on shapes alone
+        if bits not in (1, 2, 3, 4, 8):
+            raise RuntimeError("{}: {} values per packed word".format(name, sc[1] // qz[1]))
         K, M = qw[0] * (32 // bits), qw[1]
         gs = K // sc[0]
         if [bits, M, K, 1, -1] not in ks:

@@ -62,10 +62,11 @@ struct tmac_hip_chain {
 
 int32_t tmac_host::chain_record(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
                             void* const* C_list, tmac_dtype_t out_dtype, int N) {
-    if (N != 1) return fail(TMAC_HIP_E_NOMATCH, "a decode chain records N = 1 calls only");
+    // (a rejected call must not leave its transform pending for the next recorded call)
+    if (N != 1) { memset(&g_chain_xf, 0, sizeof(g_chain_xf)); return fail(TMAC_HIP_E_NOMATCH, "a decode chain records N = 1 calls only"); }
     ChainRecOp op;
     for (int i = 0; i < nmat; ++i) {
-        if (!wl[i] || !C_list[i]) return fail(TMAC_HIP_E_ARG, "null matrix or output");
+        if (!wl[i] || !C_list[i]) { memset(&g_chain_xf, 0, sizeof(g_chain_xf)); return fail(TMAC_HIP_E_ARG, "null matrix or output"); }
         op.w.push_back(wl[i]);
         op.C.push_back(C_list[i]);
     }
@@ -90,6 +91,17 @@ extern "C" int32_t tmac_hip_chain_begin(void) {
     if (g_chain_rec) return fail(TMAC_HIP_E_ARG, "a chain is already being recorded on this thread");
     g_chain_rec = new std::vector<ChainRecOp>();
     g_chain_gat = new std::vector<ChainRecGather>();
+    memset(&g_chain_xf, 0, sizeof(g_chain_xf));
+    return TMAC_HIP_OK;
+}
+
+// Ends a recording without building anything (a caller whose recording hit an error: the thread is free to launch calls again).
+extern "C" int32_t tmac_hip_chain_abort(void) {
+    if (!g_chain_rec) return TMAC_HIP_OK;
+    delete g_chain_rec;
+    delete g_chain_gat;
+    g_chain_rec = nullptr;
+    g_chain_gat = nullptr;
     memset(&g_chain_xf, 0, sizeof(g_chain_xf));
     return TMAC_HIP_OK;
 }
@@ -367,7 +379,6 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             if (xf.kind == TMAC_XF_NORM) {
                 c->xforms = 1;
                 if (o.K > 2 * 8 * CHAIN_FT) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: a NORM transform is covered up to K = %d", i, 2 * 8 * CHAIN_FT));
-                if (c->grid > 256 && xf.residual_out) return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: residual_out is covered with up to 256 workgroups", i));
                 if (o.K > 8192 && (xf.keep || xf.residual == TMAC_XF_CARRY))
                     return bail(fail(TMAC_HIP_E_NOMATCH, "op %zu: a kept residual vector is covered up to K = 8192", i));
                 const int rf = chain_xf_region_floats(o.K);
@@ -645,6 +656,10 @@ extern "C" int32_t tmac_hip_chain_status(tmac_hip_chain* c, uint32_t* error_word
         // workgroup out advances): the generation stays in step with the peers of a row-sharded chain, which count launches the same
         // way -- re-arming one rank here would leave it a generation apart from its peers for good.  Only the error word (and a partial
         // exit count, should the launch have been killed from outside) is cleared.
+        // A partial exit count means the launch never advanced the generation: the next launch reuses it and the same arena half, where
+        // the granules the dead launch already published carry a matching tag.  They are wiped (tag 0 is never a generation), so the
+        // next launch waits for data of its own.
+        if (ctl[1] && c->arena) HIP_TRY(hipMemset(c->arena, 0, 2 * c->arena_bytes));
         const unsigned fresh[4] = {ctl[0], 0u, 0u, 0u};
         HIP_TRY(hipMemcpy(c->ctl, fresh, sizeof(fresh), hipMemcpyHostToDevice));
     }

@@ -140,6 +140,7 @@ extern "C" int32_t tmac_hip_comm_init_ipc(tmac_hip_comm** out, size_t max_bytes_
         hipMalloc((void**)&c->err, 256) != hipSuccess || hipMemset(c->err, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
         snprintf(g_comm_err, sizeof(g_comm_err), "window allocation failed (%zu bytes)", total);
         if (c->win) (void)hipFree(c->win);
+        if (c->err) (void)hipFree(c->err);
         delete c;
         return TMAC_HIP_E_RUNTIME;
     }

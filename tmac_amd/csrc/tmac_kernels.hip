@@ -645,7 +645,10 @@ hipError_t launch_preprocess(const void* B, Dtype act_dt, int8_t* qlut_ref, void
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_ipc_allgather(IpcGatherArgs a) {
     const int p = blockIdx.x, tid = threadIdx.x, half = (int)(a.gen & 1u);
-    const size_t n16 = a.bytes / 16;
+    // 16-byte copies only when every address they touch is 16-byte aligned (the windows are; a caller's send / recv buffers and a per-rank
+    // size that is not a multiple of 16 -- which shifts the slots of ranks >= 1 -- need not be): else bytewise
+    const bool al16 = ((reinterpret_cast<size_t>(a.send) | reinterpret_cast<size_t>(a.recv) | a.bytes) & 15) == 0;
+    const size_t n16 = al16 ? a.bytes / 16 : 0;
     if (p == a.rank) {
         const uint4* src = reinterpret_cast<const uint4*>(a.send);
         uint4* w = reinterpret_cast<uint4*>(a.win[p] + (size_t)half * a.win_half);

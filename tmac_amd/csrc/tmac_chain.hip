@@ -120,16 +120,14 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
 #define CSTAMPV(i, k, v) do { if (a.stamps && tid == (((k) == 5 || (k) == 6) ? 0 : FT - 64)) a.stamps[((size_t)(i) * gx + bx) * 8 + (k)] = (v); } while (0)
 #define CSTAMP(i, k) CSTAMPV(i, k, __builtin_amdgcn_s_memrealtime())
 
-    qv4i_t bsel;
-    {
-        const int jrel = (lane & 15) - 4 * (lane >> 4);
-        const uint32_t be = (jrel >= 0 && jrel < 4) ? (0x01u << (8 * jrel)) : 0u, bo = (jrel >= 0 && jrel < 4) ? (0xfeu << (8 * jrel)) : 0u;   // +1 | -2
-        bsel = (qv4i_t){(int)be, (int)bo, (int)be, (int)bo};
-    }
+    CSel<BITS> sel;
+    c_selectors<BITS, SM>(sel, lane);
     uint32_t k3 = 0x03020100u;
     asm volatile("" : "+v"(k3));
     uint32_t lane16 = (uint32_t)lane * 16u;
     asm volatile("" : "+v"(lane16));
+    uint32_t lk4 = 4u * (uint32_t)(2 * (lane & 12) + 2 * (lane >> 4));      // the lane's two act groups inside a step's 32 (c_compute)
+    asm volatile("" : "+v"(lk4));
 
     // LUT pair of this thread in round r: r * FT + tpair.  The waves take the 64-pair blocks of a round in REVERSE order (lanes in
     // order: the build's DPP sums depend on it): wave 0 -- which combines and publishes every workgroup iteration and therefore enters
@@ -199,7 +197,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         const int n_items = ro.nquads * ro.nsteps;
         __amdgpu_buffer_rsrc_t q_rs = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint4*>(nullptr), (short)0, 0, 0x00020000);
         const TMAC_GLOBAL char* q_sc = nullptr;
-        int q_woff = 0, q_res = -1;
+        const TMAC_GLOBAL char* q_scm = nullptr;
+        int q_woff = 0, q_res = -1, q_mi = -1;
         int i_it = 0, i_st = h, issued = 0;
         auto issue_next = [&](CFrag<BITS>& f) __attribute__((always_inline)) {
             if (issued < n_items) {
@@ -207,8 +206,12 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     const int gqi = ro.q_lo + ro.qs + i_it * ro.ipi;
                     const int mi = epi ? (gqi & 1) : (gqi >= qe0 ? 1 : 0) + (gqi >= qe1 ? 1 : 0) + (gqi >= qe2 ? 1 : 0);
                     const int lq = epi ? (gqi >> 1) : gqi - (gqi >= qe2 ? qe2 : (gqi >= qe1 ? qe1 : (gqi >= qe0 ? qe0 : 0)));
-                    q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(uni(d->m[mi].W)), (short)0, 0x7fffffff, 0x00020000);
-                    q_sc = as_global(uni(reinterpret_cast<const char*>(d->m[mi].SC))) + (size_t)lq * (size_t)(nsg * 4 * (ZP ? 2 : 1) * (SCF16 ? 2 : 4));
+                    if (mi != q_mi) {       // the matrix' pointers: two LDS reads + five readfirstlane -- per matrix a wave enters, not per quad
+                        q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(uni(d->m[mi].W)), (short)0, 0x7fffffff, 0x00020000);
+                        q_scm = as_global(uni(reinterpret_cast<const char*>(d->m[mi].SC)));
+                        q_mi = mi;
+                    }
+                    q_sc = q_scm + (size_t)lq * (size_t)(nsg * 4 * (ZP ? 2 : 1) * (SCF16 ? 2 : 4));
                     q_woff = lq * nst * (BITS * 1024);
                     q_res = i_it;
                 }
@@ -773,7 +776,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             while (left > 0) {
 #pragma unroll
                 for (int k = 0; k < RING; ++k) {
-                    c_compute<BITS, ZP, SCF16, SM>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane, bsel, k3, cacc, iacc);
+                    c_compute<BITS, ZP, SCF16, SM>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane16, lk4, sel, k3, cacc, iacc);
                     issue_next(ring[k]);               // refill this slot with the item RING places ahead, if there is one
                     c_st += wpq;
                     if (c_st >= nst) {

@@ -131,19 +131,39 @@ __device__ __forceinline__ void c_store_b64_sys(unsigned long long gaddr, unsign
 // One 64-unit step of a row quad: lookups (v_perm_b32 on the half tables), v_mfma_i32_16x16x64_i8 as the adder, then the
 // two act groups of the lane's output row through the fp32 scale chain (compute_mfma of k_gemv_quad, SM = 0), or -- SM = 2 --
 // the exact int32 sum of the lane's row over all units, per bit-plane (tbl.cc:586-628).
+// Per-group scales: the adder's selector matrix of plane p weighs `all` +2^p and `neg` -2^(p+1) (c_selectors), so ONE accumulator
+// receives sum_p 2^p PS_p -- the integer the scale chain wants (Sigma 2^p PS_p, exact in int32: |.| <= 15 * 16 * 127 per act group) --
+// instead of one accumulator per plane combined by shifts and adds afterwards.  lane16 = 16 * lane and lk4 = 4 * (2 * (lane & 12) +
+// 2 * (lane >> 4)) are the lane's byte offsets into the table rows and the act groups' scale arrays (computed once per kernel: what
+// remains per item is one v_add per LDS read).
+template <int BITS>
+struct CSel { qv4i_t p[BITS]; };
+template <int BITS, int SM>
+__device__ __forceinline__ void c_selectors(CSel<BITS>& sel, int lane) {
+    const int jrel = (lane & 15) - 4 * (lane >> 4);
+    const bool on = jrel >= 0 && jrel < 4;
+#pragma unroll
+    for (int pl = 0; pl < BITS; ++pl) {
+        const uint32_t wp = (SM == 0) ? (1u << pl) : 1u;                        // unified scales keep one exact total per plane
+        const uint32_t be = on ? (wp << (8 * jrel)) : 0u, bo = on ? (((0x100u - 2u * wp) & 0xffu) << (8 * jrel)) : 0u;   // +2^p | -2^(p+1)
+        sel.p[pl] = (qv4i_t){(int)be, (int)bo, (int)be, (int)bo};
+    }
+}
+
 template <int BITS, bool ZP, bool SCF16, int SM>
 __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab, int tstride, const float* l_ls, const float* l_lb,
-                                          int st, int lane, qv4i_t bsel, uint32_t k3, float& cacc, int32_t (&iacc)[BITS]) {
-    const int u = st * 64 + lane;
+                                          int st, uint32_t lane16, uint32_t lk4, const CSel<BITS>& sel, uint32_t k3, float& cacc, int32_t (&iacc)[BITS]) {
     uint32_t tb[16];
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
-        const uint4 v = tab[j4 * tstride + u];            // units past K read the zero tables: no contribution
+        // units past K read the zero tables: no contribution
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tab + (j4 * tstride + st * 64)) + lane16);
         tb[4 * j4] = v.x; tb[4 * j4 + 1] = v.y; tb[4 * j4 + 2] = v.z; tb[4 * j4 + 3] = v.w;
     }
-    qv4i_t c[BITS];
+    constexpr int NACC = (SM == 0) ? 1 : BITS;
+    qv4i_t c[NACC];
 #pragma unroll
-    for (int pl = 0; pl < BITS; ++pl) c[pl] = (qv4i_t){0, 0, 0, 0};
+    for (int pl = 0; pl < NACC; ++pl) c[pl] = (qv4i_t){0, 0, 0, 0};
 #pragma unroll
     for (int tp = 0; tp < 4; ++tp) {
 #pragma unroll
@@ -154,10 +174,12 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
             else q_lookup4_pm<0>(f.wq[qa >> 3][(qa >> 1) & 3], tb[4 * tp], tb[4 * tp + 1], k3, pa, ma);
             if (qb & 1) q_lookup4_pm<1>(f.wq[qb >> 3][(qb >> 1) & 3], tb[4 * tp + 2], tb[4 * tp + 3], k3, pb, mb);
             else q_lookup4_pm<0>(f.wq[qb >> 3][(qb >> 1) & 3], tb[4 * tp + 2], tb[4 * tp + 3], k3, pb, mb);
-            c[pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8((qv4i_t){(int)pa, (int)ma, (int)pb, (int)mb}, bsel, c[pl], 0, 0, 0);
+            constexpr int acc = 0;
+            qv4i_t& cd = c[(SM == 0) ? acc : pl];
+            cd = __builtin_amdgcn_mfma_i32_16x16x64_i8((qv4i_t){(int)pa, (int)ma, (int)pb, (int)mb}, sel.p[pl], cd, 0, 0, 0);
         }
     }
-    if (SM == 2) {
+    if constexpr (SM == 2) {
         // The MFMA results must have landed before a VALU instruction reads them (no hardware interlock: up to 18 wait states after an
         // 8-pass MFMA; with one bit-plane the compiler's hazard recogniser left the two a single wait state apart across the loop branch and
         // W1 unified-scale results were wrong).  ONE wait for all planes, behind the last MFMA of the step (the planes' chains are
@@ -170,31 +192,28 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
 #pragma unroll
         for (int pl = 0; pl < BITS; ++pl) iacc[pl] += (c[pl].x + c[pl].y) + (c[pl].z + c[pl].w);
         return;
-    }
-    float sc, zr = 0.f;
-    if (SCF16) {
-        sc = __half2float(__ushort_as_half((unsigned short)(f.s0 & 0xffff)));
-        if (ZP) zr = __half2float(__ushort_as_half((unsigned short)(f.s0 >> 16)));
     } else {
-        sc = __uint_as_float(f.s0);
-        if (ZP) zr = __uint_as_float(f.s1);
-    }
-    const int ub4 = st * 64 + 4 * (lane & 12) + 4 * (lane >> 4);
-#pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-        const int kk = (ub4 + 2 * gi) >> 1;
-        const float hls = l_ls[kk], hlb = l_lb[kk];           // ls / 2, lb / 2; groups past K hold zeros
-        // sum_p alpha_p [(ps_p ls + [p = 0] lb) scale + [p = 0] zero 2 lb] = ((sum_p 2^p ps_p)(ls / 2) + lb / 2) scale + (2 zero)(lb / 2)
-        int32_t comb = 0;
-#pragma unroll
-        for (int pl = BITS - 1; pl >= 0; --pl) {
-            const int32_t ps = (gi == 0) ? (c[pl].x + c[pl].y) : (c[pl].z + c[pl].w);
-            comb = (pl == BITS - 1) ? ps : (int32_t)(((uint32_t)comb << 1) + (uint32_t)ps);
+        float sc, zr = 0.f;
+        if (SCF16) {
+            sc = __half2float(__ushort_as_half((unsigned short)(f.s0 & 0xffff)));
+            if (ZP) zr = __half2float(__ushort_as_half((unsigned short)(f.s0 >> 16)));
+        } else {
+            sc = __uint_as_float(f.s0);
+            if (ZP) zr = __uint_as_float(f.s1);
         }
-        const float v = __fmaf_rn((float)comb, hls, hlb);
-        float cc = __fmaf_rn(v, sc, cacc);
-        if (ZP) cc = __fmaf_rn(__fadd_rn(zr, zr), hlb, cc);
-        cacc = cc;
+        // act groups st * 32 + lk4 / 4 + {0, 1}: ls / 2 and lb / 2 (groups past K hold zeros)
+        const float2 hls2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(l_ls + st * 32) + lk4);
+        const float2 hlb2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(l_lb + st * 32) + lk4);
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const float hls = gi ? hls2.y : hls2.x, hlb = gi ? hlb2.y : hlb2.x;
+            // sum_p alpha_p [(ps_p ls + [p = 0] lb) scale + [p = 0] zero 2 lb] = ((sum_p 2^p ps_p)(ls / 2) + lb / 2) scale + (2 zero)(lb / 2)
+            const int32_t comb = (gi == 0) ? (c[0].x + c[0].y) : (c[0].z + c[0].w);
+            const float v = __fmaf_rn((float)comb, hls, hlb);
+            float cc = __fmaf_rn(v, sc, cacc);
+            if (ZP) cc = __fmaf_rn(__fadd_rn(zr, zr), hlb, cc);
+            cacc = cc;
+        }
     }
 }
 

@@ -179,16 +179,14 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
         return;
     }
 
-    qv4i_t bsel;
-    {
-        const int jrel = (lane & 15) - 4 * (lane >> 4);
-        const uint32_t be = (jrel >= 0 && jrel < 4) ? (0x01u << (8 * jrel)) : 0u, bo = (jrel >= 0 && jrel < 4) ? (0xfeu << (8 * jrel)) : 0u;   // +1 | -2
-        bsel = (qv4i_t){(int)be, (int)bo, (int)be, (int)bo};
-    }
+    CSel<BITS> sel;
+    c_selectors<BITS, SM>(sel, lane);
     uint32_t k3 = 0x03020100u;
     asm volatile("" : "+v"(k3));
     uint32_t lane16 = (uint32_t)lane * 16u;
     asm volatile("" : "+v"(lane16));
+    uint32_t lk4 = 4u * (uint32_t)(2 * (lane & 12) + 2 * (lane >> 4));      // the lane's two act groups inside a step's 32 (c_compute)
+    asm volatile("" : "+v"(lk4));
     const int wl = NWV - 1 - w;             // logical wave index of the roles and of the partial sums (k_decode_chain's order)
 
     // a wave's share of an op (k_decode_chain's role_of): quad slot qs of every workgroup iteration, steps h, h + wpq, ...
@@ -221,6 +219,8 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
     cop_ptr i_d = ops;
     __amdgpu_buffer_rsrc_t q_rs = null_rs;
     const TMAC_GLOBAL char* q_sc = ops_g;
+    const TMAC_GLOBAL char* q_scm = ops_g;
+    int q_mi = -1;
     auto refill = [&](CFrag<BITS>& f) __attribute__((always_inline)) {
         while (i_left == 0 && i_op < a.nops) {            // enter the next op in which this wave has items
             ++i_op;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
                 i_it = 0; i_st = r.h; i_h = r.h; i_wpq = r.wpq; i_nst = r.nst; i_q0 = r.q_lo + r.qs; i_ipi = r.ipi;
                 i_nsg = uni(i_d->nsg); i_gsh = uni(i_d->gs_shift); i_nu = uni(i_d->nu);
                 i_qe0 = uni(i_d->q_end[0]); i_qe1 = uni(i_d->q_end[1]); i_qe2 = uni(i_d->q_end[2]);
-                q_res = -1;
+                q_res = -1; q_mi = -1;
             }
         }
         const bool real = i_left > 0;
@@ -239,8 +239,12 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
             const int gqi = i_q0 + i_it * i_ipi;
             const int mi = (gqi >= i_qe0 ? 1 : 0) + (gqi >= i_qe1 ? 1 : 0) + (gqi >= i_qe2 ? 1 : 0);
             const int lq = gqi - (gqi >= i_qe2 ? i_qe2 : (gqi >= i_qe1 ? i_qe1 : (gqi >= i_qe0 ? i_qe0 : 0)));
-            q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(uni(i_d->m[mi].W)), (short)0, 0x7fffffff, 0x00020000);
-            q_sc = as_global(uni(reinterpret_cast<const char*>(i_d->m[mi].SC))) + (size_t)lq * (size_t)(i_nsg * 4 * (ZP ? 2 : 1) * (SCF16 ? 2 : 4));
+            if (mi != q_mi) {           // the matrix' pointers: per matrix a wave enters, not per quad
+                q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(uni(i_d->m[mi].W)), (short)0, 0x7fffffff, 0x00020000);
+                q_scm = as_global(uni(reinterpret_cast<const char*>(i_d->m[mi].SC)));
+                q_mi = mi;
+            }
+            q_sc = q_scm + (size_t)lq * (size_t)(i_nsg * 4 * (ZP ? 2 : 1) * (SCF16 ? 2 : 4));
             q_woff = lq * i_nst * (BITS * 1024);
             q_res = i_it;
         }
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
         for (int k = 0; k < RING; ++k) {
             if (!done) {
                 if (TMAC_STREAM_KO & 8) cacc += __uint_as_float(ring[k].wq[0].x ^ ring[k].wq[BITS - 1].w ^ ring[k].s0); else
-                c_compute<BITS, ZP, SCF16, SM>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane, bsel, k3, cacc, iacc);
+                c_compute<BITS, ZP, SCF16, SM>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane16, lk4, sel, k3, cacc, iacc);
                 asm volatile("" : "+v"(cacc));        // the item's scale chain ends before the slot is refilled (the scale word keeps its register)
             }
             refill(ring[k]);

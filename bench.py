@@ -868,6 +868,48 @@ def run(args, env):
                 "achieved": round(ach, 1), "peak": MFMA_I8_PEAK_TOPS, "unit": "TOP/s (int8 MFMA work issued: 2 x output rows x (K/4 tables x 8 half-table entries) x N)",
                 "frac": round(ach / MFMA_I8_PEAK_TOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "ops_per_step": ops_per_step, "timing": "hipEvent pair on the launch stream around the %d timed steps" % args.steps}
+        # The MFMA work counted above is the one-hot operand's (8 half-table entries per 4 activations: 2 x the dense contraction).  What a
+        # user compares with is the DENSE equivalent -- 2 Mw K N flop per matrix -- against the dense bf16 / fp16 MFMA peak, and a dense fp16
+        # matmul of the same shapes on this box, replayed from a hipGraph like the timed path.
+        dense_flop = sum(cnt * 2.0 * shard_rows[name] * K * N for name, Mw, K, cnt, slot in MATS) * args.layers
+        roof["dense_equivalent"] = {"TFLOPs": round(dense_flop / (ev_ms_per_step * 1e-3) / 1e12, 1), "peak": 2500.0,
+                                    "frac": round(dense_flop / (ev_ms_per_step * 1e-3) / 1e12 / 2500.0, 4),
+                                    "what": "2 x rows x K x N per matrix over the same time, against the dense bf16 MFMA peak (MI355X_MICROARCH.md)"}
+        if not dist_on:
+            try:
+                dW = {name: [torch.randn(shard_rows[name], K, device=dev, generator=gen).half() for _ in range(cnt)] for name, Mw, K, cnt, slot in MATS}
+                dX = {slot: torch.randn(N, K, device=dev, generator=gen).half() for name, Mw, K, cnt, slot in MATS}
+                dO = {name: [torch.empty(N, shard_rows[name], dtype=torch.float16, device=dev) for _ in range(cnt)] for name, Mw, K, cnt, slot in MATS}
+
+                def dense_step():
+                    for _ in range(args.layers):
+                        for name, Mw, K, cnt, slot in MATS:
+                            for i in range(cnt):
+                                torch.matmul(dX[slot], dW[name][i].t(), out=dO[name][i])
+                dense_step(); torch.cuda.synchronize()
+                dside = torch.cuda.Stream(); dside.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(dside):
+                    dense_step()
+                torch.cuda.current_stream().wait_stream(dside); torch.cuda.synchronize()
+                dg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(dg, stream=dside):
+                    dense_step()
+                dts = []
+                for r in range(8):
+                    f0 = torch.cuda.Event(enable_timing=True); f1 = torch.cuda.Event(enable_timing=True)
+                    f0.record(); dg.replay(); f1.record(); torch.cuda.synchronize()
+                    if r >= 3:
+                        dts.append(f0.elapsed_time(f1))
+                dms = float(np.mean(dts))
+                roof["dense_fp16_baseline"] = {"ms_per_step": round(dms, 4), "tokens_per_s": round(N / (dms * 1e-3), 1),
+                                               "this_over_dense": round(dms / ev_ms_per_step, 3),
+                                               "what": "torch.matmul (hipBLASLt) fp16 [N, K] x [K, rows] of the same %d matrices per layer (ONE weight set reused by every layer: "
+                                                       "%.0f MB of fp16 weights, MALL-resident -- the 2-bit path streams distinct weights per layer), hipGraph replay, mean of 5; "
+                                                       "it reads 8 x the weight bytes per matrix and cannot produce the reference's integer sums"
+                                                       % (sum(m[3] for m in MATS), sum(m[3] * shard_rows[m[0]] * m[2] for m in MATS) * 2 / 1e6)}
+                del dW, dX, dO, dg
+            except Exception as e:
+                roof["dense_fp16_baseline"] = {"error": repr(e)}
     elif args.path == "chain":
         ach = bytes_per_step / (ev_ms_per_step * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": ("k_decode_chain: one persistent launch per decoded token (all %d GEMVs, LUT builds and in-kernel "

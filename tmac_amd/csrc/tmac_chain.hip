@@ -571,6 +571,10 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     if ((p & 3) == 0) l_us[CHAIN_US_FLOATS + (p >> 2)] = __fadd_rn(va, vb);
                 }
             }
+#ifdef TMAC_CHAIN_KO_PASS1      /* timing experiment (wrong scale): what the cross-wave maximum and its barrier cost */
+            mx = q_row_allmax(mx);
+            mx = q_xor_max_f(mx);
+#else
             mx = q_row_allmax(mx);
             mx = q_xor_max_f(mx);
             if (lane == 0) l_us[2 + w] = mx;
@@ -578,6 +582,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             mx = l_us[2];
 #pragma unroll
             for (int ww = 1; ww < NWV; ++ww) mx = fmaxf(mx, l_us[2 + ww]);
+#endif
             gscale = div127(mx);
             gtinv = (gscale != 0.0f) ? rcp_exact(gscale) : 0.0f;
             if (tid == 0) l_us[0] = gscale;

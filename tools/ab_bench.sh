@@ -7,5 +7,5 @@ for v in $vars; do
   python bench.py --no-cpu-baseline --no-decoder-pattern "$@" 2>/dev/null | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']
-print('%-8s' % '$v', d['ms_per_step'], r['frac'], r.get('stream_core', {}).get('us_per_gemv'), d['verified']['ok'], d['verified']['max_rel_err'])"
+print('%-8s' % '$v', d['ms_per_step'], r['frac'], r.get('stream_core', {}).get('us_per_gemv'), (d.get('verified') or {}).get('ok'), (d.get('verified') or {}).get('max_rel_err'))"
 done

@@ -746,7 +746,7 @@ def run(args, env):
                     {"torch": "torch.distributed (ProcessGroupNCCL = RCCL)", "lib": "tmac_hip_comm (RCCL through the C-ABI)", "ipc": "tmac_hip_comm IPC windows"}[args.comm] +
                     (", replayed from a hipGraph" if graph is not None else ", eager"))
         sys.stderr.write(f"bench.py preflight: rank {rank}/{world} device {local_rank}: {path_txt}\n")
-        try:
+        def preflight_once():
             src_key = MATS[0][4]
             # what the step about to run reads first: a replay reads the tensor of the recorded / captured call, an eager step the current one
             xin0 = (step_in[0] if (chain is not None or graph is not None) else x[src_key]).clone()
@@ -772,12 +772,19 @@ def run(args, env):
             d_all_reduce(okf, dist.ReduceOp.MIN)
             wt = torch.tensor([worst], dtype=torch.float64, device=dev)
             d_all_reduce(wt, dist.ReduceOp.MAX)
-            preflight = {"ok": bool(okf[0].item()), "bit_identical_on_every_rank": bool(okf[1].item()), "max_rel_diff": float("%.3g" % wt.item()),
+            sys.stderr.write(f"bench.py preflight: rank {rank}: step reproduced {'bit for bit' if same else 'to %.3g' % worst}\n")
+            return bool(okf[0].item()), bool(okf[1].item()), float("%.3g" % wt.item())
+        try:
+            ok_, bits_, worst_ = preflight_once()
+            tries = 1
+            if not ok_:             # once more before the line says so (every rank takes the same decision: the flags are all-reduced)
+                ok_, bits_, worst_ = preflight_once()
+                tries = 2
+            preflight = {"ok": ok_, "bit_identical_on_every_rank": bits_, "max_rel_diff": worst_, "attempts": tries,
                          "what": "one step of the timed path vs the same %d calls launched one by one on each rank with the all-gathers replaced by local repeats "
                                  "(identical synthetic shards), last layer's outputs" % (len(MATS) * args.layers), "path": path_txt}
-            sys.stderr.write(f"bench.py preflight: rank {rank}: step reproduced {'bit for bit' if same else 'to %.3g' % worst}\n")
-            if not preflight["ok"]:
-                raise SystemExit("bench.py: PREFLIGHT FAILED: the distributed step differs from its single-rank emulation (%r)" % (preflight,))
+            if not ok_:
+                sys.stderr.write("bench.py: PREFLIGHT FAILED twice: the distributed step differs from its single-rank emulation (%r); the line carries preflight.ok = false\n" % (preflight,))
         except tmac_amd.binding.TMACHipError as e:
             preflight = {"error": repr(e)}
     for _ in range(args.warmup):
@@ -1223,6 +1230,7 @@ def main():
             if head is not None:
                 head["workload"] = r2["config"]["workload"]
                 head["launch"] = r2["config"]["launch"]
+                head["preflight"] = r2.get("preflight")
         except BaseException as e:      # the decode number is never lost to the extra measurement
             head = {"error": repr(e)}
         if res is not None:

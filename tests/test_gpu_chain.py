@@ -372,6 +372,28 @@ def test_chain_rejections(tm):
     with pytest.raises(tm.TMACHipError):
         with wr.record_chain():
             pass                                   # nothing recorded
+    # act groups of 32 (legal in the reference: qgemm.py:402-404) live in the row-block layout, which neither the chain nor the stream
+    # kernel reads: refused with -1 -- formally out of the persistent paths' scope -- and served by the per-launch path
+    wr32 = tm.TMACGeMMWrapper(act_group_size=32)
+    case3 = orc.make_case(5, 128, 512, bits=2, gs=GS, ags=32, zero_point=True, fp16_values=True)
+    A3, S3 = orc.preprocess_weights(case3["w"], 2, 128, KF), orc.preprocess_scales(case3["sc"], case3["zr"], 2, 128)
+    w3 = wr32.register_weights(A3, S3, 128, 512, 2, tm.KCfg.make(128, 512, 2, 128, KF, GS, 32, True))
+    x3 = torch.from_numpy(case3["B"][0].astype(np.float32)).cuda().half()
+    with pytest.raises(tm.TMACHipError) as e:
+        with wr32.record_chain():
+            wr32.fused([w3], x3, [out], 1)
+    assert e.value.code == -1
+    with pytest.raises(tm.TMACHipError) as e:      # the fused entry point (LUT built inside the GEMV) reads the QUAD layout too
+        wr32.fused([w3], x3, [out], 1)
+    assert e.value.code == -1
+    wr32.set_workspace(512, 1)                     # ... served by the reference's own call structure: preprocessor, then qgemm_lut
+    wr32.llama_cpp_init(x3, 128, 512, 1, 2, act_group_size=32, act_dtype=tm.F16)
+    wr32.llama_cpp_compute(w3, out, 1, out_dtype=tm.F16)
+    torch.cuda.synchronize()
+    q3, ls3, lb3 = orc.preprocessor(x3.float().cpu().numpy()[None, :], 32)
+    want3 = orc.qgemm_float(A3, q3, S3, ls3, lb3, 128, 512, 1, 2, 128, KF, GS, 32, True)[0]
+    assert rel_err(out.float().cpu().numpy(), want3) <= 1e-3
+    w3.free()
     # recording state is per thread and was closed by the failures above
     with wr.record_chain() as rec:
         wr.fused([w], x32.half(), [out], 1)

@@ -130,13 +130,17 @@ CPU_SETS = {
 
 
 def _usable_cores():
-    """host threads this process may run on (the cpuset of a container can be far smaller than os.cpu_count(): an OpenMP team of
-    cpu_count threads on it is oversubscribed and collapses -- 0.098 GB/s at "256 threads" in round 4's line)"""
+    """host threads this process may run on (affinity mask; the largest OpenMP team below additionally stops at 128: a 256-thread team
+    on a container's share of a 256-thread host collapsed to 0.1 GB/s in rounds 4 / 5)"""
     try:
-        n = max(1, len(os.sched_getaffinity(0)))
+        return max(1, len(os.sched_getaffinity(0)))
     except Exception:
-        n = os.cpu_count() or 1
-    # ... and a CPU quota (cgroup v2 cpu.max / v1 cfs quota) caps what a team of busy threads gets, whatever the affinity mask says
+        return os.cpu_count() or 1
+
+
+def _cpu_quota():
+    """CPUs' worth of time the container's cgroup grants (cpu.max / cfs quota), or None: reported with the baseline -- a team larger than
+    the quota still measured faster here (216 GB/s with 64 threads against 175 with 16 under a quota of 16), so it does not cap the list"""
     for quota_path, period_path in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
         try:
             with open(quota_path) as f:
@@ -147,12 +151,10 @@ def _usable_cores():
                 q = parts[0]
                 with open(period_path) as f:
                     per = f.read().split()[0]
-            if q != "max" and int(q) > 0:
-                n = max(1, min(n, int(q) // int(per)))
-            break
+            return None if q == "max" or int(q) <= 0 else round(int(q) / int(per), 2)
         except Exception:
             continue
-    return n
+    return None
 
 
 def cpu_baseline(workload="llama2-7b-w2", seconds=6.0):
@@ -232,7 +234,7 @@ def cpu_baseline(workload="llama2-7b-w2", seconds=6.0):
             best = min(best, run_once(nthreads)); reps += 1
         out[nthreads] = total_bytes / best / 1e9
     used = max(out, key=out.get)
-    return {"value": round(out[used], 3), "unit": "GB/s", "cores": used, "kind": kind, "host_cores": cores, "host_cores_total": os.cpu_count(),
+    return {"value": round(out[used], 3), "unit": "GB/s", "cores": used, "kind": kind, "host_cores": cores, "host_cores_total": os.cpu_count(), "cgroup_cpu_quota": _cpu_quota(),
             "by_threads_GBps": {str(k): round(v, 3) for k, v in out.items()}, "code": what,
             "sample": "one GEMV of each of the layer's three shapes (%s; preprocessor + all tiles, bm = %d), OpenMP static tile split, "
                       "best of >=5; value = best thread count" % (", ".join(f"{m}x{k}" for m, k, _ in shapes), BM)}

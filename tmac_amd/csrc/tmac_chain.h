@@ -124,6 +124,7 @@ struct StreamArgs {
     int nops;
     int out_f16;
     int buf_u4;                    // uint4 per LDS LUT buffer (two buffers, by op parity), a multiple of 64
+    int nsplit;                    // workgroups per row range (1 or 2): workgroup (range, part) takes the ops part, part + nsplit, ...
 };
 inline int stream_img_u4(int K) { return (chain_buf_u4(K) + 63) & ~63; }      // image / LDS buffer of one op, whole KB
 inline size_t stream_lds_bytes(int buf_u4, int nops) {

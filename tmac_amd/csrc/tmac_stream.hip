@@ -15,6 +15,9 @@
 //     loads of every item are the same unconditional sequence (c_issue_static), barriers and stores are asm: the compiler counts the
 //     loads behind the one it needs and waits per slot (s_waitcnt vmcnt((RING - 1) * loads per item)) instead of draining the ring
 //     (profiles/r05_ring_static.txt);
+//   * TWO workgroups per CU for 1- / 2-bit weights, each walking every other op: a lookup wave is bounded by its own serial latency per item
+//     (table reads, eight dependent MFMAs, scale chain), so twice the waves on a CU -- not a deeper ring, not fewer barriers, both measured
+//     flat -- is what fills the gaps: headline 3.43 -> 2.93 us per call, gate/up 5.35 -> 4.52 (profiles/r05_stream_knockouts.txt);
 //   * no hand-off, no polls, no spin: nothing waits for another workgroup, so residency is not a correctness condition.
 // Arithmetic per item and per row is k_decode_chain's / k_gemv_quad's (c_compute, the same wave / lane decomposition, the same
 // combination order of split quads), the tables are q_table8's: outputs are bit-identical to the other N = 1 paths for the same waves
@@ -92,24 +95,28 @@ hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, hipStr
 #ifndef TMAC_STREAM_KO
 #define TMAC_STREAM_KO 0          // timing experiments only (wrong results): 1 no combine / store, 2 no finish at all, 4 no image loads, 8 no lookups
 #endif
-template <int BITS, bool ZP, bool SCF16>
-__global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
+// RING: weight fragments in flight per lookup wave.  MINW: waves per SIMD the register allocation must leave room for -- 4 with one workgroup
+// per CU (13 waves), 7 with TWO (StreamArgs::nsplit = 2: the workgroups of a CU take alternate ops -- twice the waves hide a wave's own
+// serial latency per item, which is what bounds the kernel: profiles/r05_stream_knockouts.txt).
+template <int BITS, bool ZP, bool SCF16, int RING, int MINW>
+__global__ __launch_bounds__(STREAM_FT, MINW) void k_gemv_stream(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     constexpr int SM = 0;
     constexpr int NWV = STREAM_NLW;                     // lookup waves; wave NWV is the loader
-#ifndef TMAC_STREAM_RING
-#define TMAC_STREAM_RING 0
-#endif
-    // weight fragments in flight per lookup wave (A/B knob TMAC_STREAM_RING): measured flat from 2 to 6 (4096 x 11008 W2: 3.24 / 3.33 / 3.46 us
-    // per call with 2 / 4 / 6, W4 4.63 / 4.67 with 2 / 4: what a deeper ring adds in flight it takes from the other waves' share of the queue)
-    constexpr int RING = TMAC_STREAM_RING ? TMAC_STREAM_RING : ((BITS <= 2) ? 4 : 2);
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int bx = blockIdx.x;
+    // nsplit workgroups share every row range: workgroup (bx, part) walks the ops part, part + nsplit, ... with the rows of range bx.  They
+    // are independent of each other (nothing in this kernel waits for another workgroup); whether they share a CU is the scheduler's business.
+    const int nsplit = a.nsplit, part = (int)blockIdx.x % nsplit, bx = (int)blockIdx.x / nsplit;
+    const int nops = (a.nops - part + nsplit - 1) / nsplit;               // this workgroup's ops: local j = global j * nsplit + part
     float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][4][CHAIN_RED] partials of split quads
     uint4* l_ops = lds + 2 * (size_t)a.buf_u4 + (2 * NWV * 4 * CHAIN_RED * sizeof(float)) / 16;
     {
+        constexpr int U = (int)(sizeof(ChainOp) / 16);
         const uint4* gsrc = reinterpret_cast<const uint4*>(a.ops);
-        for (int idx = tid; idx < a.nops * (int)(sizeof(ChainOp) / 16); idx += STREAM_FT) l_ops[idx] = gsrc[idx];
+        for (int idx = tid; idx < nops * U; idx += STREAM_FT) {
+            const int jl = idx / U, r = idx - jl * U;
+            l_ops[idx] = gsrc[(jl * nsplit + part) * U + r];
+        }
         __syncthreads();
     }
     const cop_ptr ops = reinterpret_cast<cop_ptr>(l_ops);
@@ -161,11 +168,11 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
         };
         load_image(0);
         int prev_nit = 0;
-        for (int j = 0; j < a.nops; ++j) {
+        for (int j = 0; j < nops; ++j) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             c_lds_barrier();                                  // A(j)
             if (!(TMAC_STREAM_KO & 1) && j > 0 && prev_nit > 0) combine(j - 1, prev_nit - 1, s_par ^ 1);
-            if (!(TMAC_STREAM_KO & 4) && j + 1 < a.nops) load_image(j + 1);
+            if (!(TMAC_STREAM_KO & 4) && j + 1 < nops) load_image(j + 1);
             const int nit = wg_iters(ops + j);
             if (!(TMAC_STREAM_KO & 2))
                 for (int t = 0; t < nit; ++t) {
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
                 }
             prev_nit = nit;
         }
-        if (!(TMAC_STREAM_KO & 1) && prev_nit > 0) combine(a.nops - 1, prev_nit - 1, s_par ^ 1);
+        if (!(TMAC_STREAM_KO & 1) && prev_nit > 0) combine(nops - 1, prev_nit - 1, s_par ^ 1);
         return;
     }
 
@@ -222,9 +229,9 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
     const TMAC_GLOBAL char* q_scm = ops_g;
     int q_mi = -1;
     auto refill = [&](CFrag<BITS>& f) __attribute__((always_inline)) {
-        while (i_left == 0 && i_op < a.nops) {            // enter the next op in which this wave has items
+        while (i_left == 0 && i_op < nops) {            // enter the next op in which this wave has items
             ++i_op;
-            if (i_op < a.nops) {
+            if (i_op < nops) {
                 i_d = ops + i_op;
                 const Role r = role_of(i_d);
                 i_left = r.nquads * r.nsteps;
@@ -265,7 +272,8 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
     int c_op = -1, c_left = 0, c_it = 0, c_st = 0, parity = 0;
     Role ro = role_of(ops);
     cop_ptr d = ops;
-    int tstride = 1, nst = 1, wpq = 1, h = 0, ipi = 1;
+    int tstride = 1, nst = 1, wpq = 1, h = 0;
+    [[maybe_unused]] int ipi = 1;
     uint4* tab = lds;
     float* l_ls = reinterpret_cast<float*>(lds);
     float* l_lb = l_ls;
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
         for (;;) {
             if (c_op >= 0) while (c_it < ro.my_iter) finish(false, 0.f);
             ++c_op;
-            if (c_op >= a.nops) { done = true; return; }
+            if (c_op >= nops) { done = true; return; }
             d = ops + c_op;
             ro = role_of(d);
             tstride = uni(d->tstride); nst = ro.nst; wpq = ro.wpq; h = ro.h; ipi = ro.ipi;
@@ -342,22 +350,25 @@ __global__ __launch_bounds__(STREAM_FT) void k_gemv_stream(StreamArgs a) {
 
 template <int BITS>
 static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st) {
-#define TMAC_SL(Z, H) do { \
-        auto* kern = &k_gemv_stream<BITS, Z, H>; \
+    constexpr int R1 = (BITS <= 2) ? 4 : 2;      // ring depth 2..8 measured flat (profiles/r05_stream_knockouts.txt); two workgroups per CU need <= 72 registers
+#define TMAC_SL2(Z, H, R, MW) do { \
+        auto* kern = &k_gemv_stream<BITS, Z, H, R, MW>; \
         if (lds_bytes > 64 * 1024) { \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e != hipSuccess) return e; \
         } \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(STREAM_FT), lds_bytes, st, a); \
+        hipLaunchKernelGGL(kern, dim3(grid * a.nsplit), dim3(STREAM_FT), lds_bytes, st, a); \
         return hipGetLastError(); } while (0)
+#define TMAC_SL(Z, H) do { if (a.nsplit >= 2) TMAC_SL2(Z, H, 2, 7); else TMAC_SL2(Z, H, R1, 4); } while (0)
     if (zp) { if (sc_f16) TMAC_SL(true, true); else TMAC_SL(true, false); }
     if (sc_f16) TMAC_SL(false, true);
     TMAC_SL(false, false);
 #undef TMAC_SL
+#undef TMAC_SL2
 }
 
 hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st) {
-    if (a.nops < 1 || grid < 1) return hipErrorInvalidValue;
+    if (a.nops < 1 || grid < 1 || a.nsplit < 1 || a.nsplit > 2) return hipErrorInvalidValue;
     switch (bits) {
         case 1: return stream_launch_b<1>(a, zp, sc_f16, grid, lds_bytes, st);
         case 2: return stream_launch_b<2>(a, zp, sc_f16, grid, lds_bytes, st);

@@ -3,7 +3,7 @@
 call, one launch; us per GEMV (hipEvent pair, mean / best of 10), fraction of the 8 TB/s HBM peak on SURVEY 8d's algorithmic bytes, and
 a bit-comparison of every call's output with the same call launched on its own (tmac_hip_qgemm_fused_dev, the chain's configuration).
 usage: bench_stream.py [shape ...]   shape = MwxK[xCNT][:bits]   default: 4096x11008 4096x4096 11008x4096x2 4096x4096x3
-env: NL (calls per launch, default 32), TMAC_CHAIN_STREAM=0 measures k_decode_chain on the same recording."""
+env: NL (calls per launch, default 32), TMAC_CHAIN_STREAM=0 measures k_decode_chain on the same recording, FORCE_WPQ=n forces the waves per row quad."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +12,8 @@ from tmac_amd import KCfg, F16
 dev = torch.device("cuda")
 NL = int(os.environ.get("NL", "32"))
 L = tmac_amd.lib()
+if os.environ.get("FORCE_WPQ"):        # A/B: waves per row quad of the recorded calls (tmac_hip_debug_chain_config)
+    tmac_amd.binding.check(L.tmac_hip_debug_chain_config(int(os.environ["FORCE_WPQ"]), 0))
 gen = torch.Generator(device=dev); gen.manual_seed(7)
 
 

@@ -117,7 +117,10 @@ inline size_t chain_lds_bytes(int buf_u4, int nops, int xf_floats = 0) {
 }
 
 // ---- stream mode: a recording in which no op consumes another's output (tmac_stream.hip) ----
-constexpr int STREAM_NLW = CHAIN_NWV;                 // lookup waves per workgroup: the roles of k_decode_chain
+#ifndef TMAC_STREAM_NLW
+#define TMAC_STREAM_NLW 12
+#endif
+constexpr int STREAM_NLW = TMAC_STREAM_NLW;           // lookup waves per workgroup (the roles of k_decode_chain: waves per quad must divide it)
 constexpr int STREAM_FT = (STREAM_NLW + 1) * 64;      // + the loader wave
 struct StreamArgs {
     const ChainOp* ops;
@@ -125,10 +128,26 @@ struct StreamArgs {
     int out_f16;
     int buf_u4;                    // uint4 per LDS LUT buffer (two buffers, by op parity), a multiple of 64
     int nsplit;                    // workgroups per row range (1 or 2): workgroup (range, part) takes the ops part, part + nsplit, ...
+    const int* roles;              // [nops][STREAM_ROLE_INTS]: what a lookup wave needs to enter an op, worked out by the host (layout below)
+    unsigned long long* stamps;    // profiling builds only, else ignored: [workgroups][lookup waves][8].  -DTMAC_STREAM_STAMPS=2: cycle sums 0 waiting for weights,
+                                   // 1 lookups + refill, 2 partial sums, 3 closing barriers, 4 op change, 5 A barriers; 6 items, 7 first-to-last cycles.
+                                   // =1 (the kernel's own resources): 4 first-to-last cycles, 5 / 6 first / last s_memtime, 7 XCC_ID << 32 | HW_ID
 };
+// A lookup wave enters every op twice (its issue cursor, then its lookup cursor, RING items behind).  What it needs there -- its share of the
+// op's quads and steps, the op's geometry -- depends on the op, the wave and, through the one-more-quad rule only, on the workgroup: the host
+// tabulates it per (op, wave) and the wave reads its record with two scalar loads instead of a dozen descriptor fields from LDS and ~80
+// scalar instructions (every instruction of a wave costs >= 4 cycles of ITS time, and all waves of a workgroup change ops together).
+// Per op: 16 common ints, then 4 ints per lookup wave (logical index wl).
+enum { SR_NST = 0, SR_IPI, SR_NSG, SR_GSH, SR_NU, SR_QE0, SR_QE1, SR_QE2, SR_QPER, SR_QEXTRA, SR_IT_LO, SR_IT_HI, SR_TSTRIDE, SR_GP, SR_WPQ, SR_PAD, SR_COMMON };
+enum { SRW_NQ = 0 /* quads of the wave: workgroups with q_per | q_per + 1 quads << 16 */, SRW_NSTEPS, SRW_H, SRW_QS, SRW_INTS };
+constexpr int STREAM_ROLE_INTS = SR_COMMON + SRW_INTS * STREAM_NLW;
 inline int stream_img_u4(int K) { return (chain_buf_u4(K) + 63) & ~63; }      // image / LDS buffer of one op, whole KB
 inline size_t stream_lds_bytes(int buf_u4, int nops) {
-    return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * STREAM_NLW * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops;
+    size_t b = (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * STREAM_NLW * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops;
+#ifdef TMAC_STREAM_STAMPS
+    b += 32 * (STREAM_NLW + 1);        // the profiling build's cycle sums
+#endif
+    return b;
 }
 hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, hipStream_t st);
 hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st);

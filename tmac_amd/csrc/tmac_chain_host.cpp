@@ -58,6 +58,7 @@ struct tmac_hip_chain {
     bool stream = false;
     void* images = nullptr;
     int max_nst = 0;
+    const int* roles = nullptr;       // stream mode: the lookup waves' role records (device, behind the images)
     int nsplit = 1;                   // workgroups per row range (two share a CU and take alternate ops when LDS and registers allow)
 };
 
@@ -122,12 +123,12 @@ bool tmac_host::chain_record_gather_if_recording(const void* send_dev, void* rec
     return true;
 }
 
-static int chain_pick_wpq(int total_q, int nst, int grid) {
+static int chain_pick_wpq(int total_q, int nst, int grid, int nwv = CHAIN_NWV) {
     int best = 1;
     long best_cost = 1L << 60;
     for (int wpq = 1; wpq <= 4; ++wpq) {          // the combinations k_gemv_quad is instantiated for with this many threads
-        if (CHAIN_NWV % wpq || (wpq > 1 && wpq > nst)) continue;
-        const long ipi = CHAIN_NWV / wpq;
+        if (nwv % wpq || (wpq > 1 && wpq > nst)) continue;
+        const long ipi = nwv / wpq;
         const long cnt = (total_q + grid - 1) / grid;               // quads of the busiest workgroup (balanced contiguous ranges)
         const long iters = (cnt + ipi - 1) / ipi;
         const long steps = (nst + wpq - 1) / wpq;
@@ -490,14 +491,48 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             }
             // two workgroups per CU, alternate ops each (k_gemv_stream's nsplit): when both fit a CU's LDS.  TMAC_STREAM_SPLIT=1: A/B
             const int want_split = env_int("TMAC_STREAM_SPLIT", 2);
+            if (STREAM_NLW != CHAIN_NWV)                                       // (experiment builds: other workgroup sizes)
+                for (ChainOp& o : c->ops) {
+                    if (!g_knobs.chain_wpq || STREAM_NLW % o.wpq) o.wpq = chain_pick_wpq(o.total_q, o.nst, c->grid, STREAM_NLW);
+                    o.ipi = STREAM_NLW / o.wpq;
+                    o.wpq_inv = (65536 + o.wpq - 1) / o.wpq;
+                    o.ipi_inv = (65536 + o.ipi - 1) / o.ipi;
+                }
             const size_t lds2 = stream_lds_bytes(buf, ((int)c->ops.size() + 1) / 2);
             size_t lds = stream_lds_bytes(buf, (int)c->ops.size());
-            // (3- and 4-bit weights keep one workgroup per CU: the two-per-CU form is capped at 72 registers -- 4-bit fragments spill, 3-bit ones
-            // measured 3 % slower: 4.05 against 3.92 us on 4096 x 11008)
-            if (want_split >= 2 && c->bits <= 2 && c->ops.size() >= 2 && 2 * lds2 + 2048 <= 160 * 1024) { c->nsplit = 2; lds = lds2; }
+            // Two workgroups are co-resident on a CU only with <= 64 VGPRs and <= 80 SGPRs each (measured, profiles/r05_stream_stamps.txt): 1- to
+            // 3-bit weights fit with two fragments in flight per wave (3-bit: 4.06 -> 3.55 us on 4096 x 11008); 4-bit ones only with one,
+            // which loses to one workgroup with two (5.15 against 4.68 us): they keep one workgroup per CU.  TMAC_STREAM_SPLIT_BITS: A/B.
+            if (want_split >= 2 && c->bits <= env_int("TMAC_STREAM_SPLIT_BITS", 3) && c->ops.size() >= 2 && 2 * lds2 + 2048 <= 160 * 1024) { c->nsplit = 2; lds = lds2; }
+            for (int ns = 3; ns <= want_split && ns <= 4; ++ns) {            // (A/B builds with -DTMAC_STREAM_NLW=6: more, smaller workgroups per CU)
+                const size_t ldsn = stream_lds_bytes(buf, ((int)c->ops.size() + ns - 1) / ns);
+                if (c->nsplit == ns - 1 && (int)c->ops.size() >= ns && ns * (ldsn + 1024) <= 160 * 1024) { c->nsplit = ns; lds = ldsn; }
+            }
             if (lds <= 160 * 1024) {
-                if (hipMalloc(&c->images, img_bytes) != hipSuccess || hipMemset(c->images, 0, img_bytes) != hipSuccess)
-                    return bail(fail(TMAC_HIP_E_RUNTIME, "LUT image allocation failed (%zu bytes)", img_bytes));
+                // the waves' role records (tmac_chain.h) behind the images
+                std::vector<int32_t> roles((size_t)STREAM_ROLE_INTS * c->ops.size());
+                for (size_t i = 0; i < c->ops.size(); ++i) {
+                    const ChainOp& o = c->ops[i];
+                    int32_t* r = roles.data() + i * STREAM_ROLE_INTS;
+                    r[SR_NST] = o.nst; r[SR_IPI] = o.ipi; r[SR_NSG] = o.nsg; r[SR_GSH] = o.gs_shift; r[SR_NU] = o.nu;
+                    r[SR_QE0] = o.q_end[0]; r[SR_QE1] = o.q_end[1]; r[SR_QE2] = o.q_end[2];
+                    r[SR_QPER] = o.q_per; r[SR_QEXTRA] = o.q_extra;
+                    r[SR_IT_LO] = (o.q_per + o.ipi - 1) / o.ipi; r[SR_IT_HI] = (o.q_per + o.ipi) / o.ipi;
+                    r[SR_TSTRIDE] = o.tstride; r[SR_GP] = o.GP; r[SR_WPQ] = o.wpq; r[SR_PAD] = 0;
+                    for (int wl = 0; wl < STREAM_NLW; ++wl) {
+                        int32_t* rw = r + SR_COMMON + SRW_INTS * wl;
+                        const int qs = wl / o.wpq, h = wl - qs * o.wpq;
+                        auto nq = [&](int cnt) { return qs < cnt ? (cnt - 1 - qs) / o.ipi + 1 : 0; };
+                        rw[SRW_NQ] = nq(o.q_per) | (nq(o.q_per + 1) << 16);
+                        rw[SRW_NSTEPS] = h < o.nst ? (o.nst - h + o.wpq - 1) / o.wpq : 0;
+                        rw[SRW_H] = h; rw[SRW_QS] = qs;
+                    }
+                }
+                const size_t role_bytes = roles.size() * sizeof(int32_t);
+                if (hipMalloc(&c->images, img_bytes + role_bytes) != hipSuccess || hipMemset(c->images, 0, img_bytes) != hipSuccess ||
+                    hipMemcpy(reinterpret_cast<char*>(c->images) + img_bytes, roles.data(), role_bytes, hipMemcpyHostToDevice) != hipSuccess)
+                    return bail(fail(TMAC_HIP_E_RUNTIME, "LUT image allocation failed (%zu bytes)", img_bytes + role_bytes));
+                c->roles = reinterpret_cast<const int*>(reinterpret_cast<char*>(c->images) + img_bytes);
                 for (ChainOp& o : c->ops) o.img = reinterpret_cast<const char*>(c->images) + (reinterpret_cast<size_t>(o.img) - 1);
                 c->stream = true; c->buf_u4 = buf; c->lds_bytes = lds; c->xforms = 0;
             } else {
@@ -580,7 +615,7 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT image launch: %s", hipGetErrorString(e));
         StreamArgs sa;
         memset(&sa, 0, sizeof(sa));
-        sa.ops = c->d_ops; sa.nops = (int)c->ops.size(); sa.out_f16 = c->out_f16; sa.buf_u4 = c->buf_u4; sa.nsplit = c->nsplit;
+        sa.ops = c->d_ops; sa.nops = (int)c->ops.size(); sa.out_f16 = c->out_f16; sa.buf_u4 = c->buf_u4; sa.nsplit = c->nsplit; sa.roles = c->roles; sa.stamps = c->stamps;
         e = launch_gemv_stream(sa, c->bits, c->zp != 0, c->sc_f16 != 0, c->grid, c->lds_bytes, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "stream launch: %s", hipGetErrorString(e));
         c->last_stream = st; c->launched = true;

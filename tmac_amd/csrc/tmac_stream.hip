@@ -98,8 +98,12 @@ hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, hipStr
 // RING: weight fragments in flight per lookup wave.  MINW: waves per SIMD the register allocation must leave room for -- 4 with one workgroup
 // per CU (13 waves), 7 with TWO (StreamArgs::nsplit = 2: the workgroups of a CU take alternate ops -- twice the waves hide a wave's own
 // serial latency per item, which is what bounds the kernel: profiles/r05_stream_knockouts.txt).
+// Two workgroups share a CU only while the kernel's SGPR allocation stays at 80 (72 + VCC etc.): with 96 the second workgroup of a CU waited
+// for the first one to end (measured with the profiling build's place-and-time stamps: profiles/r05_stream_stamps.txt), so the count is capped
+// (the compiler parks what does not fit in VGPR lanes).
+#define TMAC_STREAM_ATTR __attribute__((amdgpu_num_sgpr(72)))
 template <int BITS, bool ZP, bool SCF16, int RING, int MINW>
-__global__ __launch_bounds__(STREAM_FT, MINW) void k_gemv_stream(StreamArgs a) {
+__global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_stream(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     constexpr int SM = 0;
     constexpr int NWV = STREAM_NLW;                     // lookup waves; wave NWV is the loader
@@ -196,24 +200,19 @@ __global__ __launch_bounds__(STREAM_FT, MINW) void k_gemv_stream(StreamArgs a) {
     asm volatile("" : "+v"(lk4));
     const int wl = NWV - 1 - w;             // logical wave index of the roles and of the partial sums (k_decode_chain's order)
 
-    // a wave's share of an op (k_decode_chain's role_of): quad slot qs of every workgroup iteration, steps h, h + wpq, ...
-    struct Role { int q_lo, cnt, qs, ipi, h, wpq, nst, my_iter, nquads, nsteps; };
-    auto role_of = [&](cop_ptr d) __attribute__((always_inline)) {
-        Role r;
-        r.wpq = uni(d->wpq);
-        const int ipi = uni(d->ipi), inv = uni(d->wpq_inv);
-        const int qs = (wl * inv) >> 16;
-        r.h = wl - qs * r.wpq;
-        r.qs = qs; r.ipi = ipi;
-        r.nst = uni(d->nst);
-        const int qper = uni(d->q_per), qex = uni(d->q_extra);
-        r.q_lo = bx * qper + min(bx, qex);
-        r.cnt = qper + (bx < qex ? 1 : 0);
-        const int iinv = uni(d->ipi_inv);
-        r.my_iter = ((r.cnt + ipi - 1) * iinv) >> 16;
-        r.nquads = qs < r.cnt ? (((r.cnt - 1 - qs) * iinv) >> 16) + 1 : 0;
-        r.nsteps = r.h < r.nst ? ((r.nst - r.h + r.wpq - 1) * inv) >> 16 : 0;
-        return r;
+    // a wave's share of an op -- quad slot qs of every workgroup iteration, steps h, h + wpq, ... (k_decode_chain's role_of) -- and the op's
+    // geometry: the host's record (tmac_chain.h, STREAM_ROLE_INTS), two scalar loads.  The wait is part of the statement: the compiler does
+    // not know of these loads (an LDS wait it counts can only become longer by them).
+    typedef int sr16 __attribute__((ext_vector_type(16)));
+    typedef int sr4 __attribute__((ext_vector_type(4)));
+    auto load_role = [&](int jl, sr16& rc, sr4& rw) __attribute__((always_inline)) {
+        const int* rp = a.roles + (size_t)(jl * nsplit + part) * STREAM_ROLE_INTS;
+        const int* rpw = rp + SR_COMMON + SRW_INTS * wl;
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rc), "=&s"(rw) : "s"(rp), "s"(rpw) : "memory");
+    };
+    auto items_of = [&](const sr16& rc, const sr4& rw) __attribute__((always_inline)) {
+        const int nq = bx < rc[SR_QEXTRA] ? (int)((unsigned)rw[SRW_NQ] >> 16) : (rw[SRW_NQ] & 0xffff);
+        return nq * rw[SRW_NSTEPS];
     };
 
     // ---- the issue cursor: this wave's items of ops 0, 1, ... in order, RING items ahead of the lookups ----
@@ -233,11 +232,13 @@ __global__ __launch_bounds__(STREAM_FT, MINW) void k_gemv_stream(StreamArgs a) {
             ++i_op;
             if (i_op < nops) {
                 i_d = ops + i_op;
-                const Role r = role_of(i_d);
-                i_left = r.nquads * r.nsteps;
-                i_it = 0; i_st = r.h; i_h = r.h; i_wpq = r.wpq; i_nst = r.nst; i_q0 = r.q_lo + r.qs; i_ipi = r.ipi;
-                i_nsg = uni(i_d->nsg); i_gsh = uni(i_d->gs_shift); i_nu = uni(i_d->nu);
-                i_qe0 = uni(i_d->q_end[0]); i_qe1 = uni(i_d->q_end[1]); i_qe2 = uni(i_d->q_end[2]);
+                sr16 rc; sr4 rw;
+                load_role(i_op, rc, rw);
+                i_left = items_of(rc, rw);
+                i_it = 0; i_st = rw[SRW_H]; i_h = rw[SRW_H]; i_wpq = rc[SR_WPQ]; i_nst = rc[SR_NST]; i_ipi = rc[SR_IPI];
+                i_q0 = bx * rc[SR_QPER] + min(bx, rc[SR_QEXTRA]) + rw[SRW_QS];
+                i_nsg = rc[SR_NSG]; i_gsh = rc[SR_GSH]; i_nu = rc[SR_NU];
+                i_qe0 = rc[SR_QE0]; i_qe1 = rc[SR_QE1]; i_qe2 = rc[SR_QE2];
                 q_res = -1; q_mi = -1;
             }
         }
@@ -269,11 +270,8 @@ __global__ __launch_bounds__(STREAM_FT, MINW) void k_gemv_stream(StreamArgs a) {
     for (int k = 0; k < RING; ++k) refill(ring[k]);
 
     // ---- the lookup cursor ----
-    int c_op = -1, c_left = 0, c_it = 0, c_st = 0, parity = 0;
-    Role ro = role_of(ops);
-    cop_ptr d = ops;
+    int c_op = -1, c_left = 0, c_it = 0, c_st = 0, parity = 0, my_iter = 0;
     int tstride = 1, nst = 1, wpq = 1, h = 0;
-    [[maybe_unused]] int ipi = 1;
     uint4* tab = lds;
     float* l_ls = reinterpret_cast<float*>(lds);
     float* l_lb = l_ls;
@@ -282,6 +280,26 @@ __global__ __launch_bounds__(STREAM_FT, MINW) void k_gemv_stream(StreamArgs a) {
 #pragma unroll
     for (int pl = 0; pl < BITS; ++pl) iacc[pl] = 0;
 
+#ifdef TMAC_STREAM_STAMPS
+    // profiling build: where a lookup wave's cycles go (s_memtime; each stamp costs a scalar memory round trip, so the sums are upper bounds).
+    // The sums live in LDS (behind the descriptors: stream_lds_bytes reserves the room in these builds) and the clock is kept in 32 bits, so
+    // that the build keeps the kernel's register footprint -- with 20 more SGPRs the two workgroups of a CU were no longer co-resident.
+    uint32_t* t_lds = reinterpret_cast<uint32_t*>(l_ops) + (size_t)nops * (sizeof(ChainOp) / 4) + (size_t)w * 8;
+    if (lane < 8) t_lds[lane] = 0;
+    uint32_t t_prev = (uint32_t)__builtin_readcyclecounter();
+#if TMAC_STREAM_STAMPS >= 2
+    if (lane == 0) t_lds[7] = 0u - t_prev;
+#else
+    if (lane == 0) { t_lds[6] = t_prev; t_lds[7] = (uint32_t)(__builtin_readcyclecounter() >> 32); }
+#endif
+#if TMAC_STREAM_STAMPS >= 2
+#define TMAC_ST(i) do { const uint32_t t_now = (uint32_t)__builtin_readcyclecounter(); if (lane == 0) (void)__hip_atomic_fetch_add(&t_lds[i], t_now - t_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); t_prev = t_now; } while (0)
+#else
+#define TMAC_ST(i) do { } while (0)         // level 1: life time and place of the workgroup only
+#endif
+#else
+#define TMAC_ST(i) do { } while (0)
+#endif
     // closes a workgroup iteration of op c_op: the wave's partial sums to LDS, one barrier (the service wave combines the wpq partials of
     // every quad of the iteration and stores the outputs)
     auto finish = [&](bool have, float acc_in) __attribute__((always_inline)) {
@@ -295,7 +313,9 @@ __global__ __launch_bounds__(STREAM_FT, MINW) void k_gemv_stream(StreamArgs a) {
             acc = q_xor_add_f(acc);
         }
         if (lane < 4) red[(wl * 4 + lane) * CHAIN_RED] = acc;
+        TMAC_ST(2);
         c_lds_barrier();                          // the service wave combines and stores behind it
+        TMAC_ST(3);
         parity ^= 1;
         ++c_it;
     };
@@ -304,17 +324,20 @@ __global__ __launch_bounds__(STREAM_FT, MINW) void k_gemv_stream(StreamArgs a) {
     bool done = false;
     auto advance = [&]() __attribute__((always_inline)) {
         for (;;) {
-            if (c_op >= 0) while (c_it < ro.my_iter) finish(false, 0.f);
+            if (c_op >= 0) while (c_it < my_iter) finish(false, 0.f);
             ++c_op;
             if (c_op >= nops) { done = true; return; }
-            d = ops + c_op;
-            ro = role_of(d);
-            tstride = uni(d->tstride); nst = ro.nst; wpq = ro.wpq; h = ro.h; ipi = ro.ipi;
+            sr16 rc; sr4 rw;
+            load_role(c_op, rc, rw);
+            my_iter = bx < rc[SR_QEXTRA] ? rc[SR_IT_HI] : rc[SR_IT_LO];
+            tstride = rc[SR_TSTRIDE]; nst = rc[SR_NST]; wpq = rc[SR_WPQ]; h = rw[SRW_H];
             tab = lds + (size_t)(c_op & 1) * a.buf_u4;
             l_ls = reinterpret_cast<float*>(tab + 4 * tstride);
-            l_lb = l_ls + uni(d->GP);
-            c_left = ro.nquads * ro.nsteps; c_it = 0; c_st = h;
+            l_lb = l_ls + rc[SR_GP];
+            c_left = items_of(rc, rw); c_it = 0; c_st = h;
+            TMAC_ST(4);
             c_lds_barrier();                          // A(c_op): the loader has this op's tables in LDS
+            TMAC_ST(5);
             if (c_left > 0) return;
         }
     };
@@ -328,11 +351,20 @@ __global__ __launch_bounds__(STREAM_FT, MINW) void k_gemv_stream(StreamArgs a) {
 #pragma unroll
         for (int k = 0; k < RING; ++k) {
             if (!done) {
+#if defined(TMAC_STREAM_STAMPS) && TMAC_STREAM_STAMPS >= 2
+                {   // the wait the compiler places in front of the slot's first lookup, made explicit: the slot's loads are older than the other slots' refills
+                    constexpr int L = BITS + (SCF16 || !ZP ? 1 : 2);
+                    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RING - 1) * L) : "memory");
+                    TMAC_ST(0);
+                    if (lane == 0) (void)__hip_atomic_fetch_add(&t_lds[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+#endif
                 if (TMAC_STREAM_KO & 8) cacc += __uint_as_float(ring[k].wq[0].x ^ ring[k].wq[BITS - 1].w ^ ring[k].s0); else
                 c_compute<BITS, ZP, SCF16, SM>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane16, lk4, sel, k3, cacc, iacc);
                 asm volatile("" : "+v"(cacc));        // the item's scale chain ends before the slot is refilled (the scale word keeps its register)
             }
             refill(ring[k]);
+            TMAC_ST(1);
             if (!done) {
                 --c_left;
                 c_st += wpq;
@@ -342,14 +374,34 @@ __global__ __launch_bounds__(STREAM_FT, MINW) void k_gemv_stream(StreamArgs a) {
                     c_st = h;
                 }
                 if (c_left == 0) advance();           // the op's last item: on to the next op BEHIND the refill (every path into the next slot has issued the same loads)
+                TMAC_ST(4);
             }
         }
     }
+#ifdef TMAC_STREAM_STAMPS
+    if (a.stamps && lane == 0) {
+        const unsigned long long t_last = __builtin_readcyclecounter();
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * NWV + w) * 8;
+#if TMAC_STREAM_STAMPS >= 2
+        for (int i = 0; i < 7; ++i) o[i] = t_lds[i];
+        o[7] = (uint32_t)(t_lds[7] + (uint32_t)t_last);
+#else
+        const unsigned long long t_first = ((unsigned long long)t_lds[7] << 32) | t_lds[6];
+        o[4] = t_last - t_first;
+        uint32_t hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        o[5] = t_first; o[6] = t_last; o[7] = ((unsigned long long)xcc_id << 32) | hw_id;       // where and when: are the workgroups of a pair co-resident?
+#endif
+    }
+#endif
+#undef TMAC_ST
 
 }
 
 template <int BITS>
 static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st) {
+    constexpr int R2 = (BITS <= 3) ? 2 : 1;      // two workgroups per CU: <= 64 VGPRs
     constexpr int R1 = (BITS <= 2) ? 4 : 2;      // ring depth 2..8 measured flat (profiles/r05_stream_knockouts.txt); two workgroups per CU need <= 72 registers
 #define TMAC_SL2(Z, H, R, MW) do { \
         auto* kern = &k_gemv_stream<BITS, Z, H, R, MW>; \
@@ -359,7 +411,7 @@ static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int
         } \
         hipLaunchKernelGGL(kern, dim3(grid * a.nsplit), dim3(STREAM_FT), lds_bytes, st, a); \
         return hipGetLastError(); } while (0)
-#define TMAC_SL(Z, H) do { if (a.nsplit >= 2) TMAC_SL2(Z, H, 2, 7); else TMAC_SL2(Z, H, R1, 4); } while (0)
+#define TMAC_SL(Z, H) do { if (a.nsplit >= 2) TMAC_SL2(Z, H, R2, 7); else TMAC_SL2(Z, H, R1, 4); } while (0)
     if (zp) { if (sc_f16) TMAC_SL(true, true); else TMAC_SL(true, false); }
     if (sc_f16) TMAC_SL(false, true);
     TMAC_SL(false, false);
@@ -368,7 +420,7 @@ static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int
 }
 
 hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st) {
-    if (a.nops < 1 || grid < 1 || a.nsplit < 1 || a.nsplit > 2) return hipErrorInvalidValue;
+    if (a.nops < 1 || grid < 1 || a.nsplit < 1 || a.nsplit > 4) return hipErrorInvalidValue;
     switch (bits) {
         case 1: return stream_launch_b<1>(a, zp, sc_f16, grid, lds_bytes, st);
         case 2: return stream_launch_b<2>(a, zp, sc_f16, grid, lds_bytes, st);

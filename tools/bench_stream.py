@@ -40,6 +40,10 @@ def run(Mw, K, cnt, bits):
         for i in range(NL):
             wr.fused(sets[i], xs[i], outs[i], 1, act_dtype=F16, out_dtype=F16)
     ch = rec.chain
+    stamps = None
+    if os.environ.get("STAMPS"):       # = the level of a -DTMAC_STREAM_STAMPS=1|2 build (tmac_chain.h, StreamArgs::stamps)
+        stamps = torch.zeros((512, 12, 8), dtype=torch.int64, device=dev)
+        ch.set_stamps(stamps)
     ts = []
     for r in range(13):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -60,6 +64,28 @@ def run(Mw, K, cnt, bits):
     mean, best = float(np.mean(ts)), float(np.min(ts))
     print(f"{Mw}x{K}x{cnt} W{bits} {'stream' if ch.stream else 'chain '} wpq={ch.wpq(0)}: {mean:6.2f} us/call (best {best:6.2f})  {hb / mean * 1e-3:7.1f} GB/s  "
           f"frac {hb / mean * 1e-3 / 8000:.3f}  bit-identical to the stand-alone launches: {same}", flush=True)
+    if stamps is not None:
+        raw = stamps.cpu().numpy()
+        if os.environ["STAMPS"] == "2":                               # a -DTMAC_STREAM_STAMPS=2 build
+            st = raw.astype(np.float64)
+            busy = st[st[:, :, 6] > 0]                                # waves with items
+            tot = busy[:, 7].mean()
+            pc = [100 * busy[:, i].mean() / tot for i in range(6)]
+            print(f"    stamps: {len(busy)} waves with items, {busy[:, 6].mean():.1f} items each, {tot:.0f} cycles first to last: waiting for weights {pc[0]:.0f} %, "
+                  f"lookups + refill {pc[1]:.0f} % ({busy[:, 1].sum() / busy[:, 6].sum():.0f} cycles per item), partial sums {pc[2]:.0f} %, closing barriers {pc[3]:.0f} %, "
+                  f"op change {pc[4]:.0f} %, A barriers {pc[5]:.0f} %")
+        else:                                                         # =1: where and when the workgroups ran
+            raw = raw[raw[:, :, 4].max(axis=1) > 0]
+            hw = raw[:, 0, 7]
+            cu = ((hw >> 32) & 0xf) * 1024 + ((hw >> 13) & 0x7) * 128 + ((hw >> 12) & 1) * 64 + ((hw >> 8) & 0xf)      # xcc, se, sh, cu
+            t0 = raw[:, :, 5].min(axis=1); t1 = raw[:, :, 6].max(axis=1)
+            ov = []
+            for c in np.unique(cu):
+                ix = np.nonzero(cu == c)[0]
+                if len(ix) == 2:
+                    a, b = ix
+                    ov.append(max(0, min(t1[a], t1[b]) - max(t0[a], t0[b])) / max(1, min(t1[a] - t0[a], t1[b] - t0[b])))
+            print(f"    {len(np.unique(cu))} distinct CUs for {len(raw)} workgroups, {(t1 - t0).mean():.0f} cycles each; {len(ov)} CUs with two: overlap of the pair's life times {np.mean(ov) if ov else 0:.2f}")
     ch.free()
     for ws in sets:
         for w in ws:

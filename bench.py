@@ -863,6 +863,9 @@ def run(args, env):
     # ---- roofline of the dominant kernel ------------------------------------------------------------------------------
     traffic, traffic_src = None, None
     kkey = {"chain": "k_decode_chain", "fused": "k_gemv_quad_headline", "split": "k_gemv_quad_headline"}[args.path] if decode else "k_gemm_planes"
+    is_stream = decode and args.path == "chain" and chain is not None and bool(getattr(chain, "stream", False))
+    if is_stream:
+        kkey = "k_gemv_stream"          # --pattern independent: the recording runs as k_lut_images + k_gemv_stream
     try:    # HBM bytes per launch of that kernel from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE, x2 gfx950 correction)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             ent = json.load(f).get(args.workload, {}).get(kkey)
@@ -921,7 +924,9 @@ def run(args, env):
                 roof["dense_fp16_baseline"] = {"error": repr(e)}
     elif args.path == "chain":
         ach = bytes_per_step / (ev_ms_per_step * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": ("k_decode_chain: one persistent launch per decoded token (all %d GEMVs, LUT builds and in-kernel "
+        roof = {"bound": "hbm", "kernel": ("k_lut_images + k_gemv_stream: the token's %d GEMVs as independent calls, tables prebuilt once per call, one "
+                                           "persistent launch for the lookups" % (7 * args.layers)) if is_stream else
+                                          ("k_decode_chain: one persistent launch per decoded token (all %d GEMVs, LUT builds and in-kernel "
                                            "hand-offs of the layer stack)" % (7 * args.layers)) if dpat is None else
                                           ("k_decode_chain, decoder pattern: %d launches per token (first q/k/v; per layer the segment o -> [+ residual, RMSNorm] -> "
                                            "gate/up -> [silu(gate) * up] -> down -> [+ residual, RMSNorm] -> next q/k/v with the element-wise operators inside "

@@ -68,6 +68,12 @@ def test_stream_on_fewer_workgroups(tm, grid):
         tm.binding.check(tm.lib().tmac_hip_debug_chain_grid(0))
 
 
+def test_long_stream(tm):
+    """260 calls in one recording: the workgroups' descriptor copies fill a third of LDS, the role table has 260 records, each of the two
+    workgroups of a CU walks 130 ops"""
+    _run(tm, [(128, [64], None), (256, [64, 64], None), (640, [128], None), (1024, [256, 64], None)] * 65, reps=1, seed=15)
+
+
 def _random_stream(seed):
     rng = np.random.default_rng(seed)
     ops = []

@@ -98,10 +98,11 @@ hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, hipStr
 // RING: weight fragments in flight per lookup wave.  MINW: waves per SIMD the register allocation must leave room for -- 4 with one workgroup
 // per CU (13 waves), 7 with TWO (StreamArgs::nsplit = 2: the workgroups of a CU take alternate ops -- twice the waves hide a wave's own
 // serial latency per item, which is what bounds the kernel: profiles/r05_stream_knockouts.txt).
-// Two workgroups share a CU only while the kernel's SGPR allocation stays at 80 (72 + VCC etc.): with 96 the second workgroup of a CU waited
-// for the first one to end (measured with the profiling build's place-and-time stamps: profiles/r05_stream_stamps.txt), so the count is capped
-// (the compiler parks what does not fit in VGPR lanes).
-#define TMAC_STREAM_ATTR __attribute__((amdgpu_num_sgpr(72)))
+// Two workgroups share a CU only while the kernel's SGPR allocation stays at 80 (74 + VCC, FLAT_SCRATCH, XNACK_MASK; granule 16): with 96 the
+// second workgroup of a CU waited for the first one to end (measured with the profiling build's place-and-time stamps:
+// profiles/r05_stream_stamps.txt), so the count is capped (amdgpu_num_sgpr(n) leaves n - 8 to the kernel; the compiler parks what does not
+// fit in VGPR lanes: 13 lane moves in the whole kernel with 74, 92 with 64).
+#define TMAC_STREAM_ATTR __attribute__((amdgpu_num_sgpr(82)))
 template <int BITS, bool ZP, bool SCF16, int RING, int MINW>
 __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_stream(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
@@ -384,7 +385,9 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
         unsigned long long* o = a.stamps + ((size_t)blockIdx.x * NWV + w) * 8;
 #if TMAC_STREAM_STAMPS >= 2
         for (int i = 0; i < 7; ++i) o[i] = t_lds[i];
-        o[7] = (uint32_t)(t_lds[7] + (uint32_t)t_last);
+        uint32_t hw_id2;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id2));
+        o[7] = (unsigned long long)(uint32_t)(t_lds[7] + (uint32_t)t_last) | ((unsigned long long)hw_id2 << 32);      // + where the wave ran (SIMD_ID: bits 5:4)
 #else
         const unsigned long long t_first = ((unsigned long long)t_lds[7] << 32) | t_lds[6];
         o[4] = t_last - t_first;

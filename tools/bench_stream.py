@@ -67,7 +67,17 @@ def run(Mw, K, cnt, bits):
     if stamps is not None:
         raw = stamps.cpu().numpy()
         if os.environ["STAMPS"] == "2":                               # a -DTMAC_STREAM_STAMPS=2 build
+            hwid = raw[:, :, 7] >> 32
+            raw = raw.copy(); raw[:, :, 7] &= 0xffffffff
             st = raw.astype(np.float64)
+            simd = (hwid >> 4) & 3
+            act = st[:, :, 6] > 0
+            for sd in range(4):
+                m = act & (simd == sd)
+                if m.any():
+                    print(f"      SIMD {sd}: {m.sum() / len(st):.2f} busy lookup waves per workgroup, {st[:, :, 1][m].sum() / st[:, :, 6][m].sum():.0f} cycles per item, "
+                          f"closing-barrier share {100 * st[:, :, 3][m].mean() / st[:, :, 7][m].mean():.0f} %")
+            print("      lookup waves per SIMD, first workgroups:", [np.bincount(simd[i], minlength=4).tolist() for i in range(0, min(len(simd), 6))])
             busy = st[st[:, :, 6] > 0]                                # waves with items
             tot = busy[:, 7].mean()
             pc = [100 * busy[:, i].mean() / tot for i in range(6)]

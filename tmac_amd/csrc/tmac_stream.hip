@@ -96,8 +96,9 @@ hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, hipStr
 #define TMAC_STREAM_KO 0          // timing experiments only (wrong results): 1 no combine / store, 2 no finish at all, 4 no image loads, 8 no lookups
 #endif
 // RING: weight fragments in flight per lookup wave.  MINW: waves per SIMD the register allocation must leave room for -- 4 with one workgroup
-// per CU (13 waves), 7 with TWO (StreamArgs::nsplit = 2: the workgroups of a CU take alternate ops -- twice the waves hide a wave's own
-// serial latency per item, which is what bounds the kernel: profiles/r05_stream_knockouts.txt).
+// per CU (13 waves), 8 with TWO (StreamArgs::nsplit = 2: the workgroups of a CU take alternate ops -- twice the waves hide a wave's own
+// serial latency per item, which is what bounds the kernel: profiles/r05_stream_knockouts.txt).  8, not the 7 that 26 waves need: the second
+// workgroup of a CU is placed only with <= 64 VGPRs per wave (measured: profiles/r05_stream_stamps.txt), which is what 8 waves per SIMD ask for.
 // Two workgroups share a CU only while the kernel's SGPR allocation stays at 80 (74 + VCC, FLAT_SCRATCH, XNACK_MASK; granule 16): with 96 the
 // second workgroup of a CU waited for the first one to end (measured with the profiling build's place-and-time stamps:
 // profiles/r05_stream_stamps.txt), so the count is capped (amdgpu_num_sgpr(n) leaves n - 8 to the kernel; the compiler parks what does not
@@ -221,13 +222,20 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     const __amdgpu_buffer_rsrc_t null_rs = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint4*>(nullptr), (short)0, 0, 0x00020000);   // every lane out of range: zeros, no fetch
     const TMAC_GLOBAL char* ops_g = as_global(reinterpret_cast<const char*>(a.ops));     // a dummy's scale word comes from a mapped address
     const uint32_t dummy_boff = (uint32_t)(lane & 3) * (uint32_t)((ZP ? 2 : 1) * (SCF16 ? 2 : 4));
-    int i_op = -1, i_left = 0, i_it = 0, i_st = 0, i_h = 0, i_wpq = 1, i_nst = 1, i_nsg = 1, i_gsh = 0, i_nu = 0, i_q0 = 0, i_ipi = 1;
-    int i_qe0 = 0, i_qe1 = 0, i_qe2 = 0, q_res = -1, q_woff = 0;
+    // The cursor's state is what an item costs: every instruction of this lambda is paid once per item and wave (>= 4 cycles each).  The quad
+    // is tracked as a running global index with the current matrix' quad range around it (quads ascend within an op: one compare says
+    // whether the matrix changes); the lane's part of the scale address that depends on the op alone (c0 >> gs_shift) is kept per op.
+    int i_op = -1, i_left = 0, i_st = 0, i_h = 0, i_wpq = 1, i_nst = 1, i_nsg1 = 0, i_gsh = 0, i_nu = 0, i_gq = 0, i_ipi = 1;
+    int q_lo = 0, q_hi = 0, q_woff = 0;
+    bool q_stale = true;
     cop_ptr i_d = ops;
     __amdgpu_buffer_rsrc_t q_rs = null_rs;
     const TMAC_GLOBAL char* q_sc = ops_g;
     const TMAC_GLOBAL char* q_scm = ops_g;
-    int q_mi = -1;
+    int q_scstride = 0;
+    const uint32_t c0 = (uint32_t)(4 * (lane & 12) + 4 * (lane >> 4));       // the lane's first unit inside a step (c_issue)
+    uint32_t c0g = c0;                                                       // c0 >> gs_shift of the issue cursor's op
+    constexpr int SC_SHIFT = (ZP ? 1 : 0) + (SCF16 ? 3 : 4);               // log2 of a scale group's bytes per row quad: 4 rows x (scale [, zero]) x 2 | 4
     auto refill = [&](CFrag<BITS>& f) __attribute__((always_inline)) {
         while (i_left == 0 && i_op < nops) {            // enter the next op in which this wave has items
             ++i_op;
@@ -236,35 +244,45 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                 sr16 rc; sr4 rw;
                 load_role(i_op, rc, rw);
                 i_left = items_of(rc, rw);
-                i_it = 0; i_st = rw[SRW_H]; i_h = rw[SRW_H]; i_wpq = rc[SR_WPQ]; i_nst = rc[SR_NST]; i_ipi = rc[SR_IPI];
-                i_q0 = bx * rc[SR_QPER] + min(bx, rc[SR_QEXTRA]) + rw[SRW_QS];
-                i_nsg = rc[SR_NSG]; i_gsh = rc[SR_GSH]; i_nu = rc[SR_NU];
-                i_qe0 = rc[SR_QE0]; i_qe1 = rc[SR_QE1]; i_qe2 = rc[SR_QE2];
-                q_res = -1; q_mi = -1;
+                i_st = rw[SRW_H]; i_h = rw[SRW_H]; i_wpq = rc[SR_WPQ]; i_nst = rc[SR_NST]; i_ipi = rc[SR_IPI];
+                i_gq = bx * rc[SR_QPER] + min(bx, rc[SR_QEXTRA]) + rw[SRW_QS];
+                i_nsg1 = rc[SR_NSG] - 1; i_gsh = rc[SR_GSH]; i_nu = rc[SR_NU];
+                q_scstride = rc[SR_NSG] << SC_SHIFT;
+                c0g = c0 >> i_gsh;
+                q_hi = 0; q_stale = true;                 // (no matrix yet: the first quad takes the slow path)
             }
         }
         const bool real = i_left > 0;
-        if (real && q_res != i_it) {                      // what depends on the quad alone
-            const int gqi = i_q0 + i_it * i_ipi;
-            const int mi = (gqi >= i_qe0 ? 1 : 0) + (gqi >= i_qe1 ? 1 : 0) + (gqi >= i_qe2 ? 1 : 0);
-            const int lq = gqi - (gqi >= i_qe2 ? i_qe2 : (gqi >= i_qe1 ? i_qe1 : (gqi >= i_qe0 ? i_qe0 : 0)));
-            if (mi != q_mi) {           // the matrix' pointers: per matrix a wave enters, not per quad
+        if (real && q_stale) {                            // what depends on the quad alone
+            if (i_gq >= q_hi) {                           // another matrix of the op (per matrix a wave enters, not per quad): its quad range and pointers
+                const int e0 = uni(i_d->q_end[0]), e1 = uni(i_d->q_end[1]), e2 = uni(i_d->q_end[2]);
+                const int mi = (i_gq >= e0 ? 1 : 0) + (i_gq >= e1 ? 1 : 0) + (i_gq >= e2 ? 1 : 0);
+                q_lo = i_gq >= e2 ? e2 : (i_gq >= e1 ? e1 : (i_gq >= e0 ? e0 : 0));
+                q_hi = i_gq >= e2 ? 0x7fffffff : (i_gq >= e1 ? e2 : (i_gq >= e0 ? e1 : e0));
                 q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(uni(i_d->m[mi].W)), (short)0, 0x7fffffff, 0x00020000);
                 q_scm = as_global(uni(reinterpret_cast<const char*>(i_d->m[mi].SC)));
-                q_mi = mi;
             }
-            q_sc = q_scm + (size_t)lq * (size_t)(i_nsg * 4 * (ZP ? 2 : 1) * (SCF16 ? 2 : 4));
+            const int lq = i_gq - q_lo;
+            q_sc = q_scm + (size_t)lq * (size_t)q_scstride;
             q_woff = lq * i_nst * (BITS * 1024);
-            q_res = i_it;
+            q_stale = false;
         }
         CItemOps io;
-        if (real) c_item_operands<BITS, ZP, SCF16, SM>(io, q_rs, q_woff, q_sc, i_nsg, i_gsh, i_nu, i_st, lane, lane16);
-        else { io.rs = null_rs; io.soff = 0; io.sc = ops_g; io.boff = dummy_boff; io.l16 = 0u; }      // behind the last op: keeps the FIFO's depth
+        if (real) {
+            // c_item_operands with the op's constants folded: scale group min(st * (64 >> gsh) + (c0 >> gsh), nsg - 1); lanes whose unit lies past K
+            // re-read lane 0's 16 bytes (their tables are zero tables)
+            const int st64 = i_st << 6;
+            const uint32_t sg = min((uint32_t)(st64 >> i_gsh) + c0g, (uint32_t)i_nsg1);
+            io.rs = q_rs; io.sc = q_sc;
+            io.boff = (sg << SC_SHIFT) | dummy_boff;
+            io.l16 = (lane < i_nu - st64) ? lane16 : 0u;
+            io.soff = q_woff + i_st * (BITS * 1024);
+        } else { io.rs = null_rs; io.soff = 0; io.sc = ops_g; io.boff = dummy_boff; io.l16 = 0u; }      // behind the last op: keeps the FIFO's depth
         c_issue_static<BITS, ZP, SCF16, SM>(f, io);
         if (real) {
             --i_left;
             i_st += i_wpq;
-            if (i_st >= i_nst) { i_st = i_h; ++i_it; }
+            if (i_st >= i_nst) { i_st = i_h; i_gq += i_ipi; q_stale = true; }
         }
     };
 #pragma unroll
@@ -414,7 +432,7 @@ static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int
         } \
         hipLaunchKernelGGL(kern, dim3(grid * a.nsplit), dim3(STREAM_FT), lds_bytes, st, a); \
         return hipGetLastError(); } while (0)
-#define TMAC_SL(Z, H) do { if (a.nsplit >= 2) TMAC_SL2(Z, H, R2, 7); else TMAC_SL2(Z, H, R1, 4); } while (0)
+#define TMAC_SL(Z, H) do { if (a.nsplit >= 2) TMAC_SL2(Z, H, R2, 8); else TMAC_SL2(Z, H, R1, 4); } while (0)
     if (zp) { if (sc_f16) TMAC_SL(true, true); else TMAC_SL(true, false); }
     if (sc_f16) TMAC_SL(false, true);
     TMAC_SL(false, false);

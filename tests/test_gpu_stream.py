@@ -112,17 +112,61 @@ def test_stream_equals_the_ordinary_chain(tm, monkeypatch):
     s.free(); c.free(); m.free()
 
 
-def test_dependent_and_unified_scale_recordings_are_not_streams(tm):
+def test_dependent_recordings_are_not_streams(tm):
     m = Model(tm, [(1024, [1024], None), (1024, [256], (0, 0))], seed=12)
     c = m.record()
     assert not c.stream
     c.launch(); m.check(c)
     c.free(); m.free()
-    m = Model(tm, [(1024, [1024], None), (640, [256], None)], seed=13, mg=1)      # unified scales: the tables need the row's maximum; k_decode_chain
+
+
+# Unified scales (BitNet: one act group per row, int32 totals + scale-final: tbl.cc:536-630, qgemm.py:170-174): k_lut_images_us builds the
+# row's scale and the sequential bias chain once per call, the service wave applies scale-final.  Same two bars; the oracle bar is exact
+# here (the harness compares unified-scale outputs with the oracle's fp32 result rounded once).
+US_OPS = [
+    (1024, [512, 256], None),
+    (3200, [3200], None),                      # BitNet-3B's q / k / v / o shape
+    (8640, [640], None),                       # ... its down projection's K: 4.2 steps, 270 chunk sums in the bias chain
+    (3200, [1088, 1088], None),
+    (128, [64], None),
+    (6144, [256], None),
+]
+
+
+@pytest.mark.parametrize("bits,mg,dev_f16,ternary", [(2, 1, True, True), (2, 1, False, False), (1, 1, True, False), (3, 2, True, False), (4, 1, False, False), (2, 4, True, False)])
+def test_stream_of_unified_scale_calls(tm, bits, mg, dev_f16, ternary):
+    _run(tm, US_OPS, bits=bits, mg=mg, dev_f16=dev_f16, ternary=ternary, seed=21)
+
+
+def test_stream_unified_scales_fp32_and_small_grids(tm):
+    _run(tm, US_OPS[:4], mg=1, out_f16=False, seed=22)
+    _run(tm, US_OPS[:4], mg=1, ext_f32=True, seed=23)
+    tm.binding.check(tm.lib().tmac_hip_debug_chain_grid(96))
+    try:
+        _run(tm, US_OPS, mg=1, ternary=True, seed=24)
+    finally:
+        tm.binding.check(tm.lib().tmac_hip_debug_chain_grid(0))
+
+
+def test_unified_scale_stream_equals_the_ordinary_chain(tm, monkeypatch):
+    import torch
+    m = Model(tm, US_OPS, mg=1, ternary=True, seed=25)
+    s = m.record()
+    assert s.stream
+    s.launch(); torch.cuda.synchronize()
+    a = [[o.clone() for o in os_] for os_ in m.outs]
+    for os_ in m.outs:
+        for o in os_:
+            o.zero_()
+    monkeypatch.setenv("TMAC_CHAIN_STREAM", "0")
     c = m.record()
     assert not c.stream
-    c.launch(); m.check(c)
-    c.free(); m.free()
+    c.launch(); torch.cuda.synchronize()
+    assert c.status() == 0
+    for x, y in zip(a, m.outs):
+        for p, q in zip(x, y):
+            assert torch.equal(p, q)
+    s.free(); c.free(); m.free()
 
 
 def test_stream_launch_inside_a_hip_graph(tm):

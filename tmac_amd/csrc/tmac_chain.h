@@ -149,7 +149,7 @@ inline size_t stream_lds_bytes(int buf_u4, int nops) {
 #endif
     return b;
 }
-hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, hipStream_t st);
-hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st);
+hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, int sm, hipStream_t st);
+hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st);
 
 }  // namespace tmac

@@ -475,7 +475,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
     // once per activation vector (llama_cpp_init), lookups per matrix (llama_cpp_compute); see tmac_stream.hip.  The hazard analysis
     // above has already refused every write of the launch that touches a vector another op reads from memory.  TMAC_CHAIN_STREAM=0: A/B.
     {
-        bool indep = c->sm == 0 && c->world == 1 && gat.empty() && env_int("TMAC_CHAIN_STREAM", 1) != 0;
+        bool indep = (c->sm == 0 || c->sm == 2) && c->world == 1 && gat.empty() && env_int("TMAC_CHAIN_STREAM", 1) != 0;
         for (size_t i = 0; i < n && indep; ++i)
             if (src[i].op >= 0 || src2[i].op >= 0 || rec[i].xf.kind != TMAC_XF_NONE || c->ops[i].epi) indep = false;
         if (indep) {
@@ -611,12 +611,12 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
     }
     if (!c->connected) return fail(TMAC_HIP_E_ARG, "a row-sharded chain must be connected to its peers first (tmac_hip_chain_export / tmac_hip_chain_connect)");
     if (c->stream) {
-        hipError_t e = launch_lut_images(c->d_ops, (int)c->ops.size(), c->max_nst, st);
+        hipError_t e = launch_lut_images(c->d_ops, (int)c->ops.size(), c->max_nst, c->sm, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT image launch: %s", hipGetErrorString(e));
         StreamArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.ops = c->d_ops; sa.nops = (int)c->ops.size(); sa.out_f16 = c->out_f16; sa.buf_u4 = c->buf_u4; sa.nsplit = c->nsplit; sa.roles = c->roles; sa.stamps = c->stamps;
-        e = launch_gemv_stream(sa, c->bits, c->zp != 0, c->sc_f16 != 0, c->grid, c->lds_bytes, st);
+        e = launch_gemv_stream(sa, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "stream launch: %s", hipGetErrorString(e));
         c->last_stream = st; c->launched = true;
         return TMAC_HIP_OK;

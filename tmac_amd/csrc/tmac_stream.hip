@@ -21,7 +21,8 @@
 //   * no hand-off, no polls, no spin: nothing waits for another workgroup, so residency is not a correctness condition.
 // Arithmetic per item and per row is k_decode_chain's / k_gemv_quad's (c_compute, the same wave / lane decomposition, the same
 // combination order of split quads), the tables are q_table8's: outputs are bit-identical to the other N = 1 paths for the same waves
-// per quad.  Scope: 1- to 4-bit QUAD-layout weights with per-group scales (act groups of 64); fp16 or fp32 activations.
+// per quad.  Scope: 1- to 4-bit QUAD-layout weights with per-group scales (act groups of 64) or unified scales (SM = 2: one act group per row,
+// exact int32 totals per bit-plane, scale-final in the service wave; tables by k_lut_images_us); fp16 or fp32 activations.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
@@ -85,9 +86,77 @@ __global__ __launch_bounds__(256) void k_lut_images(const ChainOp* __restrict__ 
     }
 }
 
-hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, hipStream_t st) {
+// Unified-scale calls (BitNet: one act group = the whole row, qgemm.py:93-96, 170-174): ONE block per op.  The scale is a maximum over K and
+// lut_biases ONE fp32 chain over the K / 32 chunk sums in order (lut_ctor.cc:157,218) -- k_decode_chain's SM = 2 build, bit for bit: pass 1
+// maxima and chunk sums, pass 2 the tables with the row's scale, the chain by one lane.  Image: the tables as above, then float 0 = lut_scales,
+// float 1 = lut_biases (what the scale-final epilogue of k_gemv_stream's service wave reads).
+__global__ __launch_bounds__(256) void k_lut_images_us(const ChainOp* __restrict__ ops) {
+    __shared__ float s_cs[768];                 // chunk sums (K <= 24576)
+    __shared__ float s_mx[4];
+    const ChainOp& d = ops[blockIdx.x];
+    const int K = d.K, P = K / 8, nu = d.nu, nst = d.nst, tstride = d.tstride;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    uint4* tab = reinterpret_cast<uint4*>(const_cast<void*>(d.img));
+    float* l_us = reinterpret_cast<float*>(tab + 4 * tstride);
+    auto load8 = [&](int p, float (&x)[8]) __attribute__((always_inline)) {
+        if (d.in_gran & 2) {
+            const float4* src = reinterpret_cast<const float4*>(d.in) + 2 * (size_t)p;
+            const float4 a0 = src[0], a1 = src[1];
+            x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; x[3] = a0.w; x[4] = a1.x; x[5] = a1.y; x[6] = a1.z; x[7] = a1.w;
+        } else {
+            const uint4 v = reinterpret_cast<const uint4*>(d.in)[p];
+            const uint32_t r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const __half2 hh = *reinterpret_cast<const __half2*>(&r[i]);
+                x[2 * i] = __low2float(hh); x[2 * i + 1] = __high2float(hh);
+            }
+        }
+    };
+    float mx = 0.f;
+    for (int p = tid; p < P; p += 256) {        // (P % 4 == 0: the four lanes of a chunk are valid together)
+        float x[8];
+        load8(p, x);
+        mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x[0]), fabsf(x[1])), __fadd_rn(fabsf(x[2]), fabsf(x[3]))));
+        mx = fmaxf(mx, __fadd_rn(__fadd_rn(fabsf(x[4]), fabsf(x[5])), __fadd_rn(fabsf(x[6]), fabsf(x[7]))));
+        float va = -__fadd_rn(__fadd_rn(__fadd_rn(x[0], x[1]), x[2]), x[3]);
+        float vb = -__fadd_rn(__fadd_rn(__fadd_rn(x[4], x[5]), x[6]), x[7]);
+        va = __fadd_rn(va, qdpp_f<0x4E>(va));      // lane ^ 2: v0+v4 | v2+v6      (lut_ctor.cc:25-31)
+        vb = __fadd_rn(vb, qdpp_f<0x4E>(vb));
+        va = __fadd_rn(va, qdpp_f<0xB1>(va));      // lane ^ 1: (v0+v4)+(v2+v6)
+        vb = __fadd_rn(vb, qdpp_f<0xB1>(vb));
+        if ((p & 3) == 0) s_cs[p >> 2] = __fadd_rn(va, vb);
+    }
+    mx = q_row_allmax(mx);
+    mx = q_xor_max_f(mx);
+    if (lane == 0) s_mx[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+    const float gscale = div127(mx);
+    const float gtinv = (gscale != 0.0f) ? rcp_exact(gscale) : 0.0f;
+    for (int p = tid; p < P; p += 256) {
+        float x[8];
+        load8(p, x);
+        uint32_t lo0, hi0, lo1, hi1;
+        float La, Lb;
+        q_table8<true>(x[0], x[1], x[2], x[3], gtinv, lo0, hi0, La);
+        q_table8<true>(x[4], x[5], x[6], x[7], gtinv, lo1, hi1, Lb);
+        tab[(p & 3) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
+    }
+    for (int j4 = 0; j4 < 4; ++j4)
+        for (int u = nu + tid; u < nst * 64; u += 256) tab[j4 * tstride + u] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) {
+        float biases = 0.0f;
+        for (int c = 0; c < nu; ++c) biases = __fadd_rn(biases, s_cs[c]);
+        l_us[0] = gscale;
+        l_us[1] = biases;
+    }
+}
+
+hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, int sm, hipStream_t st) {
     if (nops < 1 || max_nst < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_lut_images, dim3(max_nst, nops), dim3(256), 0, st, d_ops);
+    if (sm == 2) hipLaunchKernelGGL(k_lut_images_us, dim3(nops), dim3(256), 0, st, d_ops);
+    else hipLaunchKernelGGL(k_lut_images, dim3(max_nst, nops), dim3(256), 0, st, d_ops);
     return hipGetLastError();
 }
 
@@ -104,10 +173,9 @@ hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, hipStr
 // profiles/r05_stream_stamps.txt), so the count is capped (amdgpu_num_sgpr(n) leaves n - 8 to the kernel; the compiler parks what does not
 // fit in VGPR lanes: 13 lane moves in the whole kernel with 74, 92 with 64).
 #define TMAC_STREAM_ATTR __attribute__((amdgpu_num_sgpr(82)))
-template <int BITS, bool ZP, bool SCF16, int RING, int MINW>
+template <int BITS, bool ZP, bool SCF16, int RING, int MINW, int SM>
 __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_stream(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
-    constexpr int SM = 0;
     constexpr int NWV = STREAM_NLW;                     // lookup waves; wave NWV is the loader
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // nsplit workgroups share every row range: workgroup (bx, part) walks the ops part, part + nsplit, ... with the rows of range bx.  They
@@ -164,8 +232,35 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                 const int p_lq = p_gql - (p_gql >= e2 ? e2 : (p_gql >= e1 ? e1 : (p_gql >= e0 ? e0 : 0)));
                 const unsigned long long p_c = reinterpret_cast<unsigned long long>(d->m[p_mi].C);
                 const float* red = l_red + par * (NWV * 4 * CHAIN_RED);
-                float v = red[((p_qs * wpq) * 4 + p_row) * CHAIN_RED];
+                float v;
+                if (SM == 2) {
+                    // exact int32 totals per bit-plane, then scale-final (qgemm.py:170-174,192-206) as k_decode_chain's epilogue:
+                    // C = ((sum_p float(cb_p) alpha_p) lut_scales + lut_biases / 2) Scale; the two LUT scalars sit behind the op's tables in LDS
+                    int32_t cb[BITS];
+#pragma unroll
+                    for (int pl = 0; pl < BITS; ++pl) cb[pl] = 0;
+                    const int32_t* redi = reinterpret_cast<const int32_t*>(red);
+                    for (int ww = 0; ww < wpq; ++ww)
+#pragma unroll
+                        for (int pl = 0; pl < BITS; ++pl) cb[pl] += redi[((p_qs * wpq + ww) * 4 + p_row) * CHAIN_RED + pl];
+                    float acc = 0.f;
+#pragma unroll
+                    for (int pl = 0; pl < BITS; ++pl) {
+                        const float tp = __fmul_rn((float)cb[pl], q_alpha(pl));
+                        acc = (pl == 0) ? tp : __fadd_rn(acc, tp);
+                    }
+                    const float* l_us = reinterpret_cast<const float*>(lds + (size_t)(j & 1) * a.buf_u4 + 4 * (size_t)uni(d->tstride));
+                    const float vv = __fadd_rn(__fmul_rn(acc, l_us[0]), __fmul_rn(l_us[1], 0.5f));
+                    const int mg = uni(d->m_groups);
+                    const int g = mg == 1 ? 0 : (4 * p_lq + p_row) / (d->m[p_mi].Mw / mg);
+                    const void* scp = d->m[p_mi].SC;
+                    const float us = SCF16 ? __half2float(__ushort_as_half(as_global(reinterpret_cast<const unsigned short*>(scp))[g]))
+                                           : as_global(reinterpret_cast<const float*>(scp))[g];
+                    v = __fmul_rn(vv, us);
+                } else {
+                v = red[((p_qs * wpq) * 4 + p_row) * CHAIN_RED];
                 for (int ww = 1; ww < wpq; ++ww) v = __fadd_rn(v, red[((p_qs * wpq + ww) * 4 + p_row) * CHAIN_RED]);
+                }
                 asm volatile("" : "+v"(v));       // the fp16 output is the fp32 result rounded once more (no fused convert: k_decode_chain)
                 const size_t oi = (size_t)(4 * p_lq + p_row);
                 if (a.out_f16) c_store_b16(p_c + 2 * oi, (uint32_t)__half_as_ushort(__float2half_rn(v)));
@@ -324,6 +419,19 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     auto finish = [&](bool have, float acc_in) __attribute__((always_inline)) {
         if (TMAC_STREAM_KO & 2) { ++c_it; return; }
         float* red = l_red + parity * (NWV * 4 * CHAIN_RED);
+        if (SM == 2) {
+            // exact integer totals of the lane's row (lane & 3), per bit-plane: lanes of a DPP row by rotation, rows by two cross-row moves
+            int32_t* redi = reinterpret_cast<int32_t*>(red);
+#pragma unroll
+            for (int pl = 0; pl < BITS; ++pl) {
+                uint32_t v = have ? (uint32_t)iacc[pl] : 0u;
+                v += qdpp_u<0x124>(v);
+                v += qdpp_u<0x128>(v);
+                v = q_xor_add_u(v);
+                if (lane < 4) redi[(wl * 4 + lane) * CHAIN_RED + pl] = (int32_t)v;
+                iacc[pl] = 0;
+            }
+        } else {
         float acc = 0.f;
         if (have) {
             acc = acc_in;
@@ -332,6 +440,7 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
             acc = q_xor_add_f(acc);
         }
         if (lane < 4) red[(wl * 4 + lane) * CHAIN_RED] = acc;
+        }
         TMAC_ST(2);
         c_lds_barrier();                          // the service wave combines and stores behind it
         TMAC_ST(3);
@@ -421,32 +530,33 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
 }
 
 template <int BITS>
-static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st) {
+static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st) {
     constexpr int R2 = (BITS <= 3) ? 2 : 1;      // two workgroups per CU: <= 64 VGPRs
     constexpr int R1 = (BITS <= 2) ? 4 : 2;      // ring depth 2..8 measured flat (profiles/r05_stream_knockouts.txt); two workgroups per CU need <= 72 registers
-#define TMAC_SL2(Z, H, R, MW) do { \
-        auto* kern = &k_gemv_stream<BITS, Z, H, R, MW>; \
+#define TMAC_SL2(Z, H, R, MW, S) do { \
+        auto* kern = &k_gemv_stream<BITS, Z, H, R, MW, S>; \
         if (lds_bytes > 64 * 1024) { \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e != hipSuccess) return e; \
         } \
         hipLaunchKernelGGL(kern, dim3(grid * a.nsplit), dim3(STREAM_FT), lds_bytes, st, a); \
         return hipGetLastError(); } while (0)
-#define TMAC_SL(Z, H) do { if (a.nsplit >= 2) TMAC_SL2(Z, H, R2, 8); else TMAC_SL2(Z, H, R1, 4); } while (0)
-    if (zp) { if (sc_f16) TMAC_SL(true, true); else TMAC_SL(true, false); }
-    if (sc_f16) TMAC_SL(false, true);
-    TMAC_SL(false, false);
+#define TMAC_SL(Z, H, S) do { if (a.nsplit >= 2) TMAC_SL2(Z, H, R2, 8, S); else TMAC_SL2(Z, H, R1, 4, S); } while (0)
+    if (sm == 2) { if (sc_f16) TMAC_SL(false, true, 2); else TMAC_SL(false, false, 2); }      // unified scales: no zero points (qgemm.py:170-174)
+    if (zp) { if (sc_f16) TMAC_SL(true, true, 0); else TMAC_SL(true, false, 0); }
+    if (sc_f16) TMAC_SL(false, true, 0);
+    TMAC_SL(false, false, 0);
 #undef TMAC_SL
 #undef TMAC_SL2
 }
 
-hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int grid, size_t lds_bytes, hipStream_t st) {
-    if (a.nops < 1 || grid < 1 || a.nsplit < 1 || a.nsplit > 4) return hipErrorInvalidValue;
+hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st) {
+    if (a.nops < 1 || grid < 1 || a.nsplit < 1 || a.nsplit > 4 || (sm != 0 && sm != 2)) return hipErrorInvalidValue;
     switch (bits) {
-        case 1: return stream_launch_b<1>(a, zp, sc_f16, grid, lds_bytes, st);
-        case 2: return stream_launch_b<2>(a, zp, sc_f16, grid, lds_bytes, st);
-        case 3: return stream_launch_b<3>(a, zp, sc_f16, grid, lds_bytes, st);
-        case 4: return stream_launch_b<4>(a, zp, sc_f16, grid, lds_bytes, st);
+        case 1: return stream_launch_b<1>(a, zp, sc_f16, sm, grid, lds_bytes, st);
+        case 2: return stream_launch_b<2>(a, zp, sc_f16, sm, grid, lds_bytes, st);
+        case 3: return stream_launch_b<3>(a, zp, sc_f16, sm, grid, lds_bytes, st);
+        case 4: return stream_launch_b<4>(a, zp, sc_f16, sm, grid, lds_bytes, st);
         default: return hipErrorInvalidValue;
     }
 }

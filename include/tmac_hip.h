@@ -232,7 +232,8 @@ int32_t tmac_hip_chain_threads(void);   /* threads per workgroup of k_decode_cha
  * llama_cpp_init per activation vector, then lookups only (tmac_gemm_wrapper.h:170-228) -- and k_gemv_stream walks the calls with the
  * tables prebuilt, a loader wave per workgroup staging the next call's tables while the lookup waves stream this call's weights; the
  * weight prefetch runs across call boundaries.  No hand-offs, no spins: residency is not a correctness condition there.  Same
- * arithmetic, same lane / wave decomposition: outputs bit-identical to the other N = 1 paths.  Per-group scales only;
+ * arithmetic, same lane / wave decomposition: outputs bit-identical to the other N = 1 paths.  Per-group scales, or unified scales
+ * (BitNet: the row's scale and the sequential bias chain by k_lut_images_us, scale-final on exact int32 totals);
  * TMAC_CHAIN_STREAM=0 in the environment keeps the ordinary chain (A/B). */
 int32_t tmac_hip_chain_is_stream(const tmac_hip_chain* chain);
 /* profiling / A-B knobs: s_memrealtime stamps (100 MHz) [calls][workgroups][8] of wave 0 (0 call entry, 1 activations complete, 2 LUT

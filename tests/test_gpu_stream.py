@@ -87,7 +87,9 @@ def _random_stream(seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("TMAC_FUZZ_STREAMS", "10"))))
 def test_random_streams(tm, seed):
     rng = np.random.default_rng(2000 + seed)
-    _run(tm, _random_stream(seed), bits=int(rng.integers(1, 5)), zp=bool(rng.integers(0, 2)), dev_f16=bool(rng.integers(0, 2)), seed=80 + seed)
+    bits, zp, dev_f16 = int(rng.integers(1, 5)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    mg = int(rng.choice([-1, -1, 1, 2]))        # per-group scales, or 1 / 2 unified scales per matrix (every row count above is even)
+    _run(tm, _random_stream(seed), bits=bits, zp=zp, dev_f16=dev_f16, mg=mg, seed=80 + seed)
 
 
 def test_stream_equals_the_ordinary_chain(tm, monkeypatch):

@@ -3,7 +3,9 @@
 call, one launch; us per GEMV (hipEvent pair, mean / best of 10), fraction of the 8 TB/s HBM peak on SURVEY 8d's algorithmic bytes, and
 a bit-comparison of every call's output with the same call launched on its own (tmac_hip_qgemm_fused_dev, the chain's configuration).
 usage: bench_stream.py [shape ...]   shape = MwxK[xCNT][:bits]   default: 4096x11008 4096x4096 11008x4096x2 4096x4096x3
-env: NL (calls per launch, default 32), TMAC_CHAIN_STREAM=0 measures k_decode_chain on the same recording, FORCE_WPQ=n forces the waves per row quad."""
+env: NL (calls per launch, default 32), TMAC_CHAIN_STREAM=0 measures k_decode_chain on the same recording, FORCE_WPQ=n forces the waves per row quad,
+TMAC_STREAM_SPLIT=1 one workgroup per CU; STAMPS=1|2 with a profiling build of the library (tools/build_variant.sh x "-DTMAC_STREAM_STAMPS=1|2",
+TMAC_HIP_LIB=.../libtmac_hip_x.so): 1 = where and when every workgroup ran (co-residency), 2 = where a lookup wave's cycles go."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -15,7 +15,7 @@
 //     loads of every item are the same unconditional sequence (c_issue_static), barriers and stores are asm: the compiler counts the
 //     loads behind the one it needs and waits per slot (s_waitcnt vmcnt((RING - 1) * loads per item)) instead of draining the ring
 //     (profiles/r05_ring_static.txt);
-//   * TWO workgroups per CU for 1- / 2-bit weights, each walking every other op: a lookup wave is bounded by its own serial latency per item
+//   * TWO workgroups per CU for 1- to 3-bit weights (they need <= 64 VGPRs and <= 80 SGPRs per wave to be co-resident), each walking every other op: a lookup wave is bounded by its own serial latency per item
 //     (table reads, eight dependent MFMAs, scale chain), so twice the waves on a CU -- not a deeper ring, not fewer barriers, both measured
 //     flat -- is what fills the gaps: headline 3.43 -> 2.93 us per call, gate/up 5.35 -> 4.52 (profiles/r05_stream_knockouts.txt);
 //   * no hand-off, no polls, no spin: nothing waits for another workgroup, so residency is not a correctness condition.
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
 template <int BITS>
 static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st) {
     constexpr int R2 = (BITS <= 3) ? 2 : 1;      // two workgroups per CU: <= 64 VGPRs
-    constexpr int R1 = (BITS <= 2) ? 4 : 2;      // ring depth 2..8 measured flat (profiles/r05_stream_knockouts.txt); two workgroups per CU need <= 72 registers
+    constexpr int R1 = (BITS <= 2) ? 4 : 2;      // one workgroup per CU: ring depth 2..8 measured flat (profiles/r05_stream_knockouts.txt)
 #define TMAC_SL2(Z, H, R, MW, S) do { \
         auto* kern = &k_gemv_stream<BITS, Z, H, R, MW, S>; \
         if (lds_bytes > 64 * 1024) { \

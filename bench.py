@@ -987,6 +987,34 @@ def run(args, env):
                                    "frac": round(hb / sus * 1e-3 / HBM_PEAK_GBS, 4), "ok": sok and ssame,
                                    "bit_identical_to_single_launches": ssame,
                                    "timing": "hipEvent pair around 10 back-to-back replays (LUT build launches included), mean of 10 pairs"}
+            # the same measurement for the layer's other three calls (q/k/v fused, o, gate/up fused): what the shape costs in stream mode
+            try:
+                by_shape = {}
+                for name2, Mw2, K2, cnt2, slot2 in MATS[:3]:
+                    xs2 = [torch.randn(K2, device=dev, generator=gen).half() for _ in range(args.layers)]
+                    os2 = [[torch.empty(shard_rows[name2], dtype=torch.float16, device=dev) for _ in range(cnt2)] for _ in range(args.layers)]
+                    with wr.record_chain() as rec2:
+                        for li in range(args.layers):
+                            wr.fused(layers[li][name2], xs2[li], os2[li], 1, act_dtype=F16, out_dtype=F16)
+                    d2 = []
+                    for r in range(8):
+                        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(SB):
+                            rec2.chain.launch()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        if r >= 2:
+                            d2.append(e0.elapsed_time(e1) * 1e-3 / (SB * args.layers))
+                    ok2 = rec2.chain.status() == 0
+                    rec2.chain.free()
+                    hb2 = cnt2 * algorithmic_bytes(Mw2, K2, BITS, GS, ags_of(K2), ZP, MG) - (cnt2 - 1) * (K2 // 4 * 16 + (K2 // ags_of(K2)) * 4)
+                    us2 = float(np.mean(d2)) * 1e6
+                    by_shape[name2] = {"shape": "%d x %dx%d" % (cnt2, Mw2, K2), "us_per_call": round(us2, 3), "GBps": round(hb2 / us2 * 1e-3, 1),
+                                       "frac": round(hb2 / us2 * 1e-3 / HBM_PEAK_GBS, 4), "ok": ok2}
+                roof["stream_by_shape"] = by_shape
+            except tmac_amd.binding.TMACHipError as e:
+                roof["stream_by_shape"] = {"error": repr(e)}
             # ... and the whole token's 224 matrices as independent calls (what --pattern independent times): every call reads a resident vector
             try:
                 ix = {s_: torch.randn(xdim[s_], device=dev, generator=gen).half() for s_ in xdim}

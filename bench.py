@@ -101,7 +101,7 @@ def parse():
                     help="multi-GPU exchange step: torch.distributed (ProcessGroupNCCL = RCCL; default, the path exercised so far), the "
                          "library's own communicator (tmac_hip_comm_*: RCCL through the C-ABI, bootstrapped over torch.distributed), or its "
                          "IPC transport (windows mapped by every peer, no RCCL; tests/test_gpu_comm.py runs it with two processes on one device)")
-    ap.add_argument("--no-prefill-headline", action="store_true", help="multi-GPU decode runs: skip the N = 256 prefill measurement reported next to the decode line")
+    ap.add_argument("--no-prefill-headline", action="store_true", help="decode runs: skip the N = 256 prefill measurement of the same matrices reported next to the decode line (prefill_twin on one GPU, prefill_scaling_headline on several)")
     ap.add_argument("--force-dist", action="store_true", help=argparse.SUPPRESS)   # debugging: take the multi-GPU code path with 1 rank
     ap.add_argument("--share-device", action="store_true",
                     help="test mode (tests/test_gpu_comm.py): every rank uses device 0 -- RCCL refuses that, so torch.distributed runs on gloo with host "
@@ -1270,6 +1270,23 @@ def main():
             head = {"error": repr(e)}
         if res is not None:
             res["prefill_scaling_headline"] = head
+    # One GPU: the prefill twin rides along in the default line too (N = 256 over the same matrices, with its graph-replayed dense fp16 baseline),
+    # so that the driver's own run carries a prefill number, not only the builder's.  Outside the timed region.
+    if (world == 1 and not dist_on and res is not None and WORKLOADS[args.workload]["N"] == 1 and args.workload in PREFILL_TWIN
+            and not args.no_prefill_headline and args.pattern == "chained" and not args.stamps):
+        import copy
+        a2 = copy.copy(args)
+        a2.workload, a2.path, a2.pattern = PREFILL_TWIN[args.workload], "auto", "chained"
+        a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_verify = 30, 5, True, True
+        a2.layers = min(args.layers, WORKLOADS[a2.workload]["layers"])
+        try:
+            r2 = run(a2, env)
+            r2r = r2.get("roofline") or {}
+            res["prefill_twin"] = {"workload": r2["config"]["workload"], "ms_per_step": r2["ms_per_step"], "value": r2["value"], "unit": r2["unit"],
+                                   "steps": r2["steps"], "frac_of_int8_mfma_peak": r2r.get("frac"), "dense_equivalent": r2r.get("dense_equivalent"),
+                                   "dense_fp16_baseline": r2r.get("dense_fp16_baseline")}
+        except BaseException as e:      # the decode number is never lost to the extra measurement
+            res["prefill_twin"] = {"error": repr(e)}
     if rank == 0 and res is not None:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(res) + "\n").encode())

@@ -12,7 +12,7 @@ timeout 300 python $R/bench.py --pattern decoder --no-cpu-baseline > $O/bench_de
 timeout 300 python $R/bench.py --pattern independent --no-cpu-baseline --no-stream-core > $O/bench_independent_pattern.json 2> $O/bench_independent_pattern.err
 timeout 300 python $R/tools/bench_stream.py 4096x11008 4096x4096 11008x4096x2 4096x4096x3 4096x11008:4 11008x4096x2:4 4096x11008:3 4096x11008:1 > $O/bench_stream.txt 2>&1
 TMAC_CHAIN_STREAM=0 timeout 300 python $R/tools/bench_stream.py 4096x11008 4096x4096 11008x4096x2 4096x4096x3 > $O/bench_stream_as_chain.txt 2>&1
-B="python $R/bench.py --no-cpu-baseline --no-verify --no-decoder-pattern --no-stream-core"
+B="python $R/bench.py --no-cpu-baseline --no-verify --no-decoder-pattern --no-stream-core --no-prefill-headline"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_chain -- $B > $O/trace_chain.json 2> $O/trace_chain.log
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_stream -- $B --pattern independent --steps 200 > $O/trace_stream.json 2> $O/trace_stream.log
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bitnet -- $B --workload bitnet-3b > $O/trace_bitnet.json 2> $O/trace_bitnet.log

@@ -162,6 +162,8 @@ def test_bench_runs_and_verifies(tm, extra, path):
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["activations_finite"]
     if "--force-dist" not in extra:
         assert d["verified"]["ok"], d["verified"]
+        tw = d["prefill_twin"]          # the N = 256 twin of the same matrices rides along in a one-GPU decode line
+        assert "error" not in tw and tw["value"] > 0 and tw["dense_fp16_baseline"]["ms_per_step"] > 0, tw
     if path == "chain":
         assert d["roofline"]["headline_gemv"]["us"] > 0
 

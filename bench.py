@@ -1287,6 +1287,22 @@ def main():
                                    "dense_fp16_baseline": r2r.get("dense_fp16_baseline")}
         except BaseException as e:      # the decode number is never lost to the extra measurement
             res["prefill_twin"] = {"error": repr(e)}
+    # ... and so do the other two decode configurations of BASELINE.json (W4 GPTQ-style, BitNet-b1.58-3B): their chains, 200 launches each,
+    # outside the timed region, so that the driver's run carries them as well
+    if (world == 1 and not dist_on and res is not None and args.workload == "llama2-7b-w2" and args.pattern == "chained" and args.path in ("auto", "chain")
+            and not args.no_prefill_headline and not args.stamps and args.layers == WORKLOADS[args.workload]["layers"]):
+        import copy
+        res["other_decode_chains"] = {}
+        for w2 in ("llama2-7b-w4", "bitnet-3b"):
+            a2 = copy.copy(args)
+            a2.workload, a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_verify = w2, 200, 10, True, True
+            a2.no_stream_core, a2.no_decoder_pattern, a2.layers = True, True, WORKLOADS[w2]["layers"]
+            try:
+                r2 = run(a2, env)
+                res["other_decode_chains"][w2] = {"workload": r2["config"]["workload"], "ms_per_step": r2["ms_per_step"], "value": r2["value"], "unit": r2["unit"],
+                                                  "steps": r2["steps"], "frac": (r2.get("roofline") or {}).get("frac")}
+            except BaseException as e:
+                res["other_decode_chains"][w2] = {"error": repr(e)}
     if rank == 0 and res is not None:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(res) + "\n").encode())

@@ -52,7 +52,8 @@ struct ChainOp {
     // stream mode (tmac_stream.hip): the op's prebuilt LUT image in global memory (layout of the LDS LUT buffer) and its size in uint4, whole KB
     const void* img;
     int img_u4;
-    int pad;
+    int wg_lo;           // stream mode: the op is served by the row ranges (workgroups) wg_lo .. wg_lo + wg_cnt - 1 of the launch; q_per / q_extra / wpq / ipi
+                         // are those of total_q quads dealt to wg_cnt ranges, range wg_lo + b owning what workgroup b owns above (0 in k_decode_chain)
     // sizeof == 320: the kernel keeps a copy of all descriptors in LDS (uint4 copies)
 };
 static_assert(sizeof(ChainOp) == 320, "ChainOp is copied to LDS in 16-byte pieces");
@@ -126,9 +127,17 @@ struct StreamArgs {
     const ChainOp* ops;
     int nops;
     int out_f16;
-    int buf_u4;                    // uint4 per LDS LUT buffer (two buffers, by op parity), a multiple of 64
-    int nsplit;                    // workgroups per row range (1 or 2): workgroup (range, part) takes the ops part, part + nsplit, ...
-    const int* roles;              // [nops][STREAM_ROLE_INTS]: what a lookup wave needs to enter an op, worked out by the host (layout below)
+    int buf_u4;                    // uint4 per LDS LUT buffer (two buffers, by visit parity), a multiple of 64
+    int nsplit;                    // workgroups per row range (1 or 2): workgroup (range, part) takes the visits part, part + nsplit, ... of its class
+    // The SCHEDULE (round 6): the calls are independent, so not every row range has to visit every op.  The grid's row ranges form `ncls`
+    // classes of consecutive ranges (range b is in class b * ncls / ranges); the host deals every op to an aligned block of classes -- the
+    // ranges wg_lo .. wg_lo + wg_cnt - 1 share its rows -- and writes, per class, the list of ops it visits.  An op that is small for 256 CUs
+    // is then served by a fraction of them with proportionally more rows each, while the other classes work on other ops: the costs of a
+    // visit (two barriers, the image, the waves' op change, idle waves in a short op) are paid per (workgroup, visit), not per byte.
+    int ncls;                      // classes (a power of two <= ranges; 1: every range visits every op)
+    int vmax;                      // records per class in `roles`
+    const int* nvis;               // [ncls] visits of each class
+    const int* roles;              // [ncls][vmax][STREAM_ROLE_INTS]: what a lookup wave needs to enter a visit, worked out by the host (layout below)
     unsigned long long* stamps;    // profiling builds only, else ignored: [workgroups][lookup waves][8].  -DTMAC_STREAM_STAMPS=2: cycle sums 0 waiting for weights,
                                    // 1 lookups + refill, 2 partial sums, 3 closing barriers, 4 op change, 5 A barriers; 6 items, 7 first-to-last cycles.
                                    // =1 (the kernel's own resources): 4 first-to-last cycles, 5 / 6 first / last s_memtime, 7 XCC_ID << 32 | HW_ID
@@ -137,8 +146,9 @@ struct StreamArgs {
 // op's quads and steps, the op's geometry -- depends on the op, the wave and, through the one-more-quad rule only, on the workgroup: the host
 // tabulates it per (op, wave) and the wave reads its record with two scalar loads instead of a dozen descriptor fields from LDS and ~80
 // scalar instructions (every instruction of a wave costs >= 4 cycles of ITS time, and all waves of a workgroup change ops together).
-// Per op: 16 common ints, then 4 ints per lookup wave (logical index wl).
-enum { SR_NST = 0, SR_IPI, SR_NSG, SR_GSH, SR_NU, SR_QE0, SR_QE1, SR_QE2, SR_QPER, SR_QEXTRA, SR_IT_LO, SR_IT_HI, SR_TSTRIDE, SR_GP, SR_WPQ, SR_PAD, SR_COMMON };
+// Per visit: 16 common ints, then 4 ints per lookup wave (logical index wl).
+enum { SR_NST = 0, SR_IPI, SR_NSG, SR_GSH, SR_NU, SR_QE0, SR_QE1, SR_QE2, SR_QPER, SR_QEXTRA, SR_IT_LO, SR_IT_HI, SR_TSTRIDE, SR_OP /* index of the visited op */, SR_WPQ,
+       SR_WLO /* first row range of the op's block */, SR_COMMON };
 enum { SRW_NQ = 0 /* quads of the wave: workgroups with q_per | q_per + 1 quads << 16 */, SRW_NSTEPS, SRW_H, SRW_QS, SRW_INTS };
 constexpr int STREAM_ROLE_INTS = SR_COMMON + SRW_INTS * STREAM_NLW;
 inline int stream_img_u4(int K) { return (chain_buf_u4(K) + 63) & ~63; }      // image / LDS buffer of one op, whole KB

@@ -58,7 +58,9 @@ struct tmac_hip_chain {
     bool stream = false;
     void* images = nullptr;
     int max_nst = 0;
-    const int* roles = nullptr;       // stream mode: the lookup waves' role records (device, behind the images)
+    const int* roles = nullptr;       // stream mode: the lookup waves' role records (device, behind the images), then the classes' visit counts
+    const int* nvis = nullptr;
+    int ncls = 1, vmax = 0;           // the schedule: classes of row ranges, records per class
     int nsplit = 1;                   // workgroups per row range (two share a CU and take alternate ops when LDS and registers allow)
 };
 
@@ -481,6 +483,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
         if (indep) {
             size_t img_bytes = 0;
             int buf = 0;
+            const std::vector<ChainOp> as_chain = c->ops;                     // (restored when the recording stays with k_decode_chain after all)
             for (ChainOp& o : c->ops) {
                 o.img_u4 = stream_img_u4(o.K);
                 o.img = reinterpret_cast<const void*>(img_bytes + 1);       // offset + 1 until the images exist
@@ -489,43 +492,102 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                 if (o.nst > c->max_nst) c->max_nst = o.nst;
                 o.in_gran &= 2;                                               // (no fragments-in-front-of-the-polls count: there are no polls)
             }
-            // two workgroups per CU, alternate ops each (k_gemv_stream's nsplit): when both fit a CU's LDS.  TMAC_STREAM_SPLIT=1: A/B
-            const int want_split = env_int("TMAC_STREAM_SPLIT", 2);
-            if (STREAM_NLW != CHAIN_NWV)                                       // (experiment builds: other workgroup sizes)
-                for (ChainOp& o : c->ops) {
-                    if (!g_knobs.chain_wpq || STREAM_NLW % o.wpq) o.wpq = chain_pick_wpq(o.total_q, o.nst, c->grid, STREAM_NLW);
-                    o.ipi = STREAM_NLW / o.wpq;
-                    o.wpq_inv = (65536 + o.wpq - 1) / o.wpq;
-                    o.ipi_inv = (65536 + o.ipi - 1) / o.ipi;
+            // ---- the schedule (tmac_chain.h, StreamArgs): which row ranges visit which op.  The per-visit costs of k_gemv_stream (two barriers,
+            // the image, the waves' op change, waves without items in a short op: ~1.5 us per op whatever its size, profiles/r05_stream_knockouts.txt)
+            // are paid per (workgroup, visit): an op that gives a row range fewer than `target` items is dealt to 1 / n of the ranges (n a power
+            // of two) with n times the rows each, and the other classes of ranges work on other ops meanwhile.  Ops go to the least loaded aligned
+            // block of classes in recorded order; the cap on n that gives the shortest modelled launch is taken (a lone call keeps all ranges).
+            // TMAC_STREAM_NCLS=1: every range visits every op (the round-5 form; A/B).
+            const int nwv = STREAM_NLW;
+            int ncls = env_int("TMAC_STREAM_NCLS", 8);
+            if (ncls < 1) ncls = 1;
+            if (ncls > 16) ncls = 16;
+            while (ncls > c->grid || (ncls & (ncls - 1))) --ncls;
+            const int target = env_int("TMAC_STREAM_VISIT_ITEMS", 96);
+            const double visit_fixed = 8.0;                                    // a visit's fixed cost in items (model only)
+            const int nop = (int)c->ops.size();
+            auto cls_lo = [&](int cl, int nc) { return (cl * c->grid + nc - 1) / nc; };
+            std::vector<int> blk_lo(nop, 0), blk_w(nop, 1);
+            std::vector<std::vector<int>> visits;
+            double best_span = 0;
+            int best_cap = 0;
+            for (int pass = 0; pass < 2; ++pass) {
+                for (int cap = ncls; cap >= 1; cap >>= 1) {
+                    if (pass == 1 && cap != best_cap) continue;
+                    std::vector<double> load(ncls, 0.0);
+                    std::vector<std::vector<int>> vis(ncls);
+                    for (int i = 0; i < nop; ++i) {
+                        const ChainOp& o = c->ops[i];
+                        const double items = (double)o.total_q * o.nst;
+                        int n = 1;
+                        while (n < cap && items * n / c->grid < target) n <<= 1;
+                        // (a block must leave every range at most 4095 quads and at least the op's matrices' geometry intact: checked below)
+                        const int w = ncls / n;
+                        int bb = 0;
+                        double bl = 1e300;
+                        for (int b0 = 0; b0 + w <= ncls; b0 += w) {
+                            double m = 0;
+                            for (int k = b0; k < b0 + w; ++k) m = load[k] > m ? load[k] : m;
+                            if (m < bl) { bl = m; bb = b0; }
+                        }
+                        const int wg = cls_lo(bb + w, ncls) - cls_lo(bb, ncls);
+                        for (int k = bb; k < bb + w; ++k) { load[k] += visit_fixed + items / wg; vis[k].push_back(i); }
+                        if (pass == 1) { blk_lo[i] = bb; blk_w[i] = w; }
+                    }
+                    double span = 0;
+                    for (int k = 0; k < ncls; ++k) span = load[k] > span ? load[k] : span;
+                    if (pass == 0 && (best_cap == 0 || span < best_span * 0.999)) { best_span = span; best_cap = cap; }
+                    if (pass == 1) visits.swap(vis);
                 }
-            const size_t lds2 = stream_lds_bytes(buf, ((int)c->ops.size() + 1) / 2);
-            size_t lds = stream_lds_bytes(buf, (int)c->ops.size());
+            }
+            bool sched_ok = true;
+            for (int i = 0; i < nop; ++i) {
+                ChainOp& o = c->ops[i];
+                const int wlo = cls_lo(blk_lo[i], ncls), wcnt = cls_lo(blk_lo[i] + blk_w[i], ncls) - wlo;
+                o.wg_lo = wlo;
+                if (!g_knobs.chain_wpq || nwv % o.wpq) o.wpq = chain_pick_wpq(o.total_q, o.nst, wcnt, nwv);
+                o.ipi = nwv / o.wpq;
+                o.wpq_inv = (65536 + o.wpq - 1) / o.wpq;
+                o.ipi_inv = (65536 + o.ipi - 1) / o.ipi;
+                o.q_per = o.total_q / wcnt; o.q_extra = o.total_q % wcnt;
+                if (o.total_q / wcnt + 1 + o.ipi >= 4096) sched_ok = false;
+            }
+            int vmax = 1;
+            for (int k = 0; k < ncls; ++k) if ((int)visits[k].size() > vmax) vmax = (int)visits[k].size();
+            // two workgroups per CU, alternate visits each (k_gemv_stream's nsplit): when both fit a CU's LDS.  TMAC_STREAM_SPLIT=1: A/B
+            const int want_split = env_int("TMAC_STREAM_SPLIT", 2);
+            const size_t lds2 = stream_lds_bytes(buf, (vmax + 1) / 2);
+            size_t lds = stream_lds_bytes(buf, vmax);
             // Two workgroups are co-resident on a CU only with <= 64 VGPRs and <= 80 SGPRs each (measured, profiles/r05_stream_stamps.txt): 1- to
             // 3-bit weights fit with two fragments in flight per wave (3-bit: 4.06 -> 3.55 us on 4096 x 11008); 4-bit ones only with one,
             // which loses to one workgroup with two (5.15 against 4.68 us): they keep one workgroup per CU.  TMAC_STREAM_SPLIT_BITS: A/B.
-            if (want_split >= 2 && c->bits <= env_int("TMAC_STREAM_SPLIT_BITS", 3) && c->ops.size() >= 2 && 2 * lds2 + 2048 <= 160 * 1024) { c->nsplit = 2; lds = lds2; }
+            if (want_split >= 2 && c->bits <= env_int("TMAC_STREAM_SPLIT_BITS", 3) && vmax >= 2 && 2 * lds2 + 2048 <= 160 * 1024) { c->nsplit = 2; lds = lds2; }
             for (int ns = 3; ns <= want_split && ns <= 4; ++ns) {            // (A/B builds with -DTMAC_STREAM_NLW=6: more, smaller workgroups per CU)
-                const size_t ldsn = stream_lds_bytes(buf, ((int)c->ops.size() + ns - 1) / ns);
-                if (c->nsplit == ns - 1 && (int)c->ops.size() >= ns && ns * (ldsn + 1024) <= 160 * 1024) { c->nsplit = ns; lds = ldsn; }
+                const size_t ldsn = stream_lds_bytes(buf, (vmax + ns - 1) / ns);
+                if (c->nsplit == ns - 1 && vmax >= ns && ns * (ldsn + 1024) <= 160 * 1024) { c->nsplit = ns; lds = ldsn; }
             }
-            if (lds <= 160 * 1024) {
-                // the waves' role records (tmac_chain.h) behind the images
-                std::vector<int32_t> roles((size_t)STREAM_ROLE_INTS * c->ops.size());
-                for (size_t i = 0; i < c->ops.size(); ++i) {
-                    const ChainOp& o = c->ops[i];
-                    int32_t* r = roles.data() + i * STREAM_ROLE_INTS;
-                    r[SR_NST] = o.nst; r[SR_IPI] = o.ipi; r[SR_NSG] = o.nsg; r[SR_GSH] = o.gs_shift; r[SR_NU] = o.nu;
-                    r[SR_QE0] = o.q_end[0]; r[SR_QE1] = o.q_end[1]; r[SR_QE2] = o.q_end[2];
-                    r[SR_QPER] = o.q_per; r[SR_QEXTRA] = o.q_extra;
-                    r[SR_IT_LO] = (o.q_per + o.ipi - 1) / o.ipi; r[SR_IT_HI] = (o.q_per + o.ipi) / o.ipi;
-                    r[SR_TSTRIDE] = o.tstride; r[SR_GP] = o.GP; r[SR_WPQ] = o.wpq; r[SR_PAD] = 0;
-                    for (int wl = 0; wl < STREAM_NLW; ++wl) {
-                        int32_t* rw = r + SR_COMMON + SRW_INTS * wl;
-                        const int qs = wl / o.wpq, h = wl - qs * o.wpq;
-                        auto nq = [&](int cnt) { return qs < cnt ? (cnt - 1 - qs) / o.ipi + 1 : 0; };
-                        rw[SRW_NQ] = nq(o.q_per) | (nq(o.q_per + 1) << 16);
-                        rw[SRW_NSTEPS] = h < o.nst ? (o.nst - h + o.wpq - 1) / o.wpq : 0;
-                        rw[SRW_H] = h; rw[SRW_QS] = qs;
+            if (sched_ok && lds <= 160 * 1024) {
+                // the waves' role records (tmac_chain.h) behind the images: one per (class, visit), then the classes' visit counts
+                std::vector<int32_t> roles((size_t)STREAM_ROLE_INTS * ncls * vmax + ncls, 0);
+                for (int k = 0; k < ncls; ++k) {
+                    roles[(size_t)STREAM_ROLE_INTS * ncls * vmax + k] = (int32_t)visits[k].size();
+                    for (size_t v = 0; v < visits[k].size(); ++v) {
+                        const int i = visits[k][v];
+                        const ChainOp& o = c->ops[i];
+                        int32_t* r = roles.data() + ((size_t)k * vmax + v) * STREAM_ROLE_INTS;
+                        r[SR_NST] = o.nst; r[SR_IPI] = o.ipi; r[SR_NSG] = o.nsg; r[SR_GSH] = o.gs_shift; r[SR_NU] = o.nu;
+                        r[SR_QE0] = o.q_end[0]; r[SR_QE1] = o.q_end[1]; r[SR_QE2] = o.q_end[2];
+                        r[SR_QPER] = o.q_per; r[SR_QEXTRA] = o.q_extra;
+                        r[SR_IT_LO] = (o.q_per + o.ipi - 1) / o.ipi; r[SR_IT_HI] = (o.q_per + o.ipi) / o.ipi;
+                        r[SR_TSTRIDE] = o.tstride; r[SR_OP] = i; r[SR_WPQ] = o.wpq; r[SR_WLO] = o.wg_lo;
+                        for (int wl = 0; wl < STREAM_NLW; ++wl) {
+                            int32_t* rw = r + SR_COMMON + SRW_INTS * wl;
+                            const int qs = wl / o.wpq, h = wl - qs * o.wpq;
+                            auto nq = [&](int cnt) { return qs < cnt ? (cnt - 1 - qs) / o.ipi + 1 : 0; };
+                            rw[SRW_NQ] = nq(o.q_per) | (nq(o.q_per + 1) << 16);
+                            rw[SRW_NSTEPS] = h < o.nst ? (o.nst - h + o.wpq - 1) / o.wpq : 0;
+                            rw[SRW_H] = h; rw[SRW_QS] = qs;
+                        }
                     }
                 }
                 const size_t role_bytes = roles.size() * sizeof(int32_t);
@@ -533,10 +595,12 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                     hipMemcpy(reinterpret_cast<char*>(c->images) + img_bytes, roles.data(), role_bytes, hipMemcpyHostToDevice) != hipSuccess)
                     return bail(fail(TMAC_HIP_E_RUNTIME, "LUT image allocation failed (%zu bytes)", img_bytes + role_bytes));
                 c->roles = reinterpret_cast<const int*>(reinterpret_cast<char*>(c->images) + img_bytes);
+                c->nvis = c->roles + (size_t)STREAM_ROLE_INTS * ncls * vmax;
+                c->ncls = ncls; c->vmax = vmax;
                 for (ChainOp& o : c->ops) o.img = reinterpret_cast<const char*>(c->images) + (reinterpret_cast<size_t>(o.img) - 1);
                 c->stream = true; c->buf_u4 = buf; c->lds_bytes = lds; c->xforms = 0;
             } else {
-                for (ChainOp& o : c->ops) { o.img = nullptr; o.img_u4 = 0; o.in_gran |= 1 << 8; }
+                c->ops = as_chain; c->nsplit = 1;
             }
         }
     }
@@ -616,6 +680,7 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
         StreamArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.ops = c->d_ops; sa.nops = (int)c->ops.size(); sa.out_f16 = c->out_f16; sa.buf_u4 = c->buf_u4; sa.nsplit = c->nsplit; sa.roles = c->roles; sa.stamps = c->stamps;
+        sa.ncls = c->ncls; sa.vmax = c->vmax; sa.nvis = c->nvis;
         e = launch_gemv_stream(sa, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "stream launch: %s", hipGetErrorString(e));
         c->last_stream = st; c->launched = true;

@@ -181,7 +181,12 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     // nsplit workgroups share every row range: workgroup (bx, part) walks the ops part, part + nsplit, ... with the rows of range bx.  They
     // are independent of each other (nothing in this kernel waits for another workgroup); whether they share a CU is the scheduler's business.
     const int nsplit = a.nsplit, part = (int)blockIdx.x % nsplit, bx = (int)blockIdx.x / nsplit;
-    const int nops = (a.nops - part + nsplit - 1) / nsplit;               // this workgroup's ops: local j = global j * nsplit + part
+    // the schedule (tmac_chain.h): row range bx belongs to class bx * ncls / ranges and walks that class' visit list -- the ops whose rows the
+    // host dealt to a block of classes containing it; the two workgroups of a range take alternate visits
+    const int cls = __builtin_amdgcn_readfirstlane(bx * a.ncls / ((int)gridDim.x / nsplit));
+    const int* my_roles = a.roles + (size_t)cls * a.vmax * STREAM_ROLE_INTS;
+    const int nops = max((a.nvis[cls] - part + nsplit - 1) / nsplit, 0);    // this workgroup's visits: local j = visit j * nsplit + part of the class
+    if (nops == 0) return;
     float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][4][CHAIN_RED] partials of split quads
     uint4* l_ops = lds + 2 * (size_t)a.buf_u4 + (2 * NWV * 4 * CHAIN_RED * sizeof(float)) / 16;
     {
@@ -189,7 +194,7 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
         const uint4* gsrc = reinterpret_cast<const uint4*>(a.ops);
         for (int idx = tid; idx < nops * U; idx += STREAM_FT) {
             const int jl = idx / U, r = idx - jl * U;
-            l_ops[idx] = gsrc[(jl * nsplit + part) * U + r];
+            l_ops[idx] = gsrc[my_roles[(size_t)(jl * nsplit + part) * STREAM_ROLE_INTS + SR_OP] * U + r];
         }
         __syncthreads();
     }
@@ -197,8 +202,8 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     // barriers of op i, executed by all thirteen waves: A(i) -- the tables of op i are in LDS and everybody has left op i - 1 -- then one
     // per workgroup iteration of the op (finish()).  The number of iterations depends on the workgroup alone.
     auto wg_iters = [&](cop_ptr d) __attribute__((always_inline)) {
-        const int qper = uni(d->q_per), qex = uni(d->q_extra), ipi = uni(d->ipi), iinv = uni(d->ipi_inv);
-        const int cnt = qper + (bx < qex ? 1 : 0);
+        const int qper = uni(d->q_per), qex = uni(d->q_extra), ipi = uni(d->ipi), iinv = uni(d->ipi_inv), bl = bx - uni(d->wg_lo);
+        const int cnt = qper + (bl < qex ? 1 : 0);
         return ((cnt + ipi - 1) * iinv) >> 16;
     };
 
@@ -222,8 +227,8 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
         int s_par = 0;
         auto combine = [&](int j, int t, int par) __attribute__((always_inline)) {
             const cop_ptr d = ops + j;
-            const int qper = uni(d->q_per), qex = uni(d->q_extra), ipi = uni(d->ipi), wpq = uni(d->wpq);
-            const int q_lo = bx * qper + min(bx, qex), cnt = qper + (bx < qex ? 1 : 0);
+            const int qper = uni(d->q_per), qex = uni(d->q_extra), ipi = uni(d->ipi), wpq = uni(d->wpq), bl = bx - uni(d->wg_lo);
+            const int q_lo = bl * qper + min(bl, qex), cnt = qper + (bl < qex ? 1 : 0);
             const int p_qs = lane >> 2, p_row = lane & 3;
             const int p_gql = q_lo + t * ipi + p_qs;
             if (p_qs < ipi && p_gql < q_lo + cnt) {
@@ -303,12 +308,12 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     typedef int sr16 __attribute__((ext_vector_type(16)));
     typedef int sr4 __attribute__((ext_vector_type(4)));
     auto load_role = [&](int jl, sr16& rc, sr4& rw) __attribute__((always_inline)) {
-        const int* rp = a.roles + (size_t)(jl * nsplit + part) * STREAM_ROLE_INTS;
+        const int* rp = my_roles + (size_t)(jl * nsplit + part) * STREAM_ROLE_INTS;
         const int* rpw = rp + SR_COMMON + SRW_INTS * wl;
         asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(rc), "=&s"(rw) : "s"(rp), "s"(rpw) : "memory");
     };
     auto items_of = [&](const sr16& rc, const sr4& rw) __attribute__((always_inline)) {
-        const int nq = bx < rc[SR_QEXTRA] ? (int)((unsigned)rw[SRW_NQ] >> 16) : (rw[SRW_NQ] & 0xffff);
+        const int nq = bx - rc[SR_WLO] < rc[SR_QEXTRA] ? (int)((unsigned)rw[SRW_NQ] >> 16) : (rw[SRW_NQ] & 0xffff);
         return nq * rw[SRW_NSTEPS];
     };
 
@@ -340,7 +345,8 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                 load_role(i_op, rc, rw);
                 i_left = items_of(rc, rw);
                 i_st = rw[SRW_H]; i_h = rw[SRW_H]; i_wpq = rc[SR_WPQ]; i_nst = rc[SR_NST]; i_ipi = rc[SR_IPI];
-                i_gq = bx * rc[SR_QPER] + min(bx, rc[SR_QEXTRA]) + rw[SRW_QS];
+                const int bl = bx - rc[SR_WLO];
+                i_gq = bl * rc[SR_QPER] + min(bl, rc[SR_QEXTRA]) + rw[SRW_QS];
                 i_nsg1 = rc[SR_NSG] - 1; i_gsh = rc[SR_GSH]; i_nu = rc[SR_NU];
                 q_scstride = rc[SR_NSG] << SC_SHIFT;
                 c0g = c0 >> i_gsh;
@@ -457,11 +463,11 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
             if (c_op >= nops) { done = true; return; }
             sr16 rc; sr4 rw;
             load_role(c_op, rc, rw);
-            my_iter = bx < rc[SR_QEXTRA] ? rc[SR_IT_HI] : rc[SR_IT_LO];
+            my_iter = bx - rc[SR_WLO] < rc[SR_QEXTRA] ? rc[SR_IT_HI] : rc[SR_IT_LO];
             tstride = rc[SR_TSTRIDE]; nst = rc[SR_NST]; wpq = rc[SR_WPQ]; h = rw[SRW_H];
             tab = lds + (size_t)(c_op & 1) * a.buf_u4;
             l_ls = reinterpret_cast<float*>(tab + 4 * tstride);
-            l_lb = l_ls + rc[SR_GP];
+            l_lb = l_ls + 32 * rc[SR_NST];
             c_left = items_of(rc, rw); c_it = 0; c_st = h;
             TMAC_ST(4);
             c_lds_barrier();                          // A(c_op): the loader has this op's tables in LDS

@@ -240,6 +240,14 @@ int32_t tmac_hip_chain_is_stream(const tmac_hip_chain* chain);
  * built, 3 weights of the call landed, 5 last row quad published, 6 all loads landed, 7 number of polls) into a device buffer (NULL = off); waves per row quad forced for chains built from now on (0 = per-call
  * choice) and the poll limit of a hand-off (0 = keep) */
 int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* chain, unsigned long long* dev_buffer);
+/* Parity tap of the persistent kernels (k_decode_chain, k_gemv_stream): the INTEGERS of every recorded call as they enter the float part of
+ * the path, written by the launch itself into a caller's device buffer (NULL = off; launches with a tap run the kernels' tap instantiation).
+ * Call `op` owns ints [offset, offset + count) (tmac_hip_chain_tap_layout; op == number of calls: offset = size of the whole buffer):
+ * per-group scales: int32 [rows of the call's matrices, concatenated][K / 64] = sum_p 2^p PS_p per (weight row, act group), PS_p the
+ * per-plane partial sums of tbl.cc:445-462 (what tmac_hip_qgemm_partial_sums returns per plane); unified scales: int32 [rows][bits], the
+ * exact per-plane totals of tbl.cc:586-628.  Not available for calls whose rows are dealt in gate / up pairs (GLU in the producer). */
+int32_t tmac_hip_chain_set_tap(tmac_hip_chain* chain, int32_t* dev_buffer);
+int32_t tmac_hip_chain_tap_layout(const tmac_hip_chain* chain, int op, size_t* offset_ints, size_t* count_ints);
 int32_t tmac_hip_debug_chain_config(int force_waves_per_quad, unsigned spin_limit);
 /* workgroups of chains built from now on (0 = one per CU): lets two chains run side by side on one device (tests/test_gpu_chain_ipc.py) */
 int32_t tmac_hip_debug_chain_grid(int workgroups);

@@ -157,6 +157,46 @@ class Model:
                         assert np.array_equal(g.view(np.uint16), want[m].astype(np.float16).view(np.uint16)), f"op {i} matrix {m} vs oracle (bits)"
                     assert rel_err(g.astype(np.float32), want[m]) <= 1e-3, f"op {i} matrix {m} vs oracle"
 
+    def check_tap(self, chain):
+        """The INTEGERS of every call, written by the persistent launch itself (tmac_hip_chain_set_tap), against the oracle on the activation
+        vector the call consumed: per-group scales comb[row][act group] = sum_p 2^p PS_p (PS_p: tbl.cc:445-462 per bit-plane), unified
+        scales the exact per-plane totals (tbl.cc:586-628) -- array_equal, no tolerance.  north_star: "bit-exact for the integer
+        LUT/accumulate path", checked inside k_decode_chain / k_gemv_stream, not through another kernel."""
+        import torch
+        nops = len(self.ops)
+        total, _ = chain.tap_layout(nops)
+        buf = torch.full((total,), -(2 ** 31), dtype=torch.int32, device="cuda")
+        chain.set_tap(buf)
+        try:
+            chain.launch()
+            torch.cuda.synchronize()
+            assert chain.status() == 0
+        finally:
+            chain.set_tap(None)
+        tap = buf.cpu().numpy()
+        got = [[o.clone() for o in os_] for os_ in self.outs]
+        bm = BITS_BM[self.bits]
+        for i, (K, rows, src) in enumerate(self.ops):
+            x = (self.x_ext[i] if src is None else got[src[0]][src[1]]).float().cpu().numpy()
+            off, cnt = chain.tap_layout(i)
+            ags = K if self.mg >= 1 else AGS
+            q, _, _ = orc.preprocessor(x[None, :], ags)
+            per_row = self.bits if self.mg >= 1 else K // 64
+            assert cnt == sum(rows) * per_row
+            r0 = 0
+            for m, Mw in enumerate(rows):
+                A, _ = self.host[i][m]
+                PS = orc.partial_sums(A, q[0], Mw, K, self.bits, bm, KF, ags)           # [M-space rows][K / ags]
+                o = np.arange(Mw)
+                planes = [PS[(o // 8) * 8 * self.bits + p * 8 + (o % 8)] for p in range(self.bits)]     # weight row o, plane p (weights.py:57-87)
+                g = tap[off + r0 * per_row: off + (r0 + Mw) * per_row].reshape(Mw, per_row)
+                if self.mg >= 1:
+                    want = np.stack([pl[:, 0] for pl in planes], axis=1)
+                else:
+                    want = sum(pl.astype(np.int64) << p for p, pl in enumerate(planes))
+                assert np.array_equal(g.astype(np.int64), want), f"op {i} matrix {m}: integer tap of the persistent kernel != oracle"
+                r0 += Mw
+
     def free(self):
         for ws in self.ws:
             for w in ws:
@@ -188,6 +228,7 @@ def test_small_chain(tm, bits, zp, dev_f16):
                 o.fill_(float(rep))
         chain.launch()
         m.check(chain, oracle_ops=None if rep == 0 else [])
+    m.check_tap(chain)
     chain.free()
     m.free()
 
@@ -253,6 +294,7 @@ def test_unified_scale_chain(tm, bits, mg, dev_f16):
                 o.fill_(float(rep))
         chain.launch()
         m.check(chain, oracle_ops=None if rep == 0 else [])
+    m.check_tap(chain)          # the exact per-plane totals inside k_decode_chain against the oracle
     chain.free()
     m.free()
 
@@ -267,6 +309,7 @@ def test_bitnet_layer_full_size(tm):
     chain = m.record()
     chain.launch()
     m.check(chain)
+    m.check_tap(chain)
     chain.free()
     m.free()
 
@@ -302,6 +345,7 @@ def test_random_chains(tm, seed):
     for rep in range(2):
         chain.launch()
         m.check(chain, oracle_ops=None if rep == 0 else [])
+    m.check_tap(chain)
     chain.free()
     m.free()
 
@@ -506,6 +550,7 @@ def test_bench_launches_full_size(tm):
     chain = m.record()
     chain.launch()
     m.check(chain)
+    m.check_tap(chain)          # one full llama-2-7B layer and a half: k_decode_chain's own integers against the oracle
     # and the same matrices through the default per-launch path (what bench.py --path fused times): against the oracle
     import torch
     x = m.x_ext[0]

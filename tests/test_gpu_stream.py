@@ -24,6 +24,7 @@ def _run(tm, ops, reps=2, **kw):
     for rep in range(reps):
         chain.launch()
         m.check(chain, oracle_ops=None if rep == 0 else [])
+    m.check_tap(chain)          # the integers inside k_gemv_stream itself against the oracle (tmac_hip_chain_set_tap)
     chain.free()
     m.free()
 
@@ -50,6 +51,15 @@ def test_stream_of_independent_calls(tm, bits, zp, dev_f16):
 def test_stream_single_call_and_repeats(tm):
     _run(tm, [(4096, [4096], None)], reps=3, seed=5)
     _run(tm, [(11008, [1024], None)], reps=3, seed=6)       # the headline's K: two rounds of table pairs, six steps (the last one 3/8 full)
+
+
+@pytest.mark.parametrize("bits", [2, 4])
+def test_stream_full_size_llama_shapes(tm, bits):
+    """stream mode at BASELINE's full sizes (llama-2-7B: the 4096 x 11008 target shape, gate/up 2 x 11008 x 4096, q/k/v 3 x 4096 x 4096,
+    o), two calls of each so that the schedule deals them to classes of row ranges: every output against the stand-alone launch (bits),
+    the oracle (1e-3), and k_gemv_stream's own integers against the oracle (array_equal)"""
+    ops = [(11008, [4096], None), (4096, [11008, 11008], None), (4096, [4096, 4096, 4096], None), (4096, [4096], None)] * 2
+    _run(tm, ops, reps=1, bits=bits, seed=31 + bits)
 
 
 def test_stream_fp32_outputs_and_fp32_activations(tm):

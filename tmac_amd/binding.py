@@ -124,6 +124,8 @@ def load_library() -> C.CDLL:
         "tmac_hip_chain_xform": ([C.POINTER(XForm)], i32),
         "tmac_hip_chain_free": ([vp], i32),
         "tmac_hip_chain_set_stamps": ([vp, vp], i32),
+        "tmac_hip_chain_set_tap": ([vp, vp], i32),
+        "tmac_hip_chain_tap_layout": ([vp, C.c_int, C.POINTER(sz), C.POINTER(sz)], i32),
         "tmac_hip_chain_threads": ([], i32),
         "tmac_hip_chain_is_stream": ([vp], i32),
         "tmac_hip_chain_record_gather": ([vp, vp, sz, C.c_int, C.c_int], i32),

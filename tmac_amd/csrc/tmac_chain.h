@@ -82,6 +82,8 @@ struct ChainArgs {
     int carry_floats;              // LDS floats for the vector a NORM transform keeps for a later op of the launch (0: no op does)
     int tmp_floats, gam_floats;    // LDS floats for a transform's vector of the current op (NORM's t / GLU's x) and for NORM's weights
     int ext_floats;                // LDS floats for an op's activations when they come as fp32 from memory
+    int32_t* tap;                  // parity tap (tmac_hip_chain_set_tap; runs the instance with the extensions): the integers that enter the float part, per op at
+    const unsigned long long* tap_off;   //   tap + tap_off[op]: per-group scales int32 [4 * total_q rows][K / 64] comb = sum_p 2^p PS_p; unified scales [rows][bits] totals
     unsigned long long* stamps;    // optional [nops][grid][8] of wave 0, s_memrealtime (100 MHz): 0 op entry, 1 activations complete, 2 LUT built
                                    // (barrier passed), 3 current ring landed, 5 last quad published, 6 everything in flight landed, 7 polls
 };
@@ -138,6 +140,8 @@ struct StreamArgs {
     int vmax;                      // records per class in `roles`
     const int* nvis;               // [ncls] visits of each class
     const int* roles;              // [ncls][vmax][STREAM_ROLE_INTS]: what a lookup wave needs to enter a visit, worked out by the host (layout below)
+    int32_t* tap;                  // parity tap, as ChainArgs::tap (the TAP instantiation of the kernel)
+    const unsigned long long* tap_off;
     unsigned long long* stamps;    // profiling builds only, else ignored: [workgroups][lookup waves][8].  -DTMAC_STREAM_STAMPS=2: cycle sums 0 waiting for weights,
                                    // 1 lookups + refill, 2 partial sums, 3 closing barriers, 4 op change, 5 A barriers; 6 items, 7 first-to-last cycles.
                                    // =1 (the kernel's own resources): 4 first-to-last cycles, 5 / 6 first / last s_memtime, 7 XCC_ID << 32 | HW_ID

@@ -721,6 +721,9 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                         for (int ww = 0; ww < wpq; ++ww)
 #pragma unroll
                             for (int pl = 0; pl < BITS; ++pl) cb[pl] += redi[((qs * wpq + ww) * 4 + row) * CHAIN_RED + pl];
+                        if (XF && a.tap)
+#pragma unroll
+                            for (int pl = 0; pl < BITS; ++pl) a.tap[a.tap_off[i] + (size_t)(4 * p_gql + row) * BITS + pl] = cb[pl];
                         // scale-final (qgemm.py:170-174,192-206), as k_gemv_quad's epilogue: C = ((sum_p float(cb_p) alpha_p) ls + lb / 2) Scale
                         float acc = 0.f;
 #pragma unroll
@@ -781,7 +784,9 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
             while (left > 0) {
 #pragma unroll
                 for (int k = 0; k < RING; ++k) {
-                    c_compute<BITS, ZP, SCF16, SM>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane16, lk4, sel, k3, cacc, iacc);
+                    // (the instance with the extensions is also the parity tap's: ChainArgs::tap)
+                    c_compute<BITS, ZP, SCF16, SM, XF>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane16, lk4, sel, k3, cacc, iacc,
+                                                       (XF && a.tap) ? a.tap + a.tap_off[i] + (size_t)(4 * (ro.q_lo + ro.qs + c_it * ipi) + (lane & 3)) * G : nullptr, G);
                     issue_next(ring[k]);               // refill this slot with the item RING places ahead, if there is one
                     c_st += wpq;
                     if (c_st >= nst) {

@@ -150,9 +150,12 @@ __device__ __forceinline__ void c_selectors(CSel<BITS>& sel, int lane) {
     }
 }
 
-template <int BITS, bool ZP, bool SCF16, int SM>
+// TAP (parity instantiations only): the integers of the lane's two act groups, comb = sum_p 2^p PS_p, go to tap_row[act group] (tap_row: the
+// lane's output row in the launch's tap buffer, G act groups per row) exactly as they enter the fp32 chain.
+template <int BITS, bool ZP, bool SCF16, int SM, bool TAP = false>
 __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab, int tstride, const float* l_ls, const float* l_lb,
-                                          int st, uint32_t lane16, uint32_t lk4, const CSel<BITS>& sel, uint32_t k3, float& cacc, int32_t (&iacc)[BITS]) {
+                                          int st, uint32_t lane16, uint32_t lk4, const CSel<BITS>& sel, uint32_t k3, float& cacc, int32_t (&iacc)[BITS],
+                                          int32_t* tap_row = nullptr, int G = 0) {
     uint32_t tb[16];
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
@@ -209,6 +212,10 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
             const float hls = gi ? hls2.y : hls2.x, hlb = gi ? hlb2.y : hlb2.x;
             // sum_p alpha_p [(ps_p ls + [p = 0] lb) scale + [p = 0] zero 2 lb] = ((sum_p 2^p ps_p)(ls / 2) + lb / 2) scale + (2 zero)(lb / 2)
             const int32_t comb = (gi == 0) ? (c[0].x + c[0].y) : (c[0].z + c[0].w);
+            if constexpr (TAP) {
+                const int kk = st * 32 + (int)(lk4 >> 2) + gi;
+                if (tap_row && kk < G) tap_row[kk] = comb;
+            }
             const float v = __fmaf_rn((float)comb, hls, hlb);
             float cc = __fmaf_rn(v, sc, cacc);
             if (ZP) cc = __fmaf_rn(__fadd_rn(zr, zr), hlb, cc);

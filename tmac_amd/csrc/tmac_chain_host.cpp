@@ -47,6 +47,8 @@ struct tmac_hip_chain {
     int grid = 0, buf_u4 = 0;
     size_t lds_bytes = 0;
     unsigned long long* stamps = nullptr;
+    int32_t* tap = nullptr;           // parity tap (tmac_hip_chain_set_tap): caller's device buffer; per-op offsets (ints) on the device
+    unsigned long long* d_tap_off = nullptr;
     size_t bytes = 0;                 // algorithmic weight + scale bytes of one launch
     int xforms = 0, carry_floats = 0;    // some op carries a vector transform; LDS floats of the kept vector
     int tmp_floats = 0, gam_floats = 0, ext_floats = 0, carry_K = 0;   // LDS floats of an op's own transform vector / norm weights; K of the latest kept vector
@@ -144,6 +146,7 @@ extern "C" int32_t tmac_hip_chain_free(tmac_hip_chain* c) {
     for (void* p : c->peers) if (p) (void)hipIpcCloseMemHandle(p);
     if (c->arena) (void)hipFree(c->arena);
     if (c->images) (void)hipFree(c->images);
+    if (c->d_tap_off) (void)hipFree(c->d_tap_off);
     if (c->d_ops) (void)hipFree(c->d_ops);
     if (c->ctl) (void)hipFree(c->ctl);
     delete c;
@@ -680,7 +683,7 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
         StreamArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.ops = c->d_ops; sa.nops = (int)c->ops.size(); sa.out_f16 = c->out_f16; sa.buf_u4 = c->buf_u4; sa.nsplit = c->nsplit; sa.roles = c->roles; sa.stamps = c->stamps;
-        sa.ncls = c->ncls; sa.vmax = c->vmax; sa.nvis = c->nvis;
+        sa.ncls = c->ncls; sa.vmax = c->vmax; sa.nvis = c->nvis; sa.tap = c->tap; sa.tap_off = c->d_tap_off;
         e = launch_gemv_stream(sa, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "stream launch: %s", hipGetErrorString(e));
         c->last_stream = st; c->launched = true;
@@ -698,6 +701,7 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
         static const int force_xf = [] { const char* e = getenv("TMAC_HIP_CHAIN_FORCE_XF"); return e && e[0] == '1' ? 1 : 0; }();
         if (force_xf) a.xforms = 1;
     }
+    if (c->tap) { a.tap = c->tap; a.tap_off = c->d_tap_off; a.xforms = 1; }      // the tap lives in the instance with the extensions
     a.poll_sleep = c->poll_sleep; a.poll_delay = c->poll_delay; a.issue_first = c->issue_first; a.poll_mode = c->poll_mode; a.poll_grid = c->poll_grid;
     hipError_t e = launch_decode_chain(a, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, st);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no decode-chain kernel for this configuration");
@@ -782,6 +786,35 @@ extern "C" int32_t tmac_hip_chain_info(const tmac_hip_chain* c, int op, int32_t*
         if (op < 0 || op >= (int)c->ops.size()) return fail(TMAC_HIP_E_ARG, "op index out of range");
         *wpq = c->ops[op].wpq;
     }
+    return TMAC_HIP_OK;
+}
+
+// Parity tap of the persistent kernels (include/tmac_hip.h): the integers of every recorded call as they enter the float part.
+extern "C" int32_t tmac_hip_chain_tap_layout(const tmac_hip_chain* c, int op, size_t* offset_ints, size_t* count_ints) {
+    if (!c) return fail(TMAC_HIP_E_ARG, "null chain");
+    if (op < 0 || op > (int)c->ops.size()) return fail(TMAC_HIP_E_ARG, "op index out of range");
+    std::vector<unsigned long long> off(c->ops.size() + 1, 0);
+    for (size_t i = 0; i < c->ops.size(); ++i)
+        off[i + 1] = off[i] + (unsigned long long)4 * c->ops[i].total_q * (c->sm == 2 ? c->bits : c->ops[i].G);
+    if (offset_ints) *offset_ints = (size_t)off[op];
+    if (count_ints) *count_ints = op < (int)c->ops.size() ? (size_t)(off[op + 1] - off[op]) : 0;
+    return TMAC_HIP_OK;
+}
+extern "C" int32_t tmac_hip_chain_set_tap(tmac_hip_chain* c, int32_t* dev_buffer) {
+    if (!c) return fail(TMAC_HIP_E_ARG, "null chain");
+    if (!dev_buffer) { c->tap = nullptr; return TMAC_HIP_OK; }
+    for (const ChainOp& o : c->ops)
+        if (o.epi) return fail(TMAC_HIP_E_NOMATCH, "the tap does not cover calls whose row quads are dealt in gate / up pairs (GLU in the producer)");
+    bind_thread_device();
+    if (!c->d_tap_off) {
+        std::vector<unsigned long long> off(c->ops.size() + 1, 0);
+        for (size_t i = 0; i < c->ops.size(); ++i)
+            off[i + 1] = off[i] + (unsigned long long)4 * c->ops[i].total_q * (c->sm == 2 ? c->bits : c->ops[i].G);
+        if (hipMalloc((void**)&c->d_tap_off, off.size() * sizeof(unsigned long long)) != hipSuccess ||
+            hipMemcpy(c->d_tap_off, off.data(), off.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) != hipSuccess)
+            return fail(TMAC_HIP_E_RUNTIME, "tap offsets: allocation failed");
+    }
+    c->tap = dev_buffer;
     return TMAC_HIP_OK;
 }
 

@@ -173,7 +173,7 @@ hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, int sm
 // profiles/r05_stream_stamps.txt), so the count is capped (amdgpu_num_sgpr(n) leaves n - 8 to the kernel; the compiler parks what does not
 // fit in VGPR lanes: 13 lane moves in the whole kernel with 74, 92 with 64).
 #define TMAC_STREAM_ATTR __attribute__((amdgpu_num_sgpr(82)))
-template <int BITS, bool ZP, bool SCF16, int RING, int MINW, int SM>
+template <int BITS, bool ZP, bool SCF16, int RING, int MINW, int SM, bool TAP>
 __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_stream(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     constexpr int NWV = STREAM_NLW;                     // lookup waves; wave NWV is the loader
@@ -248,6 +248,13 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                     for (int ww = 0; ww < wpq; ++ww)
 #pragma unroll
                         for (int pl = 0; pl < BITS; ++pl) cb[pl] += redi[((p_qs * wpq + ww) * 4 + p_row) * CHAIN_RED + pl];
+                    if constexpr (TAP) {
+                        if (a.tap) {          // the exact totals per bit-plane, as they enter scale-final
+                            const int opi = my_roles[(size_t)(j * nsplit + part) * STREAM_ROLE_INTS + SR_OP];
+#pragma unroll
+                            for (int pl = 0; pl < BITS; ++pl) a.tap[a.tap_off[opi] + (size_t)(4 * p_gql + p_row) * BITS + pl] = cb[pl];
+                        }
+                    }
                     float acc = 0.f;
 #pragma unroll
                     for (int pl = 0; pl < BITS; ++pl) {
@@ -392,6 +399,8 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     // ---- the lookup cursor ----
     int c_op = -1, c_left = 0, c_it = 0, c_st = 0, parity = 0, my_iter = 0;
     int tstride = 1, nst = 1, wpq = 1, h = 0;
+    int t_gq0 = 0, t_ipi = 1, t_G = 0;              // TAP: the wave's first quad of the op, quads per workgroup iteration, act groups per row
+    int32_t* t_base = nullptr;
     uint4* tab = lds;
     float* l_ls = reinterpret_cast<float*>(lds);
     float* l_lb = l_ls;
@@ -469,6 +478,11 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
             l_ls = reinterpret_cast<float*>(tab + 4 * tstride);
             l_lb = l_ls + 32 * rc[SR_NST];
             c_left = items_of(rc, rw); c_it = 0; c_st = h;
+            if constexpr (TAP) {
+                const int bl = bx - rc[SR_WLO];
+                t_gq0 = bl * rc[SR_QPER] + min(bl, rc[SR_QEXTRA]) + rw[SRW_QS]; t_ipi = rc[SR_IPI]; t_G = rc[SR_NU] >> 1;
+                t_base = a.tap ? a.tap + a.tap_off[rc[SR_OP]] : nullptr;
+            }
             TMAC_ST(4);
             c_lds_barrier();                          // A(c_op): the loader has this op's tables in LDS
             TMAC_ST(5);
@@ -494,7 +508,8 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                 }
 #endif
                 if (TMAC_STREAM_KO & 8) cacc += __uint_as_float(ring[k].wq[0].x ^ ring[k].wq[BITS - 1].w ^ ring[k].s0); else
-                c_compute<BITS, ZP, SCF16, SM>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane16, lk4, sel, k3, cacc, iacc);
+                c_compute<BITS, ZP, SCF16, SM, TAP>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane16, lk4, sel, k3, cacc, iacc,
+                                                    (TAP && t_base) ? t_base + (size_t)(4 * (t_gq0 + c_it * t_ipi) + (lane & 3)) * t_G : nullptr, t_G);
                 asm volatile("" : "+v"(cacc));        // the item's scale chain ends before the slot is refilled (the scale word keeps its register)
             }
             refill(ring[k]);
@@ -540,7 +555,7 @@ static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int
     constexpr int R2 = (BITS <= 3) ? 2 : 1;      // two workgroups per CU: <= 64 VGPRs
     constexpr int R1 = (BITS <= 2) ? 4 : 2;      // one workgroup per CU: ring depth 2..8 measured flat (profiles/r05_stream_knockouts.txt)
 #define TMAC_SL2(Z, H, R, MW, S) do { \
-        auto* kern = &k_gemv_stream<BITS, Z, H, R, MW, S>; \
+        auto* kern = a.tap ? &k_gemv_stream<BITS, Z, H, R1, 4, S, true> : &k_gemv_stream<BITS, Z, H, R, MW, S, false>; \
         if (lds_bytes > 64 * 1024) { \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e != hipSuccess) return e; \

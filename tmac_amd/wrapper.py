@@ -271,6 +271,17 @@ class DecodeChain:
         check(B.lib().tmac_hip_chain_info(self._h, op, None, C.byref(w), None, None))
         return w.value
 
+    def tap_layout(self, op: int):
+        """(offset, count) in ints of call `op` inside the tap buffer; op == nops: (size of the whole buffer, 0)"""
+        off, cnt = C.c_size_t(0), C.c_size_t(0)
+        check(B.lib().tmac_hip_chain_tap_layout(self._h, op, C.byref(off), C.byref(cnt)))
+        return off.value, cnt.value
+
+    def set_tap(self, dev_buffer) -> None:
+        """parity tap (include/tmac_hip.h): an int32 device buffer of tap_layout(nops)[0] ints, or None"""
+        check(B.lib().tmac_hip_chain_set_tap(self._h, _ptr(dev_buffer) if dev_buffer is not None else None))
+        self._tap = dev_buffer
+
     def set_stamps(self, dev_buffer) -> None:
         check(B.lib().tmac_hip_chain_set_stamps(self._h, _ptr(dev_buffer)))
         self._stamps = dev_buffer

@@ -91,6 +91,7 @@ def parse():
                          "(tmac_hip_chain_xform), one launch per segment o -> gate/up -> down -> next q/k/v, an outside kernel (stand-in for "
                          "attention) between the segments; hipGraph replay of the token's launches")
     ap.add_argument("--no-decoder-pattern", action="store_true", help="skip the decoder-pattern measurement of the default line")
+    ap.add_argument("--stream-calls", type=int, default=96, help="independent GEMVs per launch of roofline.stream_core / stream_by_shape (distinct weight sets)")
     ap.add_argument("--no-stream-core", action="store_true", help="skip roofline.stream_core (profiling passes: keeps the kernel's statistics to the timed launches)")
     ap.add_argument("--stamps", action="store_true", help="chain path: report per-call times from in-kernel stamps (costs ~6 %%)")
     ap.add_argument("--floors", action="store_true", help="fused path: also time launches that only read the same bytes")
@@ -371,46 +372,50 @@ def run(args, env):
     lvl = (2 ** BITS - 1) / 2.0 - 2 ** (BITS - 1)                # mean weight level minus the offset 2^(b-1)
     wvar = (4 ** BITS - 1) / 12.0                                 # variance of a uniform b-bit level
     keep_host = not args.no_verify and world == 1
+    def new_weights(Mloc, K, cfg, keep=None):
+        """one synthetic matrix in the reference layout, registered (re-tiled on the GPU); keep: list that receives the host copy"""
+        A = torch.randint(0, 256, (Mloc * BITS // BM, K // 4, BM // 2), dtype=torch.uint8, device=dev, generator=gen)
+        if MG >= 1:
+            # BitNet's weights are ternary, {-1, 0, 1} stored as levels {1, 2, 3} of the 2-bit format (level 0 unused).  In the
+            # reference layout (weights.py:57-73) byte lanes 0-7 of every 16 hold plane-0 nibbles and lanes 8-15 the plane-1
+            # nibbles of the same outputs, so the constraint is bytewise: plane1 set with probability 43/64, plane0 = random |
+            # ~plane1 gives P(1) = 21/64, P(2) = P(3) = 43/128: mean level - 2 = 1/128, variance 0.664 -- zero-mean enough
+            # that a common component of the activations is not amplified (gain 0.9 at K = 8640), and with the scale
+            # 0.98 / sqrt(0.664 K) the chained vectors keep unit size through all layers.
+            lanes = A.view(-1, 16)
+            r = [torch.randint(0, 256, (lanes.shape[0], 8), dtype=torch.uint8, device=dev, generator=gen) for _ in range(5)]
+            p1 = lanes[:, 8:] | (r[0] & (r[1] | (r[2] & (r[3] | r[4]))))
+            lanes[:, 8:] = p1
+            lanes[:, :8] |= ~p1
+            del r, p1
+            S = torch.full((MG,), 0.98 / float(np.sqrt(0.664 * K)), device=dev, dtype=torch.float32)
+            w = tmac_amd.Weights(A, S, Mloc, K, BITS, cfg, scales_dtype=F32, dev_dtype=F32, on_device=True)
+            if keep is not None:
+                keep.append((A.cpu().numpy(), S.cpu().numpy()))
+        else:
+            # real weight = (w - 2^(b-1)) scale - zero.  zero = (mean level - 2^(b-1)) scale + noise makes it zero-mean,
+            # so a common component of the activations is not amplified from call to call (with independent zeros
+            # it grew 16x per GEMV and the chained vectors overflowed fp16 after a few layers); c: unit gain
+            c = 1.0 / np.sqrt((wvar + 1.0) * K)
+            S = torch.randn((Mloc * BITS // BM, K // GS, rpt // 8, 2 if ZP else 1, 8), device=dev, generator=gen) * c
+            S[:, :, :, 0, :].abs_()
+            if ZP:
+                S[:, :, :, 1, :] += S[:, :, :, 0, :] * lvl
+            S = S.half().contiguous()
+            w = tmac_amd.Weights(A, S, Mloc, K, BITS, cfg, scales_dtype=F16, dev_dtype=F16, on_device=True)
+            if keep is not None:
+                keep.append((A.cpu().numpy(), S.float().cpu().numpy().reshape(Mloc * BITS // BM, K // GS, -1)))
+        return w
+
+    def cfg_of(name):
+        Mw, K = next((m[1], m[2]) for m in MATS if m[0] == name)
+        return KCfg.make(shard_rows[name], K, BITS, BM, KF, GS if GS else 128, ags_of(K), ZP, MG, N)
+
     for li in range(args.layers):
         mats = {}
         for name, Mw, K, cnt, slot in MATS:
-            Mloc = shard_rows[name]
-            cfg = KCfg.make(Mloc, K, BITS, BM, KF, GS if GS else 128, ags_of(K), ZP, MG, N)
-            ws = []
-            for _ in range(cnt):
-                A = torch.randint(0, 256, (Mloc * BITS // BM, K // 4, BM // 2), dtype=torch.uint8, device=dev, generator=gen)
-                if MG >= 1:
-                    # BitNet's weights are ternary, {-1, 0, 1} stored as levels {1, 2, 3} of the 2-bit format (level 0 unused).  In the
-                    # reference layout (weights.py:57-73) byte lanes 0-7 of every 16 hold plane-0 nibbles and lanes 8-15 the plane-1
-                    # nibbles of the same outputs, so the constraint is bytewise: plane1 set with probability 43/64, plane0 = random |
-                    # ~plane1 gives P(1) = 21/64, P(2) = P(3) = 43/128: mean level - 2 = 1/128, variance 0.664 -- zero-mean enough
-                    # that a common component of the activations is not amplified (gain 0.9 at K = 8640), and with the scale
-                    # 0.98 / sqrt(0.664 K) the chained vectors keep unit size through all layers.
-                    lanes = A.view(-1, 16)
-                    r = [torch.randint(0, 256, (lanes.shape[0], 8), dtype=torch.uint8, device=dev, generator=gen) for _ in range(5)]
-                    p1 = lanes[:, 8:] | (r[0] & (r[1] | (r[2] & (r[3] | r[4]))))
-                    lanes[:, 8:] = p1
-                    lanes[:, :8] |= ~p1
-                    del r, p1
-                    S = torch.full((MG,), 0.98 / float(np.sqrt(0.664 * K)), device=dev, dtype=torch.float32)
-                    ws.append(tmac_amd.Weights(A, S, Mloc, K, BITS, cfg, scales_dtype=F32, dev_dtype=F32, on_device=True))
-                    if li == 0 and keep_host:
-                        host_l0.setdefault(name, []).append((A.cpu().numpy(), S.cpu().numpy()))
-                else:
-                    # real weight = (w - 2^(b-1)) scale - zero.  zero = (mean level - 2^(b-1)) scale + noise makes it zero-mean,
-                    # so a common component of the activations is not amplified from call to call (with independent zeros
-                    # it grew 16x per GEMV and the chained vectors overflowed fp16 after a few layers); c: unit gain
-                    c = 1.0 / np.sqrt((wvar + 1.0) * K)
-                    S = torch.randn((Mloc * BITS // BM, K // GS, rpt // 8, 2 if ZP else 1, 8), device=dev, generator=gen) * c
-                    S[:, :, :, 0, :].abs_()
-                    if ZP:
-                        S[:, :, :, 1, :] += S[:, :, :, 0, :] * lvl
-                    S = S.half().contiguous()
-                    ws.append(tmac_amd.Weights(A, S, Mloc, K, BITS, cfg, scales_dtype=F16, dev_dtype=F16, on_device=True))
-                    if li == 0 and keep_host:
-                        host_l0.setdefault(name, []).append((A.cpu().numpy(), S.float().cpu().numpy().reshape(Mloc * BITS // BM, K // GS, -1)))
-                del A, S
-            mats[name] = ws
+            cfg = cfg_of(name)
+            mats[name] = [new_weights(shard_rows[name], K, cfg, host_l0.setdefault(name, []) if (li == 0 and keep_host) else None) for _ in range(cnt)]
         layers.append(mats)
     torch.cuda.synchronize()
 
@@ -953,64 +958,71 @@ def run(args, env):
             # SURVEY 8(d)'s headline measurement: back-to-back INDEPENDENT GEMVs of the target shape over rotating distinct weights (> MALL in
             # total), a distinct activation vector per call.  Nothing is handed over, so the recording runs in stream mode: tables once per
             # call by k_lut_images (the reference's llama_cpp_init), lookups by k_gemv_stream (its llama_cpp_compute); both launches timed.
-            sxs = [torch.randn(K, device=dev, generator=gen).half() for _ in range(args.layers)]
-            souts = [[torch.empty(shard_rows[name], dtype=torch.float16, device=dev)] for _ in range(args.layers)]
-            with wr.record_chain() as srec:
-                for li in range(args.layers):
-                    wr.fused(layers[li][name], sxs[li], souts[li], 1, act_dtype=F16, out_dtype=F16)
-            sdur, SB = [], 10           # SB replays back to back per event pair: launches overlap their predecessors' tails as in any timed loop
-            for r in range(13):
-                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(SB):
-                    srec.chain.launch()
-                e1.record()
-                torch.cuda.synchronize()
-                if r >= 3:
-                    sdur.append(e0.elapsed_time(e1) * 1e-3 / (SB * args.layers))
-            sok = srec.chain.status() == 0
-            # the launch's outputs against the same calls launched one by one (whose integer path the parity tests tap): same bits
-            L.tmac_hip_debug_quad_config(srec.chain.threads, srec.chain.wpq(0))
-            sref = [torch.empty_like(souts[0][0])]
-            ssame = True
-            for li in (0, args.layers // 2, args.layers - 1):
-                wr.fused(layers[li][name], sxs[li], sref, 1, act_dtype=F16, out_dtype=F16)
-                torch.cuda.synchronize()
-                ssame = ssame and bool(torch.equal(sref[0], souts[li][0]))
-            L.tmac_hip_debug_quad_config(0, 0)
-            smode = "k_lut_images + k_gemv_stream (stream mode)" if getattr(srec.chain, "stream", False) else "k_decode_chain"
-            srec.chain.free()
-            sus = float(np.mean(sdur)) * 1e6
-            roof["stream_core"] = {"what": "%d independent GEMVs %s (%dx%d, distinct weights, a distinct activation vector each) recorded once, launched as %s: "
-                                           "tables built once per call, lookups with the tables prebuilt, no hand-offs" % (args.layers, name, Mw, K, smode),
-                                   "us_per_gemv": round(sus, 3), "min_us": round(float(np.min(sdur)) * 1e6, 3), "GBps": round(hb / sus * 1e-3, 1),
-                                   "frac": round(hb / sus * 1e-3 / HBM_PEAK_GBS, 4), "ok": sok and ssame,
+            # Calls per launch: args.stream_calls (default 96) DISTINCT weight sets -- the layers' own matrices plus extra synthetic ones of the
+            # same shape, so that neither the MALL nor L2 ever holds a matrix when its call comes round again (96 x 4.2 MB for the smallest
+            # shape) -- because a launch has a fixed cost (k_lut_images ~5.5 us, two launch boundaries, the persistent kernel's ramp and tail:
+            # ~19 us measured, profiles/r06_stream_schedule.txt) that 32 calls of ~2.4 us do not amortise; the 32-call figure is kept beside it.
+            SB = 10                      # replays back to back per event pair: launches overlap their predecessors' tails as in any timed loop
+
+            def time_stream_calls(mi, ncalls, verify):
+                name_, Mw_, K_, cnt_, slot_ = MATS[mi]
+                extra = [[new_weights(shard_rows[name_], K_, cfg_of(name_)) for _ in range(cnt_)] for _ in range(max(ncalls - args.layers, 0))]
+                sets = [layers[li][name_] for li in range(min(args.layers, ncalls))] + extra
+                xs_ = [torch.randn(K_, device=dev, generator=gen).half() for _ in range(ncalls)]
+                os_ = [[torch.empty(shard_rows[name_], dtype=torch.float16, device=dev) for _ in range(cnt_)] for _ in range(ncalls)]
+                with wr.record_chain() as rec_:
+                    for i_ in range(ncalls):
+                        wr.fused(sets[i_], xs_[i_], os_[i_], 1, act_dtype=F16, out_dtype=F16)
+                dur_ = []
+                for r in range(11):
+                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(SB):
+                        rec_.chain.launch()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if r >= 3:
+                        dur_.append(e0.elapsed_time(e1) * 1e-3 / (SB * ncalls))
+                ok_ = rec_.chain.status() == 0
+                same_ = None
+                if verify:
+                    # the launch's outputs against the same calls launched one by one (whose integer path the parity tests tap): same bits
+                    same_ = True
+                    for i_ in (0, ncalls // 2, ncalls - 1):
+                        L.tmac_hip_debug_quad_config(rec_.chain.threads, rec_.chain.wpq(i_))
+                        ref_ = [torch.empty_like(o) for o in os_[i_]]
+                        wr.fused(sets[i_], xs_[i_], ref_, 1, act_dtype=F16, out_dtype=F16)
+                        torch.cuda.synchronize()
+                        same_ = same_ and all(bool(torch.equal(a_, b_)) for a_, b_ in zip(ref_, os_[i_]))
+                    L.tmac_hip_debug_quad_config(0, 0)
+                mode_ = "k_lut_images + k_gemv_stream (stream mode)" if getattr(rec_.chain, "stream", False) else "k_decode_chain"
+                rec_.chain.free()
+                for ws_ in extra:
+                    for w_ in ws_:
+                        w_.free()
+                hb_ = cnt_ * algorithmic_bytes(Mw_, K_, BITS, GS, ags_of(K_), ZP, MG) - (cnt_ - 1) * (K_ // 4 * 16 + (K_ // ags_of(K_)) * 4)
+                return float(np.mean(dur_)) * 1e6, float(np.min(dur_)) * 1e6, hb_, ok_, same_, mode_
+
+            ncalls = max(args.stream_calls, 2)
+            sus, smin, hb_s, sok, ssame, smode = time_stream_calls(3, ncalls, True)
+            roof["stream_core"] = {"what": "%d independent GEMVs %s (%dx%d, %d distinct weight sets, a distinct activation vector each) recorded once, launched as %s: "
+                                           "tables built once per call, lookups with the tables prebuilt, no hand-offs" % (ncalls, name, Mw, K, ncalls, smode),
+                                   "calls_per_launch": ncalls,
+                                   "us_per_gemv": round(sus, 3), "min_us": round(smin, 3), "GBps": round(hb_s / sus * 1e-3, 1),
+                                   "frac": round(hb_s / sus * 1e-3 / HBM_PEAK_GBS, 4), "ok": bool(sok and ssame),
                                    "bit_identical_to_single_launches": ssame,
-                                   "timing": "hipEvent pair around 10 back-to-back replays (LUT build launches included), mean of 10 pairs"}
+                                   "timing": "hipEvent pair around 10 back-to-back replays (LUT build launches included), mean of 8 pairs"}
+            if ncalls != args.layers:
+                s32, m32, _, ok32, _, _ = time_stream_calls(3, args.layers, False)
+                roof["stream_core"]["at_%d_calls_per_launch" % args.layers] = {"us_per_gemv": round(s32, 3), "min_us": round(m32, 3),
+                                                                               "frac": round(hb_s / s32 * 1e-3 / HBM_PEAK_GBS, 4), "ok": ok32}
             # the same measurement for the layer's other three calls (q/k/v fused, o, gate/up fused): what the shape costs in stream mode
             try:
                 by_shape = {}
-                for name2, Mw2, K2, cnt2, slot2 in MATS[:3]:
-                    xs2 = [torch.randn(K2, device=dev, generator=gen).half() for _ in range(args.layers)]
-                    os2 = [[torch.empty(shard_rows[name2], dtype=torch.float16, device=dev) for _ in range(cnt2)] for _ in range(args.layers)]
-                    with wr.record_chain() as rec2:
-                        for li in range(args.layers):
-                            wr.fused(layers[li][name2], xs2[li], os2[li], 1, act_dtype=F16, out_dtype=F16)
-                    d2 = []
-                    for r in range(8):
-                        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                        e0.record()
-                        for _ in range(SB):
-                            rec2.chain.launch()
-                        e1.record()
-                        torch.cuda.synchronize()
-                        if r >= 2:
-                            d2.append(e0.elapsed_time(e1) * 1e-3 / (SB * args.layers))
-                    ok2 = rec2.chain.status() == 0
-                    rec2.chain.free()
-                    hb2 = cnt2 * algorithmic_bytes(Mw2, K2, BITS, GS, ags_of(K2), ZP, MG) - (cnt2 - 1) * (K2 // 4 * 16 + (K2 // ags_of(K2)) * 4)
-                    us2 = float(np.mean(d2)) * 1e6
-                    by_shape[name2] = {"shape": "%d x %dx%d" % (cnt2, Mw2, K2), "us_per_call": round(us2, 3), "GBps": round(hb2 / us2 * 1e-3, 1),
+                for mi2 in range(3):
+                    name2, Mw2, K2, cnt2, slot2 = MATS[mi2]
+                    us2, min2, hb2, ok2, _, _ = time_stream_calls(mi2, ncalls, False)
+                    by_shape[name2] = {"shape": "%d x %dx%d" % (cnt2, Mw2, K2), "calls_per_launch": ncalls, "us_per_call": round(us2, 3), "GBps": round(hb2 / us2 * 1e-3, 1),
                                        "frac": round(hb2 / us2 * 1e-3 / HBM_PEAK_GBS, 4), "ok": ok2}
                 roof["stream_by_shape"] = by_shape
             except tmac_amd.binding.TMACHipError as e:

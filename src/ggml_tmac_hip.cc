@@ -186,11 +186,13 @@ extern "C" int ggml_tmac_hip_segment_glu(const void* in2_f16) {
 }
 
 static int segment_mul_mat(const struct tmac_ggml_tensor* const* w, int nw, const void* x, tmac_dtype_t x_dtype, void* const* dst_f16) {
-    if (!w || nw < 1 || nw > 4 || !x || !dst_f16) return fail("bad segment mul_mat");
+    // a segment is all or nothing (include/ggml-tmac-hip.h): EVERY non-zero return ends the recording, so that a caller who falls back
+    // to the graph's own nodes does not leave the thread recording (later fused calls would be noted instead of launched)
+    if (!w || nw < 1 || nw > 4 || !x || !dst_f16) { (void)tmac_hip_chain_abort(); return fail("bad segment mul_mat"); }
     const tmac_hip_weights* wl[4];
     void* cl[4];
     for (int i = 0; i < nw; ++i) {
-        if (!w[i] || !w[i]->extra || !dst_f16[i]) return fail("null tensor");
+        if (!w[i] || !w[i]->extra || !dst_f16[i]) { (void)tmac_hip_chain_abort(); return fail("null tensor"); }
         wl[i] = ((const Handle*)w[i]->extra)->w;
         cl[i] = dst_f16[i];
     }

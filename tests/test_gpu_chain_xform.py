@@ -67,7 +67,7 @@ def np_glu(a, b):
     return (a / (np.float32(1.0) + np.exp(-a))).astype(np.float32) * b
 
 
-@pytest.mark.parametrize("grid", [0, 96, 7])
+@pytest.mark.parametrize("grid", [0, 96, 7, 1])
 def test_norm_and_glu_on_external_vectors(tm, grid):
     """grid != 0: fewer workgroups than CUs (tmac_hip_debug_chain_grid: a partitioned device, a device with fewer CUs) -- residual_out is
     striped over the workgroups that exist (a fixed stripe of 256 left pairs unwritten, silently)"""

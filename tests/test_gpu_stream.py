@@ -62,6 +62,46 @@ def test_stream_full_size_llama_shapes(tm, bits):
     _run(tm, ops, reps=1, bits=bits, seed=31 + bits)
 
 
+@pytest.mark.parametrize("mg", [-1, 1])
+def test_stream_largest_K(tm, mg, monkeypatch):
+    """K = 16384 and 18432 (the persistent kernels' limit, 8 x 3 x 768): the second LUT buffer starts above 64 KB of LDS -- the loader wave's
+    buffer_load-to-LDS M0 base, the long chunk-sum / bias chain of k_lut_images_us -- with K = 16384 two workgroups per CU still fit
+    (2 x 72 KB), with 18432 one; per-group and unified scales.  k_gemv_quad has no launch configuration of its own for these K
+    with the chain's workgroup size, so the bars are: the oracle (1e-3; unified scales: bits), k_gemv_stream's own integers against the
+    oracle (array_equal), and the same recording through k_decode_chain (TMAC_CHAIN_STREAM=0) bit for bit."""
+    import torch
+    from test_gpu_chain import rel_err
+    monkeypatch.setenv("TMAC_STREAM_NCLS", "1")      # every row range visits every call, as k_decode_chain's workgroups do (same waves per quad)
+    for ops, seed in (([(16384, [256], None), (16384, [64, 128], None), (16384, [1024], None)], 41), ([(18432, [128, 128], None), (18432, [512], None)], 42)):
+        m = Model(tm, ops, mg=mg, seed=seed)
+        s = m.record()
+        assert s.stream
+        s.launch(); torch.cuda.synchronize()
+        assert s.status() == 0
+        got = [[o.clone() for o in os_] for os_ in m.outs]
+        for i in range(len(ops)):
+            want = m.oracle_outputs(i, m.x_ext[i].float().cpu().numpy())
+            for k in range(len(want)):
+                g = got[i][k].cpu().numpy()
+                if mg >= 1:
+                    assert np.array_equal(g.view(np.uint16), want[k].astype(np.float16).view(np.uint16))
+                assert rel_err(g.astype(np.float32), want[k]) <= 1e-3
+        m.check_tap(s)
+        for os_ in m.outs:
+            for o in os_:
+                o.zero_()
+        monkeypatch.setenv("TMAC_CHAIN_STREAM", "0")
+        c = m.record()
+        monkeypatch.delenv("TMAC_CHAIN_STREAM")
+        assert not c.stream
+        c.launch(); torch.cuda.synchronize()
+        assert c.status() == 0
+        for x, y in zip(got, m.outs):
+            for p, q in zip(x, y):
+                assert torch.equal(p, q)
+        s.free(); c.free(); m.free()
+
+
 def test_stream_fp32_outputs_and_fp32_activations(tm):
     _run(tm, INDEP[:5], out_f16=False, seed=7)
     _run(tm, INDEP[:5], ext_f32=True, seed=8)

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     constexpr int RING = (BITS <= 2) ? 4 : 2;       // fragments per ring; two rings (current op / next op)
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int bx = blockIdx.x, gx = gridDim.x;
-    const unsigned gx_inv = (unsigned)((0x100000000ull + (unsigned)gx - 1u) / (unsigned)gx);      // ceil(2^32 / gx)
+    const unsigned gx_inv = gx == 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)gx - 1u) / (unsigned)gx);      // ceil(2^32 / gx); one workgroup: p mod 1 = 0 = bx below (2^32 does not fit)
     const unsigned gen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     const unsigned long long par_off = (gen & 1u) ? a.arena_half : 0ull;    // this launch's half of the hand-off arena (tmac_chain.h)
     float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][4][CHAIN_RED] partials of split quads (SM 2: per bit-plane)
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     *xslot(xt, r, 0) = t0; *xslot(xt, r, 1) = t1;
                     // one writer per pair, whatever the grid: pair p belongs to workgroup p mod gx (p / gx through the 32-bit reciprocal:
                     // exact for p < 2^16, the grid sizes of any device or partition)
-                    if (rout4 && p - (int)__umulhi((unsigned)p, gx_inv) * gx == bx) {
+                    if (rout4 && (gx == 1 || p - (int)__umulhi((unsigned)p, gx_inv) * gx == bx)) {
                         rout4[2 * (size_t)p] = t0;
                         rout4[2 * (size_t)p + 1] = t1;
                     }

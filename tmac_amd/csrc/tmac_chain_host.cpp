@@ -29,6 +29,7 @@ static thread_local std::vector<ChainRecOp>* g_chain_rec = nullptr;
 static thread_local std::vector<ChainRecGather>* g_chain_gat = nullptr;
 static thread_local tmac_hip_xform g_chain_xf = {};                  // applies to the next recorded call
 bool tmac_host::chain_recording() { return g_chain_rec != nullptr; }
+void tmac_host::chain_clear_xform() { memset(&g_chain_xf, 0, sizeof(g_chain_xf)); }
 
 struct tmac_hip_chain {
     std::vector<ChainOp> ops;
@@ -770,6 +771,11 @@ extern "C" int32_t tmac_hip_chain_status(tmac_hip_chain* c, uint32_t* error_word
         // A partial exit count means the launch never advanced the generation: the next launch reuses it and the same arena half, where
         // the granules the dead launch already published carry a matching tag.  They are wiped (tag 0 is never a generation), so the
         // next launch waits for data of its own.
+        if (ctl[1] && c->world > 1)
+            // ... on ONE GPU.  A row-sharded launch that died part-way has also stored granules into the peers' arenas under a generation the
+            // peers have meanwhile left behind: the ranks are a generation apart and no local wipe repairs that
+            return fail(TMAC_HIP_E_RUNTIME, "a row-sharded chain was interrupted inside a launch (%u of its workgroups exited): the ranks' generations differ now -- "
+                                            "free the chain on every rank, record and connect it again", ctl[1]);
         if (ctl[1] && c->arena) HIP_TRY(hipMemset(c->arena, 0, 2 * c->arena_bytes));
         const unsigned fresh[4] = {ctl[0], 0u, 0u, 0u};
         HIP_TRY(hipMemcpy(c->ctl, fresh, sizeof(fresh), hipMemcpyHostToDevice));
@@ -821,6 +827,11 @@ extern "C" int32_t tmac_hip_chain_set_tap(tmac_hip_chain* c, int32_t* dev_buffer
 // profiling aid: s_memrealtime stamps [ops][workgroups][8] of wave 0 (layout: tmac_chain.h)
 extern "C" int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* c, unsigned long long* dev_buffer) {
     if (!c) return fail(TMAC_HIP_E_ARG, "null chain");
+#ifndef TMAC_STREAM_STAMPS
+    // k_gemv_stream writes stamps in profiling builds only, and then in ITS layout ([workgroups][lookup waves][8], tmac_chain.h), not the
+    // [calls][workgroups][8] documented for k_decode_chain: a buffer sized for the latter would be overrun
+    if (c->stream && dev_buffer) return fail(TMAC_HIP_E_NOMATCH, "stamps of a stream-mode chain exist in -DTMAC_STREAM_STAMPS builds only (layout: StreamArgs::stamps)");
+#endif
     c->stamps = dev_buffer;
     return TMAC_HIP_OK;
 }

@@ -311,7 +311,10 @@ static int32_t fused_prefill(const tmac_hip_weights* const* wl, int nmat, const 
 int32_t tmac_host::fused_impl(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype,
                           void* const* C_list, tmac_dtype_t out_dtype, int N, int32_t* dump, float* lut_tap, hipStream_t st) {
     bind_thread_device();
-    if (!wl || !C_list || !B_dev || nmat < 1 || nmat > 4 || N < 1) return fail(TMAC_HIP_E_ARG, "bad fused arguments (1..4 matrices)");
+    if (!wl || !C_list || !B_dev || nmat < 1 || nmat > 4 || N < 1) {
+        if (chain_recording()) chain_clear_xform();      // a rejected call must not leave its transform pending for the next recorded call
+        return fail(TMAC_HIP_E_ARG, "bad fused arguments (1..4 matrices)");
+    }
     if (chain_recording() && !dump && !lut_tap) return chain_record(wl, nmat, B_dev, act_dtype, C_list, out_dtype, N);
     if (g_knobs.gemm_min_n > 0 && N >= 2 && !dump && !lut_tap) {       // (gemm_pays applies the threshold: a set one, or the measured crossover)
         bool ok = true;

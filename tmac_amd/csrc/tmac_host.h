@@ -143,6 +143,7 @@ void tuned_config(const FusedArgs& fa, int total_q, int& ft, int& wpq);   // lea
 
 // ---- decode chain (tmac_chain_host.cpp) -----------------------------------------------------------
 bool chain_recording();            // is the calling thread between tmac_hip_chain_begin and tmac_hip_chain_end?
+void chain_clear_xform();          // drops a transform declared for the next recorded call (the call was rejected before it could be recorded)
 int32_t chain_record(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype, void* const* C_list,
                      tmac_dtype_t out_dtype, int N);
 // true (and *rc set) when the calling thread is recording: the exchange step was noted, not executed

@@ -987,15 +987,22 @@ def run(args, env):
                 same_ = None
                 if verify:
                     # the launch's outputs against the same calls launched one by one (whose integer path the parity tests tap): same bits
+                    # (the quarter-walk form of k_gemv_stream adds a row's fp32 partial sums in another order: per-group-scale outputs within
+                    # 2e-3 of the stand-alone launch's fp16 values -- its integers are tapped against the oracle in tests/test_gpu_stream.py)
                     same_ = True
+                    qw_ = bool(getattr(rec_.chain, "quarter_walk", False))
                     for i_ in (0, ncalls // 2, ncalls - 1):
-                        L.tmac_hip_debug_quad_config(rec_.chain.threads, rec_.chain.wpq(i_))
+                        if not qw_:
+                            L.tmac_hip_debug_quad_config(rec_.chain.threads, rec_.chain.wpq(i_))
                         ref_ = [torch.empty_like(o) for o in os_[i_]]
                         wr.fused(sets[i_], xs_[i_], ref_, 1, act_dtype=F16, out_dtype=F16)
                         torch.cuda.synchronize()
-                        same_ = same_ and all(bool(torch.equal(a_, b_)) for a_, b_ in zip(ref_, os_[i_]))
+                        if qw_ and MG < 1:
+                            same_ = same_ and all(float((a_.float() - b_.float()).abs().max()) <= 2e-3 * float(a_.float().abs().max()) for a_, b_ in zip(ref_, os_[i_]))
+                        else:
+                            same_ = same_ and all(bool(torch.equal(a_, b_)) for a_, b_ in zip(ref_, os_[i_]))
                     L.tmac_hip_debug_quad_config(0, 0)
-                mode_ = "k_lut_images + k_gemv_stream (stream mode)" if getattr(rec_.chain, "stream", False) else "k_decode_chain"
+                mode_ = ("k_lut_images + k_gemv_stream (stream mode%s)" % (", qw" if getattr(rec_.chain, "quarter_walk", False) else "")) if getattr(rec_.chain, "stream", False) else "k_decode_chain"
                 rec_.chain.free()
                 for ws_ in extra:
                     for w_ in ws_:
@@ -1010,7 +1017,7 @@ def run(args, env):
                                    "calls_per_launch": ncalls,
                                    "us_per_gemv": round(sus, 3), "min_us": round(smin, 3), "GBps": round(hb_s / sus * 1e-3, 1),
                                    "frac": round(hb_s / sus * 1e-3 / HBM_PEAK_GBS, 4), "ok": bool(sok and ssame),
-                                   "bit_identical_to_single_launches": ssame,
+                                   "matches_single_launches": ssame, "form": "quarter-walk (outputs within 2e-3 of the stand-alone launches; integers tapped in tests)" if "qw" in smode else "quad x 64 units (bit-identical to the stand-alone launches)",
                                    "timing": "hipEvent pair around 10 back-to-back replays (LUT build launches included), mean of 8 pairs"}
             if ncalls != args.layers:
                 s32, m32, _, ok32, _, _ = time_stream_calls(3, args.layers, False)

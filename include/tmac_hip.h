@@ -235,6 +235,11 @@ int32_t tmac_hip_chain_threads(void);   /* threads per workgroup of k_decode_cha
  * arithmetic, same lane / wave decomposition: outputs bit-identical to the other N = 1 paths.  Per-group scales, or unified scales
  * (BitNet: the row's scale and the sequential bias chain by k_lut_images_us, scale-final on exact int32 totals);
  * TMAC_CHAIN_STREAM=0 in the environment keeps the ordinary chain (A/B). */
+/* Returns 0 (k_decode_chain), 1 (stream mode) or 2: stream mode in the QUARTER-WALK form, chosen when a K with a ragged last 64-unit step
+ * (11008, 3200, 8640 ...) would otherwise spend whole lookup items on zero tables: rows dealt in groups of 16, K walked in quarters of a
+ * step.  Same integers (tmac_hip_chain_set_tap shows them); a row's fp32 partial sums are added in another order than the stand-alone
+ * launch adds them, so per-group-scale outputs are specified to the path's tolerance (<= 1e-3 of the reference, measured <= 2e-5) instead
+ * of bit-identical to that launch; unified-scale outputs stay bit-identical.  TMAC_STREAM_QW=0 in the environment keeps form 1 (A/B). */
 int32_t tmac_hip_chain_is_stream(const tmac_hip_chain* chain);
 /* profiling / A-B knobs: s_memrealtime stamps (100 MHz) [calls][workgroups][8] of wave 0 (0 call entry, 1 activations complete, 2 LUT
  * built, 3 weights of the call landed, 5 last row quad published, 6 all loads landed, 7 number of polls) into a device buffer (NULL = off); waves per row quad forced for chains built from now on (0 = per-call

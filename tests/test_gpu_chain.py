@@ -135,15 +135,24 @@ class Model:
             assert x.numel() == K
             assert bool(torch.isfinite(x.float()).all()) and float(x.float().abs().max()) > 0, f"op {i}: degenerate activations"
             # (a) the same call on its own, the chain's threads per workgroup and waves per quad
-            L.tmac_hip_debug_quad_config(chain.threads, chain.wpq(i))
+            # (a quarter-walk stream splits quarters, not 64-unit steps, over its waves: its waves per group need not exist as a stand-alone
+            # configuration -- the default launch serves: exact totals for unified scales, a tolerance for per-group scales, below)
+            if not getattr(chain, "quarter_walk", False):
+                L.tmac_hip_debug_quad_config(chain.threads, chain.wpq(i))
             ref = [torch.empty_like(o) for o in got[i]]
             try:
                 self.wr.fused(self.ws[i], x, ref, 1, act_dtype=self.act_dtype(i))
                 torch.cuda.synchronize()
             finally:
                 L.tmac_hip_debug_quad_config(0, 0)
+            # (k_gemv_stream's quarter-walk form adds a row's fp32 partial sums in another order than the stand-alone launch: per-group-scale
+            # outputs are then held to the stand-alone launch within 1e-4 here, to the oracle below, and their integers by check_tap)
+            qw_float = getattr(chain, "quarter_walk", False) and self.mg < 1
             for m in range(len(rows)):
                 a, b = got[i][m].cpu().numpy(), ref[m].cpu().numpy()
+                if qw_float:
+                    assert rel_err(a.astype(np.float32), b.astype(np.float32)) <= (1e-4 if a.dtype == np.float32 else 2e-3), f"op {i} matrix {m}: quarter-walk stream vs stand-alone launch"
+                    continue
                 assert np.array_equal(a.view(np.uint16 if a.dtype == np.float16 else np.uint32),
                                       b.view(np.uint16 if b.dtype == np.float16 else np.uint32)), f"op {i} matrix {m}: chain != stand-alone launch"
             # (b) the oracle on the activation vector the chain produced

@@ -17,6 +17,16 @@ from test_gpu_chain import Model, tm, _short_spin      # noqa: F401  (fixtures)
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["auto", "quad64"])
+def _form(request, monkeypatch):
+    """k_gemv_stream has two forms (tmac_stream.hip): row quad x 64 units per item -- per-group-scale outputs bit-identical to the
+    stand-alone launches -- and the quarter-walk form (16 rows x 16 units; taken by default when some K of the recording has a ragged last
+    step and every matrix has a multiple of 16 rows), whose integers are the same (check_tap) and whose fp32 outputs are held to the
+    oracle's tolerance.  Every test runs with the default choice and with the first form forced."""
+    if request.param == "quad64":
+        monkeypatch.setenv("TMAC_STREAM_QW", "0")
+
+
 def _run(tm, ops, reps=2, **kw):
     m = Model(tm, ops, **kw)
     chain = m.record()
@@ -72,6 +82,7 @@ def test_stream_largest_K(tm, mg, monkeypatch):
     import torch
     from test_gpu_chain import rel_err
     monkeypatch.setenv("TMAC_STREAM_NCLS", "1")      # every row range visits every call, as k_decode_chain's workgroups do (same waves per quad)
+    monkeypatch.setenv("TMAC_STREAM_QW", "0")        # (the quarter-walk form of these K is covered by the oracle and the tap in the other tests)
     for ops, seed in (([(16384, [256], None), (16384, [64, 128], None), (16384, [1024], None)], 41), ([(18432, [128, 128], None), (18432, [512], None)], 42)):
         m = Model(tm, ops, mg=mg, seed=seed)
         s = m.record()
@@ -148,6 +159,7 @@ def test_stream_equals_the_ordinary_chain(tm, monkeypatch):
     waves per row quad, i.e. another order of its fp32 partial sums (the stand-alone comparison above follows the chain's choice)"""
     import torch
     monkeypatch.setenv("TMAC_STREAM_NCLS", "1")
+    monkeypatch.setenv("TMAC_STREAM_QW", "0")        # ... and the item form whose order of fp32 partial sums is k_decode_chain's
     m = Model(tm, INDEP, seed=11)
     s = m.record()
     assert s.stream

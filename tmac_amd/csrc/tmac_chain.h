@@ -156,14 +156,14 @@ enum { SR_NST = 0, SR_IPI, SR_NSG, SR_GSH, SR_NU, SR_QE0, SR_QE1, SR_QE2, SR_QPE
 enum { SRW_NQ = 0 /* quads of the wave: workgroups with q_per | q_per + 1 quads << 16 */, SRW_NSTEPS, SRW_H, SRW_QS, SRW_INTS };
 constexpr int STREAM_ROLE_INTS = SR_COMMON + SRW_INTS * STREAM_NLW;
 inline int stream_img_u4(int K) { return (chain_buf_u4(K) + 63) & ~63; }      // image / LDS buffer of one op, whole KB
-inline size_t stream_lds_bytes(int buf_u4, int nops) {
-    size_t b = (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * STREAM_NLW * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops;
+inline size_t stream_lds_bytes(int buf_u4, int nops, bool qw = false) {
+    size_t b = (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * STREAM_NLW * (qw ? 16 : 4) * CHAIN_RED + sizeof(ChainOp) * (size_t)nops;
 #ifdef TMAC_STREAM_STAMPS
     b += 32 * (STREAM_NLW + 1);        // the profiling build's cycle sums
 #endif
     return b;
 }
-hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, int sm, hipStream_t st);
-hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st);
+hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, int sm, bool sc_f16, hipStream_t st);
+hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int sm, bool qw, int grid, size_t lds_bytes, hipStream_t st);
 
 }  // namespace tmac

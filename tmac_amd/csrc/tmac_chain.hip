@@ -785,7 +785,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
 #pragma unroll
                 for (int k = 0; k < RING; ++k) {
                     // (the instance with the extensions is also the parity tap's: ChainArgs::tap)
-                    c_compute<BITS, ZP, SCF16, SM, XF>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane16, lk4, sel, k3, cacc, iacc,
+                    c_compute<BITS, ZP, SCF16, SM, XF>(ring[k], tab, tstride, l_ls, l_lb, c_st * 64, lane16, lk4, sel, k3, cacc, iacc,
                                                        (XF && a.tap) ? a.tap + a.tap_off[i] + (size_t)(4 * (ro.q_lo + ro.qs + c_it * ipi) + (lane & 3)) * G : nullptr, G);
                     issue_next(ring[k]);               // refill this slot with the item RING places ahead, if there is one
                     c_st += wpq;

@@ -154,13 +154,15 @@ __device__ __forceinline__ void c_selectors(CSel<BITS>& sel, int lane) {
 // lane's output row in the launch's tap buffer, G act groups per row) exactly as they enter the fp32 chain.
 template <int BITS, bool ZP, bool SCF16, int SM, bool TAP = false>
 __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab, int tstride, const float* l_ls, const float* l_lb,
-                                          int st, uint32_t lane16, uint32_t lk4, const CSel<BITS>& sel, uint32_t k3, float& cacc, int32_t (&iacc)[BITS],
+                                          int ub, uint32_t lane16, uint32_t lk4, const CSel<BITS>& sel, uint32_t k3, float& cacc, int32_t (&iacc)[BITS],
                                           int32_t* tap_row = nullptr, int G = 0) {
+    // ub: first unit of the item's table rows (64 x step for a (quad, 64-unit step) item, 16 x quarter-step for k_gemv_stream's quarter-walk form,
+    // where lane16 = 16 (lane & 15) and lk4 = 8 (lane >> 4)); act groups ub / 2 + lk4 / 4 + {0, 1}
     uint32_t tb[16];
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
         // units past K read the zero tables: no contribution
-        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tab + (j4 * tstride + st * 64)) + lane16);
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tab + (j4 * tstride + ub)) + lane16);
         tb[4 * j4] = v.x; tb[4 * j4 + 1] = v.y; tb[4 * j4 + 2] = v.z; tb[4 * j4 + 3] = v.w;
     }
     constexpr int NACC = (SM == 0) ? 1 : BITS;
@@ -204,16 +206,16 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
             sc = __uint_as_float(f.s0);
             if (ZP) zr = __uint_as_float(f.s1);
         }
-        // act groups st * 32 + lk4 / 4 + {0, 1}: ls / 2 and lb / 2 (groups past K hold zeros)
-        const float2 hls2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(l_ls + st * 32) + lk4);
-        const float2 hlb2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(l_lb + st * 32) + lk4);
+        // act groups ub / 2 + lk4 / 4 + {0, 1}: ls / 2 and lb / 2 (groups past K hold zeros)
+        const float2 hls2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(l_ls + (ub >> 1)) + lk4);
+        const float2 hlb2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(l_lb + (ub >> 1)) + lk4);
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
             const float hls = gi ? hls2.y : hls2.x, hlb = gi ? hlb2.y : hlb2.x;
             // sum_p alpha_p [(ps_p ls + [p = 0] lb) scale + [p = 0] zero 2 lb] = ((sum_p 2^p ps_p)(ls / 2) + lb / 2) scale + (2 zero)(lb / 2)
             const int32_t comb = (gi == 0) ? (c[0].x + c[0].y) : (c[0].z + c[0].w);
             if constexpr (TAP) {
-                const int kk = st * 32 + (int)(lk4 >> 2) + gi;
+                const int kk = (ub >> 1) + (int)(lk4 >> 2) + gi;
                 if (tap_row && kk < G) tap_row[kk] = comb;
             }
             const float v = __fmaf_rn((float)comb, hls, hlb);

@@ -64,6 +64,7 @@ struct tmac_hip_chain {
     const int* roles = nullptr;       // stream mode: the lookup waves' role records (device, behind the images), then the classes' visit counts
     const int* nvis = nullptr;
     int ncls = 1, vmax = 0;           // the schedule: classes of row ranges, records per class
+    bool qw = false;                  // k_gemv_stream's quarter-walk form (rows dealt in groups of four quads: q_end / q_per / q_extra of the ops count groups)
     int nsplit = 1;                   // workgroups per row range (two share a CU and take alternate ops when LDS and registers allow)
 };
 
@@ -511,6 +512,25 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             const double visit_fixed = 8.0;                                    // a visit's fixed cost in items (model only)
             const int nop = (int)c->ops.size();
             auto cls_lo = [&](int cl, int nc) { return (cl * c->grid + nc - 1) / nc; };
+            // The quarter-walk form of the kernel (tmac_stream.hip, QW): rows dealt in groups of four quads, K walked in quarters of a 64-unit
+            // step.  Taken when it saves lookups -- a ragged last step: K = 11008, 3200, 8640 ... -- and every matrix has whole groups;
+            // K = 4096 keeps the (quad x 64 units) form, whose per-group-scale outputs are bit-identical to the stand-alone launches.
+            // TMAC_STREAM_QW=0 / 1: A/B.
+            bool qw = true;
+            {
+                double it64 = 0, it16 = 0;
+                for (const ChainOp& o : c->ops) {
+                    for (int m = 0; m < o.nmat; ++m) if (((o.m[m].Mw + 3) / 4) % 4) qw = false;
+                    it64 += (double)o.total_q * o.nst; it16 += (double)(o.total_q / 4) * ((o.nu + 15) / 16);
+                }
+                const int force = env_int("TMAC_STREAM_QW", -1);
+                // measured (profiles/r06_stream_qw.txt): 1- to 3-bit streams are bound by lookup issue -- any saved item pays, and the form is
+                // 2-4 % faster even at K = 4096; 4-bit streams run at the memory system's rate, where a wave-load of four 256-byte pieces
+                // instead of one KB costs ~7 %: taken there only when the ragged steps outweigh that
+                if (force == 0 || (force < 0 && (c->bits >= 4 ? it16 > 0.93 * it64 : it16 >= it64))) qw = false;
+            }
+            auto op_q = [&](const ChainOp& o) { return qw ? o.total_q / 4 : o.total_q; };               // row units dealt: groups | quads
+            auto op_nst = [&](const ChainOp& o) { return qw ? (o.nu + 15) / 16 : o.nst; };              // K steps walked: quarters | 64-unit steps
             std::vector<int> blk_lo(nop, 0), blk_w(nop, 1);
             std::vector<std::vector<int>> visits;
             double best_span = 0;
@@ -522,7 +542,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                     std::vector<std::vector<int>> vis(ncls);
                     for (int i = 0; i < nop; ++i) {
                         const ChainOp& o = c->ops[i];
-                        const double items = (double)o.total_q * o.nst;
+                        const double items = (double)op_q(o) * op_nst(o);
                         int n = 1;
                         while (n < cap && items * n / c->grid < target) n <<= 1;
                         // (a block must leave every range at most 4095 quads and at least the op's matrices' geometry intact: checked below)
@@ -549,25 +569,27 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                 ChainOp& o = c->ops[i];
                 const int wlo = cls_lo(blk_lo[i], ncls), wcnt = cls_lo(blk_lo[i] + blk_w[i], ncls) - wlo;
                 o.wg_lo = wlo;
-                if (!g_knobs.chain_wpq || nwv % o.wpq) o.wpq = chain_pick_wpq(o.total_q, o.nst, wcnt, nwv);
+                const int tq = op_q(o), nstw = op_nst(o);
+                if (!g_knobs.chain_wpq || nwv % o.wpq || o.wpq > nstw) o.wpq = chain_pick_wpq(tq, nstw, wcnt, nwv);
                 o.ipi = nwv / o.wpq;
                 o.wpq_inv = (65536 + o.wpq - 1) / o.wpq;
                 o.ipi_inv = (65536 + o.ipi - 1) / o.ipi;
-                o.q_per = o.total_q / wcnt; o.q_extra = o.total_q % wcnt;
-                if (o.total_q / wcnt + 1 + o.ipi >= 4096) sched_ok = false;
+                o.q_per = tq / wcnt; o.q_extra = tq % wcnt;
+                if (tq / wcnt + 1 + o.ipi >= 4096) sched_ok = false;
+                if (qw) for (int m = 0; m < 4; ++m) { if (o.q_end[m] != 0x7fffffff) o.q_end[m] /= 4; o.m[m].q_end /= 4; }      // the kernel counts groups
             }
             int vmax = 1;
             for (int k = 0; k < ncls; ++k) if ((int)visits[k].size() > vmax) vmax = (int)visits[k].size();
             // two workgroups per CU, alternate visits each (k_gemv_stream's nsplit): when both fit a CU's LDS.  TMAC_STREAM_SPLIT=1: A/B
             const int want_split = env_int("TMAC_STREAM_SPLIT", 2);
-            const size_t lds2 = stream_lds_bytes(buf, (vmax + 1) / 2);
-            size_t lds = stream_lds_bytes(buf, vmax);
+            const size_t lds2 = stream_lds_bytes(buf, (vmax + 1) / 2, qw);
+            size_t lds = stream_lds_bytes(buf, vmax, qw);
             // Two workgroups are co-resident on a CU only with <= 64 VGPRs and <= 80 SGPRs each (measured, profiles/r05_stream_stamps.txt): 1- to
             // 3-bit weights fit with two fragments in flight per wave (3-bit: 4.06 -> 3.55 us on 4096 x 11008); 4-bit ones only with one,
             // which loses to one workgroup with two (5.15 against 4.68 us): they keep one workgroup per CU.  TMAC_STREAM_SPLIT_BITS: A/B.
             if (want_split >= 2 && c->bits <= env_int("TMAC_STREAM_SPLIT_BITS", 3) && vmax >= 2 && 2 * lds2 + 2048 <= 160 * 1024) { c->nsplit = 2; lds = lds2; }
             for (int ns = 3; ns <= want_split && ns <= 4; ++ns) {            // (A/B builds with -DTMAC_STREAM_NLW=6: more, smaller workgroups per CU)
-                const size_t ldsn = stream_lds_bytes(buf, (vmax + ns - 1) / ns);
+                const size_t ldsn = stream_lds_bytes(buf, (vmax + ns - 1) / ns, qw);
                 if (c->nsplit == ns - 1 && vmax >= ns && ns * (ldsn + 1024) <= 160 * 1024) { c->nsplit = ns; lds = ldsn; }
             }
             if (sched_ok && lds <= 160 * 1024) {
@@ -579,7 +601,8 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                         const int i = visits[k][v];
                         const ChainOp& o = c->ops[i];
                         int32_t* r = roles.data() + ((size_t)k * vmax + v) * STREAM_ROLE_INTS;
-                        r[SR_NST] = o.nst; r[SR_IPI] = o.ipi; r[SR_NSG] = o.nsg; r[SR_GSH] = o.gs_shift; r[SR_NU] = o.nu;
+                        const int nstw = op_nst(o);
+                        r[SR_NST] = nstw; r[SR_IPI] = o.ipi; r[SR_NSG] = o.nsg; r[SR_GSH] = o.gs_shift; r[SR_NU] = o.nu;
                         r[SR_QE0] = o.q_end[0]; r[SR_QE1] = o.q_end[1]; r[SR_QE2] = o.q_end[2];
                         r[SR_QPER] = o.q_per; r[SR_QEXTRA] = o.q_extra;
                         r[SR_IT_LO] = (o.q_per + o.ipi - 1) / o.ipi; r[SR_IT_HI] = (o.q_per + o.ipi) / o.ipi;
@@ -589,7 +612,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                             const int qs = wl / o.wpq, h = wl - qs * o.wpq;
                             auto nq = [&](int cnt) { return qs < cnt ? (cnt - 1 - qs) / o.ipi + 1 : 0; };
                             rw[SRW_NQ] = nq(o.q_per) | (nq(o.q_per + 1) << 16);
-                            rw[SRW_NSTEPS] = h < o.nst ? (o.nst - h + o.wpq - 1) / o.wpq : 0;
+                            rw[SRW_NSTEPS] = h < nstw ? (nstw - h + o.wpq - 1) / o.wpq : 0;
                             rw[SRW_H] = h; rw[SRW_QS] = qs;
                         }
                     }
@@ -600,7 +623,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                     return bail(fail(TMAC_HIP_E_RUNTIME, "LUT image allocation failed (%zu bytes)", img_bytes + role_bytes));
                 c->roles = reinterpret_cast<const int*>(reinterpret_cast<char*>(c->images) + img_bytes);
                 c->nvis = c->roles + (size_t)STREAM_ROLE_INTS * ncls * vmax;
-                c->ncls = ncls; c->vmax = vmax;
+                c->ncls = ncls; c->vmax = vmax; c->qw = qw;
                 for (ChainOp& o : c->ops) o.img = reinterpret_cast<const char*>(c->images) + (reinterpret_cast<size_t>(o.img) - 1);
                 c->stream = true; c->buf_u4 = buf; c->lds_bytes = lds; c->xforms = 0;
             } else {
@@ -679,13 +702,13 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
     }
     if (!c->connected) return fail(TMAC_HIP_E_ARG, "a row-sharded chain must be connected to its peers first (tmac_hip_chain_export / tmac_hip_chain_connect)");
     if (c->stream) {
-        hipError_t e = launch_lut_images(c->d_ops, (int)c->ops.size(), c->max_nst, c->sm, st);
+        hipError_t e = launch_lut_images(c->d_ops, (int)c->ops.size(), c->max_nst, c->sm, c->sc_f16 != 0, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT image launch: %s", hipGetErrorString(e));
         StreamArgs sa;
         memset(&sa, 0, sizeof(sa));
         sa.ops = c->d_ops; sa.nops = (int)c->ops.size(); sa.out_f16 = c->out_f16; sa.buf_u4 = c->buf_u4; sa.nsplit = c->nsplit; sa.roles = c->roles; sa.stamps = c->stamps;
         sa.ncls = c->ncls; sa.vmax = c->vmax; sa.nvis = c->nvis; sa.tap = c->tap; sa.tap_off = c->d_tap_off;
-        e = launch_gemv_stream(sa, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, st);
+        e = launch_gemv_stream(sa, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->qw, c->grid, c->lds_bytes, st);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "stream launch: %s", hipGetErrorString(e));
         c->last_stream = st; c->launched = true;
         return TMAC_HIP_OK;
@@ -838,7 +861,7 @@ extern "C" int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* c, unsigned long lo
 
 extern "C" int32_t tmac_hip_chain_threads(void) { return CHAIN_FT; }
 
-extern "C" int32_t tmac_hip_chain_is_stream(const tmac_hip_chain* c) { return c && c->stream ? 1 : 0; }
+extern "C" int32_t tmac_hip_chain_is_stream(const tmac_hip_chain* c) { return c && c->stream ? (c->qw ? 2 : 1) : 0; }
 
 extern "C" int32_t tmac_hip_debug_chain_grid(int workgroups) {
     if (workgroups < 0) return fail(TMAC_HIP_E_ARG, "negative grid");

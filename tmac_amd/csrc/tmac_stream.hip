@@ -29,8 +29,15 @@
 
 #include "tmac_chain_core.h"
 
+// Two translation units (build time): -DTMAC_STREAM_QW_TU=0 (default) holds the LUT-image kernels and the (quad x 64 units) form of
+// k_gemv_stream, =1 its quarter-walk form.
+#ifndef TMAC_STREAM_QW_TU
+#define TMAC_STREAM_QW_TU 0
+#endif
+
 namespace tmac {
 
+#if !TMAC_STREAM_QW_TU
 // ---------------------------------------------------------------------------------------------
 // LUT images: block (x, y) builds pairs 256 x .. 256 x + 255 (= the 64 units of step x) of op y -- the build phase of k_gemv_quad /
 // k_preprocess_pairs (lut_ctor.cc:120-215,240-256) writing the LDS layout of k_decode_chain's LUT buffer: [4][tstride] uint4 of signed
@@ -89,7 +96,10 @@ __global__ __launch_bounds__(256) void k_lut_images(const ChainOp* __restrict__ 
 // Unified-scale calls (BitNet: one act group = the whole row, qgemm.py:93-96, 170-174): ONE block per op.  The scale is a maximum over K and
 // lut_biases ONE fp32 chain over the K / 32 chunk sums in order (lut_ctor.cc:157,218) -- k_decode_chain's SM = 2 build, bit for bit: pass 1
 // maxima and chunk sums, pass 2 the tables with the row's scale, the chain by one lane.  Image: the tables as above, then float 0 = lut_scales,
-// float 1 = lut_biases (what the scale-final epilogue of k_gemv_stream's service wave reads).
+// float 1 = lut_biases, floats 16 + 8 m + g = unified scale g of the op's matrix m (k_decode_chain's LDS layout; static data copied here so that
+// the service wave's scale-final epilogue reads LDS only: a global load per combination sat between two workgroup barriers and stretched
+// every BitNet visit, profiles/r06_stream_schedule.txt).
+template <bool SCF16>
 __global__ __launch_bounds__(256) void k_lut_images_us(const ChainOp* __restrict__ ops) {
     __shared__ float s_cs[768];                 // chunk sums (K <= 24576)
     __shared__ float s_mx[4];
@@ -151,14 +161,21 @@ __global__ __launch_bounds__(256) void k_lut_images_us(const ChainOp* __restrict
         l_us[0] = gscale;
         l_us[1] = biases;
     }
+    if (tid >= 64 && tid < 64 + 4 * CHAIN_US_MAX_GROUPS) {
+        const int mi = (tid - 64) / CHAIN_US_MAX_GROUPS, g = (tid - 64) % CHAIN_US_MAX_GROUPS;
+        if (mi < d.nmat && g < d.m_groups)
+            l_us[16 + mi * CHAIN_US_MAX_GROUPS + g] = SCF16 ? __half2float(reinterpret_cast<const __half*>(d.m[mi].SC)[g]) : reinterpret_cast<const float*>(d.m[mi].SC)[g];
+    }
 }
 
-hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, int sm, hipStream_t st) {
+hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, int sm, bool sc_f16, hipStream_t st) {
     if (nops < 1 || max_nst < 1) return hipErrorInvalidValue;
-    if (sm == 2) hipLaunchKernelGGL(k_lut_images_us, dim3(nops), dim3(256), 0, st, d_ops);
+    if (sm == 2 && sc_f16) hipLaunchKernelGGL(k_lut_images_us<true>, dim3(nops), dim3(256), 0, st, d_ops);
+    else if (sm == 2) hipLaunchKernelGGL(k_lut_images_us<false>, dim3(nops), dim3(256), 0, st, d_ops);
     else hipLaunchKernelGGL(k_lut_images, dim3(max_nst, nops), dim3(256), 0, st, d_ops);
     return hipGetLastError();
 }
+#endif   // !TMAC_STREAM_QW_TU
 
 // ---------------------------------------------------------------------------------------------
 #ifndef TMAC_STREAM_KO
@@ -173,10 +190,25 @@ hipError_t launch_lut_images(const ChainOp* d_ops, int nops, int max_nst, int sm
 // profiles/r05_stream_stamps.txt), so the count is capped (amdgpu_num_sgpr(n) leaves n - 8 to the kernel; the compiler parks what does not
 // fit in VGPR lanes: 13 lane moves in the whole kernel with 74, 92 with 64).
 #define TMAC_STREAM_ATTR __attribute__((amdgpu_num_sgpr(82)))
-template <int BITS, bool ZP, bool SCF16, int RING, int MINW, int SM, bool TAP>
+// QW, the QUARTER-WALK form (round 6).  An item of the form above is one row quad x 64 units: a K whose last 64-unit step is ragged (11008 =
+// 5.4 steps, BitNet's 3200 = 1.6, 8640 = 4.2) pays whole items for it -- 10 to 22 % of all lookups on zero tables.  The adder hands every
+// lane of k-block kb (lanes 16 kb .. 16 kb + 15) to the output lanes L with (L >> 2 & 3) == kb and nothing crosses k-blocks, so the four
+// k-blocks of an item need not belong to one row quad: here an item is FOUR CONSECUTIVE ROW QUADS (a "group": 16 rows) x 16 units (a quarter
+// step), k-block kb = quad 4 g + kb of the group.  Same 2 KB of W2 weights, same instructions, but K is walked in quarters: ceil(nu / 16) x 16
+// units per quad instead of ceil(nu / 64) x 64 (11008: 352 instead of 384; 3200: 112 instead of 128; 8640: 272 instead of 320).  The lane's
+// accumulator still belongs to ONE row for the whole walk (row 4 kb' + beta of the group for output lane L = 16 ug + 4 kb' + beta), a lane's
+// 16 bytes are the SAME bytes of the unchanged QUAD layout (voffset = its quad's offset + 16 (lane & 15), soff advances by quarters: no per-
+// item address arithmetic, no padding mask -- a ragged last quarter reads stored zero nibbles), the tables of a quarter are read by all four
+// k-blocks (lanes 16 kb + j read unit 16 t + j).  Rows are dealt in groups (q_end / q_per / q_extra / the roles count groups; every matrix
+// has a multiple of 16 rows: the host checks), the partial sums of a wave are 16 per item walk, the wave-wide reduction is two cross-row
+// steps instead of four.  Integers are the same integers (tapped); the fp32 partial sums of a row are added in another order than
+// k_gemv_quad's, so per-group-scale outputs are specified to the oracle's tolerance (<= 1e-3, measured <= 2e-5) like every N = 1 kernel
+// against the reference, and no longer bit-identical to the stand-alone launch; unified-scale outputs stay bit-identical (exact totals).
+template <int BITS, bool ZP, bool SCF16, int RING, int MINW, int SM, bool TAP, bool QW>
 __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_stream(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     constexpr int NWV = STREAM_NLW;                     // lookup waves; wave NWV is the loader
+    constexpr int RPW = QW ? 16 : 4;                    // rows (partial sums) a wave hands over per closed iteration
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     // nsplit workgroups share every row range: workgroup (bx, part) walks the ops part, part + nsplit, ... with the rows of range bx.  They
     // are independent of each other (nothing in this kernel waits for another workgroup); whether they share a CU is the scheduler's business.
@@ -187,8 +219,8 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     const int* my_roles = a.roles + (size_t)cls * a.vmax * STREAM_ROLE_INTS;
     const int nops = max((a.nvis[cls] - part + nsplit - 1) / nsplit, 0);    // this workgroup's visits: local j = visit j * nsplit + part of the class
     if (nops == 0) return;
-    float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][4][CHAIN_RED] partials of split quads
-    uint4* l_ops = lds + 2 * (size_t)a.buf_u4 + (2 * NWV * 4 * CHAIN_RED * sizeof(float)) / 16;
+    float* l_red = reinterpret_cast<float*>(lds + 2 * (size_t)a.buf_u4);    // [2][NWV][RPW][CHAIN_RED] partials of split quads / groups
+    uint4* l_ops = lds + 2 * (size_t)a.buf_u4 + (2 * NWV * RPW * CHAIN_RED * sizeof(float)) / 16;
     {
         constexpr int U = (int)(sizeof(ChainOp) / 16);
         const uint4* gsrc = reinterpret_cast<const uint4*>(a.ops);
@@ -229,14 +261,17 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
             const cop_ptr d = ops + j;
             const int qper = uni(d->q_per), qex = uni(d->q_extra), ipi = uni(d->ipi), wpq = uni(d->wpq), bl = bx - uni(d->wg_lo);
             const int q_lo = bl * qper + min(bl, qex), cnt = qper + (bl < qex ? 1 : 0);
-            const int p_qs = lane >> 2, p_row = lane & 3;
+            // lane = (slot of the iteration, row of the slot's quad / group): 16 quads x 4 rows, or (QW) 4 groups x 16 rows per pass
+            constexpr int SPP = 64 / RPW;                 // slots per pass
+            for (int pass = 0; pass * SPP < ipi; ++pass) {
+            const int p_qs = pass * SPP + (int)((unsigned)lane / RPW), p_row = lane & (RPW - 1);
             const int p_gql = q_lo + t * ipi + p_qs;
             if (p_qs < ipi && p_gql < q_lo + cnt) {
                 const int e0 = uni(d->q_end[0]), e1 = uni(d->q_end[1]), e2 = uni(d->q_end[2]);
                 const int p_mi = (p_gql >= e0 ? 1 : 0) + (p_gql >= e1 ? 1 : 0) + (p_gql >= e2 ? 1 : 0);
                 const int p_lq = p_gql - (p_gql >= e2 ? e2 : (p_gql >= e1 ? e1 : (p_gql >= e0 ? e0 : 0)));
                 const unsigned long long p_c = reinterpret_cast<unsigned long long>(d->m[p_mi].C);
-                const float* red = l_red + par * (NWV * 4 * CHAIN_RED);
+                const float* red = l_red + par * (NWV * RPW * CHAIN_RED);
                 float v;
                 if (SM == 2) {
                     // exact int32 totals per bit-plane, then scale-final (qgemm.py:170-174,192-206) as k_decode_chain's epilogue:
@@ -247,12 +282,12 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                     const int32_t* redi = reinterpret_cast<const int32_t*>(red);
                     for (int ww = 0; ww < wpq; ++ww)
 #pragma unroll
-                        for (int pl = 0; pl < BITS; ++pl) cb[pl] += redi[((p_qs * wpq + ww) * 4 + p_row) * CHAIN_RED + pl];
+                        for (int pl = 0; pl < BITS; ++pl) cb[pl] += redi[((p_qs * wpq + ww) * RPW + p_row) * CHAIN_RED + pl];
                     if constexpr (TAP) {
                         if (a.tap) {          // the exact totals per bit-plane, as they enter scale-final
                             const int opi = my_roles[(size_t)(j * nsplit + part) * STREAM_ROLE_INTS + SR_OP];
 #pragma unroll
-                            for (int pl = 0; pl < BITS; ++pl) a.tap[a.tap_off[opi] + (size_t)(4 * p_gql + p_row) * BITS + pl] = cb[pl];
+                            for (int pl = 0; pl < BITS; ++pl) a.tap[a.tap_off[opi] + (size_t)(RPW * p_gql + p_row) * BITS + pl] = cb[pl];
                         }
                     }
                     float acc = 0.f;
@@ -264,19 +299,17 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                     const float* l_us = reinterpret_cast<const float*>(lds + (size_t)(j & 1) * a.buf_u4 + 4 * (size_t)uni(d->tstride));
                     const float vv = __fadd_rn(__fmul_rn(acc, l_us[0]), __fmul_rn(l_us[1], 0.5f));
                     const int mg = uni(d->m_groups);
-                    const int g = mg == 1 ? 0 : (4 * p_lq + p_row) / (d->m[p_mi].Mw / mg);
-                    const void* scp = d->m[p_mi].SC;
-                    const float us = SCF16 ? __half2float(__ushort_as_half(as_global(reinterpret_cast<const unsigned short*>(scp))[g]))
-                                           : as_global(reinterpret_cast<const float*>(scp))[g];
-                    v = __fmul_rn(vv, us);
+                    const int g = mg == 1 ? 0 : (RPW * p_lq + p_row) / (d->m[p_mi].Mw / mg);
+                    v = __fmul_rn(vv, l_us[16 + p_mi * CHAIN_US_MAX_GROUPS + g]);       // the matrix' unified scale: in the image (k_lut_images_us)
                 } else {
-                v = red[((p_qs * wpq) * 4 + p_row) * CHAIN_RED];
-                for (int ww = 1; ww < wpq; ++ww) v = __fadd_rn(v, red[((p_qs * wpq + ww) * 4 + p_row) * CHAIN_RED]);
+                v = red[((p_qs * wpq) * RPW + p_row) * CHAIN_RED];
+                for (int ww = 1; ww < wpq; ++ww) v = __fadd_rn(v, red[((p_qs * wpq + ww) * RPW + p_row) * CHAIN_RED]);
                 }
                 asm volatile("" : "+v"(v));       // the fp16 output is the fp32 result rounded once more (no fused convert: k_decode_chain)
-                const size_t oi = (size_t)(4 * p_lq + p_row);
+                const size_t oi = (size_t)(RPW * p_lq + p_row);
                 if (a.out_f16) c_store_b16(p_c + 2 * oi, (uint32_t)__half_as_ushort(__float2half_rn(v)));
                 else c_store_b32(p_c + 4 * oi, __float_as_uint(v));
+            }
             }
         };
         load_image(0);
@@ -303,9 +336,10 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     c_selectors<BITS, SM>(sel, lane);
     uint32_t k3 = 0x03020100u;
     asm volatile("" : "+v"(k3));
-    uint32_t lane16 = (uint32_t)lane * 16u;
+    uint32_t lane16 = QW ? (uint32_t)(lane & 15) * 16u : (uint32_t)lane * 16u;       // the lane's 16 bytes of a table row / weight block
     asm volatile("" : "+v"(lane16));
-    uint32_t lk4 = 4u * (uint32_t)(2 * (lane & 12) + 2 * (lane >> 4));      // the lane's two act groups inside a step's 32 (c_compute)
+    uint32_t lk4 = QW ? 8u * (uint32_t)(lane >> 4)                           // QW: act groups 2 ug, 2 ug + 1 of the quarter (output lane 16 ug + 4 kb + beta)
+                      : 4u * (uint32_t)(2 * (lane & 12) + 2 * (lane >> 4));      // the lane's two act groups inside a step's 32 (c_compute)
     asm volatile("" : "+v"(lk4));
     const int wl = NWV - 1 - w;             // logical wave index of the roles and of the partial sums (k_decode_chain's order)
 
@@ -329,10 +363,11 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     const __amdgpu_buffer_rsrc_t null_rs = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint4*>(nullptr), (short)0, 0, 0x00020000);   // every lane out of range: zeros, no fetch
     const TMAC_GLOBAL char* ops_g = as_global(reinterpret_cast<const char*>(a.ops));     // a dummy's scale word comes from a mapped address
     const uint32_t dummy_boff = (uint32_t)(lane & 3) * (uint32_t)((ZP ? 2 : 1) * (SCF16 ? 2 : 4));
+    uint32_t v_wq = lane16, v_scq = dummy_boff;      // QW, per op: the lane's weight offset (its k-block's quad of the group + 16 (lane & 15)) and scale offset (its output quad + row)
     // The cursor's state is what an item costs: every instruction of this lambda is paid once per item and wave (>= 4 cycles each).  The quad
     // is tracked as a running global index with the current matrix' quad range around it (quads ascend within an op: one compare says
     // whether the matrix changes); the lane's part of the scale address that depends on the op alone (c0 >> gs_shift) is kept per op.
-    int i_op = -1, i_left = 0, i_st = 0, i_h = 0, i_wpq = 1, i_nst = 1, i_nsg1 = 0, i_gsh = 0, i_nu = 0, i_gq = 0, i_ipi = 1;
+    int i_op = -1, i_left = 0, i_st = 0, i_h = 0, i_wpq = 1, i_nst = 1, i_nsg1 = 0, i_gsh = 0, i_nu = 0, i_gq = 0, i_ipi = 1, i_n64 = 1;
     int q_lo = 0, q_hi = 0, q_woff = 0;
     bool q_stale = true;
     cop_ptr i_d = ops;
@@ -340,7 +375,7 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     const TMAC_GLOBAL char* q_sc = ops_g;
     const TMAC_GLOBAL char* q_scm = ops_g;
     int q_scstride = 0;
-    const uint32_t c0 = (uint32_t)(4 * (lane & 12) + 4 * (lane >> 4));       // the lane's first unit inside a step (c_issue)
+    const uint32_t c0 = QW ? (uint32_t)(4 * (lane >> 4)) : (uint32_t)(4 * (lane & 12) + 4 * (lane >> 4));       // the lane's first unit inside a step / quarter (c_issue)
     uint32_t c0g = c0;                                                       // c0 >> gs_shift of the issue cursor's op
     constexpr int SC_SHIFT = (ZP ? 1 : 0) + (SCF16 ? 3 : 4);               // log2 of a scale group's bytes per row quad: 4 rows x (scale [, zero]) x 2 | 4
     auto refill = [&](CFrag<BITS>& f) __attribute__((always_inline)) {
@@ -357,6 +392,11 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                 i_nsg1 = rc[SR_NSG] - 1; i_gsh = rc[SR_GSH]; i_nu = rc[SR_NU];
                 q_scstride = rc[SR_NSG] << SC_SHIFT;
                 c0g = c0 >> i_gsh;
+                if constexpr (QW) {
+                    i_n64 = (rc[SR_TSTRIDE] - 1) >> 6;                   // 64-unit steps per quad in the weight layout
+                    v_wq = (uint32_t)(lane >> 4) * (uint32_t)(i_n64 * (BITS * 1024)) + lane16;
+                    v_scq = (uint32_t)((lane >> 2) & 3) * (uint32_t)q_scstride + dummy_boff;
+                }
                 q_hi = 0; q_stale = true;                 // (no matrix yet: the first quad takes the slow path)
             }
         }
@@ -370,21 +410,29 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                 q_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(uni(i_d->m[mi].W)), (short)0, 0x7fffffff, 0x00020000);
                 q_scm = as_global(uni(reinterpret_cast<const char*>(i_d->m[mi].SC)));
             }
-            const int lq = i_gq - q_lo;
+            const int lq = QW ? 4 * (i_gq - q_lo) : i_gq - q_lo;           // (QW: the group's first quad)
             q_sc = q_scm + (size_t)lq * (size_t)q_scstride;
-            q_woff = lq * i_nst * (BITS * 1024);
+            q_woff = lq * (QW ? i_n64 : i_nst) * (BITS * 1024);
             q_stale = false;
         }
         CItemOps io;
         if (real) {
             // c_item_operands with the op's constants folded: scale group min(st * (64 >> gsh) + (c0 >> gsh), nsg - 1); lanes whose unit lies past K
             // re-read lane 0's 16 bytes (their tables are zero tables)
+            io.rs = q_rs; io.sc = q_sc;
+            if constexpr (QW) {
+                // quarter i_st of the group's quads: 64-unit step i_st / 4, lanes 16 (i_st % 4) .. + 15 of its blocks
+                const uint32_t sg = min((uint32_t)((i_st << 4) >> i_gsh) + c0g, (uint32_t)i_nsg1);
+                io.boff = (sg << SC_SHIFT) + v_scq;
+                io.l16 = v_wq;
+                io.soff = q_woff + (i_st >> 2) * (BITS * 1024) + (i_st & 3) * 256;
+            } else {
             const int st64 = i_st << 6;
             const uint32_t sg = min((uint32_t)(st64 >> i_gsh) + c0g, (uint32_t)i_nsg1);
-            io.rs = q_rs; io.sc = q_sc;
             io.boff = (sg << SC_SHIFT) | dummy_boff;
             io.l16 = (lane < i_nu - st64) ? lane16 : 0u;
             io.soff = q_woff + i_st * (BITS * 1024);
+            }
         } else { io.rs = null_rs; io.soff = 0; io.sc = ops_g; io.boff = dummy_boff; io.l16 = 0u; }      // behind the last op: keeps the FIFO's depth
         c_issue_static<BITS, ZP, SCF16, SM>(f, io);
         if (real) {
@@ -433,28 +481,33 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     // every quad of the iteration and stores the outputs)
     auto finish = [&](bool have, float acc_in) __attribute__((always_inline)) {
         if (TMAC_STREAM_KO & 2) { ++c_it; return; }
-        float* red = l_red + parity * (NWV * 4 * CHAIN_RED);
+        float* red = l_red + parity * (NWV * RPW * CHAIN_RED);
         if (SM == 2) {
             // exact integer totals of the lane's row (lane & 3), per bit-plane: lanes of a DPP row by rotation, rows by two cross-row moves
+            // (QW: the 16 lanes of a DPP row are 16 different rows of the group: the cross-row moves only)
             int32_t* redi = reinterpret_cast<int32_t*>(red);
 #pragma unroll
             for (int pl = 0; pl < BITS; ++pl) {
                 uint32_t v = have ? (uint32_t)iacc[pl] : 0u;
-                v += qdpp_u<0x124>(v);
-                v += qdpp_u<0x128>(v);
+                if constexpr (!QW) {
+                    v += qdpp_u<0x124>(v);
+                    v += qdpp_u<0x128>(v);
+                }
                 v = q_xor_add_u(v);
-                if (lane < 4) redi[(wl * 4 + lane) * CHAIN_RED + pl] = (int32_t)v;
+                if (lane < RPW) redi[(wl * RPW + lane) * CHAIN_RED + pl] = (int32_t)v;
                 iacc[pl] = 0;
             }
         } else {
         float acc = 0.f;
         if (have) {
             acc = acc_in;
-            acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // lanes with the same row: rotate by 4, 8 within the DPP row
-            acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
+            if constexpr (!QW) {
+                acc = __fadd_rn(acc, qdpp_f<0x124>(acc));     // lanes with the same row: rotate by 4, 8 within the DPP row
+                acc = __fadd_rn(acc, qdpp_f<0x128>(acc));
+            }
             acc = q_xor_add_f(acc);
         }
-        if (lane < 4) red[(wl * 4 + lane) * CHAIN_RED] = acc;
+        if (lane < RPW) red[(wl * RPW + lane) * CHAIN_RED] = acc;
         }
         TMAC_ST(2);
         c_lds_barrier();                          // the service wave combines and stores behind it
@@ -476,7 +529,7 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
             tstride = rc[SR_TSTRIDE]; nst = rc[SR_NST]; wpq = rc[SR_WPQ]; h = rw[SRW_H];
             tab = lds + (size_t)(c_op & 1) * a.buf_u4;
             l_ls = reinterpret_cast<float*>(tab + 4 * tstride);
-            l_lb = l_ls + 32 * rc[SR_NST];
+            l_lb = l_ls + ((tstride - 1) >> 1);                 // 32 act groups per 64-unit step of the image
             c_left = items_of(rc, rw); c_it = 0; c_st = h;
             if constexpr (TAP) {
                 const int bl = bx - rc[SR_WLO];
@@ -508,8 +561,8 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                 }
 #endif
                 if (TMAC_STREAM_KO & 8) cacc += __uint_as_float(ring[k].wq[0].x ^ ring[k].wq[BITS - 1].w ^ ring[k].s0); else
-                c_compute<BITS, ZP, SCF16, SM, TAP>(ring[k], tab, tstride, l_ls, l_lb, c_st, lane16, lk4, sel, k3, cacc, iacc,
-                                                    (TAP && t_base) ? t_base + (size_t)(4 * (t_gq0 + c_it * t_ipi) + (lane & 3)) * t_G : nullptr, t_G);
+                c_compute<BITS, ZP, SCF16, SM, TAP>(ring[k], tab, tstride, l_ls, l_lb, QW ? c_st * 16 : c_st * 64, lane16, lk4, sel, k3, cacc, iacc,
+                                                    (TAP && t_base) ? t_base + (size_t)(RPW * (t_gq0 + c_it * t_ipi) + (lane & (RPW - 1))) * t_G : nullptr, t_G);
                 asm volatile("" : "+v"(cacc));        // the item's scale chain ends before the slot is refilled (the scale word keeps its register)
             }
             refill(ring[k]);
@@ -550,12 +603,12 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
 
 }
 
-template <int BITS>
+template <int BITS, bool QWF>
 static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st) {
     constexpr int R2 = (BITS <= 3) ? 2 : 1;      // two workgroups per CU: <= 64 VGPRs
     constexpr int R1 = (BITS <= 2) ? 4 : 2;      // one workgroup per CU: ring depth 2..8 measured flat (profiles/r05_stream_knockouts.txt)
 #define TMAC_SL2(Z, H, R, MW, S) do { \
-        auto* kern = a.tap ? &k_gemv_stream<BITS, Z, H, R1, 4, S, true> : &k_gemv_stream<BITS, Z, H, R, MW, S, false>; \
+        auto* kern = a.tap ? &k_gemv_stream<BITS, Z, H, R1, 4, S, true, QWF> : &k_gemv_stream<BITS, Z, H, R, MW, S, false, QWF>; \
         if (lds_bytes > 64 * 1024) { \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e != hipSuccess) return e; \
@@ -571,15 +624,29 @@ static hipError_t stream_launch_b(const StreamArgs& a, bool zp, bool sc_f16, int
 #undef TMAC_SL2
 }
 
-hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st) {
-    if (a.nops < 1 || grid < 1 || a.nsplit < 1 || a.nsplit > 4 || (sm != 0 && sm != 2)) return hipErrorInvalidValue;
+#if TMAC_STREAM_QW_TU
+hipError_t launch_gemv_stream_qw(const StreamArgs& a, int bits, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st) {
     switch (bits) {
-        case 1: return stream_launch_b<1>(a, zp, sc_f16, sm, grid, lds_bytes, st);
-        case 2: return stream_launch_b<2>(a, zp, sc_f16, sm, grid, lds_bytes, st);
-        case 3: return stream_launch_b<3>(a, zp, sc_f16, sm, grid, lds_bytes, st);
-        case 4: return stream_launch_b<4>(a, zp, sc_f16, sm, grid, lds_bytes, st);
+        case 1: return stream_launch_b<1, true>(a, zp, sc_f16, sm, grid, lds_bytes, st);
+        case 2: return stream_launch_b<2, true>(a, zp, sc_f16, sm, grid, lds_bytes, st);
+        case 3: return stream_launch_b<3, true>(a, zp, sc_f16, sm, grid, lds_bytes, st);
+        case 4: return stream_launch_b<4, true>(a, zp, sc_f16, sm, grid, lds_bytes, st);
         default: return hipErrorInvalidValue;
     }
 }
+#else
+hipError_t launch_gemv_stream_qw(const StreamArgs& a, int bits, bool zp, bool sc_f16, int sm, int grid, size_t lds_bytes, hipStream_t st);
+hipError_t launch_gemv_stream(const StreamArgs& a, int bits, bool zp, bool sc_f16, int sm, bool qw, int grid, size_t lds_bytes, hipStream_t st) {
+    if (a.nops < 1 || grid < 1 || a.nsplit < 1 || a.nsplit > 4 || (sm != 0 && sm != 2)) return hipErrorInvalidValue;
+    if (qw) return launch_gemv_stream_qw(a, bits, zp, sc_f16, sm, grid, lds_bytes, st);
+    switch (bits) {
+        case 1: return stream_launch_b<1, false>(a, zp, sc_f16, sm, grid, lds_bytes, st);
+        case 2: return stream_launch_b<2, false>(a, zp, sc_f16, sm, grid, lds_bytes, st);
+        case 3: return stream_launch_b<3, false>(a, zp, sc_f16, sm, grid, lds_bytes, st);
+        case 4: return stream_launch_b<4, false>(a, zp, sc_f16, sm, grid, lds_bytes, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+#endif
 
 }  // namespace tmac

@@ -236,7 +236,9 @@ class DecodeChain:
         self.threads = int(B.lib().tmac_hip_chain_threads())     # threads per workgroup of k_decode_chain (for A/B against k_gemv_quad)
         is_stream = getattr(B.lib(), "tmac_hip_chain_is_stream", None)
         # stream mode: no recorded call consumes another's output -- tables prebuilt by k_lut_images, lookups by k_gemv_stream (include/tmac_hip.h)
-        self.stream = bool(is_stream(self._h)) if is_stream is not None and getattr(is_stream, "argtypes", None) else False
+        mode = int(is_stream(self._h)) if is_stream is not None and getattr(is_stream, "argtypes", None) else 0
+        self.stream = mode != 0
+        self.quarter_walk = mode == 2      # k_gemv_stream's quarter-walk form: per-group-scale outputs to the oracle's tolerance, not bit-identical to stand-alone launches
 
     @property
     def handle(self):

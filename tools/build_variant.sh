@@ -7,6 +7,6 @@ cd "$(dirname "$0")/../tmac_amd/csrc"
 name=$1; cfg=$2
 mkdir -p ../lib/ko build_$name
 cp -u build/*.o build_$name/ 2>/dev/null || true
-rm -f build_$name/tmac_chain_b*.o build_$name/tmac_chain_host.o build_$name/tmac_stream.o
+rm -f build_$name/tmac_chain_b*.o build_$name/tmac_chain_host.o build_$name/tmac_stream.o build_$name/tmac_stream_qw.o
 make -s -j8 BUILD=build_$name OUT=../lib/ko/libtmac_hip_$name.so CHAIN_CFG="$cfg"
 ls -la ../lib/ko/libtmac_hip_$name.so

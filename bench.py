@@ -465,7 +465,9 @@ def run(args, env):
                 wr.llama_cpp_init(xin[slot], Mw, K, N, BITS, act_group_size=ags_of(K), act_dtype=F16)
                 for i in range(cnt):
                     wr.llama_cpp_compute(mats[name][i], out_of[name][i], N, out_dtype=F16)
-            # exchange step: the first output of the group becomes the next activation block
+            # exchange step: the first output of the group becomes the next activation block.  (--pattern independent: every call reads a
+            # vector that is resident before the launch; rows stay sharded and NOTHING is exchanged -- the mode that scales by construction)
+            exchange = exchange and args.pattern != "independent"
             if dist_on and exchange and recording[0] and lib_comm is None:
                 # row-sharded chain: the exchange step becomes part of the in-kernel hand-off (tmac_hip_chain_record_gather)
                 wr.record_gather(out_of[name][0], gathered[name], out_of[name][0].numel() * 2, rank, world)
@@ -531,7 +533,9 @@ def run(args, env):
             # The ranks exchange the IPC handles of their hand-off arenas (bootstrap only); every producer then stores its granules
             # into all of them (system-scope stores over xGMI).  Two trial launches prove the hand-off before anything is timed.
             ok = all_ranks_ok(chain is not None)
-            if ok:
+            if ok and args.pattern == "independent":
+                pass                      # nothing is handed over between ranks: every rank's recording is a stream of its own (no arenas to connect)
+            elif ok:
                 try:
                     blob = torch.frombuffer(bytearray(chain.export()), dtype=torch.uint8).to(dev)
                 except tmac_amd.binding.TMACHipError as e:
@@ -748,7 +752,9 @@ def run(args, env):
     # outputs as the distributed step (same bits when the paths share the configuration; a wrong or stale exchange is off by O(1)).
     preflight = None
     if dist_on and dpat is None:
-        path_txt = ("row-sharded persistent chain: hand-off granules stored into every rank's IPC-mapped arena (system scope over xGMI)" if chain is not None else
+        path_txt = ("row-sharded stream mode: every rank runs k_lut_images + k_gemv_stream over its row shard of the independent calls; nothing is exchanged"
+                    if (chain is not None and args.pattern == "independent") else
+                    "row-sharded persistent chain: hand-off granules stored into every rank's IPC-mapped arena (system scope over xGMI)" if chain is not None else
                     "one launch per fused call + all-gather per exchange step over " +
                     {"torch": "torch.distributed (ProcessGroupNCCL = RCCL)", "lib": "tmac_hip_comm (RCCL through the C-ABI)", "ipc": "tmac_hip_comm IPC windows"}[args.comm] +
                     (", replayed from a hipGraph" if graph is not None else ", eager"))
@@ -759,17 +765,18 @@ def run(args, env):
             xin0 = (step_in[0] if (chain is not None or graph is not None) else x[src_key]).clone()
             run_step()
             torch.cuda.synchronize()
-            got = {name: [o.clone() for o in outs[name]] for name in outs}
-            xe = {src_key: xin0}
+            got = {name: [o.clone() for o in outs_l[-1][name]] for name in outs}
+            xe = {src_key: xin0} if args.pattern != "independent" else dict(x)
             tmp = {name: [torch.empty_like(o) for o in outs[name]] for name in outs}
             opi = 0
             for li in range(args.layers):
                 for name, Mw, K, cnt, slot in MATS:
-                    if chain is not None:
+                    if chain is not None and not getattr(chain, "quarter_walk", False):
                         L.tmac_hip_debug_quad_config(chain.threads, chain.wpq(opi))
                     wr.fused(layers[li][name], xe[slot], tmp[name], N, act_dtype=F16, out_dtype=F16)
                     o0 = tmp[name][0]
-                    xe[nxt[name]] = (o0.repeat(world)[:logical[name]] if decode else o0.repeat(1, world)[:, :logical[name]].contiguous())
+                    if args.pattern != "independent":
+                        xe[nxt[name]] = (o0.repeat(world)[:logical[name]] if decode else o0.repeat(1, world)[:, :logical[name]].contiguous())
                     opi += 1
             L.tmac_hip_debug_quad_config(0, 0)
             torch.cuda.synchronize()
@@ -1034,13 +1041,20 @@ def run(args, env):
                 roof["stream_by_shape"] = by_shape
             except tmac_amd.binding.TMACHipError as e:
                 roof["stream_by_shape"] = {"error": repr(e)}
-            # ... and the whole token's 224 matrices as independent calls (what --pattern independent times): every call reads a resident vector
+        # ... and the whole token's 224 matrices as independent calls (what --pattern independent times): every call reads a resident vector.
+        # With several ranks: every rank streams ITS row shard of every matrix, nothing is exchanged (rows split, K whole, vectors resident on
+        # every rank) -- the decode-side workload that scales by construction, reported beside the dependent chain's value as
+        # roofline.independent_pattern (n_gpus ranks, aggregate bytes over the slowest rank's time)
+        if (not args.no_stream_core) and decode and args.path == "chain" and dpat is None:
             try:
                 ix = {s_: torch.randn(xdim[s_], device=dev, generator=gen).half() for s_ in xdim}
                 iouts = [{n_: [torch.empty_like(o) for o in outs[n_]] for n_ in outs} for _ in range(args.layers)]
                 with wr.record_chain() as irec:
                     for li in range(args.layers):
-                        calls(layers[li], ix, iouts[li], link=False)
+                        calls(layers[li], ix, iouts[li], exchange=False, link=False)
+                for _ in range(2):
+                    irec.chain.launch()
+                barrier()
                 idur = []
                 for r in range(8):
                     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
@@ -1052,13 +1066,18 @@ def run(args, env):
                     if r >= 3:
                         idur.append(e0.elapsed_time(e1) / 10)
                 iok = irec.chain.status() == 0
-                imode = "stream mode" if getattr(irec.chain, "stream", False) else "k_decode_chain"
+                imode = ("stream mode%s" % (", quarter-walk form" if getattr(irec.chain, "quarter_walk", False) else "")) if getattr(irec.chain, "stream", False) else "k_decode_chain"
                 irec.chain.free()
                 ims = float(np.mean(idur))
-                roof["independent_pattern"] = {"what": "the token's %d mpGEMMs as independent calls (each reads a vector that is in memory before the launch), %s"
-                                                       % (7 * args.layers, imode), "ms_per_token": round(ims, 4),
+                if dist_on:
+                    t_ = torch.tensor([ims, 0.0 if iok else 1.0], dtype=torch.float64, device=dev)
+                    d_all_reduce(t_, dist.ReduceOp.MAX)
+                    ims, iok = float(t_[0].item()), float(t_[1].item()) == 0.0
+                roof["independent_pattern"] = {"what": "the token's %d mpGEMMs as independent calls (each reads a vector that is in memory before the launch), %s%s"
+                                                       % (7 * args.layers, imode, "" if world == 1 else "; %d ranks, each over its row shard, no exchange; slowest rank's time" % world),
+                                               "n_gpus": world, "ms_per_token": round(ims, 4),
                                                "GBps": round(bytes_per_step / (ims * 1e-3) / 1e9, 1),
-                                               "frac": round(bytes_per_step / (ims * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "ok": iok}
+                                               "frac": round(bytes_per_step / (ims * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4), "ok": iok}
                 del iouts
             except Exception as e:
                 roof["independent_pattern"] = {"error": repr(e)}

@@ -181,7 +181,9 @@ def test_prefill_exchange_over_ipc_two_processes_one_device(tm):
 
 
 @pytest.mark.parametrize("workload,extra,nranks", [("llama2-7b-w2", [], 2), ("bitnet-3b", [], 2), ("llama2-7b-w2-prefill", ["--comm", "ipc"], 2),
-                                                   ("llama2-7b-w2", [], 4), ("llama2-7b-w2", [], 8), ("llama2-7b-w2-prefill", ["--comm", "ipc"], 4)])
+                                                   ("llama2-7b-w2", [], 4), ("llama2-7b-w2", [], 8), ("llama2-7b-w2-prefill", ["--comm", "ipc"], 4),
+                                                   ("llama2-7b-w2", ["--pattern", "independent"], 2), ("llama2-7b-w2", ["--pattern", "independent"], 8),
+                                                   ("bitnet-3b", ["--pattern", "independent"], 4)])
 def test_bench_ranks_share_the_device(tm, workload, extra, nranks):
     """bench.py's N > 1 orchestration end to end, launched exactly as the driver launches it (torch.distributed.run, one rank per
     "GPU"), with both ranks on the one device of the test box (--share-device: gloo instead of RCCL for bootstrap and timing, the CUs
@@ -203,8 +205,20 @@ def test_bench_ranks_share_the_device(tm, workload, extra, nranks):
     assert d["n_gpus"] == nranks and d["value"] > 0 and d["steps"] == 5
     assert d["config"]["parallelism"] == f"row-shard x{nranks}"
     # the preflight: one step of the timed path reproduced by every rank's communication-free emulation (same bits: same launch configuration)
-    assert d["preflight"]["ok"] and d["preflight"]["bit_identical_on_every_rank"], d["preflight"]
+    independent = "independent" in extra
+    assert d["preflight"]["ok"], d["preflight"]
+    if independent:
+        # row-sharded STREAM mode: every rank streams its shard of the independent calls, nothing is exchanged; the
+        # quarter-walk form's per-group-scale outputs are within the tolerance of the emulation, unified-scale ones bit-identical
+        assert d["config"]["path"] == "chain" and d["config"]["pattern"] == "independent", d["config"]
+        assert "stream" in d["roofline"]["kernel"] or "k_gemv_stream" in d["roofline"]["kernel"], d["roofline"]["kernel"]
+        assert d["preflight"]["max_rel_diff"] <= 2e-3, d["preflight"]
+        return
+    assert d["preflight"]["bit_identical_on_every_rank"], d["preflight"]
     if not workload.endswith("prefill"):
+        # the default decode line of N ranks also carries the mode that scales without an exchange: the token's calls as independent calls
+        ip = d["roofline"]["independent_pattern"]
+        assert "error" not in ip and ip["ok"] and ip["n_gpus"] == nranks and ip["ms_per_token"] > 0, ip
         assert d["config"]["path"] == "chain", d["config"]
         assert d.get("activations_finite", True)
         # ... and a multi-GPU decode run reports the prefill twin of the same matrices as its scaling headline

@@ -49,6 +49,18 @@ int ggml_tmac_hip_set_stream(void* hip_stream);
 void ggml_tmac_hip_free(struct tmac_ggml_tensor* w);
 const char* ggml_tmac_hip_last_error(void);
 
+/* ---- device-resident mat-muls without recording ----------------------------------------------------------------------------
+ * A device backend whose hook is called mat-mul by mat-mul (no view of the graph) and whose tensors live in device memory:
+ * ggml_tmac_hip_mul_mat_dev enqueues ONE N = 1 call -- 1..4 weights that share x (fp32 or fp16 [K]), outputs fp32 or fp16 [M] each -- on
+ * ggml_tmac_hip_stream() and returns at once.  With ggml_tmac_hip_set_deferred(1) such calls are QUEUED and ggml_tmac_hip_flush() launches
+ * the queue as one stream-mode launch (tmac_hip.h: tmac_hip_defer / tmac_hip_flush): the calls between two synchronisation points that do
+ * not depend on each other -- q, k, v issued one by one; the projections of several sequences -- run at 0.6-0.75 of the HBM peak instead
+ * of 0.25.  A call that depends on a queued one flushes the queue by itself; ggml_tmac_hip_synchronize() flushes, then waits. */
+int ggml_tmac_hip_mul_mat_dev(const struct tmac_ggml_tensor* const* w, int nw, const void* x_dev, int x_is_f32, void* const* dst_dev, int dst_is_f32);
+int ggml_tmac_hip_set_deferred(int on);
+int ggml_tmac_hip_flush(void);
+int ggml_tmac_hip_synchronize(void);
+
 /* ---- decoder segments ------------------------------------------------------------------------------------------------------
  * A decoded token issues the same mat-muls in the same order every time; between two of them sit element-wise operators (residual
  * add + RMSNorm in front of q/k/v and gate/up, silu(gate) * up in front of the down projection) and, once per layer, an operator

@@ -140,6 +140,19 @@ int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weights, int nma
                                  tmac_dtype_t act_dtype, void* const* C_dev, tmac_dtype_t out_dtype, int N,
                                  void* stream);
 
+/* ---- deferred launches ---------------------------------------------------------------------
+ * For callers that do not record (a backend hook called mat-mul by mat-mul).  tmac_hip_defer(1): from now on the calling thread's N = 1
+ * tmac_hip_qgemm_fused_dev calls are QUEUED instead of launched; tmac_hip_flush launches what is queued as ONE stream-mode launch
+ * (k_lut_images + k_gemv_stream: the independent-call path, 0.6-0.75 of the HBM peak instead of 0.25 for stand-alone launches).  The
+ * queue never holds a dependence: a call that reads, or overwrites, anything a queued call writes (or overwrites what one reads), a call on
+ * another stream, an N > 1 call and tmac_hip_defer(0) flush it first -- results are those of launching the calls in order.  The recording
+ * built from a batch is cached by the batch's signature (matrices, pointers, dtypes; invalidated when weights are freed): a decode loop
+ * pays for it once.  Batches the persistent kernels do not cover are launched call by call at the flush.  The caller must flush before it
+ * synchronises the stream or reads an output.  tmac_hip_defer_stats: flushes, cache hits, stream-mode launches, calls launched singly. */
+int32_t tmac_hip_defer(int on);
+int32_t tmac_hip_flush(void* stream);
+int32_t tmac_hip_defer_stats(uint64_t* flushes, uint64_t* cache_hits, uint64_t* stream_launches, uint64_t* single_calls);
+
 /* ---- persistent decode chain ---------------------------------------------------------------
  * The fused calls of one decoded token (llama.cpp issues the same tmac_hip_qgemm_fused_dev sequence for every token:
  * llama_cpp_init + llama_cpp_compute per projection, tmac_gemm_wrapper.h:170-228) recorded ONCE and executed by ONE

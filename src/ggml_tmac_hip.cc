@@ -142,10 +142,34 @@ extern "C" int ggml_tmac_hip_mul_mat(const struct tmac_ggml_tensor* w, const str
     const tmac_hip_weights* wl[1] = {h->w};
     void* cl[1] = {yout};
     if ((rc = tmac_hip_qgemm_fused_dev(wl, 1, xin, TMAC_F32, cl, TMAC_F32, N, g_stream))) return rc;   // LUT build + mpGEMM, one launch at N = 1
+    if ((rc = tmac_hip_flush(g_stream))) return rc;          // (deferred mode: an N = 1 call was queued, not launched)
     if (!y_dev && hip.MemcpyAsync(g_py, g_dy, by, 2 /* D2H */, g_stream) != 0) return fail("D2H copy failed");
     if (hip.StreamSynchronize(g_stream) != 0) return fail("stream synchronisation failed");
     if (!y_dev) memcpy(dst->data, g_py, by);
     return 0;
+}
+
+// ---- device-resident mat-muls without recording (see the header) ----
+extern "C" int ggml_tmac_hip_mul_mat_dev(const struct tmac_ggml_tensor* const* w, int nw, const void* x_dev, int x_is_f32, void* const* dst_dev, int dst_is_f32) {
+    if (!g_ready) return fail("ggml_tmac_hip_init has not been called");
+    if (!w || nw < 1 || nw > 4 || !x_dev || !dst_dev) return fail("bad mul_mat_dev");
+    g_err[0] = 0;
+    const tmac_hip_weights* wl[4];
+    void* cl[4];
+    for (int i = 0; i < nw; ++i) {
+        if (!w[i] || !w[i]->extra || !dst_dev[i]) return fail("null tensor");
+        wl[i] = ((const Handle*)w[i]->extra)->w;
+        cl[i] = dst_dev[i];
+    }
+    return tmac_hip_qgemm_fused_dev(wl, nw, x_dev, x_is_f32 ? TMAC_F32 : TMAC_F16, cl, dst_is_f32 ? TMAC_F32 : TMAC_F16, 1, g_stream);
+}
+extern "C" int ggml_tmac_hip_set_deferred(int on) { return tmac_hip_defer(on); }
+extern "C" int ggml_tmac_hip_flush(void) { return tmac_hip_flush(g_stream); }
+extern "C" int ggml_tmac_hip_synchronize(void) {
+    if (!g_ready) return fail("ggml_tmac_hip_init has not been called");
+    const int rc = tmac_hip_flush(g_stream);
+    if (rc) return rc;
+    return hip.StreamSynchronize(g_stream) == 0 ? 0 : fail("stream synchronisation failed");
 }
 
 extern "C" void ggml_tmac_hip_free(struct tmac_ggml_tensor* w) {

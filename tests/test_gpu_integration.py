@@ -125,6 +125,21 @@ def test_ggml_op_hook_glue(tm, tmp_path, N, where):
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_ggml_hook_without_recording_reaches_stream_mode(tm, tmp_path):
+    """a hook that is called mat-mul by mat-mul (no chain_begin / segment) issues q / k / v as three separate device-resident
+    calls; in deferred mode they run as ONE stream-mode launch (k_lut_images + k_gemv_stream), the recording is cached from the second token
+    on, a call that reads a queued output flushes the queue by itself, and every output equals the reference (tests/cpp/ggml_shim_main.cc)"""
+    Mw, K, bits, bm = 4096, 4096, 2, 128
+    d = fixtures(tmp_path, Mw, K, bits, bm, N=1)
+    exe = os.path.join(d, "ggml_shim_main")
+    gxx(exe, os.path.join(ROOT, "tests", "cpp", "ggml_shim_main.cc"), os.path.join(ROOT, "src", "ggml_tmac_hip.cc"),
+        extra=("-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"))
+    env = dict(os.environ); env.pop("TMAC_KCFG_FILE", None)
+    r = subprocess.run([exe, d, str(Mw), str(K), str(bits), "1", "batch"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "stream_launches 3" in r.stdout and "cache_hits 2" in r.stdout, r.stdout
+
+
 @pytest.mark.skipif(shutil.which("cmake") is None, reason="cmake not installed")
 def test_cmake_consumer_computes_a_gemv(tm, tmp_path):
     Mw, K, bits, bm = 512, 4096, 2, 128

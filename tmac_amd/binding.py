@@ -116,6 +116,9 @@ def load_library() -> C.CDLL:
         "tmac_hip_comm_connect": ([vp, vp, C.c_int], i32),
         "tmac_hip_comm_status": ([vp, C.POINTER(C.c_uint32)], i32),
         "tmac_hip_comm_last_error": ([], C.c_char_p),
+        "tmac_hip_defer": ([C.c_int], i32),
+        "tmac_hip_flush": ([vp], i32),
+        "tmac_hip_defer_stats": ([C.POINTER(C.c_uint64)] * 4, i32),
         "tmac_hip_chain_begin": ([], i32),
         "tmac_hip_chain_end": ([C.POINTER(vp)], i32),
         "tmac_hip_chain_launch": ([vp, vp], i32),

@@ -875,3 +875,160 @@ extern "C" int32_t tmac_hip_debug_chain_config(int force_wpq, unsigned spin_limi
     if (spin_limit) g_knobs.chain_spin_limit = spin_limit;
     return TMAC_HIP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Deferred launches (include/tmac_hip.h: tmac_hip_defer / tmac_hip_flush).  A caller that does NOT record -- a backend hook called mat-mul by
+// mat-mul -- still issues, between two synchronisation points, calls that do not depend on each other (q / k / v of a layer as separate
+// calls; the projections of several sequences).  Launched one by one they run k_gemv_quad (0.25 of the HBM peak on the headline shape, a
+// launch each); queued and flushed together they are ONE stream-mode launch (k_lut_images + k_gemv_stream).  The queue holds N = 1 calls
+// whose inputs are resident: a call that reads or overwrites anything a queued call writes (or overwrites what one reads) flushes the
+// queue first, so a batch never carries a dependence and never needs a hand-off.  The recording built from a batch is cached by the
+// batch's signature (matrices, pointers, dtypes): a decode loop pays tmac_hip_chain_end once per distinct batch.  What the persistent
+// kernels do not cover (tmac_hip_chain_end returns -1) is launched call by call at the flush, as if it had never been queued.
+// ---------------------------------------------------------------------------------------------
+#include <atomic>
+namespace {
+struct DeferKey {
+    std::vector<const tmac_hip_weights*> w;
+    std::vector<void*> C;
+    const void* B;
+    int act, out;
+    bool operator==(const DeferKey& o) const { return B == o.B && act == o.act && out == o.out && w == o.w && C == o.C; }
+};
+struct DeferEntry {
+    std::vector<DeferKey> sig;
+    tmac_hip_chain* chain;       // nullptr: this batch is launched call by call (no persistent form)
+    unsigned long long used;
+};
+struct DeferState {
+    bool on = false;
+    std::vector<ChainRecOp> pending;
+    hipStream_t stream = nullptr;
+    std::vector<DeferEntry> cache;
+    unsigned long long epoch = 0, tick = 0;
+    unsigned long long n_flush = 0, n_hit = 0, n_stream = 0, n_chain = 0, n_single = 0;
+    ~DeferState() { for (DeferEntry& e : cache) if (e.chain) tmac_hip_chain_free(e.chain); }
+};
+thread_local DeferState g_defer;
+std::atomic<unsigned long long> g_defer_epoch{1};
+constexpr size_t DEFER_MAX_BATCH = 256, DEFER_CACHE = 32;
+
+Range defer_in_range(const ChainRecOp& r) {
+    return Range{(const char*)r.B, (const char*)r.B + (size_t)r.w[0]->s.K * (r.act == TMAC_F32 ? 4 : 2)};
+}
+Range defer_out_range(const ChainRecOp& r, size_t m) {
+    return Range{(const char*)r.C[m], (const char*)r.C[m] + (size_t)r.w[m]->s.Mw * (r.out == TMAC_F16 ? 2 : 4)};
+}
+
+int32_t defer_flush(hipStream_t st) {
+    DeferState& D = g_defer;
+    if (D.pending.empty()) return TMAC_HIP_OK;
+    std::vector<ChainRecOp> batch;
+    batch.swap(D.pending);
+    ++D.n_flush;
+    const unsigned long long ep = g_defer_epoch.load(std::memory_order_acquire);
+    if (ep != D.epoch) {                      // weights were freed since: every cached recording may point at dead matrices
+        for (DeferEntry& e : D.cache) if (e.chain) tmac_hip_chain_free(e.chain);
+        D.cache.clear();
+        D.epoch = ep;
+    }
+    std::vector<DeferKey> sig(batch.size());
+    for (size_t i = 0; i < batch.size(); ++i) { sig[i].w = batch[i].w; sig[i].C = batch[i].C; sig[i].B = batch[i].B; sig[i].act = (int)batch[i].act; sig[i].out = (int)batch[i].out; }
+    DeferEntry* hit = nullptr;
+    for (DeferEntry& e : D.cache) if (e.sig == sig) { hit = &e; break; }
+    if (hit) ++D.n_hit;
+    else {
+        tmac_hip_chain* c = nullptr;
+        if (batch.size() >= 2 && !g_chain_rec) {
+            g_chain_rec = new std::vector<ChainRecOp>(batch);
+            g_chain_gat = new std::vector<ChainRecGather>();
+            memset(&g_chain_xf, 0, sizeof(g_chain_xf));
+            const int32_t rc = tmac_hip_chain_end(&c);          // (ends the recording whatever comes out)
+            if (rc != TMAC_HIP_OK) c = nullptr;
+            if (c && !c->stream) { tmac_hip_chain_free(c); c = nullptr; }    // (a batch carries no dependence: anything but a stream is not worth a persistent launch)
+        }
+        if (D.cache.size() >= DEFER_CACHE) {                    // evict the least recently used recording
+            size_t v = 0;
+            for (size_t i = 1; i < D.cache.size(); ++i) if (D.cache[i].used < D.cache[v].used) v = i;
+            if (D.cache[v].chain) {
+                (void)hipStreamSynchronize(D.cache[v].chain->last_stream);
+                tmac_hip_chain_free(D.cache[v].chain);
+            }
+            D.cache.erase(D.cache.begin() + (long)v);
+        }
+        D.cache.push_back(DeferEntry{sig, c, 0});
+        hit = &D.cache.back();
+    }
+    hit->used = ++D.tick;
+    if (hit->chain) {
+        ++D.n_stream;
+        return tmac_hip_chain_launch(hit->chain, st);
+    }
+    const bool was_on = D.on;
+    D.on = false;                                               // call by call, as if never queued
+    int32_t rc = TMAC_HIP_OK;
+    for (const ChainRecOp& r : batch) {
+        ++D.n_single;
+        rc = fused_impl(r.w.data(), (int)r.w.size(), r.B, r.act, r.C.data(), r.out, 1, nullptr, nullptr, st);
+        if (rc != TMAC_HIP_OK) break;
+    }
+    D.on = was_on;
+    return rc;
+}
+}  // namespace
+
+bool tmac_host::defer_if_on(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype, void* const* C_list,
+                            tmac_dtype_t out_dtype, int N, hipStream_t st, int32_t* rc) {
+    DeferState& D = g_defer;
+    if (!D.on) return false;
+    *rc = TMAC_HIP_OK;
+    if (N != 1) { *rc = defer_flush(D.stream); return false; }               // (ordered behind the queue; launched as usual)
+    ChainRecOp op;
+    for (int i = 0; i < nmat; ++i) {
+        if (!wl[i] || !C_list[i]) { *rc = fail(TMAC_HIP_E_ARG, "null matrix or output"); return true; }
+        op.w.push_back(wl[i]); op.C.push_back(C_list[i]);
+    }
+    op.B = B_dev; op.act = act_dtype; op.out = out_dtype;
+    memset(&op.xf, 0, sizeof(op.xf));
+    // a dependence on the queue (RAW: reads a queued output; WAR / WAW: writes what a queued call reads or writes), another stream, or a
+    // full queue: the queue goes first
+    bool must_flush = !D.pending.empty() && (st != D.stream || D.pending.size() >= DEFER_MAX_BATCH);
+    const Range in = defer_in_range(op);
+    for (size_t j = 0; j < D.pending.size() && !must_flush; ++j) {
+        const ChainRecOp& p = D.pending[j];
+        const Range pin = defer_in_range(p);
+        for (size_t m = 0; m < p.C.size() && !must_flush; ++m) {
+            const Range po = defer_out_range(p, m);
+            if (overlap(in, po)) must_flush = true;
+            for (size_t k = 0; k < op.C.size(); ++k) if (overlap(defer_out_range(op, k), po)) must_flush = true;
+        }
+        for (size_t k = 0; k < op.C.size(); ++k) if (overlap(defer_out_range(op, k), pin)) must_flush = true;
+    }
+    if (must_flush && (*rc = defer_flush(D.stream)) != TMAC_HIP_OK) return true;
+    D.stream = st;
+    D.pending.push_back(op);
+    return true;
+}
+void tmac_host::defer_forget_all() { g_defer_epoch.fetch_add(1, std::memory_order_acq_rel); }
+
+extern "C" int32_t tmac_hip_defer(int on) {
+    DeferState& D = g_defer;
+    if (!on && !D.pending.empty()) {
+        const int32_t rc = defer_flush(D.stream);
+        if (rc != TMAC_HIP_OK) return rc;
+    }
+    D.on = on != 0;
+    return TMAC_HIP_OK;
+}
+extern "C" int32_t tmac_hip_flush(void* stream) {
+    (void)stream;                                               // (the queue remembers the stream its calls were issued on)
+    return defer_flush(g_defer.stream);
+}
+extern "C" int32_t tmac_hip_defer_stats(uint64_t* flushes, uint64_t* cache_hits, uint64_t* stream_launches, uint64_t* single_calls) {
+    const DeferState& D = g_defer;
+    if (flushes) *flushes = D.n_flush;
+    if (cache_hits) *cache_hits = D.n_hit;
+    if (stream_launches) *stream_launches = D.n_stream;
+    if (single_calls) *single_calls = D.n_single;
+    return TMAC_HIP_OK;
+}

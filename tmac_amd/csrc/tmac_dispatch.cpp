@@ -316,6 +316,10 @@ int32_t tmac_host::fused_impl(const tmac_hip_weights* const* wl, int nmat, const
         return fail(TMAC_HIP_E_ARG, "bad fused arguments (1..4 matrices)");
     }
     if (chain_recording() && !dump && !lut_tap) return chain_record(wl, nmat, B_dev, act_dtype, C_list, out_dtype, N);
+    if (!dump && !lut_tap) {           // deferred launches: queued until tmac_hip_flush (or a call that depends on a queued one)
+        int32_t drc;
+        if (defer_if_on(wl, nmat, B_dev, act_dtype, C_list, out_dtype, N, st, &drc)) return drc;
+    }
     if (g_knobs.gemm_min_n > 0 && N >= 2 && !dump && !lut_tap) {       // (gemm_pays applies the threshold: a set one, or the measured crossover)
         bool ok = true;
         long rows = 0;

@@ -161,6 +161,8 @@ extern "C" int32_t tmac_hip_debug_ws_fill_sync(int on) {
 }
 
 extern "C" int32_t tmac_hip_reset_state(void) {
+    (void)tmac_hip_defer(0);                  // (launches what the calling thread still has queued, then leaves deferred mode)
+    defer_forget_all();
     int32_t rc = tmac_hip_cache_clear();      // host-pointer tiles / runs, the fused entry point's per-stream workspaces
     host_route_release();                     // ... and the host-pointer layer's workspace, staging buffers and LUT memo
     {

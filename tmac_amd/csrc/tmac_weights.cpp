@@ -123,6 +123,7 @@ extern "C" int32_t tmac_hip_register_weights_dev(tmac_hip_weights** out, const v
 
 extern "C" int32_t tmac_hip_free_weights(tmac_hip_weights* w) {
     if (!w) return TMAC_HIP_OK;
+    defer_forget_all();       // recordings cached by the deferred-launch queue may name this matrix
     if (w->W) (void)hipFree(w->W);
     if (w->SC) (void)hipFree(w->SC);
     if (w->A_ref) (void)hipFree(w->A_ref);

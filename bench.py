@@ -183,17 +183,27 @@ def cpu_baseline(workload="llama2-7b-w2", seconds=6.0):
         kind = "reference" if orc.have_ref(setname) else "port"
         what = f"prebuilt kernels deploy/tuned/{setname}/kernels.cc"
     drv = C.CDLL(os.path.join(ROOT, "oracle", "libref_driver.so")) if kind == "reference" else None
-    work = []
-    for Mw, K, pm in shapes:
-        M = Mw * BITS
-        A = rng.integers(0, 256, size=(M // BM, K // 4, BM // 2), dtype=np.uint8)
-        S = (np.array([1.0 / K], np.float32) if bitnet else
-             np.abs(rng.standard_normal((M // BM, K // GS, BM // BITS * 2))).astype(np.float32))
-        Bv = rng.standard_normal((1, K)).astype(np.float32)
-        work.append((Mw, K, pm, A, S, Bv))
+    # SURVEY 8(d) asks for rotating distinct weights, as the GPU side has them: one set of the layer's three shapes is 4-27 MB and would
+    # stay in the host's L3 when re-run (225 GB/s was a cache number).  >= 512 MB of distinct sets are walked round-robin,
+    # so every run streams its weights from DRAM; the cache-resident figure (set 0 re-run) is reported beside it.
+    def make_set():
+        ws_ = []
+        for Mw, K, pm in shapes:
+            M = Mw * BITS
+            A = rng.integers(0, 256, size=(M // BM, K // 4, BM // 2), dtype=np.uint8)
+            S = (np.array([1.0 / K], np.float32) if bitnet else
+                 np.abs(rng.standard_normal((M // BM, K // GS, BM // BITS * 2))).astype(np.float32))
+            Bv = rng.standard_normal((1, K)).astype(np.float32)
+            ws_.append((Mw, K, pm, A, S, Bv))
+        return ws_
     total_bytes = sum(algorithmic_bytes(Mw, K, BITS, GS, K if bitnet else AGS, not bitnet, 1 if bitnet else -1) for Mw, K, _ in shapes)
+    nsets = max(2, -(-(512 << 20) // total_bytes)) if kind == "reference" else 1
+    sets = [make_set() for _ in range(nsets)]
+    turn = [0]
 
-    def run_once(nthreads):
+    def run_once(nthreads, rotate=True):
+        work = sets[turn[0] % nsets] if rotate else sets[0]
+        turn[0] += 1
         t0 = time.perf_counter()
         for Mw, K, pm, A, S, Bv in work:
             ntiles = Mw * BITS // BM
@@ -235,10 +245,16 @@ def cpu_baseline(workload="llama2-7b-w2", seconds=6.0):
             best = min(best, run_once(nthreads)); reps += 1
         out[nthreads] = total_bytes / best / 1e9
     used = max(out, key=out.get)
+    resident = None
+    if nsets > 1:
+        run_once(used, rotate=False)
+        resident = round(total_bytes / min(run_once(used, rotate=False) for _ in range(5)) / 1e9, 3)
     return {"value": round(out[used], 3), "unit": "GB/s", "cores": used, "kind": kind, "host_cores": cores, "host_cores_total": os.cpu_count(), "cgroup_cpu_quota": _cpu_quota(),
             "by_threads_GBps": {str(k): round(v, 3) for k, v in out.items()}, "code": what,
+            "weights": "%d distinct sets of the three shapes (%.0f MB) walked round-robin: every run streams its weights from DRAM" % (nsets, nsets * total_bytes / 1e6) if nsets > 1 else "one set",
+            "cache_resident_GBps": resident,
             "sample": "one GEMV of each of the layer's three shapes (%s; preprocessor + all tiles, bm = %d), OpenMP static tile split, "
-                      "best of >=5; value = best thread count" % (", ".join(f"{m}x{k}" for m, k, _ in shapes), BM)}
+                      "best of >=5 per thread count over rotating weight sets; value = best thread count" % (", ".join(f"{m}x{k}" for m, k, _ in shapes), BM)}
 
 
 def cpu_baseline_prefill(workload, seconds=8.0, rows=8):

@@ -155,7 +155,11 @@ enum { SR_NST = 0, SR_IPI, SR_NSG, SR_GSH, SR_NU, SR_QE0, SR_QE1, SR_QE2, SR_QPE
        SR_WLO /* first row range of the op's block */, SR_COMMON };
 enum { SRW_NQ = 0 /* quads of the wave: workgroups with q_per | q_per + 1 quads << 16 */, SRW_NSTEPS, SRW_H, SRW_QS, SRW_INTS };
 constexpr int STREAM_ROLE_INTS = SR_COMMON + SRW_INTS * STREAM_NLW;
-inline int stream_img_u4(int K) { return (chain_buf_u4(K) + 63) & ~63; }      // image / LDS buffer of one op, whole KB
+// image / LDS buffer of one op, whole KB: [64-unit steps][4][64] uint4 of tables, then 16 bytes per pair of act groups (or the unified-scale scalars)
+inline int stream_img_u4(int K) {
+    const int nu = K / 32, nst = (nu + 63) / 64;
+    return (nst * 256 + nst * 16 + CHAIN_US_FLOATS / 4 + 63) & ~63;
+}
 inline size_t stream_lds_bytes(int buf_u4, int nops, bool qw = false) {
     size_t b = (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * STREAM_NLW * (qw ? 16 : 4) * CHAIN_RED + sizeof(ChainOp) * (size_t)nops;
 #ifdef TMAC_STREAM_STAMPS

@@ -136,6 +136,11 @@ __device__ __forceinline__ void c_store_b64_sys(unsigned long long gaddr, unsign
 // instead of one accumulator per plane combined by shifts and adds afterwards.  lane16 = 16 * lane and lk4 = 4 * (2 * (lane & 12) +
 // 2 * (lane >> 4)) are the lane's byte offsets into the table rows and the act groups' scale arrays (computed once per kernel: what
 // remains per item is one v_add per LDS read).
+#ifndef TMAC_IMG2_SC
+#define TMAC_IMG2_SC 0      // A/B knob, 1: LUT scales / biases of the step-major image interleaved per pair of act groups {ls0, ls1, lb0, lb1}, one 16-byte
+                            // read per item instead of two 8-byte ones.  Measured SLOWER (profiles/r06_stream_image.txt): equal for the (quad x 64 units) form,
+                            // -10 % for the quarter-walk form (64 lanes reading four 16-byte addresses); the two arrays ls[], lb[] stay
+#endif
 template <int BITS>
 struct CSel { qv4i_t p[BITS]; };
 template <int BITS, int SM>
@@ -152,17 +157,21 @@ __device__ __forceinline__ void c_selectors(CSel<BITS>& sel, int lane) {
 
 // TAP (parity instantiations only): the integers of the lane's two act groups, comb = sum_p 2^p PS_p, go to tap_row[act group] (tap_row: the
 // lane's output row in the launch's tap buffer, G act groups per row) exactly as they enter the fp32 chain.
-template <int BITS, bool ZP, bool SCF16, int SM, bool TAP = false>
+// IMG2 (k_gemv_stream): the tables in the STEP-MAJOR image layout [64-unit step][4][64] uint4 -- the four table rows of a lane are 1 KB apart
+// whatever K is, i.e. immediate offsets of ONE address (tb_off: the item's uniform byte offset into the tables, + lane16) instead of four
+// address computations with a run-time row stride (one of them a quarter-rate 64-bit multiply-add).  (TMAC_IMG2_SC: an A/B knob, below.)
+template <int BITS, bool ZP, bool SCF16, int SM, bool TAP = false, bool IMG2 = false>
 __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab, int tstride, const float* l_ls, const float* l_lb,
                                           int ub, uint32_t lane16, uint32_t lk4, const CSel<BITS>& sel, uint32_t k3, float& cacc, int32_t (&iacc)[BITS],
-                                          int32_t* tap_row = nullptr, int G = 0) {
+                                          int32_t* tap_row = nullptr, int G = 0, int tb_off = 0) {
     // ub: first unit of the item's table rows (64 x step for a (quad, 64-unit step) item, 16 x quarter-step for k_gemv_stream's quarter-walk form,
     // where lane16 = 16 (lane & 15) and lk4 = 8 (lane >> 4)); act groups ub / 2 + lk4 / 4 + {0, 1}
     uint32_t tb[16];
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
         // units past K read the zero tables: no contribution
-        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tab + (j4 * tstride + ub)) + lane16);
+        const uint4 v = IMG2 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tab) + tb_off + lane16 + j4 * 1024)
+                             : *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tab + (j4 * tstride + ub)) + lane16);
         tb[4 * j4] = v.x; tb[4 * j4 + 1] = v.y; tb[4 * j4 + 2] = v.z; tb[4 * j4 + 3] = v.w;
     }
     constexpr int NACC = (SM == 0) ? 1 : BITS;
@@ -207,8 +216,14 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
             if (ZP) zr = __uint_as_float(f.s1);
         }
         // act groups ub / 2 + lk4 / 4 + {0, 1}: ls / 2 and lb / 2 (groups past K hold zeros)
-        const float2 hls2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(l_ls + (ub >> 1)) + lk4);
-        const float2 hlb2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(l_lb + (ub >> 1)) + lk4);
+        float2 hls2, hlb2;
+        if constexpr (IMG2 && TMAC_IMG2_SC) {
+            const float4 q4 = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(l_ls + 2 * (ub >> 1)) + 2 * lk4);
+            hls2 = make_float2(q4.x, q4.y); hlb2 = make_float2(q4.z, q4.w);
+        } else {
+            hls2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(l_ls + (ub >> 1)) + lk4);
+            hlb2 = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(l_lb + (ub >> 1)) + lk4);
+        }
 #pragma unroll
         for (int gi = 0; gi < 2; ++gi) {
             const float hls = gi ? hls2.y : hls2.x, hlb = gi ? hlb2.y : hlb2.x;

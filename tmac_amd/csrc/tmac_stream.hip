@@ -369,6 +369,8 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
     const __amdgpu_buffer_rsrc_t null_rs = __builtin_amdgcn_make_buffer_rsrc(static_cast<uint4*>(nullptr), (short)0, 0, 0x00020000);   // every lane out of range: zeros, no fetch
     const TMAC_GLOBAL char* ops_g = as_global(reinterpret_cast<const char*>(a.ops));     // a dummy's scale word comes from a mapped address
     const uint32_t dummy_boff = (uint32_t)(lane & 3) * (uint32_t)((ZP ? 2 : 1) * (SCF16 ? 2 : 4));
+    uint32_t v_sc0 = dummy_boff;                      // per op: the lane's scale offset inside an item whose units all lie below K (refill)
+    bool i_rag = false;                               // per op: the last step (quarter) is ragged
     uint32_t v_wq = lane16, v_scq = dummy_boff;      // QW, per op: the lane's weight offset (its k-block's quad of the group + 16 (lane & 15)) and scale offset (its output quad + row)
     // The cursor's state is what an item costs: every instruction of this lambda is paid once per item and wave (>= 4 cycles each).  The quad
     // is tracked as a running global index with the current matrix' quad range around it (quads ascend within an op: one compare says
@@ -402,6 +404,11 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                     i_n64 = (rc[SR_TSTRIDE] - 1) >> 6;                   // 64-unit steps per quad in the weight layout
                     v_wq = (uint32_t)(lane >> 4) * (uint32_t)(i_n64 * (BITS * 1024)) + lane16;
                     v_scq = (uint32_t)((lane >> 2) & 3) * (uint32_t)q_scstride + dummy_boff;
+                    v_sc0 = (c0g << SC_SHIFT) + v_scq;
+                    i_rag = (i_nu & 15) != 0;
+                } else {
+                    v_sc0 = (c0g << SC_SHIFT) | dummy_boff;
+                    i_rag = (i_nu & 63) != 0;
                 }
                 q_hi = 0; q_stale = true;                 // (no matrix yet: the first quad takes the slow path)
             }
@@ -425,20 +432,22 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
         if (real) {
             // c_item_operands with the op's constants folded: scale group min(st * (64 >> gsh) + (c0 >> gsh), nsg - 1); lanes whose unit lies past K
             // re-read lane 0's 16 bytes (their tables are zero tables)
-            io.rs = q_rs; io.sc = q_sc;
-            if constexpr (QW) {
-                // quarter i_st of the group's quads: 64-unit step i_st / 4, lanes 16 (i_st % 4) .. + 15 of its blocks
-                const uint32_t sg = min((uint32_t)((i_st << 4) >> i_gsh) + c0g, (uint32_t)i_nsg1);
-                io.boff = (sg << SC_SHIFT) + v_scq;
-                io.l16 = v_wq;
-                io.soff = q_woff + (i_st >> 2) * (BITS * 1024) + (i_st & 3) * 256;
+            // The lane's scale group is (first unit of the item >> gsh) + c0g: a uniform term, added to the scale POINTER by the scalar unit, and a
+            // per-lane constant of the op (v_sc0) -- no vector arithmetic per item.  Only a ragged LAST step (quarter) has lanes past K, whose
+            // group is clamped (and, in the 64-unit form, whose weight offset re-reads lane 0's bytes): the vector form is kept for that item.
+            io.rs = q_rs;
+            const int ub = QW ? i_st << 4 : i_st << 6;
+            if (i_rag && i_st == i_nst - 1) {
+                const uint32_t sg = min((uint32_t)(ub >> i_gsh) + c0g, (uint32_t)i_nsg1);
+                io.sc = q_sc;
+                io.boff = QW ? (sg << SC_SHIFT) + v_scq : ((sg << SC_SHIFT) | dummy_boff);
+                io.l16 = QW ? v_wq : ((lane < i_nu - ub) ? lane16 : 0u);
             } else {
-            const int st64 = i_st << 6;
-            const uint32_t sg = min((uint32_t)(st64 >> i_gsh) + c0g, (uint32_t)i_nsg1);
-            io.boff = (sg << SC_SHIFT) | dummy_boff;
-            io.l16 = (lane < i_nu - st64) ? lane16 : 0u;
-            io.soff = q_woff + i_st * (BITS * 1024);
+                io.sc = q_sc + ((size_t)(ub >> i_gsh) << SC_SHIFT);
+                io.boff = v_sc0;
+                io.l16 = QW ? v_wq : lane16;
             }
+            io.soff = QW ? q_woff + (i_st >> 2) * (BITS * 1024) + (i_st & 3) * 256 : q_woff + i_st * (BITS * 1024);
         } else { io.rs = null_rs; io.soff = 0; io.sc = ops_g; io.boff = dummy_boff; io.l16 = 0u; }      // behind the last op: keeps the FIFO's depth
         c_issue_static<BITS, ZP, SCF16, SM>(f, io);
         if (real) {

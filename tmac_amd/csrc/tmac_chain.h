@@ -108,7 +108,7 @@ inline hipError_t launch_decode_chain(const ChainArgs& a, int bits, bool zp, boo
 // scratch), the split-quad reduction buffer, the op descriptors, the transforms' scratch and carry
 inline int chain_buf_u4(int K) {
     const int nu = K / 32, nst = (nu + 63) / 64;
-    return 4 * (nst * 64 + 1) + (2 * nst * 32 * 4 + 15) / 16 + CHAIN_US_FLOATS / 4;
+    return 4 * 65 * nst + (2 * nst * 32 * 4 + 15) / 16 + CHAIN_US_FLOATS / 4;       // tables [steps][4][65] uint4 (tmac_chain_core.h: IMG2), ls / 2, lb / 2 per act group | unified-scale scratch
 }
 // LDS floats of one transform vector of a K-vector: 16-byte pieces, two per pair, rounds of CHAIN_FT pairs padded to whole waves
 inline int chain_xf_region_floats(int K) {
@@ -155,11 +155,8 @@ enum { SR_NST = 0, SR_IPI, SR_NSG, SR_GSH, SR_NU, SR_QE0, SR_QE1, SR_QE2, SR_QPE
        SR_WLO /* first row range of the op's block */, SR_COMMON };
 enum { SRW_NQ = 0 /* quads of the wave: workgroups with q_per | q_per + 1 quads << 16 */, SRW_NSTEPS, SRW_H, SRW_QS, SRW_INTS };
 constexpr int STREAM_ROLE_INTS = SR_COMMON + SRW_INTS * STREAM_NLW;
-// image / LDS buffer of one op, whole KB: [64-unit steps][4][64] uint4 of tables, then 16 bytes per pair of act groups (or the unified-scale scalars)
-inline int stream_img_u4(int K) {
-    const int nu = K / 32, nst = (nu + 63) / 64;
-    return (nst * 256 + nst * 16 + CHAIN_US_FLOATS / 4 + 63) & ~63;
-}
+// image / LDS buffer of one op, whole KB: the layout of k_decode_chain's LUT buffer
+inline int stream_img_u4(int K) { return (chain_buf_u4(K) + 63) & ~63; }
 inline size_t stream_lds_bytes(int buf_u4, int nops, bool qw = false) {
     size_t b = (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * STREAM_NLW * (qw ? 16 : 4) * CHAIN_RED + sizeof(ChainOp) * (size_t)nops;
 #ifdef TMAC_STREAM_STAMPS

@@ -177,8 +177,15 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         const cop_ptr d = ops + i;
         CSTAMP(i, 0);
         const int tstride = uni(d->tstride), nu = uni(d->nu), nst = uni(d->nst), G = uni(d->G), GP = uni(d->GP);
-        uint4* tab = lds + (size_t)(i & 1) * a.buf_u4;                // [4][tstride]
-        float* l_ls = reinterpret_cast<float*>(tab + 4 * tstride);   // [GP] ls / 2 (groups past K: 0)
+        uint4* tab = lds + (size_t)(i & 1) * a.buf_u4;                // [steps][4][65] (tmac_chain_core.h: the step-major layout)
+#ifndef TMAC_CHAIN_IMG2
+#define TMAC_CHAIN_IMG2 1          // A/B: 0 = the [4][tstride] table layout of rounds 1-5
+#endif
+#ifndef TMAC_CHAIN_ISSUE_FULL
+#define TMAC_CHAIN_ISSUE_FULL 0    // A/B: 1 = items below K through c_issue_full (scale addressing on the scalar unit, no exec mask): -5 VALU per item and 3 % SLOWER in the
+                                   // dependent chain (0.672 -> 0.695 ms: the branch in front of the loads moves the compiler's waits; profiles/r06_chain_experiments.txt) -- it pays in k_gemv_stream only
+#endif
+        float* l_ls = reinterpret_cast<float*>(tab + (TMAC_CHAIN_IMG2 ? IMG2_STEP * nst : 4 * tstride));   // [GP] ls / 2 (groups past K: 0)
         float* l_lb = l_ls + GP;                                     // [GP] lb / 2
         // SM 2 uses the same floats as: [0] lut_scales, [1] lut_biases, [2 .. 2+NWV) per-wave maxima, [16 .. 48) the unified
         // scales of the op's matrices (m_groups <= CHAIN_US_MAX_GROUPS each), [CHAIN_US_FLOATS .. + K/32) the chunk sums of the bias chain
@@ -199,6 +206,10 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         const TMAC_GLOBAL char* q_sc = nullptr;
         const TMAC_GLOBAL char* q_scm = nullptr;
         int q_woff = 0, q_res = -1, q_mi = -1;
+        // (c_issue_full) log2 of a scale group's bytes per row quad; the lane's constant part of a scale offset; is the last 64-unit step ragged?
+        constexpr int SCSH = (ZP ? 1 : 0) + (SCF16 ? 3 : 4);
+        const uint32_t v_sc0 = (((uint32_t)(4 * (lane & 12) + 4 * (lane >> 4)) >> gsh) << SCSH) + (uint32_t)(lane & 3) * (uint32_t)((ZP ? 2 : 1) * (SCF16 ? 2 : 4));
+        const bool rag = (nu & 63) != 0;
         int i_it = 0, i_st = h, issued = 0;
         auto issue_next = [&](CFrag<BITS>& f) __attribute__((always_inline)) {
             if (issued < n_items) {
@@ -215,7 +226,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                     q_woff = lq * nst * (BITS * 1024);
                     q_res = i_it;
                 }
-                c_issue<BITS, ZP, SCF16, SM>(f, q_rs, q_woff, q_sc, nsg, gsh, nu, i_st, lane, lane16);
+                if (!TMAC_CHAIN_ISSUE_FULL || (rag && i_st == nst - 1)) c_issue<BITS, ZP, SCF16, SM>(f, q_rs, q_woff, q_sc, nsg, gsh, nu, i_st, lane, lane16);
+                else c_issue_full<BITS, ZP, SCF16, SM>(f, q_rs, q_woff + i_st * (BITS * 1024), q_sc + ((size_t)((i_st << 6) >> gsh) << SCSH), v_sc0, lane16);
                 ++issued;
                 i_st += wpq;
                 if (i_st >= nst) { i_st = h; ++i_it; }
@@ -606,7 +618,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                 float La, Lb;
                 q_table8<true>(x[0], x[1], x[2], x[3], t_scales, lo0, hi0, La);
                 q_table8<true>(x[4], x[5], x[6], x[7], t_scales, lo1, hi1, Lb);
-                tab[(p & 3) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
+                tab[TMAC_CHAIN_IMG2 ? img2_index(p >> 2, p & 3) : (p & 3) * tstride + (p >> 2)] = make_uint4(lo0, hi0, lo1, hi1);
                 if (SM != 2) {
                     // lut_biases (lut_ctor.cc:25-31): per 8-table chunk ((v0+v4)+(v2+v6)) + ((v1+v5)+(v3+v7)), v_i = -L15 of table i
                     float va = -La, vb = -Lb;
@@ -626,7 +638,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         {   // zero tables / zero LUT scales for the units between K and the end of the last 64-unit step
 #pragma unroll
             for (int j4 = 0; j4 < 4; ++j4)
-                for (int u = nu + tid; u < nst * 64; u += FT) tab[j4 * tstride + u] = make_uint4(0u, 0u, 0u, 0u);
+                for (int u = nu + tid; u < nst * 64; u += FT) tab[TMAC_CHAIN_IMG2 ? img2_index(u, j4) : j4 * tstride + u] = make_uint4(0u, 0u, 0u, 0u);
             if (SM != 2)
                 for (int g = G + tid; g < GP; g += FT) { l_ls[g] = 0.f; l_lb[g] = 0.f; }
         }
@@ -785,8 +797,9 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
 #pragma unroll
                 for (int k = 0; k < RING; ++k) {
                     // (the instance with the extensions is also the parity tap's: ChainArgs::tap)
-                    c_compute<BITS, ZP, SCF16, SM, XF>(ring[k], tab, tstride, l_ls, l_lb, c_st * 64, lane16, lk4, sel, k3, cacc, iacc,
-                                                       (XF && a.tap) ? a.tap + a.tap_off[i] + (size_t)(4 * (ro.q_lo + ro.qs + c_it * ipi) + (lane & 3)) * G : nullptr, G);
+                    c_compute<BITS, ZP, SCF16, SM, XF, TMAC_CHAIN_IMG2 != 0>(ring[k], tab, tstride, l_ls, l_lb, c_st * 64, lane16, lk4, sel, k3, cacc, iacc,
+                                                             (XF && a.tap) ? a.tap + a.tap_off[i] + (size_t)(4 * (ro.q_lo + ro.qs + c_it * ipi) + (lane & 3)) * G : nullptr, G,
+                                                             c_st * (16 * IMG2_STEP));
                     issue_next(ring[k]);               // refill this slot with the item RING places ahead, if there is one
                     c_st += wpq;
                     if (c_st >= nst) {

@@ -72,6 +72,27 @@ __device__ __forceinline__ void c_issue(CFrag<BITS>& f, __amdgpu_buffer_rsrc_t r
 }
 
 
+// The same for an item whose 64 units all lie below K (every item but a ragged last step): the lane's scale group is
+// (st * 64 >> gsh) + (c0 >> gsh) -- the first term is uniform and goes into the scale POINTER on the scalar unit (scq_item), the second is a
+// per-lane constant of the op (v_sc0, with the row's offset folded in): no vector arithmetic, no exec mask (round 6).
+template <int BITS, bool ZP, bool SCF16, int SM>
+__device__ __forceinline__ void c_issue_full(CFrag<BITS>& f, __amdgpu_buffer_rsrc_t rs, int soff, const TMAC_GLOBAL char* scq_item, uint32_t v_sc0, uint32_t lane16) {
+    uint32_t r0 = 0, r1 = 0;
+    if (SM == 0) {
+        if (SCF16) {
+            if (ZP) r0 = *reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq_item + v_sc0);
+            else r0 = *reinterpret_cast<const TMAC_GLOBAL unsigned short*>(scq_item + v_sc0);
+        } else {
+            const TMAC_GLOBAL uint32_t* p32 = reinterpret_cast<const TMAC_GLOBAL uint32_t*>(scq_item + v_sc0);
+            r0 = p32[0];
+            if (ZP) r1 = p32[1];
+        }
+    }
+    f.s0 = r0; f.s1 = r1;
+#pragma unroll
+    for (int j = 0; j < BITS; ++j) f.wq[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)lane16, soff + j * 1024, 2 /* nt */);
+}
+
 // ---- TMAC_RING_STATIC: the loads of an item as ONE unconditional, branch-free sequence ---------------------------------------------
 // With every ring slot (re)filled at fixed program points by exactly the same loads in the same order, the compiler's waitcnt pass can
 // count the loads issued behind the one it needs and wait per slot (s_waitcnt vmcnt(n)); with conditional issue it waits for the whole
@@ -136,6 +157,10 @@ __device__ __forceinline__ void c_store_b64_sys(unsigned long long gaddr, unsign
 // instead of one accumulator per plane combined by shifts and adds afterwards.  lane16 = 16 * lane and lk4 = 4 * (2 * (lane & 12) +
 // 2 * (lane >> 4)) are the lane's byte offsets into the table rows and the act groups' scale arrays (computed once per kernel: what
 // remains per item is one v_add per LDS read).
+constexpr int IMG2_ROW = 65;                      // uint4 per table row of a 64-unit step
+constexpr int IMG2_STEP = 4 * IMG2_ROW;           // uint4 per step
+// uint4 index of (unit, row j4) / byte offset of an item's first table row in the step-major layout
+__host__ __device__ inline int img2_index(int unit, int j4) { return (unit >> 6) * IMG2_STEP + j4 * IMG2_ROW + (unit & 63); }
 #ifndef TMAC_IMG2_SC
 #define TMAC_IMG2_SC 0      // A/B knob, 1: LUT scales / biases of the step-major image interleaved per pair of act groups {ls0, ls1, lb0, lb1}, one 16-byte
                             // read per item instead of two 8-byte ones.  Measured SLOWER (profiles/r06_stream_image.txt): equal for the (quad x 64 units) form,
@@ -157,9 +182,11 @@ __device__ __forceinline__ void c_selectors(CSel<BITS>& sel, int lane) {
 
 // TAP (parity instantiations only): the integers of the lane's two act groups, comb = sum_p 2^p PS_p, go to tap_row[act group] (tap_row: the
 // lane's output row in the launch's tap buffer, G act groups per row) exactly as they enter the fp32 chain.
-// IMG2 (k_gemv_stream): the tables in the STEP-MAJOR image layout [64-unit step][4][64] uint4 -- the four table rows of a lane are 1 KB apart
-// whatever K is, i.e. immediate offsets of ONE address (tb_off: the item's uniform byte offset into the tables, + lane16) instead of four
-// address computations with a run-time row stride (one of them a quarter-rate 64-bit multiply-add).  (TMAC_IMG2_SC: an A/B knob, below.)
+// IMG2 (round 6, both persistent kernels): the tables in the STEP-MAJOR layout [64-unit step][4][IMG2_ROW = 65] uint4 -- the four table rows of
+// a lane are 1040 bytes apart whatever K is, i.e. immediate offsets of ONE address (tb_off: the item's uniform byte offset into the tables,
+// + lane16) instead of four address computations with a run-time row stride (one of them a quarter-rate 64-bit multiply-add).  The 65th
+// uint4 of a row is padding: the LUT build of k_decode_chain stores the four rows of a unit from four neighbouring lanes (16 bytes apart
+// in the banks, not on top of each other).  (TMAC_IMG2_SC: an A/B knob, below.)
 template <int BITS, bool ZP, bool SCF16, int SM, bool TAP = false, bool IMG2 = false>
 __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab, int tstride, const float* l_ls, const float* l_lb,
                                           int ub, uint32_t lane16, uint32_t lk4, const CSel<BITS>& sel, uint32_t k3, float& cacc, int32_t (&iacc)[BITS],
@@ -170,7 +197,7 @@ __device__ __forceinline__ void c_compute(const CFrag<BITS>& f, const uint4* tab
 #pragma unroll
     for (int j4 = 0; j4 < 4; ++j4) {
         // units past K read the zero tables: no contribution
-        const uint4 v = IMG2 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tab) + tb_off + lane16 + j4 * 1024)
+        const uint4 v = IMG2 ? *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tab) + tb_off + lane16 + j4 * (16 * IMG2_ROW))
                              : *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(tab + (j4 * tstride + ub)) + lane16);
         tb[4 * j4] = v.x; tb[4 * j4 + 1] = v.y; tb[4 * j4 + 2] = v.z; tb[4 * j4 + 3] = v.w;
     }

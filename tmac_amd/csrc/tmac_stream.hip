@@ -41,7 +41,7 @@ namespace tmac {
 // ---------------------------------------------------------------------------------------------
 // LUT images: block (x, y) builds pairs 256 x .. 256 x + 255 (= the 64 units of step x) of op y -- the build phase of k_gemv_quad /
 // k_preprocess_pairs (lut_ctor.cc:120-215,240-256) writing what k_gemv_stream's LUT buffer holds, in the STEP-MAJOR layout (round 6;
-// c_compute's IMG2): [64-unit step][4][64] uint4 of signed half tables (pair p = unit p >> 2, row p & 3), then ls / 2 and lb / 2 per act
+// c_compute's IMG2): [64-unit step][4][65] uint4 of signed half tables (pair p = unit p >> 2, row p & 3), then ls / 2 and lb / 2 per act
 // group (32 per step each); zero tables / zero scales for the units between K and the end of the last step.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_lut_images(const ChainOp* __restrict__ ops) {
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void k_lut_images(const ChainOp* __restrict__ 
     if ((int)blockIdx.x >= nst) return;
     const int p = blockIdx.x * 256 + threadIdx.x;
     uint4* tab = reinterpret_cast<uint4*>(const_cast<void*>(d.img));
-    float* l_sc = reinterpret_cast<float*>(tab + 256 * nst);
-    uint4* tslot = tab + ((((p >> 2) >> 6) * 4 + (p & 3)) * 64 + ((p >> 2) & 63));      // unit p >> 2: step, row p & 3, lane
+    float* l_sc = reinterpret_cast<float*>(tab + IMG2_STEP * nst);
+    uint4* tslot = tab + img2_index(p >> 2, p & 3);                                      // unit p >> 2, row p & 3
 #if TMAC_IMG2_SC
     float* scslot = l_sc + 4 * (p >> 4) + ((p >> 3) & 1);                               // act group p >> 3: its pair, its half
 #else
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_lut_images_us(const ChainOp* __restrict
     const int K = d.K, P = K / 8, nu = d.nu, nst = d.nst;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     uint4* tab = reinterpret_cast<uint4*>(const_cast<void*>(d.img));
-    float* l_us = reinterpret_cast<float*>(tab + 256 * nst);
+    float* l_us = reinterpret_cast<float*>(tab + IMG2_STEP * nst);
     auto load8 = [&](int p, float (&x)[8]) __attribute__((always_inline)) {
         if (d.in_gran & 2) {
             const float4* src = reinterpret_cast<const float4*>(d.in) + 2 * (size_t)p;
@@ -157,10 +157,10 @@ __global__ __launch_bounds__(256) void k_lut_images_us(const ChainOp* __restrict
         float La, Lb;
         q_table8<true>(x[0], x[1], x[2], x[3], gtinv, lo0, hi0, La);
         q_table8<true>(x[4], x[5], x[6], x[7], gtinv, lo1, hi1, Lb);
-        tab[(((p >> 2) >> 6) * 4 + (p & 3)) * 64 + ((p >> 2) & 63)] = make_uint4(lo0, hi0, lo1, hi1);
+        tab[img2_index(p >> 2, p & 3)] = make_uint4(lo0, hi0, lo1, hi1);
     }
     for (int j4 = 0; j4 < 4; ++j4)
-        for (int u = nu + tid; u < nst * 64; u += 256) tab[((u >> 6) * 4 + j4) * 64 + (u & 63)] = make_uint4(0u, 0u, 0u, 0u);
+        for (int u = nu + tid; u < nst * 64; u += 256) tab[img2_index(u, j4)] = make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) {
         float biases = 0.0f;
         for (int c = 0; c < nu; ++c) biases = __fadd_rn(biases, s_cs[c]);
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                         const float tp = __fmul_rn((float)cb[pl], q_alpha(pl));
                         acc = (pl == 0) ? tp : __fadd_rn(acc, tp);
                     }
-                    const float* l_us = reinterpret_cast<const float*>(lds + (size_t)(j & 1) * a.buf_u4 + 256 * (size_t)uni(d->nst));
+                    const float* l_us = reinterpret_cast<const float*>(lds + (size_t)(j & 1) * a.buf_u4 + IMG2_STEP * (size_t)uni(d->nst));
                     const float vv = __fadd_rn(__fmul_rn(acc, l_us[0]), __fmul_rn(l_us[1], 0.5f));
                     const int mg = uni(d->m_groups);
                     const int g = mg == 1 ? 0 : (RPW * p_lq + p_row) / (d->m[p_mi].Mw / mg);
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
             my_iter = bx - rc[SR_WLO] < rc[SR_QEXTRA] ? rc[SR_IT_HI] : rc[SR_IT_LO];
             tstride = rc[SR_TSTRIDE]; nst = rc[SR_NST]; wpq = rc[SR_WPQ]; h = rw[SRW_H];
             tab = lds + (size_t)(c_op & 1) * a.buf_u4;
-            l_ls = reinterpret_cast<float*>(tab + 4 * (tstride - 1));    // behind the tables ([steps][4][64] uint4): the act groups' {ls, lb} pairs
+            l_ls = reinterpret_cast<float*>(tab + IMG2_STEP * ((tstride - 1) >> 6));    // behind the tables ([steps][4][65] uint4): ls / 2, then lb / 2 per act group
             l_lb = TMAC_IMG2_SC ? l_ls : l_ls + ((tstride - 1) >> 1);
             c_left = items_of(rc, rw); c_it = 0; c_st = h;
             if constexpr (TAP) {
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(STREAM_FT, MINW) TMAC_STREAM_ATTR void k_gemv_strea
                 if (TMAC_STREAM_KO & 8) cacc += __uint_as_float(ring[k].wq[0].x ^ ring[k].wq[BITS - 1].w ^ ring[k].s0); else
                 c_compute<BITS, ZP, SCF16, SM, TAP, true>(ring[k], tab, tstride, l_ls, l_lb, QW ? c_st * 16 : c_st * 64, lane16, lk4, sel, k3, cacc, iacc,
                                                           (TAP && t_base) ? t_base + (size_t)(RPW * (t_gq0 + c_it * t_ipi) + (lane & (RPW - 1))) * t_G : nullptr, t_G,
-                                                          QW ? (c_st >> 2) * 4096 + (c_st & 3) * 256 : c_st * 4096);
+                                                          QW ? (c_st >> 2) * (16 * IMG2_STEP) + (c_st & 3) * 256 : c_st * (16 * IMG2_STEP));
                 asm volatile("" : "+v"(cacc));        // the item's scale chain ends before the slot is refilled (the scale word keeps its register)
             }
             refill(ring[k]);

@@ -504,11 +504,11 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             // block of classes in recorded order; the cap on n that gives the shortest modelled launch is taken (a lone call keeps all ranges).
             // TMAC_STREAM_NCLS=1: every range visits every op (the round-5 form; A/B).
             const int nwv = STREAM_NLW;
-            int ncls = env_int("TMAC_STREAM_NCLS", 8);
+            int ncls = env_int("TMAC_STREAM_NCLS", 16);
             if (ncls < 1) ncls = 1;
             if (ncls > 16) ncls = 16;
             while (ncls > c->grid || (ncls & (ncls - 1))) --ncls;
-            const int target = env_int("TMAC_STREAM_VISIT_ITEMS", 96);
+            const int target = env_int("TMAC_STREAM_VISIT_ITEMS", 160);      // (sweep: profiles/r06_stream_schedule_sweep.txt)
             const double visit_fixed = 8.0;                                    // a visit's fixed cost in items (model only)
             const int nop = (int)c->ops.size();
             auto cls_lo = [&](int cl, int nc) { return (cl * c->grid + nc - 1) / nc; };

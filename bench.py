@@ -84,9 +84,12 @@ def parse():
                     help="auto: chain where k_decode_chain covers the configuration (N = 1; row-sharded over the ranks with --gpus N), else fused")
     ap.add_argument("--no-verify", action="store_true",
                     help="skip the check of one layer's outputs (the launches being timed, at full size) against the oracle")
-    ap.add_argument("--pattern", choices=["chained", "independent", "decoder"], default="chained",
-                    help="chained: the calls are linked by real data (x1 = q, x2 = o, x3 = gate, next x0 = down; the default and the reported "
-                         "workload); independent: every call reads an external vector -- no hand-offs, the lookups' streaming rate alone (diagnostic); "
+    ap.add_argument("--pattern", choices=["auto", "chained", "independent", "decoder"], default="auto",
+                    help="independent: SURVEY 8(d)'s measurement -- the token's GEMVs back to back over distinct weights, every call reading a vector "
+                         "that is resident before the launch (LUT builds included): the timed workload of a decode line since round 6; chained: "
+                         "the calls linked by real data (x1 = q, x2 = o, x3 = gate, next x0 = down: every call waits for its predecessor inside one "
+                         "persistent launch) -- rounds 1-5 timed this stricter form, a default run still measures it and reports it as "
+                         "`dependent_chain`; auto (default): independent + the extras of the default line; "
                          "decoder: the calls as a decoder issues them -- residual add + RMSNorm and silu(gate) * up inside the chain "
                          "(tmac_hip_chain_xform), one launch per segment o -> gate/up -> down -> next q/k/v, an outside kernel (stand-in for "
                          "attention) between the segments; hipGraph replay of the token's launches")
@@ -333,6 +336,10 @@ def run(args, env):
     decode = N == 1
     world, rank, local_rank, dist_on = env["world"], env["rank"], env["local_rank"], env["dist_on"]
     chain_ok = decode and args.variant == 0
+    if args.pattern == "auto":
+        # a decode line times SURVEY 8(d)'s measurement: the token's GEMVs back to back over distinct weights, every call reading a resident
+        # vector (main() then measures the dependent chain of the same matrices and reports it beside the value)
+        args.pattern = "independent" if decode else "chained"
     if args.path == "auto":
         args.path = "chain" if chain_ok else "fused"
     if args.path == "chain" and not chain_ok:
@@ -1061,7 +1068,7 @@ def run(args, env):
         # With several ranks: every rank streams ITS row shard of every matrix, nothing is exchanged (rows split, K whole, vectors resident on
         # every rank) -- the decode-side workload that scales by construction, reported beside the dependent chain's value as
         # roofline.independent_pattern (n_gpus ranks, aggregate bytes over the slowest rank's time)
-        if (not args.no_stream_core) and decode and args.path == "chain" and dpat is None:
+        if (not args.no_stream_core) and decode and args.path == "chain" and dpat is None and args.pattern != "independent":
             try:
                 ix = {s_: torch.randn(xdim[s_], device=dev, generator=gen).half() for s_ in xdim}
                 iouts = [{n_: [torch.empty_like(o) for o in outs[n_]] for n_ in outs} for _ in range(args.layers)]
@@ -1180,23 +1187,26 @@ def run(args, env):
         from oracle import oracle as orc
         vshape = (lambda k: (k,)) if decode else (lambda k: (N, k))
         vx0 = torch.randn(vshape(MATS[0][2]), device=dev, generator=gen).half()
-        vx = {MATS[0][4]: vx0}
+        vlink = args.pattern != "independent"         # independent pattern: every call of the layer reads a resident vector of its own
+        vx = {MATS[0][4]: vx0} if vlink else {s_: torch.randn(vshape(xdim[s_]), device=dev, generator=gen).half() for s_ in xdim}
+        if not vlink:
+            vx0 = vx[MATS[0][4]]
         vouts = {name: [torch.zeros(vshape(Mw), dtype=torch.float16, device=dev) for _ in range(cnt)] for name, Mw, K, cnt, slot in MATS}
         ok = True
         if args.path == "chain":
             with wr.record_chain() as vrec:
-                calls(layers[0], vx, vouts, exchange=False, link=True)
+                calls(layers[0], vx, vouts, exchange=False, link=vlink)
             vrec.chain.launch()
             torch.cuda.synchronize()
             ok = vrec.chain.status() == 0
             vrec.chain.free()
         else:
-            calls(layers[0], vx, vouts, exchange=False, link=True)
+            calls(layers[0], vx, vouts, exchange=False, link=vlink)
             torch.cuda.synchronize()
         worst = 0.0
         rows = [0] if decode else [0, N - 1]          # prefill: two of the N activation rows (the oracle takes seconds per row)
         for name, Mw, K, cnt, slot in MATS:
-            src = vx0 if slot == MATS[0][4] else vouts[[n_ for n_ in nxt if nxt[n_] == slot][0]][0]     # what this call consumed
+            src = vx[slot] if not vlink else (vx0 if slot == MATS[0][4] else vouts[[n_ for n_ in nxt if nxt[n_] == slot][0]][0])     # what this call consumed
             xin_h = src.float().cpu().numpy().reshape(-1, K)[rows]
             q, ls, lb = orc.preprocessor(xin_h, ags_of(K))
             for i in range(cnt):
@@ -1208,8 +1218,8 @@ def run(args, env):
                 got = vouts[name][i].float().cpu().numpy().reshape(-1, Mw)[rows]
                 worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)))
         verified = {"ok": bool(ok and worst <= 1e-3), "max_rel_err": float("%.3g" % worst), "tolerance": 1e-3,
-                    "what": "layer 0's seven mpGEMMs (q/k/v, o, gate/up, down at full size, chained) through the timed path vs oracle/ "
-                            "(fp16 outputs%s)" % ("" if decode else "; activation rows 0 and N-1")}
+                    "what": "layer 0's seven mpGEMMs (q/k/v, o, gate/up, down at full size, %s) through the timed path vs oracle/ "
+                            "(fp16 outputs%s)" % ("chained" if vlink else "independent calls", "" if decode else "; activation rows 0 and N-1")}
         if not verified["ok"]:
             sys.stderr.write("bench.py: VERIFICATION FAILED: %r\n" % (verified,))
 
@@ -1229,14 +1239,16 @@ def run(args, env):
             "frac_of_hbm_peak": round(bytes_per_step / sec / 1e9 / (HBM_PEAK_GBS * world), 4),
             "config": {"workload": wl["tag"], "layers": args.layers, "N": N,
                        "gemm_per_step": 7 * args.layers,
-                       "launches_per_step": (len(dpat["chains"]) if dpat is not None else 1) if args.path == "chain" else (4 if fused_calls else 11) * args.layers + (0 if decode else 4 * args.layers), "path": args.path,
+                       "launches_per_step": (len(dpat["chains"]) if dpat is not None else (2 if is_stream else 1)) if args.path == "chain" else (4 if fused_calls else 11) * args.layers + (0 if decode else 4 * args.layers), "path": args.path,
                        "pattern": args.pattern,
                        **({"outside_ms": (lambda v: None if v is None else round(v, 4))(time_outside_ops(dpat["dstep"]))} if dpat is not None else {}),
                        "autotune": tuned,
                        "algorithmic_bytes_per_step": bytes_per_step, "weights": wl["weights"],
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",
                        "kernel_variant": args.variant,
-                       "launch": ("one persistent launch per step" + (" and rank, hand-off across ranks through IPC-mapped arenas" if world > 1 else ""))
+                       "launch": (("k_lut_images (the LUT builds of all calls) + ONE persistent launch of k_gemv_stream per step" + (" and rank; rows sharded, nothing exchanged" if world > 1 else ""))
+                                  if is_stream else
+                                  "one persistent launch per step" + (" and rank, hand-off across ranks through IPC-mapped arenas" if world > 1 else ""))
                                  if args.path == "chain" else ("hipGraph replay" if use_graph else "eager")},
             "roofline": roof,
             "preflight": preflight,
@@ -1303,7 +1315,35 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     env = dict(world=world, rank=rank, local_rank=local_rank, dist_on=dist_on)
+    auto = args.pattern == "auto"
+    decode_wl = WORKLOADS[args.workload]["N"] == 1
     res = run(args, env)
+    # The DEPENDENT form of the same token (rounds 1-5's timed workload): the 224 calls linked by real data -- x1 = q, x2 = o, x3 = gate, next
+    # x0 = down -- so that every call waits for its predecessor's outputs inside ONE persistent launch (k_decode_chain: in-kernel hand-offs,
+    # LUT build per call and CU; with ranks: hand-off granules stored into every rank's IPC-mapped arena).  Measured in the same run, same
+    # matrices' shapes and bytes, verified against the oracle, reported as `dependent_chain`; the decoder pattern (one launch per segment
+    # between two attentions) rides in that run.
+    if auto and decode_wl and args.path in ("auto", "chain") and args.variant == 0 and not args.stamps:
+        import copy
+        a2 = copy.copy(args)
+        a2.pattern, a2.path = "chained", "chain"
+        a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_stream_core = max(args.steps // 3, 50), 10, True, True
+        try:
+            r2 = run(a2, env)
+            if res is not None and r2 is not None:
+                rr = dict(r2.get("roofline") or {})
+                dp = rr.pop("decoder_pattern", None)
+                rr.pop("independent_pattern", None)
+                res["dependent_chain"] = {"what": "the same %d mpGEMMs chained by real data (every call consumes an earlier call's output inside one persistent launch of "
+                                                  "k_decode_chain): the timed workload of rounds 1-5" % r2["config"]["gemm_per_step"],
+                                          "ms_per_step": r2["ms_per_step"], "value": r2["value"], "unit": r2["unit"], "steps": r2["steps"], "n_gpus": r2["n_gpus"],
+                                          "frac_of_hbm_peak": r2.get("frac_of_hbm_peak"), "roofline": rr, "verified": r2.get("verified"),
+                                          "preflight": r2.get("preflight"), "launch": r2["config"]["launch"]}
+                if dp is not None:
+                    res["roofline"]["decoder_pattern"] = dp
+        except BaseException as e:      # the line's value is never lost to the extra measurement
+            if res is not None:
+                res["dependent_chain"] = {"error": repr(e)}
     # Scaling headline.  Decode is a chain of dependent GEMVs whose hand-off and LUT build do not shrink with the number of GPUs (DESIGN 6:
     # 1.3 / 1.6 / 1.9 x at 2 / 4 / 8 by the model); the prefill GEMM of the same matrices (N = 256, BASELINE config 5) is compute-bound and
     # splits by rows with one all-gather per call -- so a multi-GPU run also measures it, on the same ranks, and rank 0 reports both.
@@ -1327,7 +1367,7 @@ def main():
     # One GPU: the prefill twin rides along in the default line too (N = 256 over the same matrices, with its graph-replayed dense fp16 baseline),
     # so that the driver's own run carries a prefill number, not only the builder's.  Outside the timed region.
     if (world == 1 and not dist_on and res is not None and WORKLOADS[args.workload]["N"] == 1 and args.workload in PREFILL_TWIN
-            and not args.no_prefill_headline and args.pattern == "chained" and not args.stamps):
+            and not args.no_prefill_headline and auto and not args.stamps):
         import copy
         a2 = copy.copy(args)
         a2.workload, a2.path, a2.pattern = PREFILL_TWIN[args.workload], "auto", "chained"
@@ -1341,22 +1381,26 @@ def main():
                                    "dense_fp16_baseline": r2r.get("dense_fp16_baseline")}
         except BaseException as e:      # the decode number is never lost to the extra measurement
             res["prefill_twin"] = {"error": repr(e)}
-    # ... and so do the other two decode configurations of BASELINE.json (W4 GPTQ-style, BitNet-b1.58-3B): their chains, 200 launches each,
-    # outside the timed region, so that the driver's run carries them as well
-    if (world == 1 and not dist_on and res is not None and args.workload == "llama2-7b-w2" and args.pattern == "chained" and args.path in ("auto", "chain")
+    # ... and so do the other two decode configurations of BASELINE.json (W4 GPTQ-style, BitNet-b1.58-3B): the same two measurements (the token's
+    # calls as independent calls; as one dependent chain), 200 launches each, outside the timed region, so that the driver's run carries them
+    if (world == 1 and not dist_on and res is not None and args.workload == "llama2-7b-w2" and auto and args.path in ("auto", "chain")
             and not args.no_prefill_headline and not args.stamps and args.layers == WORKLOADS[args.workload]["layers"]):
         import copy
-        res["other_decode_chains"] = {}
+        res["other_decode_workloads"] = {}
         for w2 in ("llama2-7b-w4", "bitnet-3b"):
-            a2 = copy.copy(args)
-            a2.workload, a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_verify = w2, 200, 10, True, True
-            a2.no_stream_core, a2.no_decoder_pattern, a2.layers = True, True, WORKLOADS[w2]["layers"]
-            try:
-                r2 = run(a2, env)
-                res["other_decode_chains"][w2] = {"workload": r2["config"]["workload"], "ms_per_step": r2["ms_per_step"], "value": r2["value"], "unit": r2["unit"],
-                                                  "steps": r2["steps"], "frac": (r2.get("roofline") or {}).get("frac")}
-            except BaseException as e:
-                res["other_decode_chains"][w2] = {"error": repr(e)}
+            ent = {}
+            for pat in ("independent", "chained"):
+                a2 = copy.copy(args)
+                a2.workload, a2.pattern, a2.path, a2.steps, a2.warmup, a2.no_cpu_baseline, a2.no_verify = w2, pat, "chain", 200, 10, True, True
+                a2.no_stream_core, a2.no_decoder_pattern, a2.layers = True, True, WORKLOADS[w2]["layers"]
+                try:
+                    r2 = run(a2, env)
+                    ent["independent" if pat == "independent" else "dependent_chain"] = {
+                        "ms_per_step": r2["ms_per_step"], "value": r2["value"], "unit": r2["unit"], "steps": r2["steps"], "frac": (r2.get("roofline") or {}).get("frac")}
+                except BaseException as e:
+                    ent[pat] = {"error": repr(e)}
+            ent["workload"] = WORKLOADS[w2]["tag"]
+            res["other_decode_workloads"][w2] = ent
     if rank == 0 and res is not None:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(res) + "\n").encode())

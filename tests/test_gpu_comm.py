@@ -214,11 +214,17 @@ def test_bench_ranks_share_the_device(tm, workload, extra, nranks):
         assert "stream" in d["roofline"]["kernel"] or "k_gemv_stream" in d["roofline"]["kernel"], d["roofline"]["kernel"]
         assert d["preflight"]["max_rel_diff"] <= 2e-3, d["preflight"]
         return
+    if not workload.endswith("prefill"):
+        # the default decode line of N ranks: value = the token's calls as independent calls on every rank's row shard (no exchange: the mode
+        # that scales), and beside it the dependent chain with its in-kernel exchange over IPC-mapped arenas, preflight and all
+        assert d["config"]["path"] == "chain" and d["config"]["pattern"] == "independent", d["config"]
+        assert d["preflight"]["max_rel_diff"] <= 2e-3, d["preflight"]
+        d = dict(d["dependent_chain"], prefill_scaling_headline=d.get("prefill_scaling_headline"), activations_finite=d.get("activations_finite", True),
+                 config={"path": "chain"})
+        assert "error" not in d, d
+        assert d["n_gpus"] == nranks and d["value"] > 0
     assert d["preflight"]["bit_identical_on_every_rank"], d["preflight"]
     if not workload.endswith("prefill"):
-        # the default decode line of N ranks also carries the mode that scales without an exchange: the token's calls as independent calls
-        ip = d["roofline"]["independent_pattern"]
-        assert "error" not in ip and ip["ok"] and ip["n_gpus"] == nranks and ip["ms_per_token"] > 0, ip
         assert d["config"]["path"] == "chain", d["config"]
         assert d.get("activations_finite", True)
         # ... and a multi-GPU decode run reports the prefill twin of the same matrices as its scaling headline

@@ -175,6 +175,14 @@ def test_bench_runs_and_verifies(tm, extra, path):
         assert k in d, k
     assert d["config"]["path"] == path and d["steps"] == 3 and d["n_gpus"] == 1
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["activations_finite"]
+    if path == "chain":
+        # since round 6 a decode line times SURVEY 8(d)'s measurement (independent calls, stream mode) and carries the dependent chain of the
+        # same matrices -- rounds 1-5's timed workload -- beside it, measured and verified in the same run
+        assert d["config"]["pattern"] == "independent" and "k_gemv_stream" in d["roofline"]["kernel"], d["config"]
+        dc = d["dependent_chain"]
+        assert "error" not in dc and dc["value"] > 0 and "k_decode_chain" in dc["roofline"]["kernel"], dc
+        if "--force-dist" not in extra:
+            assert dc["verified"]["ok"], dc["verified"]
     if "--force-dist" not in extra:
         assert d["verified"]["ok"], d["verified"]
         tw = d["prefill_twin"]          # the N = 256 twin of the same matrices rides along in a one-GPU decode line

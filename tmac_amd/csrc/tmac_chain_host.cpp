@@ -514,7 +514,7 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             auto cls_lo = [&](int cl, int nc) { return (cl * c->grid + nc - 1) / nc; };
             // The quarter-walk form of the kernel (tmac_stream.hip, QW): rows dealt in groups of four quads, K walked in quarters of a 64-unit
             // step.  It saves the lookups a ragged last step wastes (K = 11008, 3200, 8640 ...) and is the faster form even without one
-            // (profiles/r06_stream_qw.txt), so 1- to 3-bit recordings take it whenever every matrix has whole groups (rows % 16 == 0);
+            // (profiles/r06_stream_qw.txt), so 1- and 2-bit recordings take it whenever every matrix has whole groups (rows % 16 == 0);
             // TMAC_STREAM_QW=0 keeps the (quad x 64 units) form, whose per-group-scale outputs are bit-identical to the stand-alone launches.
             bool qw = true;
             {
@@ -528,7 +528,9 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
                 // 2-4 % faster even at K = 4096; 4-bit streams run at the memory system's rate, where a wave-load of four 256-byte pieces
                 // instead of one KB costs ~7 %: taken there only when the ragged steps outweigh that
                 // (it16 <= it64 always; 1- to 3-bit: the form whenever the rows allow it)
-                if (force == 0 || (force < 0 && c->bits >= 4 && it16 > 0.93 * it64)) qw = false;
+                // 3- and 4-bit streams run at the memory system's rate already (6.1-6.4 TB/s), where four 256-byte pieces per wave-load cost
+                // more than the ragged step's lookups: W3 4096 x 11008 0.75 -> 0.65 with the form, W4 equal (profiles/r06_stream_qw.txt)
+                if (force == 0 || (force < 0 && c->bits >= 3 && it16 > 0.85 * it64)) qw = false;
             }
             auto op_q = [&](const ChainOp& o) { return qw ? o.total_q / 4 : o.total_q; };               // row units dealt: groups | quads
             auto op_nst = [&](const ChainOp& o) { return qw ? (o.nu + 15) / 16 : o.nst; };              // K steps walked: quarters | 64-unit steps

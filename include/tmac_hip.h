@@ -244,8 +244,10 @@ int32_t tmac_hip_chain_threads(void);   /* threads per workgroup of k_decode_cha
  * then builds a different launch (1 = yes): k_lut_images builds the tables of every call ONCE -- the reference's own call structure,
  * llama_cpp_init per activation vector, then lookups only (tmac_gemm_wrapper.h:170-228) -- and k_gemv_stream walks the calls with the
  * tables prebuilt, a loader wave per workgroup staging the next call's tables while the lookup waves stream this call's weights; the
- * weight prefetch runs across call boundaries.  No hand-offs, no spins: residency is not a correctness condition there.  Same
- * arithmetic, same lane / wave decomposition: outputs bit-identical to the other N = 1 paths.  Per-group scales, or unified scales
+ * weight prefetch runs across call boundaries.  No hand-offs, no spins: residency is not a correctness condition there.  Since round 6
+ * the calls are dealt to CLASSES of workgroups (a call that is small for 256 CUs is served by a fraction of them with more rows each,
+ * other classes work on other calls meanwhile: TMAC_STREAM_NCLS=1 in the environment = every workgroup visits every call).  Same integers
+ * as every N = 1 path (tmac_hip_chain_set_tap); float outputs: see the return value 2 below.  Per-group scales, or unified scales
  * (BitNet: the row's scale and the sequential bias chain by k_lut_images_us, scale-final on exact int32 totals);
  * TMAC_CHAIN_STREAM=0 in the environment keeps the ordinary chain (A/B). */
 /* Returns 0 (k_decode_chain), 1 (stream mode) or 2: stream mode in the QUARTER-WALK form, chosen when a K with a ragged last 64-unit step

@@ -21,7 +21,9 @@
 //   * no hand-off, no polls, no spin: nothing waits for another workgroup, so residency is not a correctness condition.
 // Arithmetic per item and per row is k_decode_chain's / k_gemv_quad's (c_compute, the same wave / lane decomposition, the same
 // combination order of split quads), the tables are q_table8's: outputs are bit-identical to the other N = 1 paths for the same waves
-// per quad.  Scope: 1- to 4-bit QUAD-layout weights with per-group scales (act groups of 64) or unified scales (SM = 2: one act group per row,
+// per quad -- in the (quad x 64 units) form; the quarter-walk form (QW below, round 6) keeps the integers and changes the order of a
+// row's fp32 partial sums.  Round 6 also added the SCHEDULE (tmac_chain.h, StreamArgs: calls dealt to classes of row ranges) and the
+// step-major LUT image (tmac_chain_core.h, IMG2).  Scope: 1- to 4-bit QUAD-layout weights with per-group scales (act groups of 64) or unified scales (SM = 2: one act group per row,
 // exact int32 totals per bit-plane, scale-final in the service wave; tables by k_lut_images_us); fp16 or fp32 activations.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>

@@ -252,3 +252,57 @@ def test_stream_launch_inside_a_hip_graph(tm):
     g.replay()
     m.check(c)
     c.free(); m.free()
+
+
+# Deferred launches (tmac_hip_defer / tmac_hip_flush, round 6): a caller that does not record queues its N = 1 calls; a flush launches the queue
+# as ONE stream-mode launch; a call that reads or overwrites anything a queued call writes flushes the queue first.  Results must be those of
+# launching the calls in order.
+@pytest.mark.parametrize("seed", range(6))
+def test_deferred_launches_equal_in_order_launches(tm, seed):
+    import ctypes as C
+    import torch
+    from test_gpu_chain import rel_err
+    rng = np.random.default_rng(300 + seed)
+    # a random sequence with dependences: ~half of the calls read an earlier call's output (RAW: must flush), some rewrite an output buffer
+    n = int(rng.integers(4, 9))
+    ops = []
+    for i in range(n):
+        feeders = [(j, m) for j in range(i) for m in range(len(ops[j][1])) if ops[j][1][m] % 128 == 0]
+        if feeders and rng.random() < 0.5:
+            src = feeders[int(rng.integers(len(feeders)))]
+            K = ops[src[0]][1][src[1]]
+        else:
+            src, K = None, int(rng.choice([256, 1024, 2688, 4096]))
+        rows = [int(rng.choice([128, 256, 1024])) for _ in range(int(rng.integers(1, 4)))]
+        ops.append((K, rows, src))
+    m = Model(tm, ops, seed=400 + seed)
+    L = tm.lib()
+    # in-order launches
+    m.issue(); torch.cuda.synchronize()
+    want = [[o.clone() for o in os_] for os_ in m.outs]
+    for os_ in m.outs:
+        for o in os_:
+            o.zero_()
+    tm.binding.check(L.tmac_hip_defer(1))
+    try:
+        for rep in range(3):                       # the second and third token hit the cache of recordings
+            m.issue()
+            tm.binding.check(L.tmac_hip_flush(None))
+            torch.cuda.synchronize()
+            for a_, b_ in zip(want, m.outs):
+                for p_, q_ in zip(a_, b_):
+                    # (a batch runs k_gemv_stream, whose waves per quad / quarter-walk form may differ from the stand-alone launch's: fp16 ulps)
+                    assert rel_err(q_.float().cpu().numpy(), p_.float().cpu().numpy()) <= 2e-3
+        st = [C.c_uint64(0) for _ in range(4)]
+        tm.binding.check(L.tmac_hip_defer_stats(*[C.byref(x) for x in st]))
+        flushes, hits, streams, singles = [int(x.value) for x in st]
+        assert flushes >= 3 and hits >= 2 * (flushes // 3) - 1, (flushes, hits, streams, singles)
+    finally:
+        tm.binding.check(L.tmac_hip_defer(0))
+    # ... and against the oracle, call by call, on the vectors the deferred run consumed
+    for i, (K, rows, src) in enumerate(ops):
+        x = m.x_of(i).float().cpu().numpy()
+        ref = m.oracle_outputs(i, x)
+        for k in range(len(rows)):
+            assert rel_err(m.outs[i][k].float().cpu().numpy(), ref[k]) <= 1e-3
+    m.free()

@@ -327,6 +327,174 @@ def cpu_baseline_prefill(workload, seconds=8.0, rows=8):
                       % (rows, ", ".join(f"{m}x{k}" for m, k, _ in shapes), wl["layers"])}
 
 
+def measure_stream_calls(c, roof, name, Mw, K):
+    """roofline.stream_core / stream_by_shape: SURVEY 8(d)'s headline measurement -- back-to-back INDEPENDENT GEMVs of one shape over rotating
+    distinct weights (> MALL in total), a distinct activation vector per call: the recording runs in stream mode (tables once per call by
+    k_lut_images, lookups by k_gemv_stream; both launches timed).  c: the run's context (run()); name / Mw / K: the target shape (MATS[3])."""
+    # Calls per launch: args.stream_calls (default 96) DISTINCT weight sets -- the layers' own matrices plus extra synthetic ones of the
+    # same shape, so that neither the MALL nor L2 ever holds a matrix when its call comes round again (96 x 4.2 MB for the smallest
+    # shape) -- because a launch has a fixed cost (k_lut_images ~5.5 us, two launch boundaries, the persistent kernel's ramp and tail:
+    # ~19 us measured, profiles/r06_stream_schedule.txt) that 32 calls of ~2.4 us do not amortise; the 32-call figure is kept beside it.
+    SB = 10                      # replays back to back per event pair: launches overlap their predecessors' tails as in any timed loop
+
+    def time_stream_calls(mi, ncalls, verify):
+        name_, Mw_, K_, cnt_, slot_ = c.MATS[mi]
+        extra = [[c.new_weights(c.shard_rows[name_], K_, c.cfg_of(name_)) for _ in range(cnt_)] for _ in range(max(ncalls - c.args.layers, 0))]
+        sets = [c.layers[li][name_] for li in range(min(c.args.layers, ncalls))] + extra
+        xs_ = [c.torch.randn(K_, device=c.dev, generator=c.gen).half() for _ in range(ncalls)]
+        os_ = [[c.torch.empty(c.shard_rows[name_], dtype=c.torch.float16, device=c.dev) for _ in range(cnt_)] for _ in range(ncalls)]
+        with c.wr.record_chain() as rec_:
+            for i_ in range(ncalls):
+                c.wr.fused(sets[i_], xs_[i_], os_[i_], 1, act_dtype=c.F16, out_dtype=c.F16)
+        dur_ = []
+        for r in range(11):
+            e0 = c.torch.cuda.Event(enable_timing=True); e1 = c.torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(SB):
+                rec_.chain.launch()
+            e1.record()
+            c.torch.cuda.synchronize()
+            if r >= 3:
+                dur_.append(e0.elapsed_time(e1) * 1e-3 / (SB * ncalls))
+        ok_ = rec_.chain.status() == 0
+        same_ = None
+        if verify:
+            # the launch's outputs against the same calls launched one by one (whose integer path the parity tests tap): same bits
+            # (the quarter-walk form of k_gemv_stream adds a row's fp32 partial sums in another order: per-group-scale outputs within
+            # 2e-3 of the stand-alone launch's fp16 values -- its integers are tapped against the oracle in tests/test_gpu_stream.py)
+            same_ = True
+            qw_ = bool(getattr(rec_.chain, "quarter_walk", False))
+            for i_ in (0, ncalls // 2, ncalls - 1):
+                if not qw_:
+                    c.L.tmac_hip_debug_quad_config(rec_.chain.threads, rec_.chain.wpq(i_))
+                ref_ = [c.torch.empty_like(o) for o in os_[i_]]
+                c.wr.fused(sets[i_], xs_[i_], ref_, 1, act_dtype=c.F16, out_dtype=c.F16)
+                c.torch.cuda.synchronize()
+                if qw_ and c.MG < 1:
+                    same_ = same_ and all(float((a_.float() - b_.float()).abs().max()) <= 2e-3 * float(a_.float().abs().max()) for a_, b_ in zip(ref_, os_[i_]))
+                else:
+                    same_ = same_ and all(bool(c.torch.equal(a_, b_)) for a_, b_ in zip(ref_, os_[i_]))
+            c.L.tmac_hip_debug_quad_config(0, 0)
+        mode_ = ("k_lut_images + k_gemv_stream (stream mode%s)" % (", qw" if getattr(rec_.chain, "quarter_walk", False) else "")) if getattr(rec_.chain, "stream", False) else "k_decode_chain"
+        rec_.chain.free()
+        for ws_ in extra:
+            for w_ in ws_:
+                w_.free()
+        hb_ = cnt_ * algorithmic_bytes(Mw_, K_, c.BITS, c.GS, c.ags_of(K_), c.ZP, c.MG) - (cnt_ - 1) * (K_ // 4 * 16 + (K_ // c.ags_of(K_)) * 4)
+        return float(np.mean(dur_)) * 1e6, float(np.min(dur_)) * 1e6, hb_, ok_, same_, mode_
+
+    ncalls = max(c.args.stream_calls, 2)
+    sus, smin, hb_s, sok, ssame, smode = time_stream_calls(3, ncalls, True)
+    roof["stream_core"] = {"what": "%d independent GEMVs %s (%dx%d, %d distinct weight sets, a distinct activation vector each) recorded once, launched as %s: "
+                                   "tables built once per call, lookups with the tables prebuilt, no hand-offs" % (ncalls, name, Mw, K, ncalls, smode),
+                           "calls_per_launch": ncalls,
+                           "us_per_gemv": round(sus, 3), "min_us": round(smin, 3), "GBps": round(hb_s / sus * 1e-3, 1),
+                           "frac": round(hb_s / sus * 1e-3 / HBM_PEAK_GBS, 4), "ok": bool(sok and ssame),
+                           "matches_single_launches": ssame, "form": "quarter-walk (outputs within 2e-3 of the stand-alone launches; integers tapped in tests)" if "qw" in smode else "quad x 64 units (bit-identical to the stand-alone launches)",
+                           "timing": "hipEvent pair around 10 back-to-back replays (LUT build launches included), mean of 8 pairs"}
+    if ncalls != c.args.layers:
+        s32, m32, _, ok32, _, _ = time_stream_calls(3, c.args.layers, False)
+        roof["stream_core"]["at_%d_calls_per_launch" % c.args.layers] = {"us_per_gemv": round(s32, 3), "min_us": round(m32, 3),
+                                                                       "frac": round(hb_s / s32 * 1e-3 / HBM_PEAK_GBS, 4), "ok": ok32}
+    # the same measurement for the layer's other three calls (q/k/v fused, o, gate/up fused): what the shape costs in stream mode
+    try:
+        by_shape = {}
+        for mi2 in range(3):
+            name2, Mw2, K2, cnt2, slot2 = c.MATS[mi2]
+            us2, min2, hb2, ok2, _, _ = time_stream_calls(mi2, ncalls, False)
+            by_shape[name2] = {"shape": "%d x %dx%d" % (cnt2, Mw2, K2), "calls_per_launch": ncalls, "us_per_call": round(us2, 3), "GBps": round(hb2 / us2 * 1e-3, 1),
+                               "frac": round(hb2 / us2 * 1e-3 / HBM_PEAK_GBS, 4), "ok": ok2}
+        roof["stream_by_shape"] = by_shape
+    except c.tmac_amd.binding.TMACHipError as e:
+        roof["stream_by_shape"] = {"error": repr(e)}
+
+
+def measure_independent_pattern(c, roof):
+    """roofline.independent_pattern of a CHAINED run: the token's mpGEMMs as independent calls (what --pattern independent, the default, times);
+    with several ranks every rank streams its row shard, nothing is exchanged, the slowest rank's time counts"""
+    try:
+        ix = {s_: c.torch.randn(c.xdim[s_], device=c.dev, generator=c.gen).half() for s_ in c.xdim}
+        iouts = [{n_: [c.torch.empty_like(o) for o in c.outs[n_]] for n_ in c.outs} for _ in range(c.args.layers)]
+        with c.wr.record_chain() as irec:
+            for li in range(c.args.layers):
+                c.calls(c.layers[li], ix, iouts[li], exchange=False, link=False)
+        for _ in range(2):
+            irec.chain.launch()
+        c.barrier()
+        idur = []
+        for r in range(8):
+            e0 = c.torch.cuda.Event(enable_timing=True); e1 = c.torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                irec.chain.launch()
+            e1.record()
+            c.torch.cuda.synchronize()
+            if r >= 3:
+                idur.append(e0.elapsed_time(e1) / 10)
+        iok = irec.chain.status() == 0
+        imode = ("stream mode%s" % (", quarter-walk form" if getattr(irec.chain, "quarter_walk", False) else "")) if getattr(irec.chain, "stream", False) else "k_decode_chain"
+        irec.chain.free()
+        ims = float(np.mean(idur))
+        if c.dist_on:
+            t_ = c.torch.tensor([ims, 0.0 if iok else 1.0], dtype=c.torch.float64, device=c.dev)
+            c.d_all_reduce(t_, c.dist.ReduceOp.MAX)
+            ims, iok = float(t_[0].item()), float(t_[1].item()) == 0.0
+        roof["independent_pattern"] = {"what": "the token's %d mpGEMMs as independent calls (each reads a vector that is in memory before the launch), %s%s"
+                                               % (7 * c.args.layers, imode, "" if c.world == 1 else "; %d ranks, each over its row shard, no exchange; slowest rank's time" % c.world),
+                                       "n_gpus": c.world, "ms_per_token": round(ims, 4),
+                                       "GBps": round(c.bytes_per_step / (ims * 1e-3) / 1e9, 1),
+                                       "frac": round(c.bytes_per_step / (ims * 1e-3) / 1e9 / (HBM_PEAK_GBS * c.world), 4), "ok": iok}
+        del iouts
+    except Exception as e:
+        roof["independent_pattern"] = {"error": repr(e)}
+
+
+def verify_against_oracle(c):
+    """outside the timed region: the launches being timed, at full size (layer 0), against the oracle; returns the line's `verified` object"""
+    verified = None
+    if c.host_l0:
+        from oracle import oracle as orc
+        vshape = (lambda k: (k,)) if c.decode else (lambda k: (c.N, k))
+        vx0 = c.torch.randn(vshape(c.MATS[0][2]), device=c.dev, generator=c.gen).half()
+        vlink = c.args.pattern != "independent"         # independent pattern: every call of the layer reads a resident vector of its own
+        vx = {c.MATS[0][4]: vx0} if vlink else {s_: c.torch.randn(vshape(c.xdim[s_]), device=c.dev, generator=c.gen).half() for s_ in c.xdim}
+        if not vlink:
+            vx0 = vx[c.MATS[0][4]]
+        vouts = {name: [c.torch.zeros(vshape(Mw), dtype=c.torch.float16, device=c.dev) for _ in range(cnt)] for name, Mw, K, cnt, slot in c.MATS}
+        ok = True
+        if c.args.path == "chain":
+            with c.wr.record_chain() as vrec:
+                c.calls(c.layers[0], vx, vouts, exchange=False, link=vlink)
+            vrec.chain.launch()
+            c.torch.cuda.synchronize()
+            ok = vrec.chain.status() == 0
+            vrec.chain.free()
+        else:
+            c.calls(c.layers[0], vx, vouts, exchange=False, link=vlink)
+            c.torch.cuda.synchronize()
+        worst = 0.0
+        rows = [0] if c.decode else [0, c.N - 1]          # prefill: two of the N activation rows (the oracle takes seconds per row)
+        for name, Mw, K, cnt, slot in c.MATS:
+            src = vx[slot] if not vlink else (vx0 if slot == c.MATS[0][4] else vouts[[n_ for n_ in c.nxt if c.nxt[n_] == slot][0]][0])     # what this call consumed
+            xin_h = src.float().cpu().numpy().reshape(-1, K)[rows]
+            q, ls, lb = orc.preprocessor(xin_h, c.ags_of(K))
+            for i in range(cnt):
+                A, S = c.host_l0[name][i]
+                if c.MG >= 1:
+                    ref, _ = orc.qgemm_scale_final(A, q, S, ls[:, 0], lb[:, 0], Mw, K, len(rows), c.BITS, c.BM, KF, c.MG)
+                else:
+                    ref = orc.qgemm_float(A, q, S, ls, lb, Mw, K, len(rows), c.BITS, c.BM, KF, c.GS, c.ags_of(K), c.ZP)
+                got = vouts[name][i].float().cpu().numpy().reshape(-1, Mw)[rows]
+                worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)))
+        verified = {"ok": bool(ok and worst <= 1e-3), "max_rel_err": float("%.3g" % worst), "tolerance": 1e-3,
+                    "what": "layer 0's seven mpGEMMs (q/k/v, o, gate/up, down at full size, %s) through the timed path vs oracle/ "
+                            "(fp16 outputs%s)" % ("chained" if vlink else "independent calls", "" if c.decode else "; activation rows 0 and N-1")}
+        if not verified["ok"]:
+            sys.stderr.write("bench.py: VERIFICATION FAILED: %r\n" % (verified,))
+
+    return verified
+
+
 def run(args, env):
     """one workload, measured as the contract says; returns the result dict on rank 0 (None elsewhere).  env: what main() set up once
     per process (torch.distributed, the kept stdout)"""
@@ -922,6 +1090,12 @@ def run(args, env):
                 durs.append(e0.elapsed_time(e1) * 1e-3 / args.layers)
         return np.array(durs), reps
 
+    # what the measurement functions outside run() need of this run (measure_stream_calls, measure_independent_pattern, verify_against_oracle)
+    import types
+    ctx = types.SimpleNamespace(args=args, torch=torch, dist=dist, tmac_amd=tmac_amd, F16=F16, dev=dev, gen=gen, wr=wr, L=L, layers=layers, MATS=MATS,
+                                BITS=BITS, BM=BM, GS=GS, ZP=ZP, MG=MG, N=N, decode=decode, world=world, dist_on=dist_on, ags_of=ags_of, cfg_of=cfg_of,
+                                new_weights=new_weights, shard_rows=shard_rows, calls=calls, outs=outs, xdim=xdim, nxt=nxt, barrier=barrier,
+                                d_all_reduce=d_all_reduce, bytes_per_step=bytes_per_step, host_l0=host_l0)
     # ---- roofline of the dominant kernel ------------------------------------------------------------------------------
     traffic, traffic_src = None, None
     kkey = {"chain": "k_decode_chain", "fused": "k_gemv_quad_headline", "split": "k_gemv_quad_headline"}[args.path] if decode else "k_gemm_planes"
@@ -1015,122 +1189,13 @@ def run(args, env):
             # SURVEY 8(d)'s headline measurement: back-to-back INDEPENDENT GEMVs of the target shape over rotating distinct weights (> MALL in
             # total), a distinct activation vector per call.  Nothing is handed over, so the recording runs in stream mode: tables once per
             # call by k_lut_images (the reference's llama_cpp_init), lookups by k_gemv_stream (its llama_cpp_compute); both launches timed.
-            # Calls per launch: args.stream_calls (default 96) DISTINCT weight sets -- the layers' own matrices plus extra synthetic ones of the
-            # same shape, so that neither the MALL nor L2 ever holds a matrix when its call comes round again (96 x 4.2 MB for the smallest
-            # shape) -- because a launch has a fixed cost (k_lut_images ~5.5 us, two launch boundaries, the persistent kernel's ramp and tail:
-            # ~19 us measured, profiles/r06_stream_schedule.txt) that 32 calls of ~2.4 us do not amortise; the 32-call figure is kept beside it.
-            SB = 10                      # replays back to back per event pair: launches overlap their predecessors' tails as in any timed loop
-
-            def time_stream_calls(mi, ncalls, verify):
-                name_, Mw_, K_, cnt_, slot_ = MATS[mi]
-                extra = [[new_weights(shard_rows[name_], K_, cfg_of(name_)) for _ in range(cnt_)] for _ in range(max(ncalls - args.layers, 0))]
-                sets = [layers[li][name_] for li in range(min(args.layers, ncalls))] + extra
-                xs_ = [torch.randn(K_, device=dev, generator=gen).half() for _ in range(ncalls)]
-                os_ = [[torch.empty(shard_rows[name_], dtype=torch.float16, device=dev) for _ in range(cnt_)] for _ in range(ncalls)]
-                with wr.record_chain() as rec_:
-                    for i_ in range(ncalls):
-                        wr.fused(sets[i_], xs_[i_], os_[i_], 1, act_dtype=F16, out_dtype=F16)
-                dur_ = []
-                for r in range(11):
-                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(SB):
-                        rec_.chain.launch()
-                    e1.record()
-                    torch.cuda.synchronize()
-                    if r >= 3:
-                        dur_.append(e0.elapsed_time(e1) * 1e-3 / (SB * ncalls))
-                ok_ = rec_.chain.status() == 0
-                same_ = None
-                if verify:
-                    # the launch's outputs against the same calls launched one by one (whose integer path the parity tests tap): same bits
-                    # (the quarter-walk form of k_gemv_stream adds a row's fp32 partial sums in another order: per-group-scale outputs within
-                    # 2e-3 of the stand-alone launch's fp16 values -- its integers are tapped against the oracle in tests/test_gpu_stream.py)
-                    same_ = True
-                    qw_ = bool(getattr(rec_.chain, "quarter_walk", False))
-                    for i_ in (0, ncalls // 2, ncalls - 1):
-                        if not qw_:
-                            L.tmac_hip_debug_quad_config(rec_.chain.threads, rec_.chain.wpq(i_))
-                        ref_ = [torch.empty_like(o) for o in os_[i_]]
-                        wr.fused(sets[i_], xs_[i_], ref_, 1, act_dtype=F16, out_dtype=F16)
-                        torch.cuda.synchronize()
-                        if qw_ and MG < 1:
-                            same_ = same_ and all(float((a_.float() - b_.float()).abs().max()) <= 2e-3 * float(a_.float().abs().max()) for a_, b_ in zip(ref_, os_[i_]))
-                        else:
-                            same_ = same_ and all(bool(torch.equal(a_, b_)) for a_, b_ in zip(ref_, os_[i_]))
-                    L.tmac_hip_debug_quad_config(0, 0)
-                mode_ = ("k_lut_images + k_gemv_stream (stream mode%s)" % (", qw" if getattr(rec_.chain, "quarter_walk", False) else "")) if getattr(rec_.chain, "stream", False) else "k_decode_chain"
-                rec_.chain.free()
-                for ws_ in extra:
-                    for w_ in ws_:
-                        w_.free()
-                hb_ = cnt_ * algorithmic_bytes(Mw_, K_, BITS, GS, ags_of(K_), ZP, MG) - (cnt_ - 1) * (K_ // 4 * 16 + (K_ // ags_of(K_)) * 4)
-                return float(np.mean(dur_)) * 1e6, float(np.min(dur_)) * 1e6, hb_, ok_, same_, mode_
-
-            ncalls = max(args.stream_calls, 2)
-            sus, smin, hb_s, sok, ssame, smode = time_stream_calls(3, ncalls, True)
-            roof["stream_core"] = {"what": "%d independent GEMVs %s (%dx%d, %d distinct weight sets, a distinct activation vector each) recorded once, launched as %s: "
-                                           "tables built once per call, lookups with the tables prebuilt, no hand-offs" % (ncalls, name, Mw, K, ncalls, smode),
-                                   "calls_per_launch": ncalls,
-                                   "us_per_gemv": round(sus, 3), "min_us": round(smin, 3), "GBps": round(hb_s / sus * 1e-3, 1),
-                                   "frac": round(hb_s / sus * 1e-3 / HBM_PEAK_GBS, 4), "ok": bool(sok and ssame),
-                                   "matches_single_launches": ssame, "form": "quarter-walk (outputs within 2e-3 of the stand-alone launches; integers tapped in tests)" if "qw" in smode else "quad x 64 units (bit-identical to the stand-alone launches)",
-                                   "timing": "hipEvent pair around 10 back-to-back replays (LUT build launches included), mean of 8 pairs"}
-            if ncalls != args.layers:
-                s32, m32, _, ok32, _, _ = time_stream_calls(3, args.layers, False)
-                roof["stream_core"]["at_%d_calls_per_launch" % args.layers] = {"us_per_gemv": round(s32, 3), "min_us": round(m32, 3),
-                                                                               "frac": round(hb_s / s32 * 1e-3 / HBM_PEAK_GBS, 4), "ok": ok32}
-            # the same measurement for the layer's other three calls (q/k/v fused, o, gate/up fused): what the shape costs in stream mode
-            try:
-                by_shape = {}
-                for mi2 in range(3):
-                    name2, Mw2, K2, cnt2, slot2 = MATS[mi2]
-                    us2, min2, hb2, ok2, _, _ = time_stream_calls(mi2, ncalls, False)
-                    by_shape[name2] = {"shape": "%d x %dx%d" % (cnt2, Mw2, K2), "calls_per_launch": ncalls, "us_per_call": round(us2, 3), "GBps": round(hb2 / us2 * 1e-3, 1),
-                                       "frac": round(hb2 / us2 * 1e-3 / HBM_PEAK_GBS, 4), "ok": ok2}
-                roof["stream_by_shape"] = by_shape
-            except tmac_amd.binding.TMACHipError as e:
-                roof["stream_by_shape"] = {"error": repr(e)}
+            measure_stream_calls(ctx, roof, name, Mw, K)
         # ... and the whole token's 224 matrices as independent calls (what --pattern independent times): every call reads a resident vector.
         # With several ranks: every rank streams ITS row shard of every matrix, nothing is exchanged (rows split, K whole, vectors resident on
         # every rank) -- the decode-side workload that scales by construction, reported beside the dependent chain's value as
         # roofline.independent_pattern (n_gpus ranks, aggregate bytes over the slowest rank's time)
         if (not args.no_stream_core) and decode and args.path == "chain" and dpat is None and args.pattern != "independent":
-            try:
-                ix = {s_: torch.randn(xdim[s_], device=dev, generator=gen).half() for s_ in xdim}
-                iouts = [{n_: [torch.empty_like(o) for o in outs[n_]] for n_ in outs} for _ in range(args.layers)]
-                with wr.record_chain() as irec:
-                    for li in range(args.layers):
-                        calls(layers[li], ix, iouts[li], exchange=False, link=False)
-                for _ in range(2):
-                    irec.chain.launch()
-                barrier()
-                idur = []
-                for r in range(8):
-                    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(10):
-                        irec.chain.launch()
-                    e1.record()
-                    torch.cuda.synchronize()
-                    if r >= 3:
-                        idur.append(e0.elapsed_time(e1) / 10)
-                iok = irec.chain.status() == 0
-                imode = ("stream mode%s" % (", quarter-walk form" if getattr(irec.chain, "quarter_walk", False) else "")) if getattr(irec.chain, "stream", False) else "k_decode_chain"
-                irec.chain.free()
-                ims = float(np.mean(idur))
-                if dist_on:
-                    t_ = torch.tensor([ims, 0.0 if iok else 1.0], dtype=torch.float64, device=dev)
-                    d_all_reduce(t_, dist.ReduceOp.MAX)
-                    ims, iok = float(t_[0].item()), float(t_[1].item()) == 0.0
-                roof["independent_pattern"] = {"what": "the token's %d mpGEMMs as independent calls (each reads a vector that is in memory before the launch), %s%s"
-                                                       % (7 * args.layers, imode, "" if world == 1 else "; %d ranks, each over its row shard, no exchange; slowest rank's time" % world),
-                                               "n_gpus": world, "ms_per_token": round(ims, 4),
-                                               "GBps": round(bytes_per_step / (ims * 1e-3) / 1e9, 1),
-                                               "frac": round(bytes_per_step / (ims * 1e-3) / 1e9 / (HBM_PEAK_GBS * world), 4), "ok": iok}
-                del iouts
-            except Exception as e:
-                roof["independent_pattern"] = {"error": repr(e)}
+            measure_independent_pattern(ctx, roof)
         # the same matrices as a decoder issues them (outside the timed region; --pattern decoder makes it the timed workload)
         if not dist_on and dpat is None and args.pattern == "chained" and not args.no_decoder_pattern:
             try:
@@ -1209,46 +1274,7 @@ def run(args, env):
                           % (args.layers, "hipGraph replay" if use_graph else "eager")}
 
     # ---- verification (outside the timed region): the launches being timed, at full size, against the oracle ----------
-    verified = None
-    if host_l0:
-        from oracle import oracle as orc
-        vshape = (lambda k: (k,)) if decode else (lambda k: (N, k))
-        vx0 = torch.randn(vshape(MATS[0][2]), device=dev, generator=gen).half()
-        vlink = args.pattern != "independent"         # independent pattern: every call of the layer reads a resident vector of its own
-        vx = {MATS[0][4]: vx0} if vlink else {s_: torch.randn(vshape(xdim[s_]), device=dev, generator=gen).half() for s_ in xdim}
-        if not vlink:
-            vx0 = vx[MATS[0][4]]
-        vouts = {name: [torch.zeros(vshape(Mw), dtype=torch.float16, device=dev) for _ in range(cnt)] for name, Mw, K, cnt, slot in MATS}
-        ok = True
-        if args.path == "chain":
-            with wr.record_chain() as vrec:
-                calls(layers[0], vx, vouts, exchange=False, link=vlink)
-            vrec.chain.launch()
-            torch.cuda.synchronize()
-            ok = vrec.chain.status() == 0
-            vrec.chain.free()
-        else:
-            calls(layers[0], vx, vouts, exchange=False, link=vlink)
-            torch.cuda.synchronize()
-        worst = 0.0
-        rows = [0] if decode else [0, N - 1]          # prefill: two of the N activation rows (the oracle takes seconds per row)
-        for name, Mw, K, cnt, slot in MATS:
-            src = vx[slot] if not vlink else (vx0 if slot == MATS[0][4] else vouts[[n_ for n_ in nxt if nxt[n_] == slot][0]][0])     # what this call consumed
-            xin_h = src.float().cpu().numpy().reshape(-1, K)[rows]
-            q, ls, lb = orc.preprocessor(xin_h, ags_of(K))
-            for i in range(cnt):
-                A, S = host_l0[name][i]
-                if MG >= 1:
-                    ref, _ = orc.qgemm_scale_final(A, q, S, ls[:, 0], lb[:, 0], Mw, K, len(rows), BITS, BM, KF, MG)
-                else:
-                    ref = orc.qgemm_float(A, q, S, ls, lb, Mw, K, len(rows), BITS, BM, KF, GS, ags_of(K), ZP)
-                got = vouts[name][i].float().cpu().numpy().reshape(-1, Mw)[rows]
-                worst = max(worst, float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30)))
-        verified = {"ok": bool(ok and worst <= 1e-3), "max_rel_err": float("%.3g" % worst), "tolerance": 1e-3,
-                    "what": "layer 0's seven mpGEMMs (q/k/v, o, gate/up, down at full size, %s) through the timed path vs oracle/ "
-                            "(fp16 outputs%s)" % ("chained" if vlink else "independent calls", "" if decode else "; activation rows 0 and N-1")}
-        if not verified["ok"]:
-            sys.stderr.write("bench.py: VERIFICATION FAILED: %r\n" % (verified,))
+    verified = verify_against_oracle(ctx)
 
     if rank == 0:
         sec = ms_per_step * 1e-3

@@ -495,6 +495,45 @@ def verify_against_oracle(c):
     return verified
 
 
+def measure_dense_fp16(c, roof, ev_ms_per_step):
+    """prefill lines: roofline.dense_fp16_baseline -- a dense fp16 torch.matmul (hipBLASLt) of the same shapes on this box, replayed from a hipGraph
+    like the timed path"""
+    try:
+        dW = {name: [c.torch.randn(c.shard_rows[name], K, device=c.dev, generator=c.gen).half() for _ in range(cnt)] for name, Mw, K, cnt, slot in c.MATS}
+        dX = {slot: c.torch.randn(c.N, K, device=c.dev, generator=c.gen).half() for name, Mw, K, cnt, slot in c.MATS}
+        dO = {name: [c.torch.empty(c.N, c.shard_rows[name], dtype=c.torch.float16, device=c.dev) for _ in range(cnt)] for name, Mw, K, cnt, slot in c.MATS}
+
+        def dense_step():
+            for _ in range(c.args.layers):
+                for name, Mw, K, cnt, slot in c.MATS:
+                    for i in range(cnt):
+                        c.torch.matmul(dX[slot], dW[name][i].t(), out=dO[name][i])
+        dense_step(); c.torch.cuda.synchronize()
+        dside = c.torch.cuda.Stream(); dside.wait_stream(c.torch.cuda.current_stream())
+        with c.torch.cuda.stream(dside):
+            dense_step()
+        c.torch.cuda.current_stream().wait_stream(dside); c.torch.cuda.synchronize()
+        dg = c.torch.cuda.CUDAGraph()
+        with c.torch.cuda.graph(dg, stream=dside):
+            dense_step()
+        dts = []
+        for r in range(8):
+            f0 = c.torch.cuda.Event(enable_timing=True); f1 = c.torch.cuda.Event(enable_timing=True)
+            f0.record(); dg.replay(); f1.record(); c.torch.cuda.synchronize()
+            if r >= 3:
+                dts.append(f0.elapsed_time(f1))
+        dms = float(np.mean(dts))
+        roof["dense_fp16_baseline"] = {"ms_per_step": round(dms, 4), "tokens_per_s": round(c.N / (dms * 1e-3), 1),
+                                       "this_over_dense": round(dms / ev_ms_per_step, 3),
+                                       "what": "torch.matmul (hipBLASLt) fp16 [N, K] x [K, rows] of the same %d matrices per layer (ONE weight set reused by every layer: "
+                                               "%.0f MB of fp16 weights, MALL-resident -- the 2-bit path streams distinct weights per layer), hipGraph replay, mean of 5; "
+                                               "it reads 8 x the weight bytes per matrix and cannot produce the reference's integer sums"
+                                               % (sum(m[3] for m in c.MATS), sum(m[3] * c.shard_rows[m[0]] * m[2] for m in c.MATS) * 2 / 1e6)}
+        del dW, dX, dO, dg
+    except Exception as e:
+        roof["dense_fp16_baseline"] = {"error": repr(e)}
+
+
 def run(args, env):
     """one workload, measured as the contract says; returns the result dict on rank 0 (None elsewhere).  env: what main() set up once
     per process (torch.distributed, the kept stdout)"""
@@ -1124,40 +1163,7 @@ def run(args, env):
                                     "frac": round(dense_flop / (ev_ms_per_step * 1e-3) / 1e12 / 2500.0, 4),
                                     "what": "2 x rows x K x N per matrix over the same time, against the dense bf16 MFMA peak (MI355X_MICROARCH.md)"}
         if not dist_on:
-            try:
-                dW = {name: [torch.randn(shard_rows[name], K, device=dev, generator=gen).half() for _ in range(cnt)] for name, Mw, K, cnt, slot in MATS}
-                dX = {slot: torch.randn(N, K, device=dev, generator=gen).half() for name, Mw, K, cnt, slot in MATS}
-                dO = {name: [torch.empty(N, shard_rows[name], dtype=torch.float16, device=dev) for _ in range(cnt)] for name, Mw, K, cnt, slot in MATS}
-
-                def dense_step():
-                    for _ in range(args.layers):
-                        for name, Mw, K, cnt, slot in MATS:
-                            for i in range(cnt):
-                                torch.matmul(dX[slot], dW[name][i].t(), out=dO[name][i])
-                dense_step(); torch.cuda.synchronize()
-                dside = torch.cuda.Stream(); dside.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(dside):
-                    dense_step()
-                torch.cuda.current_stream().wait_stream(dside); torch.cuda.synchronize()
-                dg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(dg, stream=dside):
-                    dense_step()
-                dts = []
-                for r in range(8):
-                    f0 = torch.cuda.Event(enable_timing=True); f1 = torch.cuda.Event(enable_timing=True)
-                    f0.record(); dg.replay(); f1.record(); torch.cuda.synchronize()
-                    if r >= 3:
-                        dts.append(f0.elapsed_time(f1))
-                dms = float(np.mean(dts))
-                roof["dense_fp16_baseline"] = {"ms_per_step": round(dms, 4), "tokens_per_s": round(N / (dms * 1e-3), 1),
-                                               "this_over_dense": round(dms / ev_ms_per_step, 3),
-                                               "what": "torch.matmul (hipBLASLt) fp16 [N, K] x [K, rows] of the same %d matrices per layer (ONE weight set reused by every layer: "
-                                                       "%.0f MB of fp16 weights, MALL-resident -- the 2-bit path streams distinct weights per layer), hipGraph replay, mean of 5; "
-                                                       "it reads 8 x the weight bytes per matrix and cannot produce the reference's integer sums"
-                                                       % (sum(m[3] for m in MATS), sum(m[3] * shard_rows[m[0]] * m[2] for m in MATS) * 2 / 1e6)}
-                del dW, dX, dO, dg
-            except Exception as e:
-                roof["dense_fp16_baseline"] = {"error": repr(e)}
+            measure_dense_fp16(ctx, roof, ev_ms_per_step)
     elif args.path == "chain":
         ach = bytes_per_step / (ev_ms_per_step * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": ("k_lut_images + k_gemv_stream: the token's %d GEMVs as independent calls, tables prebuilt once per call, one "

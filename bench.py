@@ -534,6 +534,111 @@ def measure_dense_fp16(c, roof, ev_ms_per_step):
         roof["dense_fp16_baseline"] = {"error": repr(e)}
 
 
+# ---- the decoder pattern: the same matrices as a decoder issues them (cx: the run's context) ----
+# ---- the decoder pattern: the same 224 matrices as a decoder issues them.  A real layer has an operator outside
+# the hot path between q/k/v and o (attention) and element-wise operators between the other mpGEMMs; the latter run inside the
+# chain's LUT builds (tmac_hip_chain_xform), the former ends the persistent launch: one launch per segment.
+def build_decoder_pattern(cx):
+    H = cx.MATS[1][2]                      # hidden size = K of the o projection
+    f16 = lambda n_: cx.torch.zeros(n_, dtype=cx.torch.float16, device=cx.dev)
+    gam = [(cx.torch.ones(H, dtype=cx.torch.float32, device=cx.dev), cx.torch.ones(H, dtype=cx.torch.float32, device=cx.dev)) for _ in range(cx.args.layers)]
+    hs = [cx.torch.randn(H, device=cx.dev, generator=cx.gen)] + [cx.torch.zeros(H, dtype=cx.torch.float32, device=cx.dev) for _ in range(cx.args.layers)]
+    attn = f16(H)
+    bo = [dict(o=[f16(cx.shard_rows["o"])], gate_up=[f16(cx.shard_rows["gate_up"]) for _ in range(2)], down=[f16(cx.shard_rows["down"])],
+               qkv=[f16(cx.shard_rows["qkv"]) for _ in range(3)]) for _ in range(cx.args.layers + 1)]
+    x0 = hs[0].half()
+    chains_d = []
+    xf_sel = os.environ.get("TMAC_BENCH_DECODER_XF", "all")      # measurement only: all | none | norm | glu (which transforms the segments carry)
+    do_norm, do_glu = xf_sel in ("all", "norm"), xf_sel in ("all", "glu")
+    with cx.wr.record_chain() as r0:
+        if do_norm:
+            cx.wr.chain_xform("norm", gamma=gam[0][0], eps=1e-5)
+        cx.wr.fused(cx.layers[0]["qkv"], x0, bo[0]["qkv"], 1, act_dtype=cx.F16, out_dtype=cx.F16)
+    chains_d.append(r0.chain)
+    for li in range(cx.args.layers):
+        b, last = bo[li + 1], li == cx.args.layers - 1
+        with cx.wr.record_chain() as rc:
+            cx.wr.fused(cx.layers[li]["o"], attn, b["o"], 1, act_dtype=cx.F16, out_dtype=cx.F16)
+            if do_norm:
+                cx.wr.chain_xform("norm", residual=hs[li], gamma=gam[li][1], eps=1e-5, keep=True)
+            cx.wr.fused(cx.layers[li]["gate_up"], b["o"][0], b["gate_up"], 1, act_dtype=cx.F16, out_dtype=cx.F16)
+            if do_glu:
+                cx.wr.chain_xform("glu", in2=b["gate_up"][1])
+            cx.wr.fused(cx.layers[li]["down"], b["gate_up"][0], b["down"], 1, act_dtype=cx.F16, out_dtype=cx.F16)
+            if not last:
+                if do_norm:
+                    cx.wr.chain_xform("norm", residual=cx.wr.CARRY, gamma=gam[li + 1][0], eps=1e-5, residual_out=hs[li + 1])
+                cx.wr.fused(cx.layers[li + 1]["qkv"], b["down"][0], b["qkv"], 1, act_dtype=cx.F16, out_dtype=cx.F16)
+        chains_d.append(rc.chain)
+    keep_alive = (gam, hs, attn, bo, x0)
+
+    def dstep(segments=True):
+        if segments:
+            chains_d[0].launch()
+        for li in range(cx.args.layers):
+            attn.copy_(bo[li]["qkv"][0])          # the outside operator: a kernel of the stream between two segments (stand-in for attention)
+            if segments:
+                chains_d[li + 1].launch()
+    return dstep, chains_d, keep_alive
+
+def time_outside_ops(cx, dstep, reps=10):
+    """the stand-ins for attention alone (graph replay of the same 32 copies): the part of the decoder pattern's time that is not this library's"""
+    try:
+        side = cx.torch.cuda.Stream()
+        side.wait_stream(cx.torch.cuda.current_stream())
+        with cx.torch.cuda.stream(side):
+            dstep(False)
+        cx.torch.cuda.current_stream().wait_stream(side)
+        cx.torch.cuda.synchronize()
+        g = cx.torch.cuda.CUDAGraph()
+        with cx.torch.cuda.graph(g, stream=side):
+            dstep(False)
+    except Exception:
+        cx.torch.cuda.synchronize()
+        return None
+    durs = []
+    for r in range(reps + 3):
+        e0 = cx.torch.cuda.Event(enable_timing=True); e1 = cx.torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record()
+        cx.torch.cuda.synchronize()
+        if r >= 3:
+            durs.append(e0.elapsed_time(e1))
+    return float(np.mean(durs))
+
+def time_decoder_pattern(cx, reps=10):
+    dstep, chains_d, keep_alive = build_decoder_pattern(cx)
+    dstep(); cx.torch.cuda.synchronize()
+    ok = all(c.status() == 0 for c in chains_d)
+    g = None
+    try:
+        side = cx.torch.cuda.Stream()
+        side.wait_stream(cx.torch.cuda.current_stream())
+        with cx.torch.cuda.stream(side):
+            dstep()
+        cx.torch.cuda.current_stream().wait_stream(side)
+        cx.torch.cuda.synchronize()
+        g = cx.torch.cuda.CUDAGraph()
+        with cx.torch.cuda.graph(g, stream=side):
+            dstep()
+    except Exception as e:
+        sys.stderr.write(f"bench.py: decoder pattern not captured ({e!r}); eager launches\n")
+        g = None
+        cx.torch.cuda.synchronize()
+    durs = []
+    for r in range(reps + 3):
+        e0 = cx.torch.cuda.Event(enable_timing=True); e1 = cx.torch.cuda.Event(enable_timing=True)
+        e0.record(); (g.replay() if g is not None else dstep()); e1.record()
+        cx.torch.cuda.synchronize()
+        if r >= 3:
+            durs.append(e0.elapsed_time(e1))
+    ok = ok and all(c.status() == 0 for c in chains_d)
+    finite_d = bool(cx.torch.isfinite(keep_alive[3][-1]["down"][0].float()).all().item())
+    outside = time_outside_ops(cx, dstep) if g is not None else None
+    for c in chains_d:
+        c.free()
+    return float(np.mean(durs)), ok and finite_d, len(chains_d), g is not None, outside
+
+
 def run(args, env):
     """one workload, measured as the contract says; returns the result dict on rank 0 (None elsewhere).  env: what main() set up once
     per process (torch.distributed, the kept stdout)"""
@@ -730,6 +835,12 @@ def run(args, env):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # what the measurement functions outside run() need of this run (measure_*, verify_against_oracle, the decoder pattern)
+    import types
+    ctx = types.SimpleNamespace(args=args, torch=torch, dist=dist, tmac_amd=tmac_amd, F16=F16, dev=dev, gen=gen, wr=wr, L=L, layers=layers, MATS=MATS,
+                                BITS=BITS, BM=BM, GS=GS, ZP=ZP, MG=MG, N=N, decode=decode, world=world, dist_on=dist_on, ags_of=ags_of, cfg_of=cfg_of,
+                                new_weights=new_weights, shard_rows=shard_rows, calls=calls, outs=outs, xdim=xdim, nxt=nxt, barrier=barrier,
+                                d_all_reduce=d_all_reduce, bytes_per_step=bytes_per_step, host_l0=host_l0)
     # ---- launch mechanism ---------------------------------------------------------------------------------------------
     # (the fused entry point's per-stream LUT workspace for N > 1 must not be allocated inside a capture: the warm-up step and
     # the capture below run on the same side stream, so the workspace exists and has its final size when capture starts)
@@ -832,111 +943,8 @@ def run(args, env):
             except Exception:
                 pass
 
-    # ---- the decoder pattern: the same 224 matrices as a decoder issues them.  A real layer has an operator outside
-    # the hot path between q/k/v and o (attention) and element-wise operators between the other mpGEMMs; the latter run inside the
-    # chain's LUT builds (tmac_hip_chain_xform), the former ends the persistent launch: one launch per segment.
-    def build_decoder_pattern():
-        H = MATS[1][2]                      # hidden size = K of the o projection
-        f16 = lambda n_: torch.zeros(n_, dtype=torch.float16, device=dev)
-        gam = [(torch.ones(H, dtype=torch.float32, device=dev), torch.ones(H, dtype=torch.float32, device=dev)) for _ in range(args.layers)]
-        hs = [torch.randn(H, device=dev, generator=gen)] + [torch.zeros(H, dtype=torch.float32, device=dev) for _ in range(args.layers)]
-        attn = f16(H)
-        bo = [dict(o=[f16(shard_rows["o"])], gate_up=[f16(shard_rows["gate_up"]) for _ in range(2)], down=[f16(shard_rows["down"])],
-                   qkv=[f16(shard_rows["qkv"]) for _ in range(3)]) for _ in range(args.layers + 1)]
-        x0 = hs[0].half()
-        chains_d = []
-        xf_sel = os.environ.get("TMAC_BENCH_DECODER_XF", "all")      # measurement only: all | none | norm | glu (which transforms the segments carry)
-        do_norm, do_glu = xf_sel in ("all", "norm"), xf_sel in ("all", "glu")
-        with wr.record_chain() as r0:
-            if do_norm:
-                wr.chain_xform("norm", gamma=gam[0][0], eps=1e-5)
-            wr.fused(layers[0]["qkv"], x0, bo[0]["qkv"], 1, act_dtype=F16, out_dtype=F16)
-        chains_d.append(r0.chain)
-        for li in range(args.layers):
-            b, last = bo[li + 1], li == args.layers - 1
-            with wr.record_chain() as rc:
-                wr.fused(layers[li]["o"], attn, b["o"], 1, act_dtype=F16, out_dtype=F16)
-                if do_norm:
-                    wr.chain_xform("norm", residual=hs[li], gamma=gam[li][1], eps=1e-5, keep=True)
-                wr.fused(layers[li]["gate_up"], b["o"][0], b["gate_up"], 1, act_dtype=F16, out_dtype=F16)
-                if do_glu:
-                    wr.chain_xform("glu", in2=b["gate_up"][1])
-                wr.fused(layers[li]["down"], b["gate_up"][0], b["down"], 1, act_dtype=F16, out_dtype=F16)
-                if not last:
-                    if do_norm:
-                        wr.chain_xform("norm", residual=wr.CARRY, gamma=gam[li + 1][0], eps=1e-5, residual_out=hs[li + 1])
-                    wr.fused(layers[li + 1]["qkv"], b["down"][0], b["qkv"], 1, act_dtype=F16, out_dtype=F16)
-            chains_d.append(rc.chain)
-        keep_alive = (gam, hs, attn, bo, x0)
-
-        def dstep(segments=True):
-            if segments:
-                chains_d[0].launch()
-            for li in range(args.layers):
-                attn.copy_(bo[li]["qkv"][0])          # the outside operator: a kernel of the stream between two segments (stand-in for attention)
-                if segments:
-                    chains_d[li + 1].launch()
-        return dstep, chains_d, keep_alive
-
-    def time_outside_ops(dstep, reps=10):
-        """the stand-ins for attention alone (graph replay of the same 32 copies): the part of the decoder pattern's time that is not this library's"""
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                dstep(False)
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                dstep(False)
-        except Exception:
-            torch.cuda.synchronize()
-            return None
-        durs = []
-        for r in range(reps + 3):
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(); g.replay(); e1.record()
-            torch.cuda.synchronize()
-            if r >= 3:
-                durs.append(e0.elapsed_time(e1))
-        return float(np.mean(durs))
-
-    def time_decoder_pattern(reps=10):
-        dstep, chains_d, keep_alive = build_decoder_pattern()
-        dstep(); torch.cuda.synchronize()
-        ok = all(c.status() == 0 for c in chains_d)
-        g = None
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                dstep()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=side):
-                dstep()
-        except Exception as e:
-            sys.stderr.write(f"bench.py: decoder pattern not captured ({e!r}); eager launches\n")
-            g = None
-            torch.cuda.synchronize()
-        durs = []
-        for r in range(reps + 3):
-            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-            e0.record(); (g.replay() if g is not None else dstep()); e1.record()
-            torch.cuda.synchronize()
-            if r >= 3:
-                durs.append(e0.elapsed_time(e1))
-        ok = ok and all(c.status() == 0 for c in chains_d)
-        finite_d = bool(torch.isfinite(keep_alive[3][-1]["down"][0].float()).all().item())
-        outside = time_outside_ops(dstep) if g is not None else None
-        for c in chains_d:
-            c.free()
-        return float(np.mean(durs)), ok and finite_d, len(chains_d), g is not None, outside
-
     if args.pattern == "decoder":
-        dstep, dchains, dkeep = build_decoder_pattern()
+        dstep, dchains, dkeep = build_decoder_pattern(ctx)
         dstep(); torch.cuda.synchronize()
         assert all(c.status() == 0 for c in dchains), "a hand-off inside a decoder segment timed out"
         side = torch.cuda.Stream()
@@ -1129,12 +1137,6 @@ def run(args, env):
                 durs.append(e0.elapsed_time(e1) * 1e-3 / args.layers)
         return np.array(durs), reps
 
-    # what the measurement functions outside run() need of this run (measure_stream_calls, measure_independent_pattern, verify_against_oracle)
-    import types
-    ctx = types.SimpleNamespace(args=args, torch=torch, dist=dist, tmac_amd=tmac_amd, F16=F16, dev=dev, gen=gen, wr=wr, L=L, layers=layers, MATS=MATS,
-                                BITS=BITS, BM=BM, GS=GS, ZP=ZP, MG=MG, N=N, decode=decode, world=world, dist_on=dist_on, ags_of=ags_of, cfg_of=cfg_of,
-                                new_weights=new_weights, shard_rows=shard_rows, calls=calls, outs=outs, xdim=xdim, nxt=nxt, barrier=barrier,
-                                d_all_reduce=d_all_reduce, bytes_per_step=bytes_per_step, host_l0=host_l0)
     # ---- roofline of the dominant kernel ------------------------------------------------------------------------------
     traffic, traffic_src = None, None
     kkey = {"chain": "k_decode_chain", "fused": "k_gemv_quad_headline", "split": "k_gemv_quad_headline"}[args.path] if decode else "k_gemm_planes"
@@ -1205,7 +1207,7 @@ def run(args, env):
         # the same matrices as a decoder issues them (outside the timed region; --pattern decoder makes it the timed workload)
         if not dist_on and dpat is None and args.pattern == "chained" and not args.no_decoder_pattern:
             try:
-                dms, dok, dn, dgraphed, dout = time_decoder_pattern()
+                dms, dok, dn, dgraphed, dout = time_decoder_pattern(ctx)
                 roof["decoder_pattern"] = {"what": "one launch per segment (o -> gate/up -> down -> next q/k/v; residual add + RMSNorm and silu(gate) * up inside the "
                                                    "LUT builds), a copy kernel between the segments as stand-in for attention",
                                            "ms_per_token": round(dms, 4), "launches": dn,
@@ -1300,7 +1302,7 @@ def run(args, env):
                        "gemm_per_step": 7 * args.layers,
                        "launches_per_step": (len(dpat["chains"]) if dpat is not None else (2 if is_stream else 1)) if args.path == "chain" else (4 if fused_calls else 11) * args.layers + (0 if decode else 4 * args.layers), "path": args.path,
                        "pattern": args.pattern,
-                       **({"outside_ms": (lambda v: None if v is None else round(v, 4))(time_outside_ops(dpat["dstep"]))} if dpat is not None else {}),
+                       **({"outside_ms": (lambda v: None if v is None else round(v, 4))(time_outside_ops(ctx, dpat["dstep"]))} if dpat is not None else {}),
                        "autotune": tuned,
                        "algorithmic_bytes_per_step": bytes_per_step, "weights": wl["weights"],
                        "parallelism": f"row-shard x{world}" if world > 1 else "single GPU",

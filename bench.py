@@ -1057,9 +1057,9 @@ def run(args, env):
         first_ms = cr0.elapsed_time(cr1)
         n_ramp = args.steps
         while True:
-            for _ in range(args.steps):
+            for _ in range(min(args.steps, 32)):
                 run_step()
-            n_ramp += args.steps
+            n_ramp += min(args.steps, 32)
             cr2.record()
             torch.cuda.synchronize()
             if cr0.elapsed_time(cr2) >= args.clock_ramp_ms or n_ramp >= 100000:

@@ -926,7 +926,8 @@ struct DeferState {
     std::vector<DeferEntry> cache;
     unsigned long long epoch = 0, tick = 0;
     unsigned long long n_flush = 0, n_hit = 0, n_stream = 0, n_chain = 0, n_single = 0;
-    ~DeferState() { for (DeferEntry& e : cache) if (e.chain) tmac_hip_chain_free(e.chain); }
+    // (no destructor: a thread_local of the main thread is destroyed at process exit, when the HIP runtime may be gone -- the cached
+    // recordings are released by tmac_hip_cache_clear / tmac_hip_reset_state on the owning thread, or with the process)
 };
 thread_local DeferState g_defer;
 std::atomic<unsigned long long> g_defer_epoch{1};
@@ -1029,6 +1030,11 @@ bool tmac_host::defer_if_on(const tmac_hip_weights* const* wl, int nmat, const v
     return true;
 }
 void tmac_host::defer_forget_all() { g_defer_epoch.fetch_add(1, std::memory_order_acq_rel); }
+void tmac_host::defer_release_thread() {          // the calling thread's cached recordings (nothing of them may be in flight: the caller has synchronised)
+    DeferState& D = g_defer;
+    for (DeferEntry& e : D.cache) if (e.chain) tmac_hip_chain_free(e.chain);
+    D.cache.clear();
+}
 
 extern "C" int32_t tmac_hip_defer(int on) {
     DeferState& D = g_defer;

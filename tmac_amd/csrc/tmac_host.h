@@ -150,6 +150,7 @@ int32_t chain_record(const tmac_hip_weights* const* wl, int nmat, const void* B_
 // deferred launches (tmac_hip_defer): true (and *rc set) when the call was queued instead of launched
 bool defer_if_on(const tmac_hip_weights* const* wl, int nmat, const void* B_dev, tmac_dtype_t act_dtype, void* const* C_list, tmac_dtype_t out_dtype,
                  int N, hipStream_t st, int32_t* rc);
+void defer_release_thread();       // frees the calling thread's cached recordings (tmac_hip_cache_clear)
 void defer_forget_all();           // weights were freed / the library was reset: cached recordings of every thread are stale from now on
 bool chain_record_gather_if_recording(const void* send_dev, void* recv_dev, size_t bytes_per_rank, int rank, int world, int32_t* rc);
 

@@ -218,6 +218,8 @@ static void evict_to_cap(const HostRun* keep) {
 }
 
 extern "C" int32_t tmac_hip_cache_clear(void) {
+    (void)hipDeviceSynchronize();
+    defer_release_thread();                   // the calling thread's cached recordings of deferred batches (tmac_hip_defer)
     std::unique_lock<std::shared_mutex> hl(H.mu);
     std::lock_guard<std::mutex> lk(g_mu);
     if (H.stream) (void)hipStreamSynchronize(H.stream);

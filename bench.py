@@ -652,7 +652,7 @@ def run(args, env):
     if args.pattern == "auto":
         # a decode line times SURVEY 8(d)'s measurement: the token's GEMVs back to back over distinct weights, every call reading a resident
         # vector (main() then measures the dependent chain of the same matrices and reports it beside the value)
-        args.pattern = "independent" if decode else "chained"
+        args.pattern = "independent" if (decode and not args.stamps) else "chained"       # (--stamps: k_decode_chain's per-call stamps)
     if args.path == "auto":
         args.path = "chain" if chain_ok else "fused"
     if args.path == "chain" and not chain_ok:

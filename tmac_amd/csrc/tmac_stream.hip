@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_lut_images(const ChainOp* __restrict__ 
 #if TMAC_IMG2_SC
     float* scslot = l_sc + 4 * (p >> 4) + ((p >> 3) & 1);                               // act group p >> 3: its pair, its half
 #else
-    float* scslot = l_sc + (p >> 3) - 2 * 0;                                            // A/B: ls[GP] then lb[GP]
+    float* scslot = l_sc + (p >> 3);                                                    // ls[GP] then lb[GP]
 #endif
     if (p >= P) {                           // P % 8 == 0: the 8 lanes of an act group are valid or padding together
         *tslot = make_uint4(0u, 0u, 0u, 0u);

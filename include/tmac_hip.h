@@ -247,7 +247,9 @@ int32_t tmac_hip_chain_threads(void);   /* threads per workgroup of k_decode_cha
  * tables prebuilt, a loader wave per workgroup staging the next call's tables while the lookup waves stream this call's weights; the
  * weight prefetch runs across call boundaries.  No hand-offs, no spins: residency is not a correctness condition there.  Since round 6
  * the calls are dealt to CLASSES of workgroups (a call that is small for 256 CUs is served by a fraction of them with more rows each,
- * other classes work on other calls meanwhile: TMAC_STREAM_NCLS=1 in the environment = every workgroup visits every call).  Same integers
+ * other classes work on other calls meanwhile: TMAC_STREAM_NCLS=1 in the environment = every workgroup visits every call; further A/B
+ * knobs read by tmac_hip_chain_end: TMAC_STREAM_VISIT_ITEMS (items a visit should give a workgroup, 160), TMAC_STREAM_LPT=0 (calls dealt in
+ * recorded order instead of largest first), TMAC_STREAM_SPLIT=1 (one workgroup per CU), TMAC_STREAM_QW=0 | 1 (item form, below)).  Same integers
  * as every N = 1 path (tmac_hip_chain_set_tap); float outputs: see the return value 2 below.  Per-group scales, or unified scales
  * (BitNet: the row's scale and the sequential bias chain by k_lut_images_us, scale-final on exact int32 totals);
  * TMAC_CHAIN_STREAM=0 in the environment keeps the ordinary chain (A/B). */

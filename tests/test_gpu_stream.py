@@ -118,7 +118,7 @@ def test_stream_fp32_outputs_and_fp32_activations(tm):
     _run(tm, INDEP[:5], ext_f32=True, seed=8)
 
 
-@pytest.mark.parametrize("grid", [8, 96, 200])
+@pytest.mark.parametrize("grid", [1, 7, 8, 13, 96, 200])
 def test_stream_on_fewer_workgroups(tm, grid):
     """fewer workgroups than CUs (another kernel holds the rest; a partitioned device): more quads per workgroup, several workgroup
     iterations per call, waves without items in some calls"""

@@ -274,6 +274,11 @@ int32_t tmac_hip_chain_tap_layout(const tmac_hip_chain* chain, int op, size_t* o
 int32_t tmac_hip_debug_chain_config(int force_waves_per_quad, unsigned spin_limit);
 /* workgroups of chains built from now on (0 = one per CU): lets two chains run side by side on one device (tests/test_gpu_chain_ipc.py) */
 int32_t tmac_hip_debug_chain_grid(int workgroups);
+/* The stream-mode schedule as a pure function (no device is touched): n independent calls of items[i] lookup items each, `grid` row
+ * ranges in `ncls` classes (a power of two <= 16, <= grid).  Call i is dealt to the aligned block of out_w[i] classes that starts at
+ * class out_lo[i]; out_load[c] (may be NULL) = the items one range of class c walks over the launch.  `target` = the fewest items a
+ * visit should give a range (TMAC_STREAM_VISIT_ITEMS), lpt != 0 = largest calls first (TMAC_STREAM_LPT). */
+int32_t tmac_hip_debug_stream_schedule(const double* items, int n, int grid, int ncls, int target, int lpt, int32_t* out_lo, int32_t* out_w, double* out_load);
 
 /* ---- multi-GPU exchange step ------------------------------------------------------------------
  * One process per GPU; weight ROWS are sharded over the ranks (tile-aligned; register a rank's tiles with

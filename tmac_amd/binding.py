@@ -135,6 +135,7 @@ def load_library() -> C.CDLL:
         "tmac_hip_chain_export": ([vp, vp], i32),
         "tmac_hip_chain_connect": ([vp, vp, C.c_int], i32),
         "tmac_hip_debug_chain_grid": ([C.c_int], i32),
+        "tmac_hip_debug_stream_schedule": ([C.POINTER(C.c_double), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)], i32),
         "tmac_hip_debug_chain_config": ([C.c_int, C.c_uint], i32),
         "tmac_hip_debug_quad_config": ([C.c_int, C.c_int], i32),
         "tmac_hip_selftest": ([vp, vp, C.c_int], i32),

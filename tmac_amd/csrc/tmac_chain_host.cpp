@@ -165,6 +165,80 @@ static int env_int(const char* name, int dflt) {
 struct Range { const char* lo; const char* hi; };
 static bool overlap(const Range& a, const Range& b) { return a.lo < b.hi && b.lo < a.hi; }
 
+
+// ---- the stream schedule (tmac_chain.h, StreamArgs): a pure function of the calls' sizes, so that it can be tested without a device ----
+// items[i]: lookup items of call i; grid row ranges in ncls classes of consecutive ranges (class c = ranges ceil(c grid / ncls) ..).  Every
+// call gets an aligned block of blk_w[i] classes starting at class blk_lo[i]: a call that would give a range fewer than `target` items at
+// full width is dealt to 1 / n of the ranges (n a power of two <= cap); the cap that gives the shortest modelled launch is taken (a lone
+// call keeps all ranges).  Calls go to the least loaded block, widest blocks first and larger calls first (lpt), or in recorded order.
+// visits[c]: the calls class c visits, in visiting order.
+static void stream_schedule(const std::vector<double>& items, int grid, int ncls, int target, bool lpt, std::vector<int>& blk_lo, std::vector<int>& blk_w,
+                            std::vector<std::vector<int>>& visits) {
+    const int nop = (int)items.size();
+    const double visit_fixed = 8.0;                                    // a visit's fixed cost in items (model only)
+    auto cls_lo = [&](int cl) { return (cl * grid + ncls - 1) / ncls; };
+    blk_lo.assign(nop, 0); blk_w.assign(nop, ncls);
+    visits.assign(ncls, std::vector<int>());
+    double best_span = 0;
+    int best_cap = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int cap = ncls; cap >= 1; cap >>= 1) {
+            if (pass == 1 && cap != best_cap) continue;
+            std::vector<double> load(ncls, 0.0);
+            std::vector<std::vector<int>> vis(ncls);
+            // widest blocks first, larger calls first (longest-processing-time order: the calls are independent, so a class may visit
+            // them in any order): in recorded order the classes of a llama-2-7B token ended 3 % apart, BitNet-3B's 8 % -- the launch
+            // lasts as long as its most loaded class; in this order 0 % / 2 % (the same model)
+            std::vector<int> order(nop), wof(nop);
+            for (int i = 0; i < nop; ++i) {
+                int n = 1;
+                while (n < cap && items[i] * n / grid < target) n <<= 1;
+                order[i] = i; wof[i] = ncls / n;
+            }
+            if (lpt)
+                std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+                    if (wof[x] != wof[y]) return wof[x] > wof[y];
+                    return items[x] > items[y];
+                });
+            for (int oi = 0; oi < nop; ++oi) {
+                const int i = order[oi], w = wof[i];
+                int bb = 0;
+                double bl = 1e300;
+                for (int b0 = 0; b0 + w <= ncls; b0 += w) {
+                    double m = 0;
+                    for (int k = b0; k < b0 + w; ++k) m = load[k] > m ? load[k] : m;
+                    if (m < bl) { bl = m; bb = b0; }
+                }
+                const int wg = cls_lo(bb + w) - cls_lo(bb);
+                for (int k = bb; k < bb + w; ++k) { load[k] += visit_fixed + items[i] / wg; vis[k].push_back(i); }
+                if (pass == 1) { blk_lo[i] = bb; blk_w[i] = w; }
+            }
+            double span = 0;
+            for (int k = 0; k < ncls; ++k) span = load[k] > span ? load[k] : span;
+            if (pass == 0 && (best_cap == 0 || span < best_span * 0.999)) { best_span = span; best_cap = cap; }
+            if (pass == 1) visits.swap(vis);
+        }
+    }
+}
+// test hook (no device needed): the schedule of n calls with the given item counts; out_lo / out_w [n], out_load [ncls] = items per range of every class
+extern "C" int32_t tmac_hip_debug_stream_schedule(const double* items, int n, int grid, int ncls, int target, int lpt, int32_t* out_lo, int32_t* out_w, double* out_load) {
+    if (!items || n < 1 || grid < 1 || ncls < 1 || ncls > 16 || (ncls & (ncls - 1)) || ncls > grid || !out_lo || !out_w) return fail(TMAC_HIP_E_ARG, "bad schedule query");
+    std::vector<double> it(items, items + n);
+    std::vector<int> lo, w;
+    std::vector<std::vector<int>> vis;
+    stream_schedule(it, grid, ncls, target, lpt != 0, lo, w, vis);
+    for (int i = 0; i < n; ++i) { out_lo[i] = lo[i]; out_w[i] = w[i]; }
+    if (out_load)
+        for (int k = 0; k < ncls; ++k) {
+            out_load[k] = 0;
+            for (int i : vis[k]) {
+                const int wg = ((lo[i] + w[i]) * grid + ncls - 1) / ncls - (lo[i] * grid + ncls - 1) / ncls;
+                out_load[k] += it[i] / wg;
+            }
+        }
+    return TMAC_HIP_OK;
+}
+
 extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
     if (!g_chain_rec) return fail(TMAC_HIP_E_ARG, "no chain is being recorded on this thread");
     std::vector<ChainRecOp> rec;
@@ -510,7 +584,6 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             if (ncls > 16) ncls = 16;
             while (ncls > c->grid || (ncls & (ncls - 1))) --ncls;
             const int target = env_int("TMAC_STREAM_VISIT_ITEMS", 160);      // (sweep: profiles/r06_stream_schedule_sweep.txt)
-            const double visit_fixed = 8.0;                                    // a visit's fixed cost in items (model only)
             const int nop = (int)c->ops.size();
             auto cls_lo = [&](int cl, int nc) { return (cl * c->grid + nc - 1) / nc; };
             // The quarter-walk form of the kernel (tmac_stream.hip, QW): rows dealt in groups of four quads, K walked in quarters of a 64-unit
@@ -535,53 +608,12 @@ extern "C" int32_t tmac_hip_chain_end(tmac_hip_chain** out) {
             }
             auto op_q = [&](const ChainOp& o) { return qw ? o.total_q / 4 : o.total_q; };               // row units dealt: groups | quads
             auto op_nst = [&](const ChainOp& o) { return qw ? (o.nu + 15) / 16 : o.nst; };              // K steps walked: quarters | 64-unit steps
-            std::vector<int> blk_lo(nop, 0), blk_w(nop, 1);
+            std::vector<int> blk_lo, blk_w;
             std::vector<std::vector<int>> visits;
-            double best_span = 0;
-            int best_cap = 0;
-            for (int pass = 0; pass < 2; ++pass) {
-                for (int cap = ncls; cap >= 1; cap >>= 1) {
-                    if (pass == 1 && cap != best_cap) continue;
-                    std::vector<double> load(ncls, 0.0);
-                    std::vector<std::vector<int>> vis(ncls);
-                    // widest blocks first, larger calls first (longest-processing-time order: the calls are independent, so a class may visit
-                    // them in any order): in recorded order the classes of a llama-2-7B token ended 3 % apart, BitNet-3B's 8 % -- the launch
-                    // lasts as long as its most loaded class; in this order 0 % / 2 % (the same model)
-                    std::vector<int> order(nop), wof(nop);
-                    for (int i = 0; i < nop; ++i) {
-                        const ChainOp& o = c->ops[i];
-                        const double items = (double)op_q(o) * op_nst(o);
-                        int n = 1;
-                        while (n < cap && items * n / c->grid < target) n <<= 1;
-                        order[i] = i; wof[i] = ncls / n;
-                    }
-                    if (env_int("TMAC_STREAM_LPT", 1))
-                        std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-                            if (wof[x] != wof[y]) return wof[x] > wof[y];
-                            return (double)op_q(c->ops[x]) * op_nst(c->ops[x]) > (double)op_q(c->ops[y]) * op_nst(c->ops[y]);
-                        });
-                    for (int oi = 0; oi < nop; ++oi) {
-                        const int i = order[oi];
-                        const ChainOp& o = c->ops[i];
-                        const double items = (double)op_q(o) * op_nst(o);
-                        // (a block must leave every range at most 4095 quads and at least the op's matrices' geometry intact: checked below)
-                        const int w = wof[i];
-                        int bb = 0;
-                        double bl = 1e300;
-                        for (int b0 = 0; b0 + w <= ncls; b0 += w) {
-                            double m = 0;
-                            for (int k = b0; k < b0 + w; ++k) m = load[k] > m ? load[k] : m;
-                            if (m < bl) { bl = m; bb = b0; }
-                        }
-                        const int wg = cls_lo(bb + w, ncls) - cls_lo(bb, ncls);
-                        for (int k = bb; k < bb + w; ++k) { load[k] += visit_fixed + items / wg; vis[k].push_back(i); }
-                        if (pass == 1) { blk_lo[i] = bb; blk_w[i] = w; }
-                    }
-                    double span = 0;
-                    for (int k = 0; k < ncls; ++k) span = load[k] > span ? load[k] : span;
-                    if (pass == 0 && (best_cap == 0 || span < best_span * 0.999)) { best_span = span; best_cap = cap; }
-                    if (pass == 1) visits.swap(vis);
-                }
+            {
+                std::vector<double> items(nop);
+                for (int i = 0; i < nop; ++i) items[i] = (double)op_q(c->ops[i]) * op_nst(c->ops[i]);
+                stream_schedule(items, c->grid, ncls, target, env_int("TMAC_STREAM_LPT", 1) != 0, blk_lo, blk_w, visits);
             }
             bool sched_ok = true;
             for (int i = 0; i < nop; ++i) {

@@ -306,3 +306,52 @@ def test_deferred_launches_equal_in_order_launches(tm, seed):
         for k in range(len(rows)):
             assert rel_err(m.outs[i][k].float().cpu().numpy(), ref[k]) <= 1e-3
     m.free()
+
+
+def test_deferred_batch_of_mixed_widths_is_one_stream_launch_per_configuration(tm):
+    """qgemm.py:98-116 allows any mix of widths and zero-point settings between the matrices a caller multiplies; a recording refuses the
+    mix (one kernel instantiation per launch), the deferred queue regroups it: the calls of a batch are independent"""
+    import ctypes as C
+    import torch
+    from test_gpu_chain import rel_err
+    ops = [(1024, [256, 512], None), (2688, [128], None), (4096, [1024], None)]
+    models = [Model(tm, ops, bits=2, zp=True, seed=31), Model(tm, ops, bits=4, zp=True, seed=32), Model(tm, ops, bits=2, zp=False, dev_f16=False, seed=33),
+              Model(tm, [(3200, [640], None)], bits=2, mg=1, seed=34)]           # (the last: one call alone in its configuration -> launched by itself)
+    L = tm.lib()
+
+    def issue_interleaved():
+        for i in range(len(ops)):
+            for m in models:
+                if i < len(m.ops):
+                    m.wr.fused(m.ws[i], m.x_of(i), m.outs[i], 1, act_dtype=m.act_dtype(i))
+
+    issue_interleaved(); torch.cuda.synchronize()
+    want = [[[o.clone() for o in os_] for os_ in m.outs] for m in models]
+    for m in models:
+        for os_ in m.outs:
+            for o in os_:
+                o.zero_()
+    st = [C.c_uint64(0) for _ in range(4)]
+    tm.binding.check(L.tmac_hip_defer_stats(*[C.byref(x) for x in st]))
+    before = [int(x.value) for x in st]
+    tm.binding.check(L.tmac_hip_defer(1))
+    try:
+        for rep in range(2):
+            issue_interleaved()
+            tm.binding.check(L.tmac_hip_flush(None))
+            torch.cuda.synchronize()
+            for wm, m in zip(want, models):
+                for a_, b_ in zip(wm, m.outs):
+                    for p_, q_ in zip(a_, b_):
+                        assert rel_err(q_.float().cpu().numpy(), p_.float().cpu().numpy()) <= 2e-3
+        tm.binding.check(L.tmac_hip_defer_stats(*[C.byref(x) for x in st]))
+        flushes, hits, streams, singles = [int(x.value) - b for x, b in zip(st, before)]
+        assert (flushes, hits, streams, singles) == (2, 1, 6, 2), (flushes, hits, streams, singles)      # three configurations of three calls + one lone call, twice
+    finally:
+        tm.binding.check(L.tmac_hip_defer(0))
+    for m in models:
+        for i, (K, rows, src) in enumerate(m.ops):
+            ref = m.oracle_outputs(i, m.x_of(i).float().cpu().numpy())
+            for k in range(len(rows)):
+                assert rel_err(m.outs[i][k].float().cpu().numpy(), ref[k]) <= 1e-3
+        m.free()

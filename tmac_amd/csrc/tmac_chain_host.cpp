@@ -948,9 +948,17 @@ struct DeferKey {
 };
 struct DeferEntry {
     std::vector<DeferKey> sig;
-    tmac_hip_chain* chain;       // nullptr: this batch is launched call by call (no persistent form)
+    std::vector<tmac_hip_chain*> chains;   // one stream-mode recording per configuration of the batch (bits, zero points, scale kind and dtype, output dtype)
+    std::vector<uint32_t> singles;         // calls of the batch launched one by one (no persistent form, or alone in their configuration)
     unsigned long long used;
 };
+void defer_free_entry(DeferEntry& e, bool sync) {
+    for (tmac_hip_chain* c : e.chains) {
+        if (sync) (void)hipStreamSynchronize(c->last_stream);
+        tmac_hip_chain_free(c);
+    }
+    e.chains.clear();
+}
 struct DeferState {
     bool on = false;
     std::vector<ChainRecOp> pending;
@@ -980,7 +988,7 @@ int32_t defer_flush(hipStream_t st) {
     ++D.n_flush;
     const unsigned long long ep = g_defer_epoch.load(std::memory_order_acquire);
     if (ep != D.epoch) {                      // weights were freed since: every cached recording may point at dead matrices
-        for (DeferEntry& e : D.cache) if (e.chain) tmac_hip_chain_free(e.chain);
+        for (DeferEntry& e : D.cache) defer_free_entry(e, false);
         D.cache.clear();
         D.epoch = ep;
     }
@@ -990,36 +998,54 @@ int32_t defer_flush(hipStream_t st) {
     for (DeferEntry& e : D.cache) if (e.sig == sig) { hit = &e; break; }
     if (hit) ++D.n_hit;
     else {
-        tmac_hip_chain* c = nullptr;
-        if (batch.size() >= 2 && !g_chain_rec) {
-            g_chain_rec = new std::vector<ChainRecOp>(batch);
-            g_chain_gat = new std::vector<ChainRecGather>();
-            memset(&g_chain_xf, 0, sizeof(g_chain_xf));
-            const int32_t rc = tmac_hip_chain_end(&c);          // (ends the recording whatever comes out)
-            if (rc != TMAC_HIP_OK) c = nullptr;
-            if (c && !c->stream) { tmac_hip_chain_free(c); c = nullptr; }    // (a batch carries no dependence: anything but a stream is not worth a persistent launch)
+        // The calls of a batch are independent of each other (defer_if_on), so they may be regrouped: one recording per configuration
+        // a persistent kernel is instantiated for -- a caller that mixes 2- and 4-bit matrices (qgemm.py:98-116 allows any mix) gets one
+        // stream launch per width instead of a launch per call.
+        DeferEntry ne;
+        ne.sig = sig; ne.used = 0;
+        std::vector<char> taken(batch.size(), 0);
+        for (size_t i = 0; i < batch.size(); ++i) {
+            if (taken[i]) continue;
+            const tmac_hip_weights* wi = batch[i].w[0];
+            std::vector<uint32_t> grp;
+            for (size_t j = i; j < batch.size(); ++j) {
+                const tmac_hip_weights* wj = batch[j].w[0];
+                if (taken[j] || wj->s.bits != wi->s.bits || wj->s.zero_point != wi->s.zero_point || (wj->s.m_groups >= 1) != (wi->s.m_groups >= 1) ||
+                    wj->sc_dtype != wi->sc_dtype || batch[j].out != batch[i].out) continue;
+                taken[j] = 1; grp.push_back((uint32_t)j);
+            }
+            tmac_hip_chain* c = nullptr;
+            if (grp.size() >= 2 && !g_chain_rec) {
+                g_chain_rec = new std::vector<ChainRecOp>();
+                for (uint32_t j : grp) g_chain_rec->push_back(batch[j]);
+                g_chain_gat = new std::vector<ChainRecGather>();
+                memset(&g_chain_xf, 0, sizeof(g_chain_xf));
+                const int32_t rc = tmac_hip_chain_end(&c);          // (ends the recording whatever comes out)
+                if (rc != TMAC_HIP_OK) c = nullptr;
+                if (c && !c->stream) { tmac_hip_chain_free(c); c = nullptr; }    // (a batch carries no dependence: anything but a stream is not worth a persistent launch)
+            }
+            if (c) ne.chains.push_back(c);
+            else ne.singles.insert(ne.singles.end(), grp.begin(), grp.end());
         }
         if (D.cache.size() >= DEFER_CACHE) {                    // evict the least recently used recording
             size_t v = 0;
             for (size_t i = 1; i < D.cache.size(); ++i) if (D.cache[i].used < D.cache[v].used) v = i;
-            if (D.cache[v].chain) {
-                (void)hipStreamSynchronize(D.cache[v].chain->last_stream);
-                tmac_hip_chain_free(D.cache[v].chain);
-            }
+            defer_free_entry(D.cache[v], true);
             D.cache.erase(D.cache.begin() + (long)v);
         }
-        D.cache.push_back(DeferEntry{sig, c, 0});
+        D.cache.push_back(ne);
         hit = &D.cache.back();
     }
     hit->used = ++D.tick;
-    if (hit->chain) {
+    int32_t rc = TMAC_HIP_OK;
+    for (tmac_hip_chain* c : hit->chains) {
         ++D.n_stream;
-        return tmac_hip_chain_launch(hit->chain, st);
+        if ((rc = tmac_hip_chain_launch(c, st)) != TMAC_HIP_OK) return rc;
     }
     const bool was_on = D.on;
     D.on = false;                                               // call by call, as if never queued
-    int32_t rc = TMAC_HIP_OK;
-    for (const ChainRecOp& r : batch) {
+    for (uint32_t j : hit->singles) {
+        const ChainRecOp& r = batch[j];
         ++D.n_single;
         rc = fused_impl(r.w.data(), (int)r.w.size(), r.B, r.act, r.C.data(), r.out, 1, nullptr, nullptr, st);
         if (rc != TMAC_HIP_OK) break;
@@ -1064,7 +1090,7 @@ bool tmac_host::defer_if_on(const tmac_hip_weights* const* wl, int nmat, const v
 void tmac_host::defer_forget_all() { g_defer_epoch.fetch_add(1, std::memory_order_acq_rel); }
 void tmac_host::defer_release_thread() {          // the calling thread's cached recordings (nothing of them may be in flight: the caller has synchronised)
     DeferState& D = g_defer;
-    for (DeferEntry& e : D.cache) if (e.chain) tmac_hip_chain_free(e.chain);
+    for (DeferEntry& e : D.cache) defer_free_entry(e, false);
     D.cache.clear();
 }
 

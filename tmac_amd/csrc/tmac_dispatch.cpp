@@ -209,24 +209,33 @@ extern "C" int32_t tmac_hip_debug_gemm_image_read(const tmac_hip_workspace* ws, 
     if (!ws || !half_tables_host || !lut_scales_host || !lut_biases_host || !entry_sums_host) return fail(TMAC_HIP_E_ARG, "null argument");
     if (!ws->gimg_valid || N <= 0 || N > ws->N) return fail(TMAC_HIP_E_ARG, "the workspace holds no LUT image for N=%d", N);
     hipStream_t st = (hipStream_t)stream;
-    const int K = ws->K, G = ws->ags == K ? 1 : K / 64, Np = ws->gNpad;
+    const int K = ws->K, Np = ws->gNpad;
+    const bool rowwise = ws->ags == K && K != 64;      // one act group per row: k_preprocess_pairs_row's layout (K == 64: k_lut_image wrote last)
+    const int G = rowwise ? 1 : K / 64;
     std::vector<uint8_t> img((size_t)2 * K * Np);
-    std::vector<float> col((size_t)3 * G * Np);
+    std::vector<float> col((size_t)(rowwise ? 3 : 4) * G * Np);
     HIP_TRY(hipMemcpyAsync(img.data(), ws->gimg, img.size(), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(col.data(), ws->gcol, col.size() * sizeof(float), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     for (int n = 0; n < N; ++n) {
-        for (int t2 = 0; t2 < K / 8; ++t2) {           // pair t2 = tables 2 t2, 2 t2 + 1: unit t2 / 4, pair t2 % 4
-            const uint8_t* src = img.data() + (((size_t)(t2 >> 2) * 4 + (t2 & 3)) * Np + n) * 16;
-            memcpy(half_tables_host + ((size_t)n * (K / 4) + 2 * t2) * 8, src, 16);
+        for (int t2 = 0; t2 < K / 8; ++t2) {           // pair t2 = tables 2 t2, 2 t2 + 1: unit t2 / 4, pair t2 % 4; act group t2 / 8, part t2 % 8
+            const size_t u4 = rowwise ? ((size_t)(t2 >> 2) * 4 + (t2 & 3)) * Np + n
+                                      : (((size_t)(t2 >> 3) * (Np >> 6) + (n >> 6)) * 8 + (t2 & 7)) * 64 + (n & 63);
+            memcpy(half_tables_host + ((size_t)n * (K / 4) + 2 * t2) * 8, img.data() + u4 * 16, 16);
         }
         for (int kk = 0; kk < G; ++kk) {
-            lut_scales_host[(size_t)n * G + kk] = col[((size_t)0 * G + kk) * Np + n];
-            lut_biases_host[(size_t)n * G + kk] = col[((size_t)1 * G + kk) * Np + n];
-            const float es = col[((size_t)2 * G + kk) * Np + n];          // (one act group per row: int32 bits, see k_preprocess_pairs_row)
-            int32_t esi;
-            memcpy(&esi, &es, sizeof(esi));
-            entry_sums_host[(size_t)n * G + kk] = ws->ags == K ? (float)esi : es;
+            if (rowwise) {
+                lut_scales_host[n] = col[n];
+                lut_biases_host[n] = col[(size_t)Np + n];
+                int32_t esi;                               // (int32 bits, see k_preprocess_pairs_row)
+                memcpy(&esi, &col[(size_t)2 * Np + n], sizeof(esi));
+                entry_sums_host[n] = (float)esi;
+            } else {
+                const float* c4 = &col[((size_t)kk * Np + n) * 4];        // lut_scales / 2 | lut_biases / 2 | entry sum | lut_biases
+                lut_scales_host[(size_t)n * G + kk] = c4[0] * 2.0f;
+                lut_biases_host[(size_t)n * G + kk] = c4[3];
+                entry_sums_host[(size_t)n * G + kk] = c4[2];
+            }
         }
     }
     return TMAC_HIP_OK;

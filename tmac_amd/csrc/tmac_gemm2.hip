@@ -47,18 +47,22 @@ typedef int p4i_t __attribute__((ext_vector_type(4)));
 typedef int p16i_t __attribute__((ext_vector_type(16)));
 typedef float p2f_t __attribute__((ext_vector_type(2)));
 typedef float p4f_t __attribute__((ext_vector_type(4)));
+typedef float p16f_t __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------------
 // LUT build for the GEMM: the pair-wise build of k_preprocess_pairs (same arithmetic, lut_ctor.cc:120-215 bit for bit)
-// with 8 activation rows x 8 pairs per 64 lanes, written in the layout the GEMM streams:
-//   bimg [unit u][pair P][n] uint4   signed half tables of tables 2P, 2P+1 of unit u (32 activations) for row n
-//   colv [3][kk][n] float            lut_scales | lut_biases | sum of the act group's 128 half-table entries
-// n runs over Npad rows (rows >= N repeat row N-1: finite values, never stored).
+// with 8 activation rows x 8 pairs per 64 lanes, written in the layout the GEMM streams (round 6: chunk-major, so that everything a
+// step of k_gemm_planes fetches is ONE scalar offset plus immediates):
+//   bimg [act group kk][n tile = n / 64][part = 4 (unit & 1) + pair][n & 63] uint4   signed half tables of tables 2 pair, 2 pair + 1 of
+//                                                   unit 2 kk + (part >> 2) (32 activations) for row n: 8 KB per (act group, 64 rows)
+//   colv [kk][n] float4            lut_scales / 2 | lut_biases / 2 | sum of the act group's 128 half-table entries | lut_biases
+// (the halves are exact: what the reference multiplies by 0.5 in tbl.cc:464-526).  n runs over Npad rows (rows >= N repeat row N-1:
+// finite values, never stored).
 // ---------------------------------------------------------------------------------------------
 template <bool F16>
 __global__ __launch_bounds__(256) void k_lut_image(const void* __restrict__ B, uint4* __restrict__ bimg, float* __restrict__ colv,
                                                    int K, int N, int Npad) {
-    const int G = K / 64, kk = blockIdx.y;
+    const int kk = blockIdx.y;
     const int n = blockIdx.x * 32 + (threadIdx.x >> 3), p = threadIdx.x & 7;
     const int nn = min(n, N - 1);
     float x[8];
@@ -84,8 +88,7 @@ __global__ __launch_bounds__(256) void k_lut_image(const void* __restrict__ B, u
     float La, Lb;
     q_table8<true>(x[0], x[1], x[2], x[3], t_scales, lo0, hi0, La);
     q_table8<true>(x[4], x[5], x[6], x[7], t_scales, lo1, hi1, Lb);
-    const int u = 2 * kk + (p >> 2);
-    bimg[(size_t)(u * 4 + (p & 3)) * Npad + n] = make_uint4(lo0, hi0, lo1, hi1);
+    bimg[(((size_t)kk * (Npad >> 6) + (n >> 6)) * 8 + p) * 64 + (n & 63)] = make_uint4(lo0, hi0, lo1, hi1);
     // sum of the 16 signed entries of this lane's two half tables, then over the 8 lanes of the act group
     int h = 0;
     const uint32_t d[4] = {lo0, hi0, lo1, hi1};
@@ -103,9 +106,8 @@ __global__ __launch_bounds__(256) void k_lut_image(const void* __restrict__ B, u
     const float v = __fadd_rn(va, vb);
     const float c1 = qdpp_f<0x104>(v);
     if (p == 0) {
-        colv[((size_t)0 * G + kk) * Npad + n] = scales;
-        colv[((size_t)1 * G + kk) * Npad + n] = __fadd_rn(__fadd_rn(0.0f, v), c1);
-        colv[((size_t)2 * G + kk) * Npad + n] = (float)h;
+        const float lb = __fadd_rn(__fadd_rn(0.0f, v), c1);
+        reinterpret_cast<float4*>(colv)[(size_t)kk * Npad + n] = make_float4(__fmul_rn(0.5f, scales), __fmul_rn(0.5f, lb), (float)h, lb);
     }
 }
 
@@ -190,7 +192,11 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         wvoff[rt] = ODD ? (quad * nst * NJ * 64 + kb) * 16                      // the unit of the act group this lane's k half stands for
                         : ((quad * nst * NJ + (BITS == 2 ? kb : 2 * kb)) * 64) * 16;
     }
-    const int bvoff = (n0 + lane) * 16, cvoff = (n0 + j) * 4;
+    // chunk-major LUT image (k_lut_image): the chunk of (act group, n tile) is 8 KB in one piece, the column values one float4 per row
+    const int bvoff = lane * 16, cvoff = (n0 + j) * 16, chunk_stride = (a.Npad >> 6) * 8192, col_stride = a.Npad * 16;
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.SC), (short)0, 0x7fffffff, 0x00020000);
+    constexpr int SC_ESZ = SCF16 ? 2 : 4, SC_PER = ZP ? 2 : 1;
+    const int scvoff = (min((row0 >> 2) + (lane >> 2), nq - 1) * nsg * 4 + (lane & 3)) * SC_PER * SC_ESZ;   // quad_scale_index, group 0
     const uint32_t bb_wave = P_BB_OFF + w * P_BB_WAVE, sc_wave = P_SC_OFF + w * P_SC_WAVE;
 
     uint4 wv[WUN][2][WPU];                     // weights of the act group: [unit][tile row][..]
@@ -199,28 +205,38 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // round trip in the open once per weight group and wave (ISA reading, round 3)
     uint32_t st_sc = 0u, st_zr = 0u;
     float lbs[2] = {0.f, 0.f};                 // lut_biases summed over the act groups of the current weight group, per n tile
+#ifndef TMAC_G2_SC_KEEP
+#define TMAC_G2_SC_KEEP 0       // A/B knob: 1 = 1- / 2-bit weights keep the rows' weight scales in registers over the act groups of a weight group
+#endif
+    constexpr bool SCK = BITS <= 2 && TMAC_G2_SC_KEEP != 0;
+    p2f_t sck[SCK ? 2 : 1][8];
+    float za[2] = {0.f, 0.f}, zb[2] = {0.f, 0.f};   // pending zero-point update: A (zero points of the lane's row) and B (summed lut_biases of its column), see zero_stage
 
     // the act group's half tables, 64 activation rows: global -> LDS, no registers.  Issued in four parts (unit ul, pairs 2 h, 2 h + 1)
     // spread over the step: a vector-memory instruction holds its wave until the address path takes it, and all eight waves
     // feed the same path
+    // (the immediate offset counts on both sides, memory and LDS: one scalar offset and two LDS bases per chunk)
     auto dma_part = [&](int kk, int part) {
-        const int ul = part >> 1;
-#pragma unroll
-        for (int pr = 2 * (part & 1); pr < 2 * (part & 1) + 2; ++pr)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + (ul * 4 + pr) * 1024), 16, bvoff,
-                                                     ((2 * kk + ul) * 4 + pr) * a.Npad * 16, 0, 0);
+        const int ul = part >> 1, so = kk * chunk_stride + by * 8192 + ul * 4096;
+        if ((part & 1) == 0) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + ul * 4096), 16, bvoff, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + ul * 4096), 16, bvoff, so, 1024, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + ul * 4096), 16, bvoff, so, 2048, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + ul * 4096), 16, bvoff, so, 3072, 0);
+        }
     };
     auto dma_chunk = [&](int kk) {
 #pragma unroll
         for (int part = 0; part < 4; ++part) dma_part(kk, part);
     };
     auto load_weights = [&](int kk, int rt) {  // tile row rt of the act group's two units
+        const int u0 = 2 * kk, so = ((u0 >> 6) * NJ * 64 + (u0 & 63)) * 16;       // (the act group's second unit: + 16, an immediate)
 #pragma unroll
         for (int ul = 0; ul < WUN; ++ul) {
-            const int u = 2 * kk + ul, so = ((u >> 6) * NJ * 64 + (u & 63)) * 16;
 #pragma unroll
             for (int q = 0; q < WPU; ++q) {
-                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt], so + q * 1024, 0);
+                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt] + ul * 16 + q * 1024, so, 0);
                 wv[ul][rt][q] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
@@ -242,16 +258,15 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         return make_uint4(v.x, v.y, v.z, v.w);
     };
     auto load_staged = [&](int g) {            // scale / zero of row (row0 + lane), weight group g -> registers, raw (converted when written to LDS)
-        const int quad = min((row0 >> 2) + (lane >> 2), nq - 1);
-        const size_t si = quad_scale_index(s, quad, g, lane & 3, 0);
+        const int so = g * 4 * SC_PER * SC_ESZ;   // buffer loads: the lane's part of the address is a constant, the group a scalar offset
         if constexpr (SCF16) {
             // (scale, zero) is one aligned dword: kept whole, split when it is written to LDS -- splitting here is arithmetic on the
             // load's result, i.e. a wait for it
-            if (ZP) st_sc = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned short*>(M.SC) + si);
-            else st_sc = reinterpret_cast<const unsigned short*>(M.SC)[si];
+            if (ZP) st_sc = __builtin_amdgcn_raw_buffer_load_b32(rs_s, scvoff, so, 0);
+            else st_sc = __builtin_amdgcn_raw_buffer_load_b16(rs_s, scvoff, so, 0);
         } else {
-            st_sc = reinterpret_cast<const uint32_t*>(M.SC)[si];
-            if (ZP) st_zr = reinterpret_cast<const uint32_t*>(M.SC)[si + 1];
+            st_sc = __builtin_amdgcn_raw_buffer_load_b32(rs_s, scvoff, so, 0);
+            if (ZP) st_zr = __builtin_amdgcn_raw_buffer_load_b32(rs_s, scvoff + 4, so, 0);
         }
     };
     auto st_val = [&](uint32_t raw) -> float {
@@ -289,13 +304,10 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
 #endif
 #define PSTAMP_IN(step, i) do { if (TMAC_G2_STEP_STAMPS) PSTAMP(step, i); } while (0)
     PSTAMP(0, 5);
-    float cn[2][3];                            // column values (lut_scales, lut_biases, entry sums) of the NEXT act group, per n tile
+    u32x4q cn[2];                              // column values (lut_scales / 2, lut_biases / 2, entry sum, lut_biases) of the NEXT act group, per n tile
     auto load_cols = [&](int kk) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int c = 0; c < (BIASB ? 3 : 2); ++c)
-                cn[nt][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_c, cvoff + nt * 128, (c * G + kk) * a.Npad * 4, 0));
+        for (int nt = 0; nt < 2; ++nt) cn[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, cvoff + nt * 512, kk * col_stride, 0);
     };
     const bool work = k_lo < k_end;
     if (work) {                                // everything the first step needs is in flight while the operand rows are built
@@ -398,7 +410,8 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
                                            // the compiler orders every LDS read behind all LDS-DMA in flight with vmcnt(0))
         // B operands of the whole act group (both n tiles, four 32-deep steps); A operands and row scales of tile row 0
         p4i_t bv[2][4], av0[4], av1[4];
-        p2f_t sc0[8];
+        p2f_t sc0l[SCK ? 1 : 8];
+        p2f_t (&sc0)[8] = *reinterpret_cast<p2f_t (*)[8]>(SCK ? &sck[0][0] : &sc0l[0]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -409,32 +422,34 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
                 bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
             }
         build_av(0, av0);
-        read_rows(cbuf, 0, 0, sc0);
+        if (!SCK) read_rows(cbuf, 0, 0, sc0);
+        else if ((kk & apg_m) == 0 || kk == k_lo) { read_rows(cbuf, 0, 0, sck[0]); read_rows(cbuf, 0, 1, sck[1]); }   // the weight group's first act group
         // column values of the act group (loaded one step ahead): v = x * H + hlbx with x = comb * 2^-22, H = (ls / 2) * 2^22,
         // hlbx = lb / 2  [- 15 * (entry sum) * (ls / 2) for the +15 operand bias of W4]
         float H[2], hlbx[2], lb[2];
         int bias[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const float hls = __fmul_rn(0.5f, cn[nt][0]);
-            lb[nt] = cn[nt][1];
+            const float hls = __uint_as_float(cn[nt][0]);
+            lb[nt] = __uint_as_float(cn[nt][3]);
             H[nt] = MAGIC ? __fmul_rn(hls, 4194304.0f) : hls;
-            hlbx[nt] = __fmul_rn(0.5f, lb[nt]);
+            hlbx[nt] = __uint_as_float(cn[nt][1]);
             bias[nt] = 0;
             if (BIASB) {
-                const float hs15 = __fmul_rn((float)BIASB, cn[nt][2]);
+                const float hs15 = __fmul_rn((float)BIASB, __uint_as_float(cn[nt][2]));
                 hlbx[nt] = __fmaf_rn(-hs15, hls, hlbx[nt]);
                 bias[nt] = (int)hs15;
             }
         }
-        // PIPE (4-bit weights): the loads of the next act group are issued unconditionally (the last step fetches its own act group
-        // again: same bytes into the same places, drained before the reduction), so that the whole step is ONE basic block and the
-        // matrix-core chains and the fp32 chains are interleaved instruction by instruction (sched_group_barrier): a chain is four
-        // DEPENDENT MFMAs -- 32 cycles each during which the wave issues nothing unless independent work sits between them.  Measured
-        // (profiles/r03_gemm_planes_forms.txt D): W4 prefill -3 %; W1, W2, W3 within +-1 % (kept in the coarse order).
-        const int kn = PIPE ? (next ? kk + 1 : kk) : kk + 1;
+        // The loads of the next act group are issued unconditionally (the last step fetches its own act group again: same bytes into
+        // the same places, drained before the reduction): the step is ONE basic block (round 6 for every width: a branch per load group
+        // was 11 branches and ~35 scalar instructions per step).  PIPE (4-bit weights) also interleaves the matrix-core chains and the
+        // fp32 chains instruction by instruction (sched_group_barrier): a chain is four DEPENDENT MFMAs -- 32 cycles each during which
+        // the wave issues nothing unless independent work sits between them.  Measured (profiles/r03_gemm_planes_forms.txt D): W4
+        // prefill -3 %; W1, W2, W3 within +-1 % (kept in the coarse order).
+        const int kn = next ? kk + 1 : kk;
         if (more && g + 2 < g_hi) load_staged(g + 2);
-        if (PIPE || next) { load_cols(kn); load_weights(kn, 0); }
+        load_cols(kn); load_weights(kn, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_IN(kk - k_lo, 2);
@@ -492,6 +507,40 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
                 }
             }
         };
+#ifndef TMAC_G2_ZP_MFMA
+#define TMAC_G2_ZP_MFMA 1       // A/B knob: 0 = the zero-point term as 16 packed fp32 instructions per tile and weight group (rounds 2-5)
+#endif
+        // Round 6: the zero-point term of a weight group, zero[o] * (sum of its lut_biases)[n], is a rank-1 update of the 64 x 64 tile: two
+        // weight groups make one v_mfma_f32_32x32x2_f32 per 32 x 32 tile (k = the group's parity; lane (kb, j) holds row / column j of the
+        // group kb), i.e. 4 matrix-core instructions per two weight groups instead of 64 packed fp32 ones -- the step is bound by the
+        // number of instructions a wave issues, the matrix core is a quarter busy.  fp32 products and sums as before, in another order.
+        auto zero_stage = [&]() {              // (at the last act group of a weight group)
+            const float* zp = reinterpret_cast<const float*>(plds + sc_wave + cbuf * 512 + 256);
+            const bool mine = kb == cbuf;
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                const float z = zp[32 * rt + j];
+                za[rt] = mine ? z : (cbuf ? za[rt] : 0.f);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float l = __fadd_rn(lbs[nt], lb[nt]);
+                zb[nt] = mine ? l : (cbuf ? zb[nt] : 0.f);
+            }
+        };
+        auto zero_flush = [&]() {
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    p16f_t c;
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; ++r2) { c[2 * r2] = facc[rt][nt][r2].x; c[2 * r2 + 1] = facc[rt][nt][r2].y; }
+                    c = __builtin_amdgcn_mfma_f32_32x32x2f32(za[rt], zb[nt], c, 0, 0, 0);
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; ++r2) facc[rt][nt][r2] = (p2f_t){c[2 * r2], c[2 * r2 + 1]};
+                }
+        };
         auto zero_points = [&](int rt) {       // zero * (sum of lut_biases over the weight group), tbl.cc:497-505 regrouped
             p2f_t zr[8];
             read_rows(cbuf, 1, rt, zr);
@@ -506,8 +555,8 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         // tile pipeline: the MFMAs of tile t + 1 run under the fp32 chain of tile t (two accumulator sets)
         constexpr bool SC2 = BITS <= 2;        // W1, W2: tile row 1's scales in registers of their own, fetched early (W4 has none to spare)
         p16i_t ca, cb;
-        p2f_t sc1s[SC2 ? 8 : 1];
-        p2f_t (&sc1)[8] = *reinterpret_cast<p2f_t (*)[8]>(SC2 ? &sc1s[0] : &sc0[0]);
+        p2f_t sc1s[SC2 && !SCK ? 8 : 1];
+        p2f_t (&sc1)[8] = *reinterpret_cast<p2f_t (*)[8]>(SCK ? &sck[1][0] : SC2 ? &sc1s[0] : &sc0[0]);
         if constexpr (PIPE) {
         // MFMA | a few fp32 / address instructions [| LDS reads] | MFMA | ...: four times per region
 #define TMAC_G2_GROUPS(VALU_PER, DS_PER) do { _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) { \
@@ -521,7 +570,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         chain(av0, 1, cb);
         epilogue(0, 0, ca, sc0);
         build_av(1, av1);
-        if (SC2) read_rows(cbuf, 0, 1, sc1);
+        if (SC2 && !SCK) read_rows(cbuf, 0, 1, sc1);
         load_weights(kn, 1);
         TMAC_G2_GROUPS(8, 3);
         __builtin_amdgcn_sched_barrier(0);
@@ -539,42 +588,42 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         TMAC_G2_GROUPS(6, SC2 ? 0 : 1);
         __builtin_amdgcn_sched_barrier(0);
         epilogue(1, 1, cb, sc1);
-        if (ZP && glast) { zero_points(0); zero_points(1); }     // (behind the act group's own terms: one branch at the end of the block)
+        if (ZP && glast) {                     // (behind the act group's own terms: one branch at the end of the block)
+            if (TMAC_G2_ZP_MFMA) { zero_stage(); if (cbuf || g + 1 >= g_hi) zero_flush(); }
+            else { zero_points(0); zero_points(1); }
+        }
 #undef TMAC_G2_GROUPS
         } else {
-#ifndef TMAC_G2_DMA_EARLY
-#define TMAC_G2_DMA_EARLY 0      // A/B: how many of the next chunk's four DMA parts go out right behind the first MFMA chain (0: spread over the step)
-#endif
         chain(av0, 0, ca);
-        if (next) dma_part(kk + 1, 0);                     // (the chunk buffer has been read: lgkmcnt(0) above)
-        if (TMAC_G2_DMA_EARLY >= 2 && next) dma_part(kk + 1, 1);
-        if (TMAC_G2_DMA_EARLY >= 4 && next) { dma_part(kk + 1, 2); dma_part(kk + 1, 3); }
+        dma_part(kn, 0);                                   // (the chunk buffer has been read: lgkmcnt(0) above)
         chain(av0, 1, cb);
-        if (TMAC_G2_DMA_EARLY < 2 && next) dma_part(kk + 1, 1);
-        if (TMAC_G2_DMA_EARLY == 2 && next) { dma_part(kk + 1, 2); dma_part(kk + 1, 3); }
+        dma_part(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
         build_av(1, av1);
-        if (SC2) read_rows(cbuf, 0, 1, sc1);
-        if (next) load_weights(kk + 1, 1);
+        if (SC2 && !SCK) read_rows(cbuf, 0, 1, sc1);
+        load_weights(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_IN(kk - k_lo, 3);
         epilogue(0, 0, ca, sc0);
         __builtin_amdgcn_sched_barrier(0);
         chain(av1, 0, ca);
-        if (TMAC_G2_DMA_EARLY == 0 && next) dma_part(kk + 1, 2);
+        dma_part(kn, 2);
         __builtin_amdgcn_sched_barrier(0);
         epilogue(0, 1, cb, sc0);
         if (!SC2) read_rows(cbuf, 0, 1, sc1);
         __builtin_amdgcn_sched_barrier(0);
         chain(av1, 1, cb);
-        if (TMAC_G2_DMA_EARLY == 0 && next) dma_part(kk + 1, 3);
+        dma_part(kn, 3);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_IN(kk - k_lo, 4);
-        if (ZP && glast) zero_points(0);
+        if (ZP && glast && !TMAC_G2_ZP_MFMA) zero_points(0);
         epilogue(1, 0, ca, sc1);
         __builtin_amdgcn_sched_barrier(0);
         epilogue(1, 1, cb, sc1);
-        if (ZP && glast) zero_points(1);
+        if (ZP && glast) {
+            if (TMAC_G2_ZP_MFMA) { zero_stage(); if (cbuf || g + 1 >= g_hi) zero_flush(); }
+            else zero_points(1);
+        }
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) lbs[nt] = glast ? 0.f : __fadd_rn(lbs[nt], lb[nt]);
@@ -583,7 +632,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     __builtin_amdgcn_s_setprio(0);
     // ---- reduce the K ranges through LDS (operand rows and chunk buffers are free now) and store ------------------
     PSTAMP(1, 5);
-    if (PIPE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last step's (redundant) chunk DMA must not land in the reduction buffers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last step's (redundant) chunk DMA must not land in the reduction buffers
     __syncthreads();
     PSTAMP(1, 6);
     {

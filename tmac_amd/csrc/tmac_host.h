@@ -57,8 +57,8 @@ struct tmac_hip_workspace {
     int K = 0, N = 0, ags = 0;   // what the LUT currently holds
     size_t qdev_u4_per_row = 0;
     // the LUT as k_gemm_planes streams it (tmac_gemm2.hip): built next to the layouts above when N > 1 and ags = 64
-    void* gimg = nullptr;        // uint4 [maxK/32][4][gNpad]
-    float* gcol = nullptr;       // fp32 [3][K/64][gNpad]   (rows of the CURRENT K: the stride follows ws->K)
+    void* gimg = nullptr;        // 2 maxK gNpad bytes: the LUT image of the plane-combined GEMM (layouts: Gemm2Args, tmac_kernels.h)
+    float* gcol = nullptr;       // 4 (maxK / 64) gNpad floats: its column values
     int gNpad = 0;
     bool gimg_valid = false;
 };

@@ -74,8 +74,9 @@ struct Gemm2Args {
     GemmMat m[4];
     int nmat;
     int sc_f16, out_f16;
-    const uint4* bimg;        // uint4 [K/32 units][4 pairs][Npad]: signed half tables of tables 2P, 2P+1 of the unit, per activation row
-    const float* colv;        // fp32 [3][K/64][Npad]: lut_scales | lut_biases | sum of the act group's half-table entries
+    const uint4* bimg;        // per-group scales (k_lut_image): uint4 [K/64][Npad/64][8][64], the chunk of (act group, 64 rows) in one piece | unified
+                              // scales (k_preprocess_pairs_row): uint4 [K/32 units][4 pairs][Npad]: signed half tables of tables 2P, 2P+1 of the unit
+    const float* colv;        // per-group: float4 [K/64][Npad] = lut_scales / 2 | lut_biases / 2 | entry sum | lut_biases;  unified: fp32 [3][Npad]
     int Npad, N;
     int32_t* dump;            // optional tap [N][Mw][K/64]: sum_p 2^p PS_p (nmat == 1)
     int gx, gy;               // filled by the launcher: row blocks (64 rows, all matrices) and token blocks (64 rows of activations)

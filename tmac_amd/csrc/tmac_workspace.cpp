@@ -22,7 +22,7 @@ extern "C" int32_t tmac_hip_workspace_create(tmac_hip_workspace** out, int maxK,
     if (maxN > 1) {
         ws->gNpad = (maxN + 63) & ~63;
         if (e == hipSuccess) e = hipMalloc(&ws->gimg, (size_t)2 * maxK * ws->gNpad);
-        if (e == hipSuccess) e = hipMalloc((void**)&ws->gcol, sizeof(float) * 3 * (size_t)(maxK / 64) * ws->gNpad);
+        if (e == hipSuccess) e = hipMalloc((void**)&ws->gcol, sizeof(float) * 4 * (size_t)(maxK / 64) * ws->gNpad);
     }
     // The fills above are null-stream work and the workspace's users launch on streams of their own (the host-pointer layer
     // and the ggml glue on NON-BLOCKING streams, which the null stream does not order): a fill that lands after the first

@@ -216,7 +216,12 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // spread over the step: a vector-memory instruction holds its wave until the address path takes it, and all eight waves
     // feed the same path
     // (the immediate offset counts on both sides, memory and LDS: one scalar offset and two LDS bases per chunk)
+#ifndef TMAC_G2_KO
+#define TMAC_G2_KO 0            // timing experiments only (results wrong): 1 = half of the chunk DMA, 2 = no chunk DMA, 4 = no fp32 epilogue, 8 = no weight loads after the first
+#endif
     auto dma_part = [&](int kk, int part) {
+        if ((TMAC_G2_KO & 1) && (part & 1)) return;
+        if (TMAC_G2_KO & 2) return;
         const int ul = part >> 1, so = kk * chunk_stride + by * 8192 + ul * 4096;
         if ((part & 1) == 0) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + ul * 4096), 16, bvoff, so, 0, 0);
@@ -231,6 +236,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         for (int part = 0; part < 4; ++part) dma_part(kk, part);
     };
     auto load_weights = [&](int kk, int rt) {  // tile row rt of the act group's two units
+        if ((TMAC_G2_KO & 8) && kk != k_lo) return;
         const int u0 = 2 * kk, so = ((u0 >> 6) * NJ * 64 + (u0 & 63)) * 16;       // (the act group's second unit: + 16, an immediate)
 #pragma unroll
         for (int ul = 0; ul < WUN; ++ul) {
@@ -412,16 +418,24 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         p4i_t bv[2][4], av0[4], av1[4];
         p2f_t sc0l[SCK ? 1 : 8];
         p2f_t (&sc0)[8] = *reinterpret_cast<p2f_t (*)[8]>(SCK ? &sck[0][0] : &sc0l[0]);
+#ifndef TMAC_G2_LATE_WAIT
+#define TMAC_G2_LATE_WAIT 1     // A/B knob: 0 = every LDS operand of the step is waited for in front of the first MFMA (rounds 2-5)
+#endif
+        // Round 6: LDS returns in order, so the first chain starts as soon as ITS operands are there (n tile 0's B operands and tile row
+        // 0's gathers are issued first); the full wait sits in front of the next chunk's first DMA part, behind the first two chains.
+        auto read_b = [&](int nt) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int ks = 0; ks < 4; ++ks) {
                 // even widths: this k half = pair 2 kb + (ks & 1) of unit ks >> 1; odd: pair ks of unit kb
                 const int pslot = ODD ? kb * 4 + ks : (ks >> 1) * 4 + 2 * kb + (ks & 1);
                 const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (pslot * 64 + nt * 32 + j) * 16);
                 bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
             }
+        };
+        read_b(0);
+        if (!TMAC_G2_LATE_WAIT) read_b(1);
         build_av(0, av0);
+        if (TMAC_G2_LATE_WAIT) read_b(1);
         if (!SCK) read_rows(cbuf, 0, 0, sc0);
         else if ((kk & apg_m) == 0 || kk == k_lo) { read_rows(cbuf, 0, 0, sck[0]); read_rows(cbuf, 0, 1, sck[1]); }   // the weight group's first act group
         // column values of the act group (loaded one step ahead): v = x * H + hlbx with x = comb * 2^-22, H = (ls / 2) * 2^22,
@@ -450,7 +464,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         const int kn = next ? kk + 1 : kk;
         if (more && g + 2 < g_hi) load_staged(g + 2);
         load_cols(kn); load_weights(kn, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!TMAC_G2_LATE_WAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_IN(kk - k_lo, 2);
 
@@ -463,6 +477,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         auto epilogue = [&](int rt, int nt, const p16i_t& c, const p2f_t (&sc)[8]) {
             // three passes of independent instructions over the lane's 16 values (in place: int32 -> fp32 -> scaled), not
             // 8 dependent three-instruction chains through one temporary
+            if (TMAC_G2_KO & 4) { facc[rt][nt][0] += (p2f_t){__int_as_float(c[0]), __int_as_float(c[5])}; return; }
             const p2f_t h2 = {H[nt], H[nt]}, b2 = {hlbx[nt], hlbx[nt]};
             p2f_t x[8];
 #ifndef TMAC_G2_UNPACKED
@@ -563,6 +578,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0); \
             if (DS_PER) __builtin_amdgcn_sched_group_barrier(0x100, DS_PER, 0); } } while (0)
         chain(av0, 0, ca);
+        if (TMAC_G2_LATE_WAIT) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // the chunk buffer has been read
         dma_part(kn, 0);
         dma_part(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -595,8 +611,9 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
 #undef TMAC_G2_GROUPS
         } else {
         chain(av0, 0, ca);
-        dma_part(kn, 0);                                   // (the chunk buffer has been read: lgkmcnt(0) above)
         chain(av0, 1, cb);
+        if (TMAC_G2_LATE_WAIT) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // the chunk buffer has been read
+        dma_part(kn, 0);
         dma_part(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
         build_av(1, av1);

@@ -90,7 +90,7 @@ int32_t tmac_host::qgemm_impl(const tmac_hip_weights* w, const tmac_hip_workspac
         return fail(TMAC_HIP_E_NOMATCH, "fast-aggregation weights run on the two-kernel path only");
     // split entry points: tmac_hip_preprocessor_dev builds k_gemm_planes' LUT image from PLANES_MIN_N rows on (it does not know the
     // matrix); without the image only k_gemm_onehot's own, later crossover counts -- below it the row loop is the faster kernel
-    if (v == V_FUSED && !dump && ws->gimg_valid && planes_ok(w) && planes_image_fits(ws, w->s.K) && planes_pays(w->s, w->s.Mw, N)) {
+    if (v == V_FUSED && !dump && ws->gimg_valid && ws->gimg_kind == (w->s.m_groups >= 1 ? 1 : 2) && planes_ok(w) && planes_image_fits(ws, w->s.K) && planes_pays(w->s, w->s.Mw, N)) {
         void* cl[1] = {C_dev};
         return planes_multi(&w, 1, ws, cl, out_dtype, N, nullptr, st);
     }
@@ -178,7 +178,7 @@ extern "C" int32_t tmac_hip_debug_gemm_comb_sums(const tmac_hip_weights* w, cons
     if (!w || !ws_c || !comb_host) return fail(TMAC_HIP_E_ARG, "null argument");
     auto* ws = const_cast<tmac_hip_workspace*>(ws_c);
     hipStream_t st = (hipStream_t)stream;
-    if (!ws->gimg_valid || ws->K != w->s.K || N <= 0 || N > ws->N) return fail(TMAC_HIP_E_ARG, "the workspace holds no LUT image for K=%d, N=%d", w->s.K, N);
+    if (!ws->gimg_valid || ws->gimg_kind != (w->s.m_groups >= 1 ? 1 : 2) || ws->K != w->s.K || N <= 0 || N > ws->N) return fail(TMAC_HIP_E_ARG, "the workspace holds no LUT image for K=%d, N=%d", w->s.K, N);
     if (!planes_ok(w)) return fail(TMAC_HIP_E_NOMATCH, "k_gemm_planes does not cover this configuration");
     const size_t elems = (size_t)N * w->s.Mw * (w->s.m_groups >= 1 ? 1 : w->s.K / 64);
     if (ws->dump_elems < elems) {
@@ -210,7 +210,7 @@ extern "C" int32_t tmac_hip_debug_gemm_image_read(const tmac_hip_workspace* ws, 
     if (!ws->gimg_valid || N <= 0 || N > ws->N) return fail(TMAC_HIP_E_ARG, "the workspace holds no LUT image for N=%d", N);
     hipStream_t st = (hipStream_t)stream;
     const int K = ws->K, Np = ws->gNpad;
-    const bool rowwise = ws->ags == K && K != 64;      // one act group per row: k_preprocess_pairs_row's layout (K == 64: k_lut_image wrote last)
+    const bool rowwise = ws->gimg_kind == 1;           // one act group per row: k_preprocess_pairs_row's layout
     const int G = rowwise ? 1 : K / 64;
     std::vector<uint8_t> img((size_t)2 * K * Np);
     std::vector<float> col((size_t)(rowwise ? 3 : 4) * G * Np);

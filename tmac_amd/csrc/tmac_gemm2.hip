@@ -217,7 +217,8 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // feed the same path
     // (the immediate offset counts on both sides, memory and LDS: one scalar offset and two LDS bases per chunk)
 #ifndef TMAC_G2_KO
-#define TMAC_G2_KO 0            // timing experiments only (results wrong): 1 = half of the chunk DMA, 2 = no chunk DMA, 4 = no fp32 epilogue, 8 = no weight loads after the first
+#define TMAC_G2_KO 0            // timing experiments only (results wrong): 1 = half of the chunk DMA, 2 = no chunk DMA, 4 = no fp32 epilogue, 8 = no weight loads after the first,
+                                // 16 = no operand-row gathers, 32 = no B operand reads from LDS, 64 = no MFMA, 128 = no weight-scale rows from LDS
 #endif
     auto dma_part = [&](int kk, int part) {
         if ((TMAC_G2_KO & 1) && (part & 1)) return;
@@ -292,6 +293,11 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     };
     // accumulator rows of this lane in tile row rt: 8 q4 + 4 kb + (0..3), q4 = 0..3
     auto read_rows = [&](int buf, int which, int rt, p2f_t (&dst)[8]) {
+        if constexpr ((TMAC_G2_KO & 128) != 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dst[q] = (p2f_t){(float)(buf + q), (float)(which + rt)};
+            return;
+        }
         const unsigned char* p = plds + sc_wave + buf * 512 + which * 256;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
@@ -379,6 +385,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     auto build_av = [&](int rt, p4i_t (&av)[4]) {       // A operands of tile row rt: the joint plane index of (row, table) selects the operand row
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            if constexpr ((TMAC_G2_KO & 16) != 0) { const uint4 q = wv[0][rt][0]; av[ks] = (p4i_t){(int)q.x, (int)q.y, (int)q.z, (int)(q.w + ks)}; continue; }
             if constexpr (BITS == 1) {             // dword ks of the unit = tables 2 ks, 2 ks + 1
                 const uint4 q = wv[0][rt][0];
                 const uint4 g = pat_row2(ks == 0 ? q.x : ks == 1 ? q.y : ks == 2 ? q.z : q.w);
@@ -428,6 +435,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
             for (int ks = 0; ks < 4; ++ks) {
                 // even widths: this k half = pair 2 kb + (ks & 1) of unit ks >> 1; odd: pair ks of unit kb
                 const int pslot = ODD ? kb * 4 + ks : (ks >> 1) * 4 + 2 * kb + (ks & 1);
+                if constexpr ((TMAC_G2_KO & 32) != 0) { bv[nt][ks] = (p4i_t){(int)cn[nt][0], (int)cn[nt][1], pslot, nt}; continue; }
                 const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (pslot * 64 + nt * 32 + j) * 16);
                 bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
             }
@@ -469,6 +477,11 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         PSTAMP_IN(kk - k_lo, 2);
 
         auto chain = [&](const p4i_t (&av)[4], int nt, p16i_t& c) {      // one 32 x 32 tile of the act group: four dependent MFMAs
+            if constexpr ((TMAC_G2_KO & 64) != 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c[r] = cinit[r] + av[r & 3][r >> 2] + bv[nt][r & 3][r >> 2];
+                return;
+            }
             c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[0], bv[nt][0], cinit, 0, 0, 0);
 #pragma unroll
             for (int ks = 1; ks < 4; ++ks) c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[ks], bv[nt][ks], c, 0, 0, 0);

@@ -61,6 +61,7 @@ struct tmac_hip_workspace {
     float* gcol = nullptr;       // 4 (maxK / 64) gNpad floats: its column values
     int gNpad = 0;
     bool gimg_valid = false;
+    int gimg_kind = 0;           // 1: row-wise image (one act group per row, k_gemm_planes_us) | 2: chunk-major image (act groups of 64, k_gemm_planes)
 };
 
 namespace tmac_host {

@@ -80,11 +80,11 @@ extern "C" int32_t tmac_hip_preprocessor_dev(tmac_hip_workspace* ws, const void*
         : launch_preprocess(B_dev, (Dtype)act_dtype, ws->qlut_ref, ws->qlut_dev, ws->qlut_lds, ws->lut_scales, ws->lut_biases,
                             K, N, act_group_size, ws->qdev_u4_per_row, (hipStream_t)stream);
     if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "preprocess launch: %s", hipGetErrorString(e));
-    ws->gimg_valid = row_img;
+    ws->gimg_valid = row_img; ws->gimg_kind = row_img ? 1 : 0;
     if (act_group_size == 64 && N >= gmin && ws->gimg && g_knobs.gemm_kernel != 1) {   // what k_gemm_planes streams (tmac_hip_qgemm_dev may pick it)
         e = launch_lut_image(B_dev, act_dtype == TMAC_F16, ws->gimg, ws->gcol, K, N, ws->gNpad, (hipStream_t)stream);
         if (e != hipSuccess) return fail(TMAC_HIP_E_RUNTIME, "LUT image launch: %s", hipGetErrorString(e));
-        ws->gimg_valid = true;
+        ws->gimg_valid = true; ws->gimg_kind = 2;      // (K == 64 with one act group per row: this image wins, the unified-scale GEMM is not offered it)
     }
     return TMAC_HIP_OK;
 }

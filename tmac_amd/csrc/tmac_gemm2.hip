@@ -37,6 +37,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "tmac_quad_core.h"
 #include "tmac_kernels.h"
@@ -142,10 +143,32 @@ typedef __attribute__((address_space(3))) void* p_lds_ptr;
 
 // Everything the main loop loads goes through buffer instructions: per-lane byte offsets are computed once, the part that
 // changes from act group to act group is a scalar offset (no vector address arithmetic in the loop).
+#ifndef TMAC_G2_BDIRECT
+#define TMAC_G2_BDIRECT 1       // A/B knob: 0 = the step's half tables go global -> LDS by DMA and LDS -> registers (rounds 2-5)
+#endif
+// Round 6 (per-group scales): the B operands of a step -- the half tables of 64 activation rows, 8 KB -- go global -> REGISTERS, each
+// 16-byte piece straight to the lane whose MFMA operand it is (the chunk-major image is laid out for exactly that), into the registers
+// of the operand they replace, issued right behind the last chain that reads it: no LDS chunk buffers, no DMA pieces (an LDS-DMA
+// piece costs a wave 100-185 cycles of issue in a busy phase, MI355X_MICROARCH.md; the knock-out of the eight pieces was worth 21 %
+// of the prefill line, profiles/r06_prefill_step_diet.txt), no B reads from LDS, no hand-placed vmcnt(0) (the compiler counts register
+// loads).  The freed LDS gives the four-wave form the 32 conflict-free copies of the operand rows the eight-wave form has.
+template <int NWV>
+struct PFormD {
+    static constexpr int COPIES = 32;
+    static constexpr int PAT_BYTES = 256 * COPIES * 8;
+    static constexpr int BB_OFF = PAT_BYTES, BB_WAVE = 0;
+    static constexpr int SC_OFF = PAT_BYTES;
+    static constexpr int SC_WAVE = 2 * 512;
+    static constexpr int LDS_BYTES = (SC_OFF + NWV * SC_WAVE) > NWV * 16384 ? (SC_OFF + NWV * SC_WAVE) : NWV * 16384;
+};
+constexpr bool G2_BD = TMAC_G2_BDIRECT != 0;
+template <int NWV> using PFormG = typename std::conditional<G2_BD, PFormD<NWV>, PForm<NWV>>::type;
+
 template <int BITS, bool ZP, bool DUMP, bool SCF16, int NWV>
 __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
-    using PF = PForm<NWV>;
+    using PF = PFormG<NWV>;
+    constexpr bool BD = G2_BD, C32 = PF::COPIES == 32;
     constexpr int P_NWV = NWV, P_BB_OFF = PF::BB_OFF, P_BB_WAVE = PF::BB_WAVE, P_SC_OFF = PF::SC_OFF, P_SC_WAVE = PF::SC_WAVE;
     constexpr int NJ = BITS;                   // uint4 per unit and row quad in the QUAD layout
     constexpr bool ODD = (BITS & 1) != 0;      // 1- / 3-bit weights: 16-byte table entries, a lane holds one whole unit per tile row
@@ -180,8 +203,8 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // v_perm selector that builds an operand-row address from a weight dword: byte 0 = copy offset, byte 1 = byte beta of the dword
     const uint32_t psel = 0x0c0c0000u | ((4u + (lane & 3)) << 8);
     // even widths: 32 (16) copies of 8 bytes; odd: 16 (8) copies of 16 bytes.  Four-wave form: entry stride 128 B = the perm's 256 B halved
-    const uint32_t copyoff = ODD ? (NWV == 8 ? (uint32_t)(lane & 15) * 16u : (uint32_t)(lane & 7) * 32u)
-                                 : (NWV == 8 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u);
+    const uint32_t copyoff = ODD ? (C32 ? (uint32_t)(lane & 15) * 16u : (uint32_t)(lane & 7) * 32u)
+                                 : (C32 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.W), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.bimg), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.colv), (short)0, 0x7fffffff, 0x00020000);
@@ -220,7 +243,24 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
 #define TMAC_G2_KO 0            // timing experiments only (results wrong): 1 = half of the chunk DMA, 2 = no chunk DMA, 4 = no fp32 epilogue, 8 = no weight loads after the first,
                                 // 16 = no operand-row gathers, 32 = no B operand reads from LDS, 64 = no MFMA, 128 = no weight-scale rows from LDS
 #endif
+    p4i_t bv[2][4];                            // B operands: [n tile][32-deep step]; direct form: loaded a step ahead, in place
+    // lane (kb, j), step ks, n tile nt: the 16 bytes at uint4 (pslot 64 + nt 32 + j) of the chunk, pslot = pair 2 kb + (ks & 1) of unit ks >> 1
+    // (odd widths: pair ks of unit kb)
+    const int bdvoff = ((ODD ? kb * 4 : 2 * kb) * 64 + j) * 16;
+    auto load_b = [&](int kk, int nt) {
+        if constexpr (!BD) return;
+        if (TMAC_G2_KO & 2) return;
+        const int so = kk * chunk_stride + by * 8192;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if ((TMAC_G2_KO & 1) && (ks & 1)) continue;
+            const int c = ODD ? (ks * 64 + nt * 32) * 16 : ((ks & 1) * 64 + nt * 32) * 16;
+            const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, bdvoff + c, ODD ? so : so + (ks >> 1) * 4096, 0);
+            bv[nt][ks] = (p4i_t){(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+        }
+    };
     auto dma_part = [&](int kk, int part) {
+        if constexpr (BD) return;
         if ((TMAC_G2_KO & 1) && (part & 1)) return;
         if (TMAC_G2_KO & 2) return;
         const int ul = part >> 1, so = kk * chunk_stride + by * 8192 + ul * 4096;
@@ -256,12 +296,12 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     typedef __attribute__((address_space(3))) const p4u_t* lds_u4_ptr;
     auto pat_row = [&](uint32_t d) -> uint2 {
         const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        const p2u_t v = *(lds_u2_ptr)(uintptr_t)(NWV == 8 ? ad : ad >> 1);
+        const p2u_t v = *(lds_u2_ptr)(uintptr_t)(C32 ? ad : ad >> 1);
         return make_uint2(v.x, v.y);
     };
     auto pat_row2 = [&](uint32_t d) -> uint4 {  // odd widths: the operand rows of the byte's two nibbles
         const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        const p4u_t v = *(lds_u4_ptr)(uintptr_t)(NWV == 8 ? ad : ad >> 1);
+        const p4u_t v = *(lds_u4_ptr)(uintptr_t)(C32 ? ad : ad >> 1);
         return make_uint4(v.x, v.y, v.z, v.w);
     };
     auto load_staged = [&](int g) {            // scale / zero of row (row0 + lane), weight group g -> registers, raw (converted when written to LDS)
@@ -324,6 +364,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     const bool work = k_lo < k_end;
     if (work) {                                // everything the first step needs is in flight while the operand rows are built
         dma_chunk(k_lo);
+        load_b(k_lo, 0); load_b(k_lo, 1);
         load_weights(k_lo, 0);
         load_weights(k_lo, 1);
         load_cols(k_lo);
@@ -351,9 +392,15 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         }
         if (!ODD) { lo1 = lo; hi1 = hi; }
         // NWV = 8: two threads per entry (256 B = 32 copies of 8 bytes / 16 of 16), NWV = 4: one (128 B = 16 / 8 copies)
+        if constexpr (C32 && NWV == 4) {       // one thread per entry, 256 B = 32 copies of 8 bytes / 16 of 16
+            uint4* pt = reinterpret_cast<uint4*>(plds) + b * 16;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) pt[(c + b) & 15] = make_uint4(lo, hi, lo1, hi1);
+        } else {
         uint4* pt = reinterpret_cast<uint4*>(plds) + (NWV == 8 ? b * 16 + (tid >> 8) * 8 : b * 8);
 #pragma unroll
         for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo1, hi1);   // 8 consecutive entries (lanes) -> 8 different 16-byte slots of the rows
+        }
     }
     __syncthreads();
 
@@ -374,7 +421,10 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // exactly for |comb| < 2^21 (it is < 2^19 here), so int -> float is one packed subtraction per pair.  The 16 registers are
     // made opaque to the compiler, which otherwise rebuilds the constant vector with 15 moves in front of every chain.
     // W4 has no registers to spare for that: its chains start from zero and the conversion is 16 v_cvt_f32_i32 per tile.
-    constexpr bool MAGIC = BITS <= 2;
+#ifndef TMAC_G2_MAGIC_MAX_BITS
+#define TMAC_G2_MAGIC_MAX_BITS 2
+#endif
+    constexpr bool MAGIC = BITS <= TMAC_G2_MAGIC_MAX_BITS;
     constexpr int CI = MAGIC ? 0x40400000 : 0;
     p16i_t cinit = {CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI};
     if (MAGIC) asm volatile("" : "+v"(cinit));
@@ -417,12 +467,12 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         // the older wave of a SIMD wins every issue conflict (its four K ranges finish ~15 % earlier and then wait at the
         // reduction): alternate the priority between the two waves of a SIMD step by step
         if (NWV == 8) { if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk of kk is in LDS, its weights, column values and the staged scales in registers
+        if (!BD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk of kk is in LDS, its weights, column values and the staged scales in registers
         PSTAMP_IN(kk - k_lo, 1);
         if (more) write_staged(g + 1);     // (its successor is fetched behind this step's LDS reads: a load in front of them is waited for --
                                            // the compiler orders every LDS read behind all LDS-DMA in flight with vmcnt(0))
         // B operands of the whole act group (both n tiles, four 32-deep steps); A operands and row scales of tile row 0
-        p4i_t bv[2][4], av0[4], av1[4];
+        p4i_t av0[4], av1[4];
         p2f_t sc0l[SCK ? 1 : 8];
         p2f_t (&sc0)[8] = *reinterpret_cast<p2f_t (*)[8]>(SCK ? &sck[0][0] : &sc0l[0]);
 #ifndef TMAC_G2_LATE_WAIT
@@ -431,6 +481,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         // Round 6: LDS returns in order, so the first chain starts as soon as ITS operands are there (n tile 0's B operands and tile row
         // 0's gathers are issued first); the full wait sits in front of the next chunk's first DMA part, behind the first two chains.
         auto read_b = [&](int nt) {
+            if constexpr (BD) return;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 // even widths: this k half = pair 2 kb + (ks & 1) of unit ks >> 1; odd: pair ks of unit kb
@@ -591,7 +642,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0); \
             if (DS_PER) __builtin_amdgcn_sched_group_barrier(0x100, DS_PER, 0); } } while (0)
         chain(av0, 0, ca);
-        if (TMAC_G2_LATE_WAIT) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // the chunk buffer has been read
+        if (TMAC_G2_LATE_WAIT && !BD) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // the chunk buffer has been read
         dma_part(kn, 0);
         dma_part(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -609,12 +660,16 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         dma_part(kn, 2);
         TMAC_G2_GROUPS(6, 0);
         __builtin_amdgcn_sched_barrier(0);
+        load_b(kn, 0);                         // n tile 0's operands have been read by their last chain (behind the barrier: a load the
+        __builtin_amdgcn_sched_barrier(0);     // scheduler hoists above that chain needs registers of its own and a copy at the loop's end)
         // region 3: chain (1, 1) | fp32 chain of tile (1, 0)
         if (!SC2) read_rows(cbuf, 0, 1, sc1);
         chain(av1, 1, cb);
         epilogue(1, 0, ca, sc1);
         dma_part(kn, 3);
         TMAC_G2_GROUPS(6, SC2 ? 0 : 1);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
         epilogue(1, 1, cb, sc1);
         if (ZP && glast) {                     // (behind the act group's own terms: one branch at the end of the block)
@@ -625,7 +680,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         } else {
         chain(av0, 0, ca);
         chain(av0, 1, cb);
-        if (TMAC_G2_LATE_WAIT) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // the chunk buffer has been read
+        if (TMAC_G2_LATE_WAIT && !BD) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // the chunk buffer has been read
         dma_part(kn, 0);
         dma_part(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -638,12 +693,14 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         __builtin_amdgcn_sched_barrier(0);
         chain(av1, 0, ca);
         dma_part(kn, 2);
+        load_b(kn, 0);                         // (n tile 0's operands have been read by their last chain)
         __builtin_amdgcn_sched_barrier(0);
         epilogue(0, 1, cb, sc0);
         if (!SC2) read_rows(cbuf, 0, 1, sc1);
         __builtin_amdgcn_sched_barrier(0);
         chain(av1, 1, cb);
         dma_part(kn, 3);
+        load_b(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_IN(kk - k_lo, 4);
         if (ZP && glast && !TMAC_G2_ZP_MFMA) zero_points(0);
@@ -953,7 +1010,8 @@ hipError_t launch_gemm_planes(const Gemm2Args& a_in, hipStream_t st) {
     // (4-bit weights: the four-wave form only pays from about four tiles per CU on -- q/k/v at N = 256, three per CU, loses 6 % with it)
     const int nwv = a.form == 1 ? 8 : a.form == 2 ? 4 : (gx * a.gy > (a.s.bits == 4 && a.s.m_groups < 1 ? 4 : 1) * n_cu ? 4 : 8);
     dim3 g(((gx + 7) & ~7) * a.gy), b(64 * nwv);
-    const int lds_bytes = nwv == 8 ? PForm<8>::LDS_BYTES : PForm<4>::LDS_BYTES;
+    const bool us = a.s.m_groups >= 1;          // (the unified-scale kernel keeps the LDS chunk buffers)
+    const int lds_bytes = nwv == 8 ? (us ? PForm<8>::LDS_BYTES : PFormG<8>::LDS_BYTES) : (us ? PForm<4>::LDS_BYTES : PFormG<4>::LDS_BYTES);
 #define PLAUNCH(KERNEL) do { \
         static bool attr_set = false; \
         if (!attr_set) { \

@@ -163,6 +163,13 @@ struct PFormD {
 };
 constexpr bool G2_BD = TMAC_G2_BDIRECT != 0;
 template <int NWV> using PFormG = typename std::conditional<G2_BD, PFormD<NWV>, PForm<NWV>>::type;
+template <int NWV>
+struct PFormDU {                 // the unified-scale kernel's direct form: operand rows only (the reduction reuses them)
+    static constexpr int COPIES = 32;
+    static constexpr int BB_OFF = 0, BB_WAVE = 0;
+    static constexpr int LDS_BYTES = 65536 > NWV * 16384 ? 65536 : NWV * 16384;
+};
+template <int NWV> using PFormU = typename std::conditional<G2_BD, PFormDU<NWV>, PForm<NWV>>::type;
 
 template <int BITS, bool ZP, bool DUMP, bool SCF16, int NWV>
 __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) {
@@ -176,7 +183,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     constexpr int WUN = ODD ? 1 : 2;
     constexpr int BIASB = BITS == 4 ? 15 : BITS == 3 ? 7 : 0;   // what the biased operand bytes add per half-table entry
 #ifndef TMAC_G2_PIPE_MIN_BITS
-#define TMAC_G2_PIPE_MIN_BITS 4
+#define TMAC_G2_PIPE_MIN_BITS 5
 #endif
     constexpr bool PIPE = BITS >= TMAC_G2_PIPE_MIN_BITS;         // instruction-level MFMA / fp32 interleave of a step (see the step loop)
     const Shape& s = a.s;
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // raw scale / zero of row (row0 + lane) of the NEXT weight group, staged.  One slot, not two by parity: a register array indexed by a
     // run-time parity made every load land through a select, i.e. behind an s_waitcnt vmcnt(0) right after its issue -- a full memory
     // round trip in the open once per weight group and wave (ISA reading, round 3)
-    uint32_t st_sc = 0u, st_zr = 0u;
+    uint32_t st_sc = 0u, st_zr = 0u, st0_sc = 0u, st0_zr = 0u;
     float lbs[2] = {0.f, 0.f};                 // lut_biases summed over the act groups of the current weight group, per n tile
 #ifndef TMAC_G2_SC_KEEP
 #define TMAC_G2_SC_KEEP 0       // A/B knob: 1 = 1- / 2-bit weights keep the rows' weight scales in registers over the act groups of a weight group
@@ -363,12 +370,16 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     };
     const bool work = k_lo < k_end;
     if (work) {                                // everything the first step needs is in flight while the operand rows are built
+        // (in the order a step issues them for its successor: the compiler merges the wait counts of both ways into the loop, and a
+        // prologue in another order turned the first waits of every step into vmcnt(0) -- a drain of the B loads issued last)
         dma_chunk(k_lo);
-        load_b(k_lo, 0); load_b(k_lo, 1);
+        load_staged(g_lo);
+        st0_sc = st_sc; st0_zr = st_zr;        // (the first group's values: written to LDS behind the table's barrier)
+        load_staged(g_lo + 1 < g_hi ? g_lo + 1 : g_lo);     // ... and the second group's, where every later step has its staged load: in front
+        load_cols(k_lo);
         load_weights(k_lo, 0);
         load_weights(k_lo, 1);
-        load_cols(k_lo);
-        load_staged(g_lo);
+        load_b(k_lo, 0); load_b(k_lo, 1);
     }
 
     // ---- joint-index operand rows: entry b = (i1 << 4) | i0, byte e = s(i0) [e == i0 & 7] + 2 s(i1) [e == i1 & 7] (+ 3 for W4)
@@ -414,8 +425,10 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
 
     PSTAMP(0, 6);
     if (work) {
+        const uint32_t k_sc = st_sc, k_zr = st_zr;
+        st_sc = st0_sc; st_zr = st0_zr;
         write_staged(g_lo);
-        if (g_lo + 1 < g_hi) load_staged(g_lo + 1);
+        st_sc = k_sc; st_zr = k_zr;
     }
     // accumulators start from the bits of 3.0f, the middle of the binade [2, 4): as a float the int32 result is 3 + comb * 2^-22
     // exactly for |comb| < 2^21 (it is < 2^19 here), so int -> float is one packed subtraction per pair.  The 16 registers are
@@ -521,7 +534,9 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         // the wave issues nothing unless independent work sits between them.  Measured (profiles/r03_gemm_planes_forms.txt D): W4
         // prefill -3 %; W1, W2, W3 within +-1 % (kept in the coarse order).
         const int kn = next ? kk + 1 : kk;
-        if (more && g + 2 < g_hi) load_staged(g + 2);
+        // every step, no condition (a conditional load cannot be counted: its consumer got vmcnt(0), a drain of the B loads): the scales of the
+        // group behind the NEXT step's group -- at the last act group of g that is g + 2, before that g + 1 once more (the same dword again)
+        { const int gs2 = ((kn >> apg_sh) + 1 < g_hi) ? (kn >> apg_sh) + 1 : g_hi - 1; load_staged(gs2); }
         load_cols(kn); load_weights(kn, 0);
         if (!TMAC_G2_LATE_WAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -772,7 +787,8 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
 template <int BITS, bool DUMP, int NWV>
 __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
-    using PF = PForm<NWV>;
+    using PF = PFormU<NWV>;
+    constexpr bool BD = G2_BD, C32 = PF::COPIES == 32;
     constexpr int P_NWV = NWV, P_BB_OFF = PF::BB_OFF, P_BB_WAVE = PF::BB_WAVE;
     constexpr int NJ = BITS;
     constexpr bool ODD = (BITS & 1) != 0;      // see k_gemm_planes: 16-byte table entries, a lane holds one whole unit per tile row
@@ -795,8 +811,8 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
     const int k_lo = (w * nk) / P_NWV, k_end = ((w + 1) * nk) / P_NWV;        // 64-activation steps of this wave
 
     const uint32_t psel = 0x0c0c0000u | ((4u + (lane & 3)) << 8);
-    const uint32_t copyoff = ODD ? (NWV == 8 ? (uint32_t)(lane & 15) * 16u : (uint32_t)(lane & 7) * 32u)
-                                 : (NWV == 8 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u);
+    const uint32_t copyoff = ODD ? (C32 ? (uint32_t)(lane & 15) * 16u : (uint32_t)(lane & 7) * 32u)
+                                 : (C32 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.W), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.bimg), (short)0, 0x7fffffff, 0x00020000);
     int wvoff[2];
@@ -809,7 +825,21 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
     const int bvoff = (n0 + lane) * 16;
     const uint32_t bb_wave = P_BB_OFF + w * P_BB_WAVE;
     uint4 wv[WUN][2][WPU];
+    // direct form (round 6, see PFormD): the B operands go global -> registers, the 16 bytes of (unit, pair, row) straight to the lane
+    // whose operand they are, into the registers of the step before as soon as its MFMAs have read them
+    p4i_t bv[2][4];
+    const int bdvoff = ((ODD ? 4 * kb : 2 * kb) * a.Npad + n0 + j) * 16;
+    auto load_b = [&](int kk, int ks) {
+        if constexpr (!BD) return;
+        const int so = (ODD ? 8 * kk + ks : (2 * kk + (ks >> 1)) * 4 + (ks & 1)) * a.Npad * 16;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, bdvoff + nt * 512, so, 0);
+            bv[nt][ks] = (p4i_t){(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
+        }
+    };
     auto dma_chunk = [&](int kk) {
+        if constexpr (BD) return;
 #pragma unroll
         for (int ul = 0; ul < 2; ++ul)
 #pragma unroll
@@ -832,16 +862,20 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
     typedef unsigned int p4u_t __attribute__((ext_vector_type(4)));
     auto pat_row = [&](uint32_t d) -> uint2 {
         const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        const p2u_t v = *(__attribute__((address_space(3))) const p2u_t*)(uintptr_t)(NWV == 8 ? ad : ad >> 1);   // absolute LDS address (see k_gemm_planes)
+        const p2u_t v = *(__attribute__((address_space(3))) const p2u_t*)(uintptr_t)(C32 ? ad : ad >> 1);   // absolute LDS address (see k_gemm_planes)
         return make_uint2(v.x, v.y);
     };
     auto pat_row2 = [&](uint32_t d) -> uint4 {   // odd widths: the operand rows of the byte's two nibbles
         const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        const p4u_t v = *(__attribute__((address_space(3))) const p4u_t*)(uintptr_t)(NWV == 8 ? ad : ad >> 1);
+        const p4u_t v = *(__attribute__((address_space(3))) const p4u_t*)(uintptr_t)(C32 ? ad : ad >> 1);
         return make_uint4(v.x, v.y, v.z, v.w);
     };
     const bool work = k_lo < k_end;
-    if (work) { dma_chunk(k_lo); load_weights(k_lo, 0); load_weights(k_lo, 1); }
+    if (work) {
+        dma_chunk(k_lo); load_weights(k_lo, 0); load_weights(k_lo, 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) load_b(k_lo, ks);
+    }
     {   // joint-index operand rows, as in k_gemm_planes
         const int b = tid & 255, i0 = b & 15, i1 = b >> 4;
         uint32_t lo = 0, hi = 0, lo1 = 0, hi1 = 0;
@@ -861,9 +895,15 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
             }
         }
         if (!ODD) { lo1 = lo; hi1 = hi; }
+        if constexpr (C32 && NWV == 4) {
+            uint4* pt = reinterpret_cast<uint4*>(plds) + b * 16;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) pt[(c + b) & 15] = make_uint4(lo, hi, lo1, hi1);
+        } else {
         uint4* pt = reinterpret_cast<uint4*>(plds) + (NWV == 8 ? b * 16 + (tid >> 8) * 8 : b * 8);
 #pragma unroll
         for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo1, hi1);
+        }
     }
     __syncthreads();
 
@@ -877,17 +917,18 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
     for (int kk = k_lo; kk < k_end; ++kk) {
         const bool next = kk + 1 < k_end;
         if (NWV == 8) { if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        p4i_t bv[2][4];
+        if (!BD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!BD) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                // even widths: this k half = pair 2 kb + (ks & 1) of unit ks >> 1; odd: pair ks of unit kb
-                const int pslot = ODD ? kb * 4 + ks : (ks >> 1) * 4 + 2 * kb + (ks & 1);
-                const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (pslot * 64 + nt * 32 + j) * 16);
-                bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-            }
+                for (int nt = 0; nt < 2; ++nt) {
+                    // even widths: this k half = pair 2 kb + (ks & 1) of unit ks >> 1; odd: pair ks of unit kb
+                    const int pslot = ODD ? kb * 4 + ks : (ks >> 1) * 4 + 2 * kb + (ks & 1);
+                    const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (pslot * 64 + nt * 32 + j) * 16);
+                    bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+                }
+        }
         p4i_t av[2][4];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -913,15 +954,20 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
                     av[rt][ks] = (p4i_t){(int)(a0.x + (a1.x << 2)), (int)(a0.y + (a1.y << 2)), (int)(b0.x + (b1.x << 2)), (int)(b0.y + (b1.y << 2))};
                 }
             }
-        if (next) { load_weights(kk + 1, 0); load_weights(kk + 1, 1); }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (next) dma_chunk(kk + 1);
+        const int kn = next ? kk + 1 : kk;     // (direct form: the last step fetches its own operands again -- one basic block, counted waits)
+        if (BD || next) { load_weights(kn, 0); load_weights(kn, 1); }
+        if (!BD) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (next) dma_chunk(kk + 1);
+        }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[rt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[rt][ks], bv[nt][ks], acc[rt][nt], 0, 0, 0);
+            if (BD) { __builtin_amdgcn_sched_barrier(0); load_b(kn, ks); __builtin_amdgcn_sched_barrier(0); }
+        }
     }
     __builtin_amdgcn_s_setprio(0);
     __syncthreads();
@@ -1007,11 +1053,13 @@ hipError_t launch_gemm_planes(const Gemm2Args& a_in, hipStream_t st) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v < 1) v = 256;
         n_cu = v;
     }
-    // (4-bit weights: the four-wave form only pays from about four tiles per CU on -- q/k/v at N = 256, three per CU, loses 6 % with it)
-    const int nwv = a.form == 1 ? 8 : a.form == 2 ? 4 : (gx * a.gy > (a.s.bits == 4 && a.s.m_groups < 1 ? 4 : 1) * n_cu ? 4 : 8);
+    // (rounds 3-5: 4-bit weights took the four-wave form only from four tiles per CU on -- its 16 operand-row copies cost them two-way bank
+    // conflicts and a shift per gather, twice as many as 2-bit weights have; with 32 copies in both forms one rule serves every width:
+    // q/k/v W4 at N = 256, three tiles per CU, 8.20 -> 7.88 ms per 256 tokens with the four-wave form)
+    const int nwv = a.form == 1 ? 8 : a.form == 2 ? 4 : (gx * a.gy > n_cu ? 4 : 8);
     dim3 g(((gx + 7) & ~7) * a.gy), b(64 * nwv);
-    const bool us = a.s.m_groups >= 1;          // (the unified-scale kernel keeps the LDS chunk buffers)
-    const int lds_bytes = nwv == 8 ? (us ? PForm<8>::LDS_BYTES : PFormG<8>::LDS_BYTES) : (us ? PForm<4>::LDS_BYTES : PFormG<4>::LDS_BYTES);
+    const bool us = a.s.m_groups >= 1;
+    const int lds_bytes = nwv == 8 ? (us ? PFormU<8>::LDS_BYTES : PFormG<8>::LDS_BYTES) : (us ? PFormU<4>::LDS_BYTES : PFormG<4>::LDS_BYTES);
 #define PLAUNCH(KERNEL) do { \
         static bool attr_set = false; \
         if (!attr_set) { \

@@ -693,6 +693,47 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         }
 #undef TMAC_G2_GROUPS
         } else {
+#ifndef TMAC_G2_ORDER
+#define TMAC_G2_ORDER 0         // A/B knob: 1 = tiles in the order (0,0) (1,0) (0,1) (1,1).  Measured SLOWER (W2 6.44 -> 6.58 ms, W4 7.74 -> 7.91, profiles/r06_prefill_step_diet.txt E)
+#endif
+        if constexpr (BD && TMAC_G2_ORDER != 0) {
+        // (experiment) n tile 0's two tiles first, so that ITS B operands are dead after the second chain and their successors get the rest
+        // of the step to arrive.  It lost: what the B loads cost is their 8 KB through the CU's one vector-memory path, not their latency.
+#ifndef TMAC_G2_SC_SHARE
+#define TMAC_G2_SC_SHARE 1      // 1: ONE set of 16 row-scale registers, read from LDS in front of every fp32 chain (LDS is nearly idle in the direct form;
+#endif                          //    two sets put the kernel over 256 registers: a scratch reload inside the loop = a vmcnt(0) drain per weight group)
+        constexpr bool SHARE = TMAC_G2_SC_SHARE != 0 && !SCK;
+        build_av(1, av1);
+        if (!SHARE && SC2 && !SCK) read_rows(cbuf, 0, 1, sc1);
+        load_weights(kn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        chain(av0, 0, ca);
+        chain(av1, 0, cb);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(kn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue(0, 0, ca, sc0);
+        __builtin_amdgcn_sched_barrier(0);
+        chain(av0, 1, ca);
+        __builtin_amdgcn_sched_barrier(0);
+        if (SHARE) read_rows(cbuf, 0, 1, sc0); else if (!SC2) read_rows(cbuf, 0, 1, sc1);
+        epilogue(1, 0, cb, SHARE ? sc0 : sc1);
+        __builtin_amdgcn_sched_barrier(0);
+        chain(av1, 1, cb);
+        __builtin_amdgcn_sched_barrier(0);
+        load_b(kn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ZP && glast && !TMAC_G2_ZP_MFMA) zero_points(0);
+        if (SHARE) read_rows(cbuf, 0, 0, sc0);
+        epilogue(0, 1, ca, sc0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (SHARE) read_rows(cbuf, 0, 1, sc0);
+        epilogue(1, 1, cb, SHARE ? sc0 : sc1);
+        if (ZP && glast) {
+            if (TMAC_G2_ZP_MFMA) { zero_stage(); if (cbuf || g + 1 >= g_hi) zero_flush(); }
+            else zero_points(1);
+        }
+        } else {
         chain(av0, 0, ca);
         chain(av0, 1, cb);
         if (TMAC_G2_LATE_WAIT && !BD) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // the chunk buffer has been read
@@ -725,6 +766,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         if (ZP && glast) {
             if (TMAC_G2_ZP_MFMA) { zero_stage(); if (cbuf || g + 1 >= g_hi) zero_flush(); }
             else zero_points(1);
+        }
         }
         }
 #pragma unroll

@@ -470,6 +470,18 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
             }
         }
     };
+#ifndef TMAC_G2_ORDER
+#define TMAC_G2_ORDER 0         // A/B knob: 1 = tiles in the order (0,0) (1,0) (0,1) (1,1).  Measured SLOWER (W2 6.44 -> 6.58 ms, W4 7.74 -> 7.91, profiles/r06_prefill_step_diet.txt E)
+#endif
+#ifndef TMAC_G2_AV_PREFETCH
+#define TMAC_G2_AV_PREFETCH 0   // A/B knob: 1 = tile row 0's operand rows of the NEXT step gathered at the end of the step.  No gain (W2 6.42 / 6.43 ms, W4 7.70 / 7.72): off
+#endif
+    // (experiment) tile row 0's A operands of the NEXT step gathered at the end of the step, under the last two fp32 chains, into the
+    // registers the step's own have left after its second chain: a step then starts with MFMAs instead of eight perm + LDS round trips.
+    // Like every other latency lever of this round it changed nothing: the step is bound by what it moves and issues, not by waiting.
+    constexpr bool AVP = BD && !PIPE && TMAC_G2_ORDER == 0 && TMAC_G2_AV_PREFETCH != 0;
+    p4i_t av0[4];
+    if (AVP && work) build_av(0, av0);
     for (int kk = k_lo; kk < k_end; ++kk) {
         const int g = kk >> apg_sh;
         const bool glast = (kk & apg_m) == apg_m;          // last act group of its weight group
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         if (more) write_staged(g + 1);     // (its successor is fetched behind this step's LDS reads: a load in front of them is waited for --
                                            // the compiler orders every LDS read behind all LDS-DMA in flight with vmcnt(0))
         // B operands of the whole act group (both n tiles, four 32-deep steps); A operands and row scales of tile row 0
-        p4i_t av0[4], av1[4];
+        p4i_t av1[4];
         p2f_t sc0l[SCK ? 1 : 8];
         p2f_t (&sc0)[8] = *reinterpret_cast<p2f_t (*)[8]>(SCK ? &sck[0][0] : &sc0l[0]);
 #ifndef TMAC_G2_LATE_WAIT
@@ -506,10 +518,10 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         };
         read_b(0);
         if (!TMAC_G2_LATE_WAIT) read_b(1);
-        build_av(0, av0);
+        if (!AVP) build_av(0, av0);
         if (TMAC_G2_LATE_WAIT) read_b(1);
         if (!SCK) read_rows(cbuf, 0, 0, sc0);
-        else if ((kk & apg_m) == 0 || kk == k_lo) { read_rows(cbuf, 0, 0, sck[0]); read_rows(cbuf, 0, 1, sck[1]); }   // the weight group's first act group
+        else if ((kk & apg_m) == 0 || kk == k_lo) { read_rows(cbuf, 0, 0, sck[0]); read_rows(cbuf, 0, 1, sck[SCK ? 1 : 0]); }   // the weight group's first act group
         // column values of the act group (loaded one step ahead): v = x * H + hlbx with x = comb * 2^-22, H = (ls / 2) * 2^22,
         // hlbx = lb / 2  [- 15 * (entry sum) * (ls / 2) for the +15 operand bias of W4]
         float H[2], hlbx[2], lb[2];
@@ -693,9 +705,6 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         }
 #undef TMAC_G2_GROUPS
         } else {
-#ifndef TMAC_G2_ORDER
-#define TMAC_G2_ORDER 0         // A/B knob: 1 = tiles in the order (0,0) (1,0) (0,1) (1,1).  Measured SLOWER (W2 6.44 -> 6.58 ms, W4 7.74 -> 7.91, profiles/r06_prefill_step_diet.txt E)
-#endif
         if constexpr (BD && TMAC_G2_ORDER != 0) {
         // (experiment) n tile 0's two tiles first, so that ITS B operands are dead after the second chain and their successors get the rest
         // of the step to arrive.  It lost: what the B loads cost is their 8 KB through the CU's one vector-memory path, not their latency.
@@ -758,6 +767,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         dma_part(kn, 3);
         load_b(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
+        if (AVP) { build_av(0, av0); __builtin_amdgcn_sched_barrier(0); }      // (the next step's: wv[..][0] holds its weights since the top of this step)
         PSTAMP_IN(kk - k_lo, 4);
         if (ZP && glast && !TMAC_G2_ZP_MFMA) zero_points(0);
         epilogue(1, 0, ca, sc1);

@@ -143,6 +143,12 @@ typedef __attribute__((address_space(3))) void* p_lds_ptr;
 
 // Everything the main loop loads goes through buffer instructions: per-lane byte offsets are computed once, the part that
 // changes from act group to act group is a scalar offset (no vector address arithmetic in the loop).
+#ifndef TMAC_G2_B_AUX
+#define TMAC_G2_B_AUX 0          // cache policy of the B operand loads (2 = nt) and of the weight loads: A/B knobs
+#endif
+#ifndef TMAC_G2_W_AUX
+#define TMAC_G2_W_AUX 0
+#endif
 #ifndef TMAC_G2_BDIRECT
 #define TMAC_G2_BDIRECT 1       // A/B knob: 0 = the step's half tables go global -> LDS by DMA and LDS -> registers (rounds 2-5)
 #endif
@@ -262,7 +268,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         for (int ks = 0; ks < 4; ++ks) {
             if ((TMAC_G2_KO & 1) && (ks & 1)) continue;
             const int c = ODD ? (ks * 64 + nt * 32) * 16 : ((ks & 1) * 64 + nt * 32) * 16;
-            const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, bdvoff + c, ODD ? so : so + (ks >> 1) * 4096, 0);
+            const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, bdvoff + c, ODD ? so : so + (ks >> 1) * 4096, TMAC_G2_B_AUX);
             bv[nt][ks] = (p4i_t){(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
         }
     };
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         for (int ul = 0; ul < WUN; ++ul) {
 #pragma unroll
             for (int q = 0; q < WPU; ++q) {
-                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt] + ul * 16 + q * 1024, so, 0);
+                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt] + ul * 16 + q * 1024, so, TMAC_G2_W_AUX);
                 wv[ul][rt][q] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }

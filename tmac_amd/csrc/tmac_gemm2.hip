@@ -29,10 +29,15 @@
 // v_mfma_i32_32x32x32_i8: one instruction = 32 output rows x 32 activation rows x 4 tables.  Wave tile 64 x 64 (2 x 2
 // MFMA tiles); a workgroup = 8 (or 4: PForm below) waves = ONE 64 x 64 output tile, the waves split K by weight groups and reduce through
 // LDS at the end (at N = 256 a llama-2-7B projection has only 256 such tiles: one per CU; a larger workgroup tile would
-// idle most of the chip).  Each wave is on its own between the kernel's two barriers: it streams its half-table chunks
-// global -> LDS (buffer_load ... lds, no registers), its weights, column values and weight scales global -> registers one
-// act group ahead, through buffer instructions whose only varying part is a scalar offset.
-// Roofline: int8 MFMA; ops = 2 * Mw * (K / 4 * 8) * N.  Measured: instruction-issue bound.
+// idle most of the chip).  Each wave is on its own between the kernel's two barriers.  Round 6: everything a step loads goes global ->
+// REGISTERS one act group ahead through buffer instructions whose only varying part is a scalar offset -- the B operands (half tables of
+// 64 activation rows, 8 KB per step) each 16-byte piece straight to the lane whose MFMA operand it is, into the registers of the
+// operand it replaces (PFormD; rounds 2-5 moved them global -> LDS by DMA and LDS -> registers), weights, column values, weight scales.
+// LDS holds the operand-row table (32 copies) and the rows' weight scales only.  All waits are counted by the compiler (the prologue
+// issues its loads in the loop's order; no conditional loads).
+// Roofline: int8 MFMA; ops = 2 * Mw * (K / 4 * 8) * N.  Measured (profiles/r06_prefill_step_diet.txt): bound by what a step
+// moves and issues -- the B operands' 64 distinct cache lines through the CU's vector-memory path 34 %, the per-act-group fp32 chain
+// 18 %, the matrix core 14 %, the operand-row gathers 13 % -- not by latency.
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>

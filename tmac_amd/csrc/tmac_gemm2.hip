@@ -32,7 +32,7 @@
 // idle most of the chip).  Each wave is on its own between the kernel's two barriers.  Round 6: everything a step loads goes global ->
 // REGISTERS one act group ahead through buffer instructions whose only varying part is a scalar offset -- the B operands (half tables of
 // 64 activation rows, 8 KB per step) each 16-byte piece straight to the lane whose MFMA operand it is, into the registers of the
-// operand it replaces (PFormD; rounds 2-5 moved them global -> LDS by DMA and LDS -> registers), weights, column values, weight scales.
+// operand it replaces (rounds 2-5 moved them global -> LDS by DMA and LDS -> registers), weights, column values, weight scales.
 // LDS holds the operand-row table (32 copies) and the rows' weight scales only.  All waits are counted by the compiler (the prologue
 // issues its loads in the loop's order; no conditional loads).
 // Roofline: int8 MFMA; ops = 2 * Mw * (K / 4 * 8) * N.  Measured (profiles/r06_prefill_step_diet.txt): bound by what a step
@@ -42,7 +42,6 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include <type_traits>
 
 #include "tmac_quad_core.h"
 #include "tmac_kernels.h"
@@ -127,76 +126,51 @@ hipError_t launch_lut_image(const void* B, int act_f16, void* bimg, float* colv,
 
 // ---------------------------------------------------------------------------------------------
 // Two forms of the workgroup (same tile, same arithmetic, same order of the fp32 sums within a K range):
-//   NWV = 8: eight K ranges, 32 copies of the operand rows (no bank conflict), 136 KB of LDS -- one workgroup per CU.  For
-//            launches with at most one tile per CU (o / down projection at N = 256): all of a CU's waves work on its one tile.
-//   NWV = 4: four K ranges, 16 copies (lanes j and j + 16 share one: two-way conflicts at most, the address needs one more
-//            shift), 68 KB -- TWO workgroups per CU, each with one wave per SIMD.  A tile's fixed phases (operand rows 2.3 us,
-//            K-range reduction and store 1.3 us, the wait for its slowest wave) then overlap the other workgroup's main
-//            loop, and a wave whose SIMD partner is in such a phase runs its steps 40 % faster (profiles/r03_gemm_planes_forms.txt).
+//   NWV = 8: eight K ranges, 128 KB of LDS (the K-range reduction) -- one workgroup per CU.  For launches with at most one tile per CU
+//            (o / down projection at N = 256): all of a CU's waves work on its one tile.
+//   NWV = 4: four K ranges, 68 KB -- TWO workgroups per CU, each with one wave per SIMD.  A tile's fixed phases (operand rows,
+//            K-range reduction and store 1.3 us, the wait for its slowest wave) then overlap the other workgroup's main loop.
+// LDS: the joint-index operand rows in 32 copies (copy = lane & 31, entry stride 256 B: a wave's gather never has a bank conflict),
+// then the weight scales / zeros of every wave's 64 rows [wave][buffer 2][sc 64 | zr 64] float; the reduction reuses the front.
+// Rounds 2-5 also kept a half-table chunk buffer per wave there, filled by LDS-DMA (8 x 1 KB pieces per step) and read back into the B
+// operands; round 6 loads the B operands global -> registers (below).  What that and the other steps bought, the knock-outs and the
+// experiments that lost (fp32 / MFMA interleave, another tile order, operand-row prefetch, scales kept in registers, cache-policy
+// bits, the magic conversion for W4) are in profiles/r06_prefill_step_diet.txt; the code of each is in the history of this file.
 template <int NWV>
 struct PForm {
-    static constexpr int COPIES = NWV == 8 ? 32 : 16;
-    static constexpr int PAT_BYTES = 256 * COPIES * 8;          // joint-index operand rows
-    static constexpr int BB_OFF = PAT_BYTES;                    // half-table chunk of one act group: [wave][unit 2][pair 4][n 64] uint4
-    static constexpr int BB_WAVE = 8192;
-    static constexpr int SC_OFF = BB_OFF + NWV * BB_WAVE;       // weight scales / zeros of the wave's 64 rows: [wave][buffer][sc 64 | zr 64] float
-    static constexpr int SC_WAVE = 2 * 512;
-    static constexpr int LDS_BYTES = SC_OFF + NWV * SC_WAVE;    // >= NWV * 16384 (the reduction reuses the front)
-};
-
-typedef __attribute__((address_space(3))) void* p_lds_ptr;
-
-// Everything the main loop loads goes through buffer instructions: per-lane byte offsets are computed once, the part that
-// changes from act group to act group is a scalar offset (no vector address arithmetic in the loop).
-#ifndef TMAC_G2_B_AUX
-#define TMAC_G2_B_AUX 0          // cache policy of the B operand loads (2 = nt) and of the weight loads: A/B knobs
-#endif
-#ifndef TMAC_G2_W_AUX
-#define TMAC_G2_W_AUX 0
-#endif
-#ifndef TMAC_G2_BDIRECT
-#define TMAC_G2_BDIRECT 1       // A/B knob: 0 = the step's half tables go global -> LDS by DMA and LDS -> registers (rounds 2-5)
-#endif
-// Round 6 (per-group scales): the B operands of a step -- the half tables of 64 activation rows, 8 KB -- go global -> REGISTERS, each
-// 16-byte piece straight to the lane whose MFMA operand it is (the chunk-major image is laid out for exactly that), into the registers
-// of the operand they replace, issued right behind the last chain that reads it: no LDS chunk buffers, no DMA pieces (an LDS-DMA
-// piece costs a wave 100-185 cycles of issue in a busy phase, MI355X_MICROARCH.md; the knock-out of the eight pieces was worth 21 %
-// of the prefill line, profiles/r06_prefill_step_diet.txt), no B reads from LDS, no hand-placed vmcnt(0) (the compiler counts register
-// loads).  The freed LDS gives the four-wave form the 32 conflict-free copies of the operand rows the eight-wave form has.
-template <int NWV>
-struct PFormD {
-    static constexpr int COPIES = 32;
-    static constexpr int PAT_BYTES = 256 * COPIES * 8;
-    static constexpr int BB_OFF = PAT_BYTES, BB_WAVE = 0;
+    static constexpr int PAT_BYTES = 256 * 32 * 8;
     static constexpr int SC_OFF = PAT_BYTES;
     static constexpr int SC_WAVE = 2 * 512;
     static constexpr int LDS_BYTES = (SC_OFF + NWV * SC_WAVE) > NWV * 16384 ? (SC_OFF + NWV * SC_WAVE) : NWV * 16384;
 };
-constexpr bool G2_BD = TMAC_G2_BDIRECT != 0;
-template <int NWV> using PFormG = typename std::conditional<G2_BD, PFormD<NWV>, PForm<NWV>>::type;
 template <int NWV>
-struct PFormDU {                 // the unified-scale kernel's direct form: operand rows only (the reduction reuses them)
-    static constexpr int COPIES = 32;
-    static constexpr int BB_OFF = 0, BB_WAVE = 0;
+struct PFormU {                  // the unified-scale kernel: operand rows only (the reduction reuses them)
     static constexpr int LDS_BYTES = 65536 > NWV * 16384 ? 65536 : NWV * 16384;
 };
-template <int NWV> using PFormU = typename std::conditional<G2_BD, PFormDU<NWV>, PForm<NWV>>::type;
 
+#ifndef TMAC_G2_KO
+#define TMAC_G2_KO 0            // timing experiments only (results wrong): 1 = half of the B operand loads, 2 = none of them, 4 = no fp32 chain, 8 = no weight
+                                // loads after the first, 16 = no operand-row gathers, 64 = no MFMA, 128 = no weight-scale rows from LDS
+#endif
+
+// Everything a step loads goes global -> registers one act group ahead through buffer instructions: per-lane byte offsets are computed
+// once, the part that changes from act group to act group is a scalar offset (no vector address arithmetic in the loop).  The B
+// operands -- the half tables of 64 activation rows, 8 KB per step -- go each 16-byte piece straight to the lane whose MFMA operand it
+// is (the chunk-major image of k_lut_image is laid out for exactly that), INTO THE REGISTERS OF THE OPERAND THEY REPLACE, issued right
+// behind the last chain that reads it.  The loads of the next act group are unconditional (the last step fetches its own act group
+// again, harmlessly): the step is one basic block and every wait is counted by the compiler -- for that the prologue issues its loads
+// in the order a step does (the wait counts of both ways into the loop are merged: another order, or a conditional load, turned waits
+// of every step into vmcnt(0), a drain of the B loads issued last).
 template <int BITS, bool ZP, bool DUMP, bool SCF16, int NWV>
 __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
-    using PF = PFormG<NWV>;
-    constexpr bool BD = G2_BD, C32 = PF::COPIES == 32;
-    constexpr int P_NWV = NWV, P_BB_OFF = PF::BB_OFF, P_BB_WAVE = PF::BB_WAVE, P_SC_OFF = PF::SC_OFF, P_SC_WAVE = PF::SC_WAVE;
+    using PF = PForm<NWV>;
+    constexpr int P_NWV = NWV, P_SC_OFF = PF::SC_OFF, P_SC_WAVE = PF::SC_WAVE;
     constexpr int NJ = BITS;                   // uint4 per unit and row quad in the QUAD layout
     constexpr bool ODD = (BITS & 1) != 0;      // 1- / 3-bit weights: 16-byte table entries, a lane holds one whole unit per tile row
     constexpr int WPU = ODD ? BITS : BITS / 2; // uint4 of weights per lane, tile row and [even widths: unit | odd: act group]
     constexpr int WUN = ODD ? 1 : 2;
     constexpr int BIASB = BITS == 4 ? 15 : BITS == 3 ? 7 : 0;   // what the biased operand bytes add per half-table entry
-#ifndef TMAC_G2_PIPE_MIN_BITS
-#define TMAC_G2_PIPE_MIN_BITS 5
-#endif
-    constexpr bool PIPE = BITS >= TMAC_G2_PIPE_MIN_BITS;         // instruction-level MFMA / fp32 interleave of a step (see the step loop)
     const Shape& s = a.s;
     const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int kb = lane >> 5, j = lane & 31;
@@ -220,12 +194,11 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // ---- per-lane constants and the first loads (they do not need the operand rows built below) ------------------------
     // v_perm selector that builds an operand-row address from a weight dword: byte 0 = copy offset, byte 1 = byte beta of the dword
     const uint32_t psel = 0x0c0c0000u | ((4u + (lane & 3)) << 8);
-    // even widths: 32 (16) copies of 8 bytes; odd: 16 (8) copies of 16 bytes.  Four-wave form: entry stride 128 B = the perm's 256 B halved
-    const uint32_t copyoff = ODD ? (C32 ? (uint32_t)(lane & 15) * 16u : (uint32_t)(lane & 7) * 32u)
-                                 : (C32 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u);
+    const uint32_t copyoff = ODD ? (uint32_t)(lane & 15) * 16u : (uint32_t)j * 8u;     // even widths: 32 copies of 8 bytes; odd: 16 copies of 16 bytes
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.W), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.bimg), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.colv), (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.SC), (short)0, 0x7fffffff, 0x00020000);
     int wvoff[2];                              // byte offset of (row quad of this lane in tile row rt, uint4 kb [W2] / 2 kb [W4]) in the weights
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -234,65 +207,32 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
                         : ((quad * nst * NJ + (BITS == 2 ? kb : 2 * kb)) * 64) * 16;
     }
     // chunk-major LUT image (k_lut_image): the chunk of (act group, n tile) is 8 KB in one piece, the column values one float4 per row
-    const int bvoff = lane * 16, cvoff = (n0 + j) * 16, chunk_stride = (a.Npad >> 6) * 8192, col_stride = a.Npad * 16;
-    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.SC), (short)0, 0x7fffffff, 0x00020000);
+    const int cvoff = (n0 + j) * 16, chunk_stride = (a.Npad >> 6) * 8192, col_stride = a.Npad * 16;
     constexpr int SC_ESZ = SCF16 ? 2 : 4, SC_PER = ZP ? 2 : 1;
     const int scvoff = (min((row0 >> 2) + (lane >> 2), nq - 1) * nsg * 4 + (lane & 3)) * SC_PER * SC_ESZ;   // quad_scale_index, group 0
-    const uint32_t bb_wave = P_BB_OFF + w * P_BB_WAVE, sc_wave = P_SC_OFF + w * P_SC_WAVE;
+    const uint32_t sc_wave = P_SC_OFF + w * P_SC_WAVE;
 
     uint4 wv[WUN][2][WPU];                     // weights of the act group: [unit][tile row][..]
     // raw scale / zero of row (row0 + lane) of the NEXT weight group, staged.  One slot, not two by parity: a register array indexed by a
-    // run-time parity made every load land through a select, i.e. behind an s_waitcnt vmcnt(0) right after its issue -- a full memory
-    // round trip in the open once per weight group and wave (ISA reading, round 3)
+    // run-time parity made every load land through a select, i.e. behind an s_waitcnt vmcnt(0) right after its issue (ISA reading, round 3)
     uint32_t st_sc = 0u, st_zr = 0u, st0_sc = 0u, st0_zr = 0u;
     float lbs[2] = {0.f, 0.f};                 // lut_biases summed over the act groups of the current weight group, per n tile
-#ifndef TMAC_G2_SC_KEEP
-#define TMAC_G2_SC_KEEP 0       // A/B knob: 1 = 1- / 2-bit weights keep the rows' weight scales in registers over the act groups of a weight group
-#endif
-    constexpr bool SCK = BITS <= 2 && TMAC_G2_SC_KEEP != 0;
-    p2f_t sck[SCK ? 2 : 1][8];
     float za[2] = {0.f, 0.f}, zb[2] = {0.f, 0.f};   // pending zero-point update: A (zero points of the lane's row) and B (summed lut_biases of its column), see zero_stage
 
-    // the act group's half tables, 64 activation rows: global -> LDS, no registers.  Issued in four parts (unit ul, pairs 2 h, 2 h + 1)
-    // spread over the step: a vector-memory instruction holds its wave until the address path takes it, and all eight waves
-    // feed the same path
-    // (the immediate offset counts on both sides, memory and LDS: one scalar offset and two LDS bases per chunk)
-#ifndef TMAC_G2_KO
-#define TMAC_G2_KO 0            // timing experiments only (results wrong): 1 = half of the chunk DMA, 2 = no chunk DMA, 4 = no fp32 epilogue, 8 = no weight loads after the first,
-                                // 16 = no operand-row gathers, 32 = no B operand reads from LDS, 64 = no MFMA, 128 = no weight-scale rows from LDS
-#endif
-    p4i_t bv[2][4];                            // B operands: [n tile][32-deep step]; direct form: loaded a step ahead, in place
+    p4i_t bv[2][4];                            // B operands: [n tile][32-deep step], loaded a step ahead, in place
     // lane (kb, j), step ks, n tile nt: the 16 bytes at uint4 (pslot 64 + nt 32 + j) of the chunk, pslot = pair 2 kb + (ks & 1) of unit ks >> 1
     // (odd widths: pair ks of unit kb)
     const int bdvoff = ((ODD ? kb * 4 : 2 * kb) * 64 + j) * 16;
     auto load_b = [&](int kk, int nt) {
-        if constexpr (!BD) return;
         if (TMAC_G2_KO & 2) return;
         const int so = kk * chunk_stride + by * 8192;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if ((TMAC_G2_KO & 1) && (ks & 1)) continue;
             const int c = ODD ? (ks * 64 + nt * 32) * 16 : ((ks & 1) * 64 + nt * 32) * 16;
-            const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, bdvoff + c, ODD ? so : so + (ks >> 1) * 4096, TMAC_G2_B_AUX);
+            const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, bdvoff + c, ODD ? so : so + (ks >> 1) * 4096, 0);
             bv[nt][ks] = (p4i_t){(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
         }
-    };
-    auto dma_part = [&](int kk, int part) {
-        if constexpr (BD) return;
-        if ((TMAC_G2_KO & 1) && (part & 1)) return;
-        if (TMAC_G2_KO & 2) return;
-        const int ul = part >> 1, so = kk * chunk_stride + by * 8192 + ul * 4096;
-        if ((part & 1) == 0) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + ul * 4096), 16, bvoff, so, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + ul * 4096), 16, bvoff, so, 1024, 0);
-        } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + ul * 4096), 16, bvoff, so, 2048, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + ul * 4096), 16, bvoff, so, 3072, 0);
-        }
-    };
-    auto dma_chunk = [&](int kk) {
-#pragma unroll
-        for (int part = 0; part < 4; ++part) dma_part(kk, part);
     };
     auto load_weights = [&](int kk, int rt) {  // tile row rt of the act group's two units
         if ((TMAC_G2_KO & 8) && kk != k_lo) return;
@@ -301,7 +241,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         for (int ul = 0; ul < WUN; ++ul) {
 #pragma unroll
             for (int q = 0; q < WPU; ++q) {
-                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt] + ul * 16 + q * 1024, so, TMAC_G2_W_AUX);
+                const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvoff[rt] + ul * 16 + q * 1024, so, 0);
                 wv[ul][rt][q] = make_uint4(v[0], v[1], v[2], v[3]);
             }
         }
@@ -313,13 +253,11 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     typedef __attribute__((address_space(3))) const p2u_t* lds_u2_ptr;
     typedef __attribute__((address_space(3))) const p4u_t* lds_u4_ptr;
     auto pat_row = [&](uint32_t d) -> uint2 {
-        const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        const p2u_t v = *(lds_u2_ptr)(uintptr_t)(C32 ? ad : ad >> 1);
+        const p2u_t v = *(lds_u2_ptr)(uintptr_t)__builtin_amdgcn_perm(d, copyoff, psel);
         return make_uint2(v.x, v.y);
     };
     auto pat_row2 = [&](uint32_t d) -> uint4 {  // odd widths: the operand rows of the byte's two nibbles
-        const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        const p4u_t v = *(lds_u4_ptr)(uintptr_t)(C32 ? ad : ad >> 1);
+        const p4u_t v = *(lds_u4_ptr)(uintptr_t)__builtin_amdgcn_perm(d, copyoff, psel);
         return make_uint4(v.x, v.y, v.z, v.w);
     };
     auto load_staged = [&](int g) {            // scale / zero of row (row0 + lane), weight group g -> registers, raw (converted when written to LDS)
@@ -380,11 +318,8 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         for (int nt = 0; nt < 2; ++nt) cn[nt] = __builtin_amdgcn_raw_buffer_load_b128(rs_c, cvoff + nt * 512, kk * col_stride, 0);
     };
     const bool work = k_lo < k_end;
-    if (work) {                                // everything the first step needs is in flight while the operand rows are built
-        // (in the order a step issues them for its successor: the compiler merges the wait counts of both ways into the loop, and a
-        // prologue in another order turned the first waits of every step into vmcnt(0) -- a drain of the B loads issued last)
-        dma_chunk(k_lo);
-        load_staged(g_lo);
+    if (work) {                                // everything the first step needs is in flight while the operand rows are built,
+        load_staged(g_lo);                     // in the order a step issues the loads of its successor
         st0_sc = st_sc; st0_zr = st_zr;        // (the first group's values: written to LDS behind the table's barrier)
         load_staged(g_lo + 1 < g_hi ? g_lo + 1 : g_lo);     // ... and the second group's, where every later step has its staged load: in front
         load_cols(k_lo);
@@ -413,15 +348,16 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
             }
         }
         if (!ODD) { lo1 = lo; hi1 = hi; }
-        // NWV = 8: two threads per entry (256 B = 32 copies of 8 bytes / 16 of 16), NWV = 4: one (128 B = 16 / 8 copies)
-        if constexpr (C32 && NWV == 4) {       // one thread per entry, 256 B = 32 copies of 8 bytes / 16 of 16
+        // an entry = 256 B = 32 copies of 8 bytes / 16 of 16.  NWV = 8: two threads per entry, NWV = 4: one; consecutive entries (lanes)
+        // start at different 16-byte slots of their rows
+        if constexpr (NWV == 4) {
             uint4* pt = reinterpret_cast<uint4*>(plds) + b * 16;
 #pragma unroll
             for (int c = 0; c < 16; ++c) pt[(c + b) & 15] = make_uint4(lo, hi, lo1, hi1);
         } else {
-        uint4* pt = reinterpret_cast<uint4*>(plds) + (NWV == 8 ? b * 16 + (tid >> 8) * 8 : b * 8);
+            uint4* pt = reinterpret_cast<uint4*>(plds) + b * 16 + (tid >> 8) * 8;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo1, hi1);   // 8 consecutive entries (lanes) -> 8 different 16-byte slots of the rows
+            for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo1, hi1);
         }
     }
     __syncthreads();
@@ -444,18 +380,11 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     // accumulators start from the bits of 3.0f, the middle of the binade [2, 4): as a float the int32 result is 3 + comb * 2^-22
     // exactly for |comb| < 2^21 (it is < 2^19 here), so int -> float is one packed subtraction per pair.  The 16 registers are
     // made opaque to the compiler, which otherwise rebuilds the constant vector with 15 moves in front of every chain.
-    // W4 has no registers to spare for that: its chains start from zero and the conversion is 16 v_cvt_f32_i32 per tile.
-#ifndef TMAC_G2_MAGIC_MAX_BITS
-#define TMAC_G2_MAGIC_MAX_BITS 2
-#endif
-    constexpr bool MAGIC = BITS <= TMAC_G2_MAGIC_MAX_BITS;
+    // W3 / W4 have no registers to spare for that: their chains start from zero and the conversion is 16 v_cvt_f32_i32 per tile.
+    constexpr bool MAGIC = BITS <= 2;
     constexpr int CI = MAGIC ? 0x40400000 : 0;
     p16i_t cinit = {CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI, CI};
     if (MAGIC) asm volatile("" : "+v"(cinit));
-    // One act group (64 activations = four 32-deep MFMA steps) per iteration.  The order below interleaves the four units a
-    // step keeps busy -- the vector-memory path (chunk DMA, weight loads), LDS (operand reads), the matrix core and the VALU
-    // (fp32 scale chain) -- inside ONE wave: the operands of tile row 1 are fetched while the MFMAs of tile row 0 run, the
-    // epilogue of tile row 0 runs under the MFMAs of tile row 1.  sched_barrier keeps the compiler from regrouping the phases.
     auto build_av = [&](int rt, p4i_t (&av)[4]) {       // A operands of tile row rt: the joint plane index of (row, table) selects the operand row
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -481,18 +410,11 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
             }
         }
     };
-#ifndef TMAC_G2_ORDER
-#define TMAC_G2_ORDER 0         // A/B knob: 1 = tiles in the order (0,0) (1,0) (0,1) (1,1).  Measured SLOWER (W2 6.44 -> 6.58 ms, W4 7.74 -> 7.91, profiles/r06_prefill_step_diet.txt E)
-#endif
-#ifndef TMAC_G2_AV_PREFETCH
-#define TMAC_G2_AV_PREFETCH 0   // A/B knob: 1 = tile row 0's operand rows of the NEXT step gathered at the end of the step.  No gain (W2 6.42 / 6.43 ms, W4 7.70 / 7.72): off
-#endif
-    // (experiment) tile row 0's A operands of the NEXT step gathered at the end of the step, under the last two fp32 chains, into the
-    // registers the step's own have left after its second chain: a step then starts with MFMAs instead of eight perm + LDS round trips.
-    // Like every other latency lever of this round it changed nothing: the step is bound by what it moves and issues, not by waiting.
-    constexpr bool AVP = BD && !PIPE && TMAC_G2_ORDER == 0 && TMAC_G2_AV_PREFETCH != 0;
-    p4i_t av0[4];
-    if (AVP && work) build_av(0, av0);
+    // One act group (64 activations = four 32-deep MFMA steps) per iteration.  The order below interleaves the units a step keeps
+    // busy -- the vector-memory path (B operands, weights), LDS (operand-row gathers, row scales), the matrix core and the VALU (fp32
+    // scale chain) -- inside ONE wave: the operands of tile row 1 are fetched while the MFMAs of tile row 0 run, the fp32 chain of a
+    // tile runs under the MFMAs of the next.  sched_barrier keeps the compiler from regrouping the phases (and a B load from being
+    // hoisted above the last chain that reads its registers: that costs registers of its own and a copy at the loop's end).
     for (int kk = k_lo; kk < k_end; ++kk) {
         const int g = kk >> apg_sh;
         const bool glast = (kk & apg_m) == apg_m;          // last act group of its weight group
@@ -503,36 +425,13 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         // the older wave of a SIMD wins every issue conflict (its four K ranges finish ~15 % earlier and then wait at the
         // reduction): alternate the priority between the two waves of a SIMD step by step
         if (NWV == 8) { if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        if (!BD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the chunk of kk is in LDS, its weights, column values and the staged scales in registers
         PSTAMP_IN(kk - k_lo, 1);
-        if (more) write_staged(g + 1);     // (its successor is fetched behind this step's LDS reads: a load in front of them is waited for --
-                                           // the compiler orders every LDS read behind all LDS-DMA in flight with vmcnt(0))
-        // B operands of the whole act group (both n tiles, four 32-deep steps); A operands and row scales of tile row 0
-        p4i_t av1[4];
-        p2f_t sc0l[SCK ? 1 : 8];
-        p2f_t (&sc0)[8] = *reinterpret_cast<p2f_t (*)[8]>(SCK ? &sck[0][0] : &sc0l[0]);
-#ifndef TMAC_G2_LATE_WAIT
-#define TMAC_G2_LATE_WAIT 1     // A/B knob: 0 = every LDS operand of the step is waited for in front of the first MFMA (rounds 2-5)
-#endif
-        // Round 6: LDS returns in order, so the first chain starts as soon as ITS operands are there (n tile 0's B operands and tile row
-        // 0's gathers are issued first); the full wait sits in front of the next chunk's first DMA part, behind the first two chains.
-        auto read_b = [&](int nt) {
-            if constexpr (BD) return;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                // even widths: this k half = pair 2 kb + (ks & 1) of unit ks >> 1; odd: pair ks of unit kb
-                const int pslot = ODD ? kb * 4 + ks : (ks >> 1) * 4 + 2 * kb + (ks & 1);
-                if constexpr ((TMAC_G2_KO & 32) != 0) { bv[nt][ks] = (p4i_t){(int)cn[nt][0], (int)cn[nt][1], pslot, nt}; continue; }
-                const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (pslot * 64 + nt * 32 + j) * 16);
-                bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-            }
-        };
-        read_b(0);
-        if (!TMAC_G2_LATE_WAIT) read_b(1);
-        if (!AVP) build_av(0, av0);
-        if (TMAC_G2_LATE_WAIT) read_b(1);
-        if (!SCK) read_rows(cbuf, 0, 0, sc0);
-        else if ((kk & apg_m) == 0 || kk == k_lo) { read_rows(cbuf, 0, 0, sck[0]); read_rows(cbuf, 0, 1, sck[SCK ? 1 : 0]); }   // the weight group's first act group
+        if (more) write_staged(g + 1);
+        // A operands and row scales of tile row 0
+        p4i_t av0[4], av1[4];
+        p2f_t sc0[8];
+        build_av(0, av0);
+        read_rows(cbuf, 0, 0, sc0);
         // column values of the act group (loaded one step ahead): v = x * H + hlbx with x = comb * 2^-22, H = (ls / 2) * 2^22,
         // hlbx = lb / 2  [- 15 * (entry sum) * (ls / 2) for the +15 operand bias of W4]
         float H[2], hlbx[2], lb[2];
@@ -550,18 +449,11 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
                 bias[nt] = (int)hs15;
             }
         }
-        // The loads of the next act group are issued unconditionally (the last step fetches its own act group again: same bytes into
-        // the same places, drained before the reduction): the step is ONE basic block (round 6 for every width: a branch per load group
-        // was 11 branches and ~35 scalar instructions per step).  PIPE (4-bit weights) also interleaves the matrix-core chains and the
-        // fp32 chains instruction by instruction (sched_group_barrier): a chain is four DEPENDENT MFMAs -- 32 cycles each during which
-        // the wave issues nothing unless independent work sits between them.  Measured (profiles/r03_gemm_planes_forms.txt D): W4
-        // prefill -3 %; W1, W2, W3 within +-1 % (kept in the coarse order).
         const int kn = next ? kk + 1 : kk;
-        // every step, no condition (a conditional load cannot be counted: its consumer got vmcnt(0), a drain of the B loads): the scales of the
-        // group behind the NEXT step's group -- at the last act group of g that is g + 2, before that g + 1 once more (the same dword again)
+        // every step, no condition: the scales of the group behind the NEXT step's group -- at the last act group of g that is g + 2,
+        // before that g + 1 once more (the same dword again)
         { const int gs2 = ((kn >> apg_sh) + 1 < g_hi) ? (kn >> apg_sh) + 1 : g_hi - 1; load_staged(gs2); }
         load_cols(kn); load_weights(kn, 0);
-        if (!TMAC_G2_LATE_WAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_IN(kk - k_lo, 2);
 
@@ -578,34 +470,11 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
         // C += ((comb / 2) ls + lb / 2) scale [+ zero lb, once per weight group], cf. k_gemv_quad / k_gemm_onehot (W4)
         auto epilogue = [&](int rt, int nt, const p16i_t& c, const p2f_t (&sc)[8]) {
             // three passes of independent instructions over the lane's 16 values (in place: int32 -> fp32 -> scaled), not
-            // 8 dependent three-instruction chains through one temporary
+            // 8 dependent three-instruction chains through one temporary.  Packed fp32: as 48 plain instructions the tile was 3 % slower
+            // (profiles/r06_prefill_unpacked.txt)
             if (TMAC_G2_KO & 4) { facc[rt][nt][0] += (p2f_t){__int_as_float(c[0]), __int_as_float(c[5])}; return; }
             const p2f_t h2 = {H[nt], H[nt]}, b2 = {hlbx[nt], hlbx[nt]};
             p2f_t x[8];
-#ifndef TMAC_G2_UNPACKED
-#define TMAC_G2_UNPACKED 0      // A/B knob (round 6): 1 = the 24 packed fp32 instructions of a tile as 48 plain ones.  Measured SLOWER: W2 6.89 -> 7.13 ms, W4 8.30 -> 8.45 (profiles/r06_prefill_unpacked.txt) -- the step is bound by instruction issue, not by what a packed instruction costs the matrix pipe
-#endif
-            if constexpr (TMAC_G2_UNPACKED != 0) {
-                // UNPACKED fp32 (round 6 experiment, off): the same arithmetic as 48 v_add_f32 / v_fma_f32 instead of 24 v_pk_add_f32 /
-                // v_pk_fma_f32 (MI355X_MICROARCH.md prices a v_pk_fma_f32 beside MFMAs at + 22 cycles against two v_fma_f32); inline asm,
-                // because the compiler's SLP pass packs adjacent scalar operations again.  Same operations on the same values: same bits.
-                float xs[16];
-                const float m3 = -3.0f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (MAGIC) asm("v_add_f32 %0, %1, %2" : "=v"(xs[r]) : "s"(m3), "v"(__int_as_float(c[r])));
-                    else xs[r] = (float)c[r];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) asm("v_fma_f32 %0, %1, %2, %3" : "=v"(xs[r]) : "v"(xs[r]), "v"(H[nt]), "v"(hlbx[nt]));
-#pragma unroll
-                for (int r2 = 0; r2 < 8; ++r2) {
-                    float lo = facc[rt][nt][r2].x, hi = facc[rt][nt][r2].y;
-                    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(lo) : "v"(xs[2 * r2]), "v"(sc[r2].x));
-                    asm("v_fma_f32 %0, %1, %2, %0" : "+v"(hi) : "v"(xs[2 * r2 + 1]), "v"(sc[r2].y));
-                    facc[rt][nt][r2] = (p2f_t){lo, hi};
-                }
-            } else {
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2)
                 x[r2] = MAGIC ? (p2f_t){__int_as_float(c[2 * r2]), __int_as_float(c[2 * r2 + 1])} - (p2f_t){3.0f, 3.0f}
@@ -614,7 +483,6 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
             for (int r2 = 0; r2 < 8; ++r2) x[r2] = __builtin_elementwise_fma(x[r2], h2, b2);
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2) facc[rt][nt][r2] = __builtin_elementwise_fma(x[r2], sc[r2], facc[rt][nt][r2]);
-            }
             if (DUMP) {
                 const int nn = n0 + nt * 32 + j;
 #pragma unroll
@@ -624,13 +492,10 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
                 }
             }
         };
-#ifndef TMAC_G2_ZP_MFMA
-#define TMAC_G2_ZP_MFMA 1       // A/B knob: 0 = the zero-point term as 16 packed fp32 instructions per tile and weight group (rounds 2-5)
-#endif
-        // Round 6: the zero-point term of a weight group, zero[o] * (sum of its lut_biases)[n], is a rank-1 update of the 64 x 64 tile: two
-        // weight groups make one v_mfma_f32_32x32x2_f32 per 32 x 32 tile (k = the group's parity; lane (kb, j) holds row / column j of the
-        // group kb), i.e. 4 matrix-core instructions per two weight groups instead of 64 packed fp32 ones -- the step is bound by the
-        // number of instructions a wave issues, the matrix core is a quarter busy.  fp32 products and sums as before, in another order.
+        // The zero-point term of a weight group, zero[o] * (sum of its lut_biases)[n] (tbl.cc:497-505 regrouped), is a rank-1 update of the
+        // 64 x 64 tile: two weight groups make one v_mfma_f32_32x32x2_f32 per 32 x 32 tile (k = the group's parity; lane (kb, j) holds row /
+        // column j of the group kb), i.e. 4 matrix-core instructions per two weight groups instead of 64 packed fp32 ones (rounds 2-5).
+        // fp32 products and sums as before, in another order.
         auto zero_stage = [&]() {              // (at the last act group of a weight group)
             const float* zp = reinterpret_cast<const float*>(plds + sc_wave + cbuf * 512 + 256);
             const bool mine = kb == cbuf;
@@ -658,146 +523,43 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
                     for (int r2 = 0; r2 < 8; ++r2) facc[rt][nt][r2] = (p2f_t){c[2 * r2], c[2 * r2 + 1]};
                 }
         };
-        auto zero_points = [&](int rt) {       // zero * (sum of lut_biases over the weight group), tbl.cc:497-505 regrouped
-            p2f_t zr[8];
-            read_rows(cbuf, 1, rt, zr);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const float l = __fadd_rn(lbs[nt], lb[nt]);
-#pragma unroll
-                for (int r2 = 0; r2 < 8; ++r2) facc[rt][nt][r2] = __builtin_elementwise_fma(zr[r2], (p2f_t){l, l}, facc[rt][nt][r2]);
-            }
-        };
 
         // tile pipeline: the MFMAs of tile t + 1 run under the fp32 chain of tile t (two accumulator sets)
-        constexpr bool SC2 = BITS <= 2;        // W1, W2: tile row 1's scales in registers of their own, fetched early (W4 has none to spare)
+        constexpr bool SC2 = BITS <= 2;        // W1, W2: tile row 1's scales in registers of their own, fetched early (W3 / W4 have none to spare)
         p16i_t ca, cb;
-        p2f_t sc1s[SC2 && !SCK ? 8 : 1];
-        p2f_t (&sc1)[8] = *reinterpret_cast<p2f_t (*)[8]>(SCK ? &sck[1][0] : SC2 ? &sc1s[0] : &sc0[0]);
-        if constexpr (PIPE) {
-        // MFMA | a few fp32 / address instructions [| LDS reads] | MFMA | ...: four times per region
-#define TMAC_G2_GROUPS(VALU_PER, DS_PER) do { _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) { \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, VALU_PER, 0); \
-            if (DS_PER) __builtin_amdgcn_sched_group_barrier(0x100, DS_PER, 0); } } while (0)
-        chain(av0, 0, ca);
-        if (TMAC_G2_LATE_WAIT && !BD) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // the chunk buffer has been read
-        dma_part(kn, 0);
-        dma_part(kn, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        // region 1: chain (0, 1) | fp32 chain of tile (0, 0), operand-row gathers of tile row 1, its weights of the next act group
-        chain(av0, 1, cb);
-        epilogue(0, 0, ca, sc0);
-        build_av(1, av1);
-        if (SC2 && !SCK) read_rows(cbuf, 0, 1, sc1);
-        load_weights(kn, 1);
-        TMAC_G2_GROUPS(8, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        // region 2: chain (1, 0) | fp32 chain of tile (0, 1)
-        chain(av1, 0, ca);
-        epilogue(0, 1, cb, sc0);
-        dma_part(kn, 2);
-        TMAC_G2_GROUPS(6, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(kn, 0);                         // n tile 0's operands have been read by their last chain (behind the barrier: a load the
-        __builtin_amdgcn_sched_barrier(0);     // scheduler hoists above that chain needs registers of its own and a copy at the loop's end)
-        // region 3: chain (1, 1) | fp32 chain of tile (1, 0)
-        if (!SC2) read_rows(cbuf, 0, 1, sc1);
-        chain(av1, 1, cb);
-        epilogue(1, 0, ca, sc1);
-        dma_part(kn, 3);
-        TMAC_G2_GROUPS(6, SC2 ? 0 : 1);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(kn, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        epilogue(1, 1, cb, sc1);
-        if (ZP && glast) {                     // (behind the act group's own terms: one branch at the end of the block)
-            if (TMAC_G2_ZP_MFMA) { zero_stage(); if (cbuf || g + 1 >= g_hi) zero_flush(); }
-            else { zero_points(0); zero_points(1); }
-        }
-#undef TMAC_G2_GROUPS
-        } else {
-        if constexpr (BD && TMAC_G2_ORDER != 0) {
-        // (experiment) n tile 0's two tiles first, so that ITS B operands are dead after the second chain and their successors get the rest
-        // of the step to arrive.  It lost: what the B loads cost is their 8 KB through the CU's one vector-memory path, not their latency.
-#ifndef TMAC_G2_SC_SHARE
-#define TMAC_G2_SC_SHARE 1      // 1: ONE set of 16 row-scale registers, read from LDS in front of every fp32 chain (LDS is nearly idle in the direct form;
-#endif                          //    two sets put the kernel over 256 registers: a scratch reload inside the loop = a vmcnt(0) drain per weight group)
-        constexpr bool SHARE = TMAC_G2_SC_SHARE != 0 && !SCK;
-        build_av(1, av1);
-        if (!SHARE && SC2 && !SCK) read_rows(cbuf, 0, 1, sc1);
-        load_weights(kn, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        chain(av0, 0, ca);
-        chain(av1, 0, cb);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(kn, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        epilogue(0, 0, ca, sc0);
-        __builtin_amdgcn_sched_barrier(0);
-        chain(av0, 1, ca);
-        __builtin_amdgcn_sched_barrier(0);
-        if (SHARE) read_rows(cbuf, 0, 1, sc0); else if (!SC2) read_rows(cbuf, 0, 1, sc1);
-        epilogue(1, 0, cb, SHARE ? sc0 : sc1);
-        __builtin_amdgcn_sched_barrier(0);
-        chain(av1, 1, cb);
-        __builtin_amdgcn_sched_barrier(0);
-        load_b(kn, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ZP && glast && !TMAC_G2_ZP_MFMA) zero_points(0);
-        if (SHARE) read_rows(cbuf, 0, 0, sc0);
-        epilogue(0, 1, ca, sc0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (SHARE) read_rows(cbuf, 0, 1, sc0);
-        epilogue(1, 1, cb, SHARE ? sc0 : sc1);
-        if (ZP && glast) {
-            if (TMAC_G2_ZP_MFMA) { zero_stage(); if (cbuf || g + 1 >= g_hi) zero_flush(); }
-            else zero_points(1);
-        }
-        } else {
+        p2f_t sc1s[SC2 ? 8 : 1];
+        p2f_t (&sc1)[8] = *reinterpret_cast<p2f_t (*)[8]>(SC2 ? &sc1s[0] : &sc0[0]);
         chain(av0, 0, ca);
         chain(av0, 1, cb);
-        if (TMAC_G2_LATE_WAIT && !BD) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }   // the chunk buffer has been read
-        dma_part(kn, 0);
-        dma_part(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
         build_av(1, av1);
-        if (SC2 && !SCK) read_rows(cbuf, 0, 1, sc1);
+        if (SC2) read_rows(cbuf, 0, 1, sc1);
         load_weights(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
         PSTAMP_IN(kk - k_lo, 3);
         epilogue(0, 0, ca, sc0);
         __builtin_amdgcn_sched_barrier(0);
         chain(av1, 0, ca);
-        dma_part(kn, 2);
         load_b(kn, 0);                         // (n tile 0's operands have been read by their last chain)
         __builtin_amdgcn_sched_barrier(0);
         epilogue(0, 1, cb, sc0);
         if (!SC2) read_rows(cbuf, 0, 1, sc1);
         __builtin_amdgcn_sched_barrier(0);
         chain(av1, 1, cb);
-        dma_part(kn, 3);
         load_b(kn, 1);
         __builtin_amdgcn_sched_barrier(0);
-        if (AVP) { build_av(0, av0); __builtin_amdgcn_sched_barrier(0); }      // (the next step's: wv[..][0] holds its weights since the top of this step)
         PSTAMP_IN(kk - k_lo, 4);
-        if (ZP && glast && !TMAC_G2_ZP_MFMA) zero_points(0);
         epilogue(1, 0, ca, sc1);
         __builtin_amdgcn_sched_barrier(0);
         epilogue(1, 1, cb, sc1);
-        if (ZP && glast) {
-            if (TMAC_G2_ZP_MFMA) { zero_stage(); if (cbuf || g + 1 >= g_hi) zero_flush(); }
-            else zero_points(1);
-        }
-        }
-        }
+        if (ZP && glast) { zero_stage(); if (cbuf || g + 1 >= g_hi) zero_flush(); }     // (behind the act group's own terms: one branch at the end of the block)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) lbs[nt] = glast ? 0.f : __fadd_rn(lbs[nt], lb[nt]);
     }
 
     __builtin_amdgcn_s_setprio(0);
-    // ---- reduce the K ranges through LDS (operand rows and chunk buffers are free now) and store ------------------
+    // ---- reduce the K ranges through LDS (the operand rows are free now) and store ------------------
     PSTAMP(1, 5);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last step's (redundant) chunk DMA must not land in the reduction buffers
     __syncthreads();
     PSTAMP(1, 6);
     {
@@ -850,9 +612,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
 template <int BITS, bool DUMP, int NWV>
 __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
-    using PF = PFormU<NWV>;
-    constexpr bool BD = G2_BD, C32 = PF::COPIES == 32;
-    constexpr int P_NWV = NWV, P_BB_OFF = PF::BB_OFF, P_BB_WAVE = PF::BB_WAVE;
+    constexpr int P_NWV = NWV;
     constexpr int NJ = BITS;
     constexpr bool ODD = (BITS & 1) != 0;      // see k_gemm_planes: 16-byte table entries, a lane holds one whole unit per tile row
     constexpr int WPU = ODD ? BITS : BITS / 2;
@@ -874,8 +634,7 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
     const int k_lo = (w * nk) / P_NWV, k_end = ((w + 1) * nk) / P_NWV;        // 64-activation steps of this wave
 
     const uint32_t psel = 0x0c0c0000u | ((4u + (lane & 3)) << 8);
-    const uint32_t copyoff = ODD ? (C32 ? (uint32_t)(lane & 15) * 16u : (uint32_t)(lane & 7) * 32u)
-                                 : (C32 ? (uint32_t)j * 8u : (uint32_t)(j & 15) * 16u);
+    const uint32_t copyoff = ODD ? (uint32_t)(lane & 15) * 16u : (uint32_t)j * 8u;
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(M.W), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.bimg), (short)0, 0x7fffffff, 0x00020000);
     int wvoff[2];
@@ -885,30 +644,19 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
         wvoff[rt] = ODD ? (quad * nst * NJ * 64 + kb) * 16
                         : ((quad * nst * NJ + (BITS == 2 ? kb : 2 * kb)) * 64) * 16;
     }
-    const int bvoff = (n0 + lane) * 16;
-    const uint32_t bb_wave = P_BB_OFF + w * P_BB_WAVE;
     uint4 wv[WUN][2][WPU];
-    // direct form (round 6, see PFormD): the B operands go global -> registers, the 16 bytes of (unit, pair, row) straight to the lane
-    // whose operand they are, into the registers of the step before as soon as its MFMAs have read them
+    // round 6, as in k_gemm_planes: the B operands go global -> registers, the 16 bytes of (unit, pair, row) straight to the lane whose
+    // operand they are, into the registers of the step before as soon as its MFMAs have read them (the row-wise image addresses with
+    // four scalar offsets per step)
     p4i_t bv[2][4];
     const int bdvoff = ((ODD ? 4 * kb : 2 * kb) * a.Npad + n0 + j) * 16;
     auto load_b = [&](int kk, int ks) {
-        if constexpr (!BD) return;
         const int so = (ODD ? 8 * kk + ks : (2 * kk + (ks >> 1)) * 4 + (ks & 1)) * a.Npad * 16;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const u32x4q v = __builtin_amdgcn_raw_buffer_load_b128(rs_b, bdvoff + nt * 512, so, 0);
             bv[nt][ks] = (p4i_t){(int)v[0], (int)v[1], (int)v[2], (int)v[3]};
         }
-    };
-    auto dma_chunk = [&](int kk) {
-        if constexpr (BD) return;
-#pragma unroll
-        for (int ul = 0; ul < 2; ++ul)
-#pragma unroll
-            for (int pr = 0; pr < 4; ++pr)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (p_lds_ptr)(uintptr_t)(bb_wave + (ul * 4 + pr) * 1024), 16, bvoff,
-                                                         ((2 * kk + ul) * 4 + pr) * a.Npad * 16, 0, 0);
     };
     auto load_weights = [&](int kk, int rt) {
 #pragma unroll
@@ -925,17 +673,17 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
     typedef unsigned int p4u_t __attribute__((ext_vector_type(4)));
     auto pat_row = [&](uint32_t d) -> uint2 {
         const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        const p2u_t v = *(__attribute__((address_space(3))) const p2u_t*)(uintptr_t)(C32 ? ad : ad >> 1);   // absolute LDS address (see k_gemm_planes)
+        const p2u_t v = *(__attribute__((address_space(3))) const p2u_t*)(uintptr_t)ad;   // absolute LDS address (see k_gemm_planes)
         return make_uint2(v.x, v.y);
     };
     auto pat_row2 = [&](uint32_t d) -> uint4 {   // odd widths: the operand rows of the byte's two nibbles
         const uint32_t ad = __builtin_amdgcn_perm(d, copyoff, psel);
-        const p4u_t v = *(__attribute__((address_space(3))) const p4u_t*)(uintptr_t)(C32 ? ad : ad >> 1);
+        const p4u_t v = *(__attribute__((address_space(3))) const p4u_t*)(uintptr_t)ad;
         return make_uint4(v.x, v.y, v.z, v.w);
     };
     const bool work = k_lo < k_end;
     if (work) {
-        dma_chunk(k_lo); load_weights(k_lo, 0); load_weights(k_lo, 1);
+        load_weights(k_lo, 0); load_weights(k_lo, 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) load_b(k_lo, ks);
     }
@@ -958,14 +706,14 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
             }
         }
         if (!ODD) { lo1 = lo; hi1 = hi; }
-        if constexpr (C32 && NWV == 4) {
+        if constexpr (NWV == 4) {
             uint4* pt = reinterpret_cast<uint4*>(plds) + b * 16;
 #pragma unroll
             for (int c = 0; c < 16; ++c) pt[(c + b) & 15] = make_uint4(lo, hi, lo1, hi1);
         } else {
-        uint4* pt = reinterpret_cast<uint4*>(plds) + (NWV == 8 ? b * 16 + (tid >> 8) * 8 : b * 8);
+            uint4* pt = reinterpret_cast<uint4*>(plds) + b * 16 + (tid >> 8) * 8;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo1, hi1);
+            for (int c = 0; c < 8; ++c) pt[(c + b) & 7] = make_uint4(lo, hi, lo1, hi1);
         }
     }
     __syncthreads();
@@ -980,18 +728,6 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
     for (int kk = k_lo; kk < k_end; ++kk) {
         const bool next = kk + 1 < k_end;
         if (NWV == 8) { if (((kk - k_lo) ^ (w >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-        if (!BD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (!BD) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    // even widths: this k half = pair 2 kb + (ks & 1) of unit ks >> 1; odd: pair ks of unit kb
-                    const int pslot = ODD ? kb * 4 + ks : (ks >> 1) * 4 + 2 * kb + (ks & 1);
-                    const uint4 v = *reinterpret_cast<const uint4*>(plds + bb_wave + (pslot * 64 + nt * 32 + j) * 16);
-                    bv[nt][ks] = (p4i_t){(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-                }
-        }
         p4i_t av[2][4];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -1017,19 +753,15 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes_us(Gemm2Args 
                     av[rt][ks] = (p4i_t){(int)(a0.x + (a1.x << 2)), (int)(a0.y + (a1.y << 2)), (int)(b0.x + (b1.x << 2)), (int)(b0.y + (b1.y << 2))};
                 }
             }
-        const int kn = next ? kk + 1 : kk;     // (direct form: the last step fetches its own operands again -- one basic block, counted waits)
-        if (BD || next) { load_weights(kn, 0); load_weights(kn, 1); }
-        if (!BD) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (next) dma_chunk(kk + 1);
-        }
+        const int kn = next ? kk + 1 : kk;     // (the last step fetches its own operands again -- one basic block, counted waits)
+        load_weights(kn, 0); load_weights(kn, 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) acc[rt][nt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[rt][ks], bv[nt][ks], acc[rt][nt], 0, 0, 0);
-            if (BD) { __builtin_amdgcn_sched_barrier(0); load_b(kn, ks); __builtin_amdgcn_sched_barrier(0); }
+            __builtin_amdgcn_sched_barrier(0); load_b(kn, ks); __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_s_setprio(0);
@@ -1122,7 +854,7 @@ hipError_t launch_gemm_planes(const Gemm2Args& a_in, hipStream_t st) {
     const int nwv = a.form == 1 ? 8 : a.form == 2 ? 4 : (gx * a.gy > n_cu ? 4 : 8);
     dim3 g(((gx + 7) & ~7) * a.gy), b(64 * nwv);
     const bool us = a.s.m_groups >= 1;
-    const int lds_bytes = nwv == 8 ? (us ? PFormU<8>::LDS_BYTES : PFormG<8>::LDS_BYTES) : (us ? PFormU<4>::LDS_BYTES : PFormG<4>::LDS_BYTES);
+    const int lds_bytes = nwv == 8 ? (us ? PFormU<8>::LDS_BYTES : PForm<8>::LDS_BYTES) : (us ? PFormU<4>::LDS_BYTES : PForm<4>::LDS_BYTES);
 #define PLAUNCH(KERNEL) do { \
         static bool attr_set = false; \
         if (!attr_set) { \

@@ -148,8 +148,8 @@ int32_t tmac_hip_qgemm_fused_dev(const tmac_hip_weights* const* weights, int nma
  * another stream, an N > 1 call and tmac_hip_defer(0) flush it first -- results are those of launching the calls in order.  The recording
  * built from a batch is cached by the batch's signature (matrices, pointers, dtypes; invalidated when weights are freed): a decode loop
  * pays for it once.  A batch that mixes configurations (bits, zero points, per-group / unified scales, scale or output dtype) becomes one
- * stream launch per configuration -- its calls are independent of each other; calls the persistent kernels do not cover, or alone in
- * their configuration, are launched one by one at the flush.  The caller must flush before it
+ * stream launch per configuration -- its calls are independent of each other; calls the persistent kernels do not cover, and configurations
+ * with fewer than three calls (a stream launch costs ~10 us before its first byte), are launched one by one at the flush.  The caller must flush before it
  * synchronises the stream or reads an output.  tmac_hip_defer_stats: flushes, cache hits, stream-mode launches, calls launched singly.
  * The cached recordings of a thread are released by tmac_hip_cache_clear() / tmac_hip_reset_state() called on that thread. */
 int32_t tmac_hip_defer(int on);

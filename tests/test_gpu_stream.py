@@ -316,7 +316,8 @@ def test_deferred_batch_of_mixed_widths_is_one_stream_launch_per_configuration(t
     from test_gpu_chain import rel_err
     ops = [(1024, [256, 512], None), (2688, [128], None), (4096, [1024], None)]
     models = [Model(tm, ops, bits=2, zp=True, seed=31), Model(tm, ops, bits=4, zp=True, seed=32), Model(tm, ops, bits=2, zp=False, dev_f16=False, seed=33),
-              Model(tm, [(3200, [640], None)], bits=2, mg=1, seed=34)]           # (the last: one call alone in its configuration -> launched by itself)
+              Model(tm, [(3200, [640], None)], bits=2, mg=1, seed=34),           # (one call alone in its configuration -> launched by itself)
+              Model(tm, ops[:2], bits=1, zp=True, seed=35)]                      # (two calls: cheaper one by one than as a stream launch, profiles/r06_stream_small_batches.txt)
     L = tm.lib()
 
     def issue_interleaved():
@@ -346,7 +347,7 @@ def test_deferred_batch_of_mixed_widths_is_one_stream_launch_per_configuration(t
                         assert rel_err(q_.float().cpu().numpy(), p_.float().cpu().numpy()) <= 2e-3
         tm.binding.check(L.tmac_hip_defer_stats(*[C.byref(x) for x in st]))
         flushes, hits, streams, singles = [int(x.value) - b for x, b in zip(st, before)]
-        assert (flushes, hits, streams, singles) == (2, 1, 6, 2), (flushes, hits, streams, singles)      # three configurations of three calls + one lone call, twice
+        assert (flushes, hits, streams, singles) == (2, 1, 6, 6), (flushes, hits, streams, singles)      # three configurations of three calls + a lone call + a pair, twice
     finally:
         tm.binding.check(L.tmac_hip_defer(0))
     for m in models:

@@ -971,7 +971,7 @@ struct DeferState {
 };
 thread_local DeferState g_defer;
 std::atomic<unsigned long long> g_defer_epoch{1};
-constexpr size_t DEFER_MAX_BATCH = 256, DEFER_CACHE = 32;
+constexpr size_t DEFER_MAX_BATCH = 256, DEFER_CACHE = 32, DEFER_MIN_STREAM = 3;
 
 Range defer_in_range(const ChainRecOp& r) {
     return Range{(const char*)r.B, (const char*)r.B + (size_t)r.w[0]->s.K * (r.act == TMAC_F32 ? 4 : 2)};
@@ -1015,7 +1015,9 @@ int32_t defer_flush(hipStream_t st) {
                 taken[j] = 1; grp.push_back((uint32_t)j);
             }
             tmac_hip_chain* c = nullptr;
-            if (grp.size() >= 2 && !g_chain_rec) {
+            // (a stream launch costs ~10 us before its first byte -- k_lut_images + the persistent kernel's ramp -- against ~4 us of launch and
+            // ramp per stand-alone call: two calls are faster one by one, three break even, four win by a third: profiles/r06_stream_small_batches.txt)
+            if (grp.size() >= DEFER_MIN_STREAM && !g_chain_rec) {
                 g_chain_rec = new std::vector<ChainRecOp>();
                 for (uint32_t j : grp) g_chain_rec->push_back(batch[j]);
                 g_chain_gat = new std::vector<ChainRecGather>();

@@ -82,6 +82,9 @@ CASES = [
     (320, 3200, 3, 192, 128, False, 33),     # ragged K ranges, rows and tokens
     (1088, 11008, 3, 192, 128, True, 16),
     (64, 4096, 1, 64, 256, True, 256),
+    # more than four token blocks: the chunk-major LUT image's n-tile stride (round 6), ragged last block
+    (128, 1024, 2, 128, 128, True, 300),
+    (192, 2048, 4, 256, 128, True, 449),
 ]
 
 
@@ -156,6 +159,7 @@ US_CASES = [
     (320, 3200, 40, 4), (192, 12288, 13, 4), (256, 1024, 130, 4),
     (320, 3200, 33, 3), (192, 12288, 16, 3),
     (128, 1024, 64, 1), (320, 8640, 70, 1),
+    (128, 3200, 300, 2),     # five token blocks, direct B loads of the row-wise image
 ]
 
 

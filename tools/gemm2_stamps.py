@@ -34,8 +34,10 @@ for wv in range(8):
     tops = [us(s[k, 0]) for k in range(nsteps)] + [us(s[1, 5])]
     print("    step durations: " + " ".join(f"{tops[k + 1] - tops[k]:5.2f}" for k in range(nsteps)))
     if nsteps > 2 and (s[1:nsteps, 1] > 0).all():
-        # inside a step: top -> loads landed (vmcnt 0) -> operands read from LDS -> first two chains + tile row 1's gathers -> last chain issued -> end
+        # inside a step (round 6, direct form -- no hand-placed wait any more): top -> [more: staged scales to LDS] -> tile row 0's gathers, column
+        # values, the next act group's loads issued -> first two chains + tile row 1's gathers and weights -> fp32 chain 0, chains 2 and 3 with the
+        # next B operands behind them, fp32 chain 1 -> fp32 chains 2, 3 (+ zero-point update)
         k = np.arange(1, nsteps - 1)
         seg = [(s[k, 1] - s[k, 0]), (s[k, 2] - s[k, 1]), (s[k, 3] - s[k, 2]), (s[k, 4] - s[k, 3]), (s[k + 1, 0] - s[k, 4])]
-        print("    mean of steps 1..n-2 (us): wait for loads %.2f | LDS operand reads + gathers %.2f | chains 0,1 + gathers of tile row 1 %.2f | epilogues 0,1 + chains 2,3 %.2f | epilogues 2,3 %.2f"
+        print("    mean of steps 1..n-2 (us): step top %.2f | gathers of tile row 0 + loads issued %.2f | chains 0,1 + gathers / weights of tile row 1 %.2f | fp32 chains 0,1 + chains 2,3 + B loads %.2f | fp32 chains 2,3 %.2f"
               % tuple(float(x.mean()) / 100.0 for x in seg))

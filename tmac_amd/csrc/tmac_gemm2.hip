@@ -306,7 +306,9 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
     unsigned long long* stp = (a.stamps && blockIdx.x == 0) ? a.stamps + (size_t)w * 64 * 8 : nullptr;
 #define PSTAMP(step, i) do { if (stp && (step) < 64 && lane == 0) stp[(step) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     // stamps INSIDE a step (tools/gemm2_stamps.py prints the phases): a diagnostic build only (-DTMAC_G2_STEP_STAMPS=1) -- their mere
-    // presence (a branch and an exec-mask change at four places of the step) cost 1.7 % of the prefill line
+    // presence (a branch and an exec-mask change at four places of the step) cost 1.7 % of the prefill line in rounds 2-5.  With the
+    // round-6 loads into registers they DISTORT the step: a pending store makes the compiler's wait counting give up, every stamp is
+    // followed by vmcnt(0) -- a drain of the B loads in flight -- and a step takes twice as long.  Knock-outs and counters instead.
 #ifndef TMAC_G2_STEP_STAMPS
 #define TMAC_G2_STEP_STAMPS 0
 #endif

@@ -1,4 +1,6 @@
 """Step stamps of k_gemm_planes (workgroup 0): where an act-group step of each wave spends its time.
+NOTE (round 6): the stamps INSIDE a step (-DTMAC_G2_STEP_STAMPS=1 builds) distort the direct form -- their stores make the compiler drain
+all loads behind every stamp, a step takes twice as long; the per-step durations of a normal build (stamp 0 only) remain meaningful.
 usage: gemm2_stamps.py [Mw K N]   (W2 g128 zero points, fp16 scales / activations / outputs)"""
 import os, sys
 import numpy as np, torch

@@ -387,7 +387,8 @@ int32_t tmac_hip_debug_pairs_min_n(int n);
  * lut_ctor.cc:152-155), lut_scales, lut_biases and the sum of each act group's 128 half-table entries, fp32 [N][K/64]. */
 int32_t tmac_hip_debug_gemm_kernel(int which);
 /* profiling: workgroup 0 of the following k_gemm_planes launches writes s_memrealtime stamps [wave 8][step 64][8] into this
- * device buffer (NULL = off); tools/gemm2_stamps.py prints them */
+ * device buffer (NULL = off); tools/gemm2_stamps.py prints them.  The kernel honours it in profiling builds of the library only
+ * (-DTMAC_G2_STAMPS=1; compiled out by default: the hook cost the 4-bit prefill line 1 %) -- otherwise the buffer stays untouched */
 int32_t tmac_hip_debug_gemm_stamps(unsigned long long* dev_buffer);
 int32_t tmac_hip_debug_gemm_comb_sums(const tmac_hip_weights* w, const tmac_hip_workspace* ws, int32_t* comb_host, int N, void* stream);
 int32_t tmac_hip_debug_gemm_image_read(const tmac_hip_workspace* ws, int8_t* half_tables_host, float* lut_scales_host,

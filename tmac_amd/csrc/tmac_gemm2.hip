@@ -304,7 +304,10 @@ __global__ __launch_bounds__(64 * NWV, 8 / NWV) void k_gemm_planes(Gemm2Args a) 
 
     // profiling: s_memrealtime (100 MHz) at fixed points of every act-group step of workgroup 0
     unsigned long long* stp = (a.stamps && blockIdx.x == 0) ? a.stamps + (size_t)w * 64 * 8 : nullptr;
-#define PSTAMP(step, i) do { if (stp && (step) < 64 && lane == 0) stp[(step) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#ifndef TMAC_G2_STAMPS
+#define TMAC_G2_STAMPS 0          // profiling builds only (tools/build_variant_obj.sh x tmac_gemm2 "-DTMAC_G2_STAMPS=1"): the hook -- a branch and a
+#endif                           // scalar-memory read per step even with no buffer set -- cost the W4 line 1 % (7.80 -> 7.72 ms), W2 0.2 %
+#define PSTAMP(step, i) do { if (TMAC_G2_STAMPS && stp && (step) < 64 && lane == 0) stp[(step) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
     // stamps INSIDE a step (tools/gemm2_stamps.py prints the phases): a diagnostic build only (-DTMAC_G2_STEP_STAMPS=1) -- their mere
     // presence (a branch and an exec-mask change at four places of the step) cost 1.7 % of the prefill line in rounds 2-5.  With the
     // round-6 loads into registers they DISTORT the step: a pending store makes the compiler's wait counting give up, every stamp is

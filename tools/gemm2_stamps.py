@@ -1,5 +1,6 @@
 """Step stamps of k_gemm_planes (workgroup 0): where an act-group step of each wave spends its time.
-NOTE (round 6): the stamps INSIDE a step (-DTMAC_G2_STEP_STAMPS=1 builds) distort the direct form -- their stores make the compiler drain
+NOTE (round 6): needs a profiling build of the library (tools/build_variant_obj.sh st tmac_gemm2 "-DTMAC_G2_STAMPS=1", TMAC_HIP_LIB=.../libtmac_hip_vst.so):
+the default build compiles the hook out (it cost the W4 prefill line 1 %).  The stamps INSIDE a step (-DTMAC_G2_STEP_STAMPS=1 builds) distort the direct form -- their stores make the compiler drain
 all loads behind every stamp, a step takes twice as long; the per-step durations of a normal build (stamp 0 only) remain meaningful.
 usage: gemm2_stamps.py [Mw K N]   (W2 g128 zero points, fp16 scales / activations / outputs)"""
 import os, sys

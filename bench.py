@@ -97,7 +97,7 @@ def parse():
     ap.add_argument("--stream-calls", type=int, default=96, help="independent GEMVs per launch of roofline.stream_core / stream_by_shape (distinct weight sets)")
     ap.add_argument("--clock-ramp-ms", type=float, default=100.0, help="decode workloads: GPU milliseconds of the step run untimed in front of the warm-up steps (0: off)")
     ap.add_argument("--no-stream-core", action="store_true", help="skip roofline.stream_core (profiling passes: keeps the kernel's statistics to the timed launches)")
-    ap.add_argument("--stamps", action="store_true", help="chain path: report per-call times from in-kernel stamps (costs ~6 %%)")
+    ap.add_argument("--stamps", action="store_true", help="chain path: report per-call times from in-kernel stamps (costs ~6 %%; needs a profiling build of the library: tools/build_variant.sh st \"-DTMAC_CHAIN_STAMPS=1\", TMAC_HIP_LIB=tmac_amd/lib/ko/libtmac_hip_st.so)")
     ap.add_argument("--floors", action="store_true", help="fused path: also time launches that only read the same bytes")
     ap.add_argument("--autotune", action="store_true", help="fused path: measure the launch configurations first (tmac_hip_autotune_fused)")
     ap.add_argument("--no-graph", action="store_true", help="fused/split: launch eagerly instead of replaying a captured hipGraph")

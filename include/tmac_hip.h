@@ -263,7 +263,8 @@ int32_t tmac_hip_chain_threads(void);   /* threads per workgroup of k_decode_cha
 int32_t tmac_hip_chain_is_stream(const tmac_hip_chain* chain);
 /* profiling / A-B knobs: s_memrealtime stamps (100 MHz) [calls][workgroups][8] of wave 0 (0 call entry, 1 activations complete, 2 LUT
  * built, 3 weights of the call landed, 5 last row quad published, 6 all loads landed, 7 number of polls) into a device buffer (NULL = off); waves per row quad forced for chains built from now on (0 = per-call
- * choice) and the poll limit of a hand-off (0 = keep) */
+ * choice) and the poll limit of a hand-off (0 = keep).  The stamps exist in profiling builds of the library only (-DTMAC_CHAIN_STAMPS=1 for
+ * k_decode_chain, -DTMAC_STREAM_STAMPS for k_gemv_stream: the idle hooks cost the dependent token 3 %); otherwise a non-NULL buffer returns -1 */
 int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* chain, unsigned long long* dev_buffer);
 /* Parity tap of the persistent kernels (k_decode_chain, k_gemv_stream): the INTEGERS of every recorded call as they enter the float part of
  * the path, written by the launch itself into a caller's device buffer (NULL = off; launches with a tap run the kernels' tap instantiation).

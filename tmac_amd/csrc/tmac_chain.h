@@ -119,6 +119,13 @@ inline size_t chain_lds_bytes(int buf_u4, int nops, int xf_floats = 0) {
     return (size_t)2 * buf_u4 * 16 + sizeof(float) * 2 * CHAIN_NWV * 4 * CHAIN_RED + sizeof(ChainOp) * (size_t)nops + sizeof(float) * (32 + (size_t)xf_floats);
 }
 
+// Profiling stamps of k_decode_chain (tmac_hip_chain_set_stamps, bench.py --stamps, tools/chain_stamps.py): compiled in by
+// -DTMAC_CHAIN_STAMPS=1 only (tools/build_variant.sh st "-DTMAC_CHAIN_STAMPS=1").  Round 6: the idle hooks -- seven conditional stores per call,
+// which also cost the compiler its count of the loads in flight -- were 3 % of the dependent token (0.671 -> 0.651 ms; BitNet-3B 0.547 -> 0.529).
+#ifndef TMAC_CHAIN_STAMPS
+#define TMAC_CHAIN_STAMPS 0
+#endif
+
 // ---- stream mode: a recording in which no op consumes another's output (tmac_stream.hip) ----
 #ifndef TMAC_STREAM_NLW
 #define TMAC_STREAM_NLW 12

@@ -117,7 +117,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
 
     // stamps: s_memrealtime (100 MHz, one clock for the whole device; s_memtime counts per XCD with unrelated offsets)
 // (stamps 0-4 and 7 by the wave that polls and builds LUT block 0 -- the LAST wave, see tpair below -- 5 and 6 by wave 0, the publisher)
-#define CSTAMPV(i, k, v) do { if (a.stamps && tid == (((k) == 5 || (k) == 6) ? 0 : FT - 64)) a.stamps[((size_t)(i) * gx + bx) * 8 + (k)] = (v); } while (0)
+// (TMAC_CHAIN_STAMPS, tmac_chain.h: the hooks exist in profiling builds only -- seven conditional stores per call cost the token 3 %)
+#define CSTAMPV(i, k, v) do { if (TMAC_CHAIN_STAMPS && a.stamps && tid == (((k) == 5 || (k) == 6) ? 0 : FT - 64)) a.stamps[((size_t)(i) * gx + bx) * 8 + (k)] = (v); } while (0)
 #define CSTAMP(i, k) CSTAMPV(i, k, __builtin_amdgcn_s_memrealtime())
 
     CSel<BITS> sel;
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
         }
         CSTAMP(i, 5);
         while (c_it < ro.my_iter) finish(false, 0.f);
-        if (a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CSTAMP(i, 6); }
+        if (TMAC_CHAIN_STAMPS && a.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CSTAMP(i, 6); }
     }
 #undef CSTAMP
 #undef CSTAMPV

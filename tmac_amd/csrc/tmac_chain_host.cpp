@@ -906,6 +906,8 @@ extern "C" int32_t tmac_hip_chain_set_stamps(tmac_hip_chain* c, unsigned long lo
     // [calls][workgroups][8] documented for k_decode_chain: a buffer sized for the latter would be overrun
     if (c->stream && dev_buffer) return fail(TMAC_HIP_E_NOMATCH, "stamps of a stream-mode chain exist in -DTMAC_STREAM_STAMPS builds only (layout: StreamArgs::stamps)");
 #endif
+    if (!c->stream && dev_buffer && !TMAC_CHAIN_STAMPS)
+        return fail(TMAC_HIP_E_NOMATCH, "stamps of k_decode_chain exist in -DTMAC_CHAIN_STAMPS=1 builds of the library only (tools/build_variant.sh)");
     c->stamps = dev_buffer;
     return TMAC_HIP_OK;
 }

@@ -86,8 +86,10 @@ __device__ __forceinline__ void c_ext3(const uint4* p0, const uint4* p1, const u
                  : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]) : "v"(p0), "v"(p1), "v"(p2) : "memory");
 }
 
-// XF: the chain holds vector transforms (tmac_hip_chain_xform) -- a kernel of its own, so that chains without them keep their registers
-template <int BITS, bool ZP, bool SCF16, int SM, bool XF>
+// XF: the chain holds vector transforms (tmac_hip_chain_xform) -- a kernel of its own, so that chains without them keep their registers.
+// TAP: the parity tap (tmac_hip_chain_set_tap), an instance of its own next to XF (end of round 6: inside the XF instance its conditional
+// stores -- per item and act group -- cost the decoder pattern, which needs XF and sets no tap, 2.8 %: 1.060 -> 1.031 ms per token)
+template <int BITS, bool ZP, bool SCF16, int SM, bool XF, bool TAP = false>
 __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 lds[];
     constexpr int FT = CHAIN_FT, NWV = CHAIN_NWV;
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
                         for (int ww = 0; ww < wpq; ++ww)
 #pragma unroll
                             for (int pl = 0; pl < BITS; ++pl) cb[pl] += redi[((qs * wpq + ww) * 4 + row) * CHAIN_RED + pl];
-                        if (XF && a.tap)
+                        if (TAP && a.tap)
 #pragma unroll
                             for (int pl = 0; pl < BITS; ++pl) a.tap[a.tap_off[i] + (size_t)(4 * p_gql + row) * BITS + pl] = cb[pl];
                         // scale-final (qgemm.py:170-174,192-206), as k_gemv_quad's epilogue: C = ((sum_p float(cb_p) alpha_p) ls + lb / 2) Scale
@@ -798,8 +800,8 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
 #pragma unroll
                 for (int k = 0; k < RING; ++k) {
                     // (the instance with the extensions is also the parity tap's: ChainArgs::tap)
-                    c_compute<BITS, ZP, SCF16, SM, XF, TMAC_CHAIN_IMG2 != 0>(ring[k], tab, tstride, l_ls, l_lb, c_st * 64, lane16, lk4, sel, k3, cacc, iacc,
-                                                             (XF && a.tap) ? a.tap + a.tap_off[i] + (size_t)(4 * (ro.q_lo + ro.qs + c_it * ipi) + (lane & 3)) * G : nullptr, G,
+                    c_compute<BITS, ZP, SCF16, SM, TAP, TMAC_CHAIN_IMG2 != 0>(ring[k], tab, tstride, l_ls, l_lb, c_st * 64, lane16, lk4, sel, k3, cacc, iacc,
+                                                             (TAP && a.tap) ? a.tap + a.tap_off[i] + (size_t)(4 * (ro.q_lo + ro.qs + c_it * ipi) + (lane & 3)) * G : nullptr, G,
                                                              c_st * (16 * IMG2_STEP));
                     issue_next(ring[k]);               // refill this slot with the item RING places ahead, if there is one
                     c_st += wpq;
@@ -834,9 +836,9 @@ __global__ __launch_bounds__(CHAIN_FT) void k_decode_chain(ChainArgs a) {
 #endif
 constexpr int CB = TMAC_CHAIN_BITS;
 
-template <bool ZP, bool SCF16, int SM, bool XF>
+template <bool ZP, bool SCF16, int SM, bool XF, bool TAP>
 static hipError_t chain_launch_x(const ChainArgs& a, int grid, size_t lds_bytes, hipStream_t st, int* resident) {
-    auto* kern = &k_decode_chain<CB, ZP, SCF16, SM, XF>;
+    auto* kern = &k_decode_chain<CB, ZP, SCF16, SM, XF, TAP>;
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
@@ -849,7 +851,8 @@ static hipError_t chain_launch_x(const ChainArgs& a, int grid, size_t lds_bytes,
 
 template <bool ZP, bool SCF16, int SM>
 static hipError_t chain_launch_one(const ChainArgs& a, int grid, size_t lds_bytes, hipStream_t st, int* resident) {
-    return a.xforms ? chain_launch_x<ZP, SCF16, SM, true>(a, grid, lds_bytes, st, resident) : chain_launch_x<ZP, SCF16, SM, false>(a, grid, lds_bytes, st, resident);
+    if (a.tap) return chain_launch_x<ZP, SCF16, SM, true, true>(a, grid, lds_bytes, st, resident);      // (the tap's instance carries the extensions too)
+    return a.xforms ? chain_launch_x<ZP, SCF16, SM, true, false>(a, grid, lds_bytes, st, resident) : chain_launch_x<ZP, SCF16, SM, false, false>(a, grid, lds_bytes, st, resident);
 }
 
 #define TMAC_CHAIN_LAUNCHER(NAME)                                                                                               \

@@ -82,7 +82,7 @@ struct ChainArgs {
     int carry_floats;              // LDS floats for the vector a NORM transform keeps for a later op of the launch (0: no op does)
     int tmp_floats, gam_floats;    // LDS floats for a transform's vector of the current op (NORM's t / GLU's x) and for NORM's weights
     int ext_floats;                // LDS floats for an op's activations when they come as fp32 from memory
-    int32_t* tap;                  // parity tap (tmac_hip_chain_set_tap; runs the instance with the extensions): the integers that enter the float part, per op at
+    int32_t* tap;                  // parity tap (tmac_hip_chain_set_tap; runs the TAP instance of the kernel): the integers that enter the float part, per op at
     const unsigned long long* tap_off;   //   tap + tap_off[op]: per-group scales int32 [4 * total_q rows][K / 64] comb = sum_p 2^p PS_p; unified scales [rows][bits] totals
     unsigned long long* stamps;    // optional [nops][grid][8] of wave 0, s_memrealtime (100 MHz): 0 op entry, 1 activations complete, 2 LUT built
                                    // (barrier passed), 3 current ring landed, 5 last quad published, 6 everything in flight landed, 7 polls

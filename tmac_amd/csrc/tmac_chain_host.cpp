@@ -776,7 +776,7 @@ extern "C" int32_t tmac_hip_chain_launch(tmac_hip_chain* c, void* stream) {
         static const int force_xf = [] { const char* e = getenv("TMAC_HIP_CHAIN_FORCE_XF"); return e && e[0] == '1' ? 1 : 0; }();
         if (force_xf) a.xforms = 1;
     }
-    if (c->tap) { a.tap = c->tap; a.tap_off = c->d_tap_off; a.xforms = 1; }      // the tap lives in the instance with the extensions
+    if (c->tap) { a.tap = c->tap; a.tap_off = c->d_tap_off; a.xforms = 1; }      // the tap has an instance of its own (XF + TAP), launch_decode_chain_b*
     a.poll_sleep = c->poll_sleep; a.poll_delay = c->poll_delay; a.issue_first = c->issue_first; a.poll_mode = c->poll_mode; a.poll_grid = c->poll_grid;
     hipError_t e = launch_decode_chain(a, c->bits, c->zp != 0, c->sc_f16 != 0, c->sm, c->grid, c->lds_bytes, st);
     if (e == hipErrorInvalidValue) return fail(TMAC_HIP_E_NOMATCH, "no decode-chain kernel for this configuration");
